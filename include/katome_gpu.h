@@ -1,0 +1,226 @@
+/*
+ * katome_gpu.h -- C ABI of the MI355X-native replacement for katome's `build` stage.
+ *
+ * Drop-in boundary: `Build::create(input_files, ft, reverse_complement, minimal_weight_threshold)
+ * -> (Self, usize)` (reference src/katome/algorithms/builder.rs:42-54), called by
+ * `BasicAsm::assemble` / `assemble_with_gir` (asm/basic_assembler.rs:22-26, 37-40) after
+ * `set_global_k_sizes(config.k_mer_size)` (basic_assembler.rs:19-21, prelude.rs:34-43).
+ * A Rust `GpuGIR` type binds these symbols with `extern "C"` and implements
+ * `Convert<GpuGIR> for PtGraph` (collections/girs/mod.rs:16-29) from the arrays of `katome_graph`.
+ *
+ * Plain pointers and sizes only; nothing unwinds across the boundary (the reference panics:
+ * builder.rs:62,67,71,124,148,153, pt_graph.rs:278 -- here every entry returns a status code and
+ * `katome_last_error()` holds the message the reference would have panicked with).
+ *
+ * Threading: synchronous, one build at a time per process (the reference keeps k in `static mut`
+ * globals, prelude.rs:21-25); the library uses HIP streams internally.
+ */
+#ifndef KATOME_GPU_H
+#define KATOME_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KATOME_ABI_VERSION 1
+
+/* status codes: the reference's panics, one code each */
+enum {
+    KATOME_OK = 0,
+    KATOME_E_PATH = -1,        /* builder.rs:62  "Coulndt resolve path: ..."            */
+    KATOME_E_IS_DIR = -2,      /* builder.rs:67  "... is a directory"                   */
+    KATOME_E_NOT_EXIST = -3,   /* builder.rs:71  "... does not exist"                   */
+    KATOME_E_OPEN = -4,        /* builder.rs:124,148 "Couldn't open all files: ..."     */
+    KATOME_E_PARSE = -5,       /* builder.rs:128,153 record `.unwrap()` on a bad record */
+    KATOME_E_SHORT_READ = -6,  /* pt_graph.rs:278 / hm_gir.rs:40 "Read is too short!"   */
+    KATOME_E_ARG = -7,         /* prelude.rs:35 `assert!(k_size > 1)`, bad settings     */
+    KATOME_E_DEVICE = -8,      /* no usable MI355X / HIP error: there is NO CPU fallback */
+    KATOME_E_OOM = -9,
+    KATOME_E_UNSUPPORTED = -10
+};
+
+/* Config<P> (config.rs:18-37) + prelude globals, as a plain struct */
+typedef struct {
+    uint32_t k;                  /* k_mer_size; supported 3..63 (k<=31: 64-bit keys, else 128-bit) */
+    uint8_t  file_type;          /* InputFileType (config.rs:5-14): 0 Fasta, 1 Fastq, 2 BFCounter   */
+    uint8_t  reverse_complement; /* Config::reverse_complement                                     */
+    uint16_t _pad;
+    uint32_t min_weight;         /* minimal_weight_threshold (BFCounter ingest only, builder.rs:106)*/
+    int32_t  device;             /* HIP device ordinal of the MI355X to build on                     */
+    uint64_t table_slots_hint;   /* 0 = size the (k-1)-mer/edge table automatically                 */
+} katome_settings;
+
+/* Result of a build, host memory, owned by the library until katome_graph_free().
+ * What `Convert<GpuGIR> for PtGraph` needs (pt_graph.rs:33): node count, and per edge
+ * (source, target, weight, label) with the label in compress_edge format (compress.rs:250-271),
+ * i.e. what SEQUENCES[EdgeSlice.idx()] holds after PtGraph::create (pt_graph.rs:339-343).
+ * Edge order = ascending packed k-mer; node ids = rank of the packed (k-1)-mer (deterministic). */
+typedef struct {
+    uint64_t n_nodes, n_edges;
+    uint64_t read_bytes;          /* sum of accepted read lengths (builder.rs:158)              */
+    uint32_t k;
+    uint32_t key_words;           /* u64 words per key: 1 (k<=31) or 2                          */
+    uint32_t label_stride;        /* 1 + ceil(k/4)                                              */
+    uint32_t _pad;
+    const uint64_t *edge_src;     /* [n_edges] dense node id of the source (k-1)-mer            */
+    const uint64_t *edge_dst;     /* [n_edges] dense node id of the target (k-1)-mer            */
+    const uint32_t *edge_weight;  /* [n_edges] EdgeWeight = u32 (prelude.rs:9), wrapping        */
+    const uint8_t  *edge_label;   /* [n_edges][label_stride] compress_edge format               */
+    const uint64_t *edge_key;     /* [n_edges][key_words] packed k-mer, right-aligned, w[0] = high word */
+    const uint64_t *node_key;     /* [n_nodes][key_words] packed (k-1)-mer, right-aligned       */
+} katome_graph;
+
+/* CollectionStats (stats/collections.rs:38-57) as computed for PtGraph (137-168) */
+typedef struct {
+    uint64_t node_count, edge_count;
+    uint32_t max_edge_weight;
+    uint32_t _pad;
+    double   avg_edge_weight;
+    uint64_t max_in_degree, max_out_degree;
+    double   avg_out_degree;
+    uint64_t incoming_vert_count, outgoing_vert_count;
+} katome_stats;
+
+/* ---- the drop-in entry points --------------------------------------------------------- */
+
+/* Build::create over files (builder.rs:42-54 -> check_files 57-77 -> create_fastq 142-165 /
+ * create_fasta 118-140): parse, skip reads with a non-ACGT byte, pack 2 bits/base, build on
+ * the GPU, copy the graph back. */
+int katome_build_files(const katome_settings *s, const char *const *paths, size_t n_paths,
+                       katome_graph **out);
+
+/* Same build from reads that are already 2-bit packed (A0 C1 G2 T3, 4 bases per byte, first
+ * base in the two most significant bits: the bit order of compress_node, compress.rs:55-73).
+ * Read r occupies bytes [r*ceil(read_len/4), +ceil(read_len/4)).  `skip` (nullable) has one
+ * byte per read; non-zero = the read held a non-ACGT byte and is not added (builder.rs:155-157).
+ * read_len < k is KATOME_E_SHORT_READ (pt_graph.rs:278). */
+int katome_build_packed(const katome_settings *s, const uint8_t *packed, uint64_t n_reads,
+                        uint32_t read_len, const uint8_t *skip, katome_graph **out);
+
+void katome_graph_free(katome_graph *g);
+
+/* Stats<CollectionStats>::stats for the built graph (stats/collections.rs:137-168); host side */
+int katome_graph_stats(const katome_graph *g, katome_stats *out);
+
+/* message of the last failing call on this thread's process (what the reference panics with) */
+const char *katome_last_error(void);
+
+uint32_t katome_abi_version(void);
+
+/* ---- host ingest alone (the step in front of the path; builder.rs:57-77,118-165) -------- */
+typedef struct {
+    uint64_t n_records;       /* records seen                                              */
+    uint64_t n_reads;         /* accepted (all-ACGT) reads                                 */
+    uint64_t read_bytes;      /* sum of accepted read lengths                              */
+    uint64_t packed_bytes;
+    uint64_t total_windows;   /* sum over reads of (len - k + 1)                           */
+    uint32_t fixed_len;       /* != 0 iff every accepted read has this length              */
+    uint32_t _pad;
+    const uint8_t  *packed;   /* reads packed back to back, each starting on a byte        */
+    const uint64_t *byte_off; /* [n_reads+1] start byte of each read in `packed`           */
+    const uint32_t *len;      /* [n_reads] bases                                           */
+} katome_reads;
+
+int  katome_ingest_files(const katome_settings *s, const char *const *paths, size_t n_paths,
+                         katome_reads **out);
+void katome_reads_free(katome_reads *r);
+
+/* ---- device-resident API -----------------------------------------------------------------
+ * Used by bench.py (inputs already in HBM when the timed region starts) and by the multi-GPU
+ * driver (one process per GPU; the k-mer exchange between extraction and insertion is an RCCL
+ * all-to-all done by the caller).  All `d_` pointers are device pointers on settings.device;
+ * `stream` is a hipStream_t (NULL = the default stream).  Calls are asynchronous on `stream`
+ * unless they return a count.                                                              */
+typedef struct katome_builder katome_builder;
+
+int  katome_builder_create(const katome_settings *s, katome_builder **out);
+void katome_builder_destroy(katome_builder *b);
+
+/* u64 words per k-mer record for this k (1 or 2) */
+uint32_t katome_record_words(uint32_t k);
+
+/* k-mer extraction (compress_kmer / compress_kmer_with_rev_compl, compress.rs:18-48, over
+ * read.windows(K), pt_graph.rs:294,310): one record per forward window, record =
+ * packed k-mer (reverse_complement=0) or min(k-mer, reverse complement) (=1);
+ * windows of skipped reads hold the invalid marker (all ones).
+ * d_records: [n_reads*(read_len-k+1)][record_words] u64.                                   */
+int katome_dev_extract_fixed(katome_builder *b, const uint8_t *d_packed, uint64_t n_reads,
+                             uint32_t read_len, const uint8_t *d_skip, uint64_t *d_records,
+                             void *stream);
+/* variable-length reads: d_byte_off[n_reads+1], d_len[n_reads], d_win_prefix[n_reads+1]
+ * (exclusive prefix sum of len-k+1); d_records: [total_windows][record_words]              */
+int katome_dev_extract_var(katome_builder *b, const uint8_t *d_packed, uint64_t packed_bytes,
+                           const uint64_t *d_byte_off, const uint32_t *d_len,
+                           const uint64_t *d_win_prefix, uint64_t n_reads, uint64_t total_windows,
+                           uint64_t *d_records, void *stream);
+
+/* group records by owner rank = mulhi(mix(key), n_parts) (invalid records are dropped);
+ * d_out: same size as d_records; h_counts[n_parts] receives the records per part (synchronises) */
+int katome_dev_partition(katome_builder *b, const uint64_t *d_records, uint64_t n_records,
+                         uint32_t n_parts, uint64_t *d_out, uint64_t *h_counts, void *stream);
+
+/* add_single_edge_fastaq (pt_graph.rs:172-198) for a batch: find-or-insert each record's
+ * k-mer in the open-address table and add 1 to its weight (u32, wrapping).  Grows the table
+ * when needed (synchronises).                                                              */
+int katome_dev_insert(katome_builder *b, const uint64_t *d_records, uint64_t n_records, void *stream);
+/* same with an explicit weight per record (BFCounter input, pt_graph.rs:201-213; and merging
+ * pre-aggregated partial tables)                                                           */
+int katome_dev_insert_weighted(katome_builder *b, const uint64_t *d_records, const uint32_t *d_weights,
+                               uint64_t n_records, void *stream);
+
+/* number of distinct keys in the table so far (synchronises) */
+int katome_dev_table_count(katome_builder *b, uint64_t *out);
+
+/* device-resident graph; arrays owned by the builder until destroy / next finalize */
+typedef struct {
+    uint64_t n_nodes, n_edges;
+    uint32_t key_words, label_stride;
+    uint64_t *d_edge_key;     /* [n_edges][key_words], ascending */
+    uint32_t *d_edge_weight;
+    uint64_t *d_edge_src, *d_edge_dst;
+    uint8_t  *d_edge_label;
+    uint64_t *d_node_key;     /* [n_nodes][key_words], ascending */
+} katome_dev_graph;
+
+/* Table -> distinct oriented edges, sorted by packed k-mer (both strands when
+ * reverse_complement, pt_graph.rs:282-308); then node numbering, endpoints and labels
+ * (the PtGraph::create post-pass, pt_graph.rs:339-343 -> kmer_to_edge compress.rs:231-233). */
+int katome_dev_finalize(katome_builder *b, katome_dev_graph *out, void *stream);
+
+/* first half of finalize only: sorted distinct edges (key, weight); used by the multi-GPU
+ * driver, which resolves node ids across ranks itself                                      */
+int katome_dev_edges(katome_builder *b, uint64_t **d_edge_key, uint32_t **d_edge_weight,
+                     uint64_t *n_edges, void *stream);
+
+/* ---- device primitives the finalize is built from (exported for the multi-GPU driver and
+ * for unit tests; each is a hand-written HIP kernel set) -------------------------------- */
+/* LSD radix sort of n keys of `key_words` u64 words on bits [0, key_bits); optional u32
+ * values.  d_keys/d_vals are sorted in place (a temporary of equal size is allocated).     */
+int katome_dev_sort(int device, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t key_words,
+                    uint32_t key_bits, void *stream);
+/* in-place unique of sorted keys; returns the new count (synchronises)                     */
+int katome_dev_unique(int device, uint64_t *d_keys, uint64_t n, uint32_t key_words, uint64_t *n_out,
+                      void *stream);
+/* rank of each query key in a sorted unique key array (every query must be present; absent
+ * keys yield UINT64_MAX)                                                                   */
+int katome_dev_rank(int device, const uint64_t *d_sorted, uint64_t n_sorted, uint32_t key_words,
+                    uint32_t key_bits, const uint64_t *d_queries, uint64_t n_queries,
+                    uint64_t *d_rank_out, void *stream);
+/* derive (k-1)-mer endpoint keys of each edge: d_src/d_dst [n][key_words]                  */
+int katome_dev_endpoints(int device, const uint64_t *d_edge_key, uint64_t n, uint32_t k,
+                         uint64_t *d_src_key, uint64_t *d_dst_key, void *stream);
+/* compress_edge-format labels (compress.rs:250-271) of packed k-mers                       */
+int katome_dev_labels(int device, const uint64_t *d_edge_key, uint64_t n, uint32_t k,
+                      uint8_t *d_label, void *stream);
+
+/* ---- synthetic workload generator (bench/tests; DESIGN.md "Synthetic workload") ---------- */
+int katome_dev_synth_reads(int device, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                           uint64_t genome_len, double err_rate, uint32_t n_inject_percent,
+                           uint8_t *d_packed, uint8_t *d_skip, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,102 @@
+"""ctypes binding of include/katome_gpu.h (the same symbols a Rust `extern "C"` block binds)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+u8p = C.POINTER(C.c_uint8)
+u32p = C.POINTER(C.c_uint32)
+u64p = C.POINTER(C.c_uint64)
+
+STATUS = {0: "OK", -1: "E_PATH", -2: "E_IS_DIR", -3: "E_NOT_EXIST", -4: "E_OPEN", -5: "E_PARSE", -6: "E_SHORT_READ",
+          -7: "E_ARG", -8: "E_DEVICE", -9: "E_OOM", -10: "E_UNSUPPORTED"}
+
+
+class Settings(C.Structure):
+    _fields_ = [("k", C.c_uint32), ("file_type", C.c_uint8), ("reverse_complement", C.c_uint8), ("_pad", C.c_uint16),
+                ("min_weight", C.c_uint32), ("device", C.c_int32), ("table_slots_hint", C.c_uint64)]
+
+
+class Graph(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("read_bytes", C.c_uint64), ("k", C.c_uint32),
+                ("key_words", C.c_uint32), ("label_stride", C.c_uint32), ("_pad", C.c_uint32),
+                ("edge_src", u64p), ("edge_dst", u64p), ("edge_weight", u32p), ("edge_label", u8p),
+                ("edge_key", u64p), ("node_key", u64p)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("node_count", C.c_uint64), ("edge_count", C.c_uint64), ("max_edge_weight", C.c_uint32),
+                ("_pad", C.c_uint32), ("avg_edge_weight", C.c_double), ("max_in_degree", C.c_uint64),
+                ("max_out_degree", C.c_uint64), ("avg_out_degree", C.c_double), ("incoming_vert_count", C.c_uint64),
+                ("outgoing_vert_count", C.c_uint64)]
+
+
+class Reads(C.Structure):
+    _fields_ = [("n_records", C.c_uint64), ("n_reads", C.c_uint64), ("read_bytes", C.c_uint64),
+                ("packed_bytes", C.c_uint64), ("total_windows", C.c_uint64), ("fixed_len", C.c_uint32),
+                ("_pad", C.c_uint32), ("packed", u8p), ("byte_off", u64p), ("len", u32p)]
+
+
+class DevGraph(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("key_words", C.c_uint32),
+                ("label_stride", C.c_uint32), ("d_edge_key", C.c_void_p), ("d_edge_weight", C.c_void_p),
+                ("d_edge_src", C.c_void_p), ("d_edge_dst", C.c_void_p), ("d_edge_label", C.c_void_p),
+                ("d_node_key", C.c_void_p)]
+
+
+# every symbol include/katome_gpu.h declares: name -> (restype, argtypes)
+_vp, _sz, _i, _u32, _u64, _dbl = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.c_uint64, C.c_double
+_pp = C.POINTER(C.c_char_p)
+SYMBOLS = {
+    "katome_build_files": (_i, [C.POINTER(Settings), _pp, _sz, C.POINTER(C.POINTER(Graph))]),
+    "katome_build_packed": (_i, [C.POINTER(Settings), _vp, _u64, _u32, _vp, C.POINTER(C.POINTER(Graph))]),
+    "katome_graph_free": (None, [C.POINTER(Graph)]),
+    "katome_graph_stats": (_i, [C.POINTER(Graph), C.POINTER(Stats)]),
+    "katome_last_error": (C.c_char_p, []),
+    "katome_abi_version": (_u32, []),
+    "katome_ingest_files": (_i, [C.POINTER(Settings), _pp, _sz, C.POINTER(C.POINTER(Reads))]),
+    "katome_reads_free": (None, [C.POINTER(Reads)]),
+    "katome_builder_create": (_i, [C.POINTER(Settings), C.POINTER(_vp)]),
+    "katome_builder_destroy": (None, [_vp]),
+    "katome_record_words": (_u32, [_u32]),
+    "katome_dev_extract_fixed": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
+    "katome_dev_extract_var": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
+    "katome_dev_partition": (_i, [_vp, _vp, _u64, _u32, _vp, u64p, _vp]),
+    "katome_dev_insert": (_i, [_vp, _vp, _u64, _vp]),
+    "katome_dev_insert_weighted": (_i, [_vp, _vp, _vp, _u64, _vp]),
+    "katome_dev_table_count": (_i, [_vp, u64p]),
+    "katome_dev_finalize": (_i, [_vp, C.POINTER(DevGraph), _vp]),
+    "katome_dev_edges": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
+    "katome_dev_sort": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp]),
+    "katome_dev_unique": (_i, [_i, _vp, _u64, _u32, u64p, _vp]),
+    "katome_dev_rank": (_i, [_i, _vp, _u64, _u32, _u32, _vp, _u64, _vp, _vp]),
+    "katome_dev_endpoints": (_i, [_i, _vp, _u64, _u32, _vp, _vp, _vp]),
+    "katome_dev_labels": (_i, [_i, _vp, _u64, _u32, _vp, _vp]),
+    "katome_dev_synth_reads": (_i, [_i, _u64, _u64, _u32, _u64, _dbl, _u32, _vp, _vp, _vp]),
+}
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libkatome_gpu.so")
+
+
+def lib():
+    """Load the HIP library.  Fails loudly when it has not been built: there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "or `make -C katome_amd/csrc` (no CPU fallback exists)" % path)
+        L = C.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def last_error():
+    return lib().katome_last_error().decode(errors="replace")

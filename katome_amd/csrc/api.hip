@@ -1,0 +1,413 @@
+// api.hip -- the C ABI of include/katome_gpu.h: the build driver behind `Build::create`
+// (reference src/katome/algorithms/builder.rs:42-54) and the PtGraph::create post-pass
+// (collections/graphs/pt_graph.rs:333-345), composed from the kernels in extract.hip, table.hip
+// and radix.hip.  No CPU fallback: every entry that needs the device fails with KATOME_E_DEVICE
+// when there is none.
+#include <stdlib.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "common.h"
+
+using namespace katome;
+
+struct katome_builder {
+    katome_settings s;
+    uint32_t nw = 1;
+    bool rc = false;
+    Table table;
+    bool table_ready = false;
+    // sorted distinct oriented edges
+    bool edges_ready = false;
+    DevBuf edge_key, edge_weight;
+    uint64_t n_edges = 0;
+    // finalized graph
+    DevBuf edge_src, edge_dst, edge_label, node_key;
+    uint64_t n_nodes = 0;
+};
+
+extern "C" {
+
+uint32_t katome_abi_version(void) { return KATOME_ABI_VERSION; }
+const char* katome_last_error(void) { return get_error(); }
+uint32_t katome_record_words(uint32_t k) { return (uint32_t)key_words_for_k(k); }
+
+int katome_builder_create(const katome_settings* s, katome_builder** out) {
+    if (!s || !out) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    KCHECK(check_k(s->k));
+    KCHECK(use_device(s->device));
+    katome_builder* b = new (std::nothrow) katome_builder();
+    if (!b) { set_error("out of host memory"); return KATOME_E_OOM; }
+    b->s = *s;
+    b->nw = (uint32_t)key_words_for_k(s->k);
+    b->rc = s->reverse_complement != 0;
+    *out = b;
+    return KATOME_OK;
+}
+
+void katome_builder_destroy(katome_builder* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->s.device);
+    delete b;
+}
+
+int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
+                             const uint8_t* d_skip, uint64_t* d_records, void* stream) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream);
+}
+
+int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
+                           const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
+                           uint64_t* d_records, void* stream) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    return launch_extract_var(b->s.k, b->rc, d_packed, packed_bytes, d_byte_off, d_len, d_win_prefix, n_reads, total_windows,
+                              d_records, (hipStream_t)stream);
+}
+
+int katome_dev_partition(katome_builder* b, const uint64_t* d_records, uint64_t n_records, uint32_t n_parts, uint64_t* d_out,
+                         uint64_t* h_counts, void* stream) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    return dev_partition(d_records, n_records, b->nw, n_parts, d_out, h_counts, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// make room for `incoming` more distinct keys at load factor <= 0.7
+static int ensure_table(katome_builder* b, uint64_t incoming, hipStream_t stream) {
+    const size_t slot = b->nw == 1 ? 16 : 32;
+    size_t free_b = 0, total_b = 0;
+    KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    if (!b->table_ready) {
+        uint64_t want = b->s.table_slots_hint ? b->s.table_slots_hint : incoming * 2;
+        want = std::max<uint64_t>(want, (uint64_t)((double)incoming / 0.7) + 1024);
+        const uint64_t budget = (uint64_t)(free_b * 0.6) / slot;
+        if (want > budget) want = budget;
+        if ((double)incoming > 0.7 * (double)want) { set_error("k-mer table does not fit in device memory (%llu keys)", (unsigned long long)incoming); return KATOME_E_OOM; }
+        KCHECK(table_alloc(b->table, b->nw, want, stream));
+        b->table_ready = true;
+        return KATOME_OK;
+    }
+    uint64_t occ = 0;
+    KCHECK(table_occupied(b->table, &occ, stream));
+    if ((double)(occ + incoming) <= 0.7 * (double)b->table.cap) return KATOME_OK;
+    uint64_t want = std::max<uint64_t>(b->table.cap * 2, (uint64_t)((double)(occ + incoming) / 0.5));
+    const uint64_t budget = (uint64_t)(free_b * 0.9) / slot;
+    if (want > budget) want = budget;
+    if ((double)(occ + incoming) > 0.7 * (double)want) { set_error("k-mer table cannot grow to %llu keys in device memory", (unsigned long long)(occ + incoming)); return KATOME_E_OOM; }
+    return table_grow(b->table, want, stream);
+}
+
+extern "C" {
+
+int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n_records,
+                               void* stream) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
+    KCHECK(ensure_table(b, n_records, (hipStream_t)stream));
+    return table_insert(b->table, d_records, d_weights, n_records, (hipStream_t)stream);
+}
+int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_records, void* stream) {
+    return katome_dev_insert_weighted(b, d_records, nullptr, n_records, stream);
+}
+
+int katome_dev_table_count(katome_builder* b, uint64_t* out) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    *out = 0;
+    if (!b->table_ready) return KATOME_OK;
+    return table_occupied(b->table, out, nullptr);
+}
+
+int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge_weight, uint64_t* n_edges, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (!b->edges_ready) {
+        b->n_edges = 0;
+        if (b->table_ready) {
+            KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->edge_key, b->edge_weight, &b->n_edges, stream));
+            b->table.slots.release();                 // the table is spent; its memory serves the sort
+            b->table.counter.release();
+            b->table_ready = false;
+            KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
+        } else {
+            KCHECK(b->edge_key.alloc(16)); KCHECK(b->edge_weight.alloc(16));
+        }
+        b->edges_ready = true;
+    }
+    if (d_edge_key) *d_edge_key = b->edge_key.as<u64>();
+    if (d_edge_weight) *d_edge_weight = b->edge_weight.as<u32>();
+    if (n_edges) *n_edges = b->n_edges;
+    return KATOME_OK;
+}
+
+int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK(katome_dev_edges(b, nullptr, nullptr, nullptr, stream_));
+    const uint64_t E = b->n_edges;
+    const uint32_t nw = b->nw, k = b->s.k, node_bits = 2 * (k - 1);
+    // node set = every source and target (k-1)-mer (add_fasta_node, pt_graph.rs:142-154),
+    // numbered by ascending packed key
+    KCHECK(b->node_key.alloc((2 * E + 1) * 8 * nw));
+    u64* cand = b->node_key.as<u64>();
+    KCHECK(dev_endpoints(b->edge_key.as<u64>(), E, k, cand, cand + E * nw, stream));
+    KCHECK(dev_sort(cand, nullptr, 2 * E, nw, node_bits, stream));
+    b->n_nodes = 2 * E;
+    KCHECK(dev_unique(cand, 2 * E, nw, &b->n_nodes, stream));
+    KCHECK(b->edge_src.alloc((E + 1) * 8));
+    KCHECK(b->edge_dst.alloc((E + 1) * 8));
+    {
+        DevBuf sk, dk;
+        KCHECK(sk.alloc((E + 1) * 8 * nw));
+        KCHECK(dk.alloc((E + 1) * 8 * nw));
+        KCHECK(dev_endpoints(b->edge_key.as<u64>(), E, k, sk.as<u64>(), dk.as<u64>(), stream));
+        KCHECK(dev_rank(cand, b->n_nodes, nw, node_bits, sk.as<u64>(), E, b->edge_src.as<u64>(), stream));
+        KCHECK(dev_rank(cand, b->n_nodes, nw, node_bits, dk.as<u64>(), E, b->edge_dst.as<u64>(), stream));
+    }
+    const uint32_t stride = label_stride_for_k(k);
+    KCHECK(b->edge_label.alloc((E + 1) * (size_t)stride + 16));
+    KCHECK(dev_labels(b->edge_key.as<u64>(), E, k, b->edge_label.as<uint8_t>(), stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    if (out) {
+        out->n_nodes = b->n_nodes; out->n_edges = E;
+        out->key_words = nw; out->label_stride = stride;
+        out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
+        out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
+        out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = cand;
+    }
+    return KATOME_OK;
+}
+
+int katome_dev_sort(int device, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t key_words, uint32_t key_bits, void* stream) {
+    KCHECK(use_device(device));
+    return dev_sort(d_keys, d_vals, n, key_words, key_bits, (hipStream_t)stream);
+}
+int katome_dev_unique(int device, uint64_t* d_keys, uint64_t n, uint32_t key_words, uint64_t* n_out, void* stream) {
+    KCHECK(use_device(device));
+    if (key_words != 1 && key_words != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
+    return dev_unique(d_keys, n, key_words, n_out, (hipStream_t)stream);
+}
+int katome_dev_rank(int device, const uint64_t* d_sorted, uint64_t n_sorted, uint32_t key_words, uint32_t key_bits,
+                    const uint64_t* d_queries, uint64_t n_queries, uint64_t* d_rank_out, void* stream) {
+    KCHECK(use_device(device));
+    if (key_words != 1 && key_words != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
+    return dev_rank(d_sorted, n_sorted, key_words, key_bits, d_queries, n_queries, d_rank_out, (hipStream_t)stream);
+}
+int katome_dev_endpoints(int device, const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src_key, uint64_t* d_dst_key, void* stream) {
+    KCHECK(use_device(device));
+    KCHECK(check_k(k));
+    return dev_endpoints(d_edge_key, n, k, d_src_key, d_dst_key, (hipStream_t)stream);
+}
+int katome_dev_labels(int device, const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, void* stream) {
+    KCHECK(use_device(device));
+    KCHECK(check_k(k));
+    return dev_labels(d_edge_key, n, k, d_label, (hipStream_t)stream);
+}
+int katome_dev_synth_reads(int device, uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len,
+                           double err_rate, uint32_t n_inject_percent, uint8_t* d_packed, uint8_t* d_skip, void* stream) {
+    KCHECK(use_device(device));
+    return launch_synth(first_read, n_reads, read_len, genome_len, err_rate, n_inject_percent, d_packed, d_skip, (hipStream_t)stream);
+}
+
+// ---- host-memory entry points ---------------------------------------------------------------------
+struct GraphOwner {            // katome_graph followed by what it owns
+    katome_graph g;
+    std::vector<void*> mem;
+};
+
+void katome_graph_free(katome_graph* g) {
+    if (!g) return;
+    GraphOwner* o = reinterpret_cast<GraphOwner*>(g);
+    for (void* p : o->mem) free(p);
+    delete o;
+}
+
+}  // extern "C"
+
+template <class T> static int d2h(GraphOwner* o, const T** dst, const void* d_src, size_t count) {
+    T* h = (T*)malloc(std::max<size_t>(count, 1) * sizeof(T));
+    if (!h) { set_error("out of host memory"); return KATOME_E_OOM; }
+    o->mem.push_back(h);
+    if (count) KCHECK_HIP(hipMemcpy(h, d_src, count * sizeof(T), hipMemcpyDeviceToHost));
+    *dst = h;
+    return KATOME_OK;
+}
+
+static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** out) {
+    katome_dev_graph dg;
+    KCHECK(katome_dev_finalize(b, &dg, nullptr));
+    GraphOwner* o = new (std::nothrow) GraphOwner();
+    if (!o) { set_error("out of host memory"); return KATOME_E_OOM; }
+    memset(&o->g, 0, sizeof o->g);
+    katome_graph* g = &o->g;
+    g->n_nodes = dg.n_nodes; g->n_edges = dg.n_edges; g->read_bytes = read_bytes;
+    g->k = b->s.k; g->key_words = dg.key_words; g->label_stride = dg.label_stride;
+    int rc = KATOME_OK;
+    if ((rc = d2h(o, &g->edge_src, dg.d_edge_src, dg.n_edges)) || (rc = d2h(o, &g->edge_dst, dg.d_edge_dst, dg.n_edges)) ||
+        (rc = d2h(o, &g->edge_weight, dg.d_edge_weight, dg.n_edges)) ||
+        (rc = d2h(o, &g->edge_label, dg.d_edge_label, dg.n_edges * (size_t)dg.label_stride)) ||
+        (rc = d2h(o, &g->edge_key, dg.d_edge_key, dg.n_edges * dg.key_words)) ||
+        (rc = d2h(o, &g->node_key, dg.d_node_key, dg.n_nodes * dg.key_words))) {
+        katome_graph_free(g);
+        return rc;
+    }
+    *out = g;
+    return KATOME_OK;
+}
+
+// records per extraction batch: bounded by a slice of free device memory
+static uint64_t batch_records(uint32_t nw) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1ull << 24;
+    uint64_t r = (uint64_t)(free_b / 8) / (8ull * nw);
+    return std::min<uint64_t>(std::max<uint64_t>(r, 1ull << 20), 1ull << 30);
+}
+
+extern "C" {
+
+int katome_build_packed(const katome_settings* s, const uint8_t* packed, uint64_t n_reads, uint32_t read_len,
+                        const uint8_t* skip, katome_graph** out) {
+    if (!s || !out || (!packed && n_reads)) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    KCHECK(check_k(s->k));
+    if (n_reads && read_len < s->k) {
+        // only an ACCEPTED read can be too short (builder.rs:155-158 filters first)
+        bool any = !skip;
+        for (uint64_t r = 0; skip && r < n_reads && !any; ++r) any = skip[r] == 0;
+        if (any) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }
+        n_reads = 0;
+    }
+    katome_builder* b = nullptr;
+    KCHECK(katome_builder_create(s, &b));
+    int rc = KATOME_OK;
+    do {
+        const uint32_t stride = (read_len + 3) / 4, W = read_len >= s->k ? read_len - s->k + 1 : 0;
+        uint64_t read_bytes = 0;
+        for (uint64_t r = 0; r < n_reads; ++r) if (!skip || !skip[r]) read_bytes += read_len;
+        DevBuf d_packed, d_skip, d_rec;
+        if ((rc = d_packed.alloc(n_reads * stride + 32))) break;
+        if (n_reads && hipMemcpy(d_packed.p, packed, n_reads * stride, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+        if (skip) {
+            if ((rc = d_skip.alloc(n_reads + 16))) break;
+            if (n_reads && hipMemcpy(d_skip.p, skip, n_reads, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+        }
+        if (n_reads && W) {
+            uint64_t reads_per_batch = std::max<uint64_t>(batch_records(b->nw) / W, 64);
+            reads_per_batch = (reads_per_batch / 64) * 64;       // keeps batch starts 16-byte aligned
+            if ((rc = d_rec.alloc(std::min(reads_per_batch, n_reads) * W * 8 * b->nw + 16))) break;
+            for (uint64_t r0 = 0; r0 < n_reads && !rc; r0 += reads_per_batch) {
+                const uint64_t nr = std::min(reads_per_batch, n_reads - r0);
+                rc = katome_dev_extract_fixed(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len,
+                                              skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);
+                if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), nr * W, nullptr);
+            }
+            if (rc) break;
+        }
+        d_rec.release(); d_packed.release(); d_skip.release();
+        rc = graph_to_host(b, read_bytes, out);
+    } while (0);
+    katome_builder_destroy(b);
+    return rc;
+}
+
+int katome_ingest_files(const katome_settings* s, const char* const* paths, size_t n_paths, katome_reads** out) {
+    if (!s || !out || (!paths && n_paths)) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    HostReads* hr = new (std::nothrow) HostReads();
+    if (!hr) { set_error("out of host memory"); return KATOME_E_OOM; }
+    int rc = ingest_files(s, paths, n_paths, *hr);
+    if (rc) { delete hr; return rc; }
+    struct Owner { katome_reads r; HostReads* hr; };
+    Owner* o = new (std::nothrow) Owner();
+    if (!o) { delete hr; set_error("out of host memory"); return KATOME_E_OOM; }
+    o->hr = hr;
+    o->r.n_records = hr->n_records; o->r.n_reads = hr->n_reads; o->r.read_bytes = hr->read_bytes;
+    o->r.packed_bytes = hr->packed_bytes; o->r.total_windows = hr->total_windows; o->r.fixed_len = hr->fixed_len; o->r._pad = 0;
+    o->r.packed = hr->packed; o->r.byte_off = hr->byte_off; o->r.len = hr->len;
+    *out = &o->r;
+    return KATOME_OK;
+}
+void katome_reads_free(katome_reads* r) {
+    if (!r) return;
+    struct Owner { katome_reads r; HostReads* hr; };
+    Owner* o = reinterpret_cast<Owner*>(r);
+    delete o->hr;
+    delete o;
+}
+
+int katome_build_files(const katome_settings* s, const char* const* paths, size_t n_paths, katome_graph** out) {
+    if (!s || !out || (!paths && n_paths)) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    HostReads hr;
+    KCHECK(ingest_files(s, paths, n_paths, hr));           // path / parse / short-read errors surface before any GPU work
+    if (hr.fixed_len) {
+        katome_graph* g = nullptr;
+        KCHECK(katome_build_packed(s, hr.packed, hr.n_reads, hr.fixed_len, nullptr, &g));
+        g->read_bytes = hr.read_bytes;
+        *out = g;
+        return KATOME_OK;
+    }
+    katome_builder* b = nullptr;
+    KCHECK(katome_builder_create(s, &b));
+    int rc = KATOME_OK;
+    do {
+        if (hr.n_reads == 0) { rc = graph_to_host(b, hr.read_bytes, out); break; }
+        DevBuf d_packed, d_off, d_len, d_pref, d_rec;
+        if ((rc = d_packed.alloc(hr.packed_bytes + 32)) || (rc = d_off.alloc((hr.n_reads + 1) * 8)) || (rc = d_len.alloc(hr.n_reads * 4))) break;
+        if (hipMemcpy(d_packed.p, hr.packed, hr.packed_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_off.p, hr.byte_off, (hr.n_reads + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(d_len.p, hr.len, hr.n_reads * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+        const uint64_t cap = batch_records(b->nw);
+        std::vector<uint64_t> pref;
+        for (uint64_t r0 = 0; r0 < hr.n_reads && !rc;) {
+            pref.assign(1, 0);
+            uint64_t r1 = r0;
+            while (r1 < hr.n_reads && (r1 == r0 || pref.back() + (hr.len[r1] - s->k + 1) <= cap)) {
+                pref.push_back(pref.back() + (hr.len[r1] - s->k + 1));
+                ++r1;
+            }
+            const uint64_t windows = pref.back();
+            if ((rc = d_pref.alloc(pref.size() * 8)) || (rc = d_rec.alloc(windows * 8 * b->nw + 16))) break;
+            if (hipMemcpy(d_pref.p, pref.data(), pref.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+            rc = katome_dev_extract_var(b, d_packed.as<uint8_t>(), hr.packed_bytes, d_off.as<u64>() + r0, d_len.as<u32>() + r0,
+                                        d_pref.as<u64>(), r1 - r0, windows, d_rec.as<u64>(), nullptr);
+            if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), windows, nullptr);
+            if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("device failure during build"); rc = KATOME_E_DEVICE; }
+            r0 = r1;
+        }
+        if (rc) break;
+        d_rec.release(); d_packed.release(); d_off.release(); d_len.release(); d_pref.release();
+        rc = graph_to_host(b, hr.read_bytes, out);
+    } while (0);
+    katome_builder_destroy(b);
+    return rc;
+}
+
+// Stats<CollectionStats> for PtGraph (stats/collections.rs:137-168), from the host arrays
+int katome_graph_stats(const katome_graph* g, katome_stats* st) {
+    if (!g || !st) { set_error("null argument"); return KATOME_E_ARG; }
+    memset(st, 0, sizeof *st);
+    st->node_count = g->n_nodes; st->edge_count = g->n_edges;
+    std::vector<uint32_t> outd(g->n_nodes, 0), ind(g->n_nodes, 0);
+    uint64_t sum_w = 0;
+    for (uint64_t e = 0; e < g->n_edges; ++e) {
+        st->max_edge_weight = std::max(st->max_edge_weight, g->edge_weight[e]);
+        sum_w += g->edge_weight[e];
+        ++outd[g->edge_src[e]]; ++ind[g->edge_dst[e]];
+    }
+    st->avg_edge_weight = (double)sum_w / (double)g->n_edges;
+    uint64_t sum_out = 0;
+    for (uint64_t n = 0; n < g->n_nodes; ++n) {
+        st->max_out_degree = std::max<uint64_t>(st->max_out_degree, outd[n]);
+        st->max_in_degree = std::max<uint64_t>(st->max_in_degree, ind[n]);
+        sum_out += outd[n];
+        if (ind[n] == 0) ++st->incoming_vert_count;      // externals(Incoming)
+        if (outd[n] == 0) ++st->outgoing_vert_count;     // externals(Outgoing)
+    }
+    st->avg_out_degree = (double)sum_out / (double)g->n_nodes;
+    return KATOME_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,137 @@
+// common.h -- shared host-side plumbing of libkatome_gpu (error state, HIP checks, device buffers)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/katome_gpu.h"
+#include "kmer_bits.h"
+
+namespace katome {
+
+// ---- error state (katome_last_error) -------------------------------------------------------
+void set_error(const char* fmt, ...);
+const char* get_error();
+
+#define KCHECK_HIP(expr)                                                                         \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            katome::set_error("HIP error %d (%s) at %s:%d: %s", (int)_e, hipGetErrorString(_e),  \
+                              __FILE__, __LINE__, #expr);                                        \
+            return _e == hipErrorOutOfMemory ? KATOME_E_OOM : KATOME_E_DEVICE;                   \
+        }                                                                                        \
+    } while (0)
+
+#define KCHECK(expr)                  \
+    do {                              \
+        int _rc = (expr);             \
+        if (_rc != KATOME_OK) return _rc; \
+    } while (0)
+
+// device buffer with RAII
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    int alloc(size_t n) {
+        release();
+        if (n == 0) n = 16;
+        hipError_t e = hipMalloc(&p, n);
+        if (e != hipSuccess) {
+            p = nullptr;
+            set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
+            (void)hipGetLastError();
+            return KATOME_E_OOM;
+        }
+        bytes = n;
+        return KATOME_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+    }
+    void* take() { void* q = p; p = nullptr; bytes = 0; return q; }
+    template <class T> T* as() const { return (T*)p; }
+};
+
+inline int use_device(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s): this library has no CPU fallback",
+                  e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+        (void)hipGetLastError();
+        return KATOME_E_DEVICE;
+    }
+    if (device < 0 || device >= n) { set_error("device ordinal %d out of range (0..%d)", device, n - 1); return KATOME_E_DEVICE; }
+    KCHECK_HIP(hipSetDevice(device));
+    return KATOME_OK;
+}
+
+inline int check_k(uint32_t k) {
+    if (k <= 1) { set_error("assertion failed: k_size > 1"); return KATOME_E_ARG; }   // prelude.rs:35
+    if (k < 3 || k > 63) { set_error("k = %u unsupported (3..63)", k); return KATOME_E_ARG; }
+    return KATOME_OK;
+}
+
+constexpr int BLOCK = 256;
+inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap = 256u * 16u) {
+    uint64_t g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    return (unsigned)(g > cap ? cap : g);
+}
+
+// ---- launchers implemented in the .hip files (all asynchronous on `stream`) -----------------
+int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream);
+int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
+                       const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
+                       uint64_t* d_records, hipStream_t stream);
+
+// radix.hip
+int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
+int dev_partition(const uint64_t* d_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out, uint64_t* h_counts,
+                  hipStream_t stream);
+int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipStream_t stream);
+int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t key_bits, const uint64_t* d_q, uint64_t nq,
+             uint64_t* d_out, hipStream_t stream);
+int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream);
+int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream);
+
+// table.hip
+struct Table {
+    DevBuf slots;          // NW=1: {u64 key|OCC, u32 count, u32 pad}; NW=2: {u64 hi|flags, u64 lo, u32 count, u32 pad[3]}
+    DevBuf counter;        // u64 occupied
+    uint64_t cap = 0;
+    uint32_t nw = 1;
+    size_t slot_bytes() const { return nw == 1 ? 16 : 32; }
+};
+int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream);
+int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream);
+int table_occupied(Table& t, uint64_t* out, hipStream_t stream);
+int table_grow(Table& t, uint64_t new_cap, hipStream_t stream);
+// distinct oriented edges (unsorted): allocates d_keys/d_weights
+int table_emit_edges(Table& t, uint32_t k, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_edges, hipStream_t stream);
+
+// synth.hip
+int launch_synth(uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, double err_rate,
+                 uint32_t n_inject_percent, uint8_t* d_packed, uint8_t* d_skip, hipStream_t stream);
+
+// ingest.cpp (host only)
+struct HostReads {
+    uint64_t n_records = 0, n_reads = 0, read_bytes = 0, total_windows = 0;
+    uint32_t fixed_len = 0;
+    bool all_fixed = true;
+    uint8_t* packed = nullptr; uint64_t packed_bytes = 0, packed_cap = 0;
+    uint64_t* byte_off = nullptr; uint32_t* len = nullptr; uint64_t cap_reads = 0;
+    ~HostReads();
+};
+int ingest_files(const katome_settings* s, const char* const* paths, size_t n_paths, HostReads& out);
+
+}  // namespace katome

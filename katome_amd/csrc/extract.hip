@@ -1,0 +1,213 @@
+// extract.hip -- k-mer extraction kernels (gfx950).
+//
+// Restates, per window, compress_kmer / compress_kmer_with_rev_compl (reference
+// src/katome/compress.rs:18-48) over `read.windows(K)` (collections/graphs/pt_graph.rs:294,310):
+// one record per forward window.  With reverse_complement the record is min(k-mer, rc(k-mer));
+// the reverse strand the reference inserts separately (pt_graph.rs:282-308) is re-created when
+// the table is turned into edges (table.hip), so the edge multiset is the same.
+//
+// HBM-bound streaming kernel: algorithmic traffic per read = ceil(L/4) bytes in,
+// (L-k+1) * 8*NW bytes out (998 B for L=150, k=31).  No MFMA: integer shift/compare work.
+#include "common.h"
+
+namespace katome {
+
+// ---------------------------------------------------------------------------------------------
+// Fixed-length reads, LDS-staged.  A workgroup (256 threads = 4 waves) owns tiles of 64 reads:
+//   1. the tile's packed bytes are pulled in with 16-byte coalesced loads, each dword is
+//      byte-swapped once and parked in LDS (so every later use sees "16 bases, first base on top");
+//   2. every lane produces output records 2p, 2p+1 (NW=1) or record p (NW=2) of the tile's
+//      contiguous output range, so each wave store is 64 x 16 contiguous bytes;
+//      a record = 2*NW+1 LDS dwords -> funnel shift -> (canonical) key.
+// ---------------------------------------------------------------------------------------------
+constexpr int TILE_READS = 64;
+
+template <int NW, bool RC>
+__device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t* lds_skip, u32 i, u32 W, u32 magicW,
+                                                    u32 stride_bytes, u32 k) {
+    u32 r = __umulhi(i, magicW);           // i / W, exact for i, W < 2^16
+    u32 w = i - r * W;
+    if (lds_skip[r]) return key_invalid<NW>();
+    u32 bit = r * stride_bytes * 8 + 2 * w;
+    u32 di = bit >> 5, sh = bit & 31;
+    u32 d[2 * NW + 1];
+#pragma unroll
+    for (int j = 0; j < 2 * NW + 1; ++j) d[j] = lds[di + j];
+    Key<NW> key = extract_window(d, sh, k, (Key<NW>*)nullptr);
+    if (RC) key = canonical(key, k);
+    return key;
+}
+
+template <int NW, bool RC>
+__global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __restrict__ packed, u64 n_reads,
+                                                               u32 stride_bytes, u32 k, u32 W, u32 magicW,
+                                                               const uint8_t* __restrict__ skip, u64* __restrict__ out) {
+    extern __shared__ u32 lds[];
+    const u32 tile_bytes_max = TILE_READS * stride_bytes;
+    const u32 tile_dwords = ((tile_bytes_max + 15) / 16) * 4;
+    uint8_t* lds_skip = (uint8_t*)(lds + tile_dwords + 8);
+    const u64 total_bytes = n_reads * stride_bytes;
+    const u64 n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
+    const u32 tid = threadIdx.x;
+
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const u64 r0 = tile * TILE_READS;
+        const u32 nr = (u32)((n_reads - r0) < (u64)TILE_READS ? (n_reads - r0) : (u64)TILE_READS);
+        const u64 byte0 = r0 * stride_bytes;
+        const u32 nchunks = (nr * stride_bytes + 15) / 16;
+        for (u32 c = tid; c < nchunks; c += BLOCK) {
+            u64 off = byte0 + (u64)c * 16;
+            uint4 v;
+            if (off + 16 <= total_bytes) {
+                v = *reinterpret_cast<const uint4*>(packed + off);
+            } else {   // last chunk of the whole buffer: byte loads, zero fill
+                u32 t[4] = {0, 0, 0, 0};
+                for (u32 b = 0; b < 16 && off + b < total_bytes; ++b) t[b >> 2] |= (u32)packed[off + b] << (8 * (b & 3));
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            lds[c * 4 + 0] = __builtin_bswap32(v.x);
+            lds[c * 4 + 1] = __builtin_bswap32(v.y);
+            lds[c * 4 + 2] = __builtin_bswap32(v.z);
+            lds[c * 4 + 3] = __builtin_bswap32(v.w);
+        }
+        if (tid < 8) lds[nchunks * 4 + tid] = 0;      // windows near the tile end read past it
+        if (tid < TILE_READS) lds_skip[tid] = (skip && tid < nr) ? skip[r0 + tid] : 0;
+        __syncthreads();
+
+        const u32 nrec = nr * W;
+        const u64 out0 = r0 * (u64)W;
+        if (NW == 1) {
+            for (u32 p = tid; 2 * p < nrec; p += BLOCK) {
+                u32 i0 = 2 * p;
+                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i0, W, magicW, stride_bytes, k);
+                if (i0 + 1 < nrec) {
+                    Key<NW> b = record_from_lds<NW, RC>(lds, lds_skip, i0 + 1, W, magicW, stride_bytes, k);
+                    *reinterpret_cast<ulonglong2*>(out + out0 + i0) = make_ulonglong2(a.w[0], b.w[0]);
+                } else {
+                    out[out0 + i0] = a.w[0];
+                }
+            }
+        } else {
+            for (u32 i = tid; i < nrec; i += BLOCK) {
+                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i, W, magicW, stride_bytes, k);
+                *reinterpret_cast<ulonglong2*>(out + (out0 + i) * 2) = make_ulonglong2(a.w[0], a.w[NW - 1]);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// General reads (variable length, or fixed length too long for the LDS tile): one record per
+// thread, read located by binary search over the window prefix sums, bytes fetched through L1/L2.
+// ---------------------------------------------------------------------------------------------
+struct ArrayAddr {
+    const u64* byte_off; const u32* len; const u64* win_prefix; u64 n_reads;
+    __device__ __forceinline__ void locate(u64 i, u64& boff, u32& w) const {
+        u64 lo = 0, hi = n_reads;            // largest r with win_prefix[r] <= i
+        while (hi - lo > 1) {
+            u64 mid = (lo + hi) >> 1;
+            if (win_prefix[mid] <= i) lo = mid; else hi = mid;
+        }
+        boff = byte_off[lo];
+        w = (u32)(i - win_prefix[lo]);
+    }
+    __device__ __forceinline__ bool skipped(u64) const { return false; }
+};
+struct FixedAddr {
+    u64 stride_bytes; u64 W; const uint8_t* skip; u64 r;
+    __device__ __forceinline__ void locate(u64 i, u64& boff, u32& w) {
+        r = i / W;
+        boff = r * stride_bytes;
+        w = (u32)(i - r * W);
+    }
+    __device__ __forceinline__ bool skipped(u64) const { return skip && skip[r]; }
+};
+
+template <int NW, bool RC, class Addr>
+__global__ __launch_bounds__(BLOCK) void extract_general_kernel(const uint8_t* __restrict__ packed, u64 packed_bytes,
+                                                                 Addr addr, u64 total_windows, u32 k,
+                                                                 u64* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < total_windows; i += (u64)gridDim.x * BLOCK) {
+        u64 boff; u32 w;
+        addr.locate(i, boff, w);
+        Key<NW> key;
+        if (addr.skipped(i)) {
+            key = key_invalid<NW>();
+        } else {
+            u64 b0 = boff + (w >> 2);
+            u32 sh = 2 * (w & 3);
+            u32 d[2 * NW + 1];
+#pragma unroll
+            for (int j = 0; j < 2 * NW + 1; ++j) {
+                u32 v = 0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    u64 idx = b0 + 4 * j + b;
+                    u32 byte = idx < packed_bytes ? packed[idx] : 0u;
+                    v = (v << 8) | byte;
+                }
+                d[j] = v;
+            }
+            key = extract_window(d, sh, k, (Key<NW>*)nullptr);
+            if (RC) key = canonical(key, k);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) out[i * NW + j] = key.w[j];
+    }
+}
+
+template <int NW, bool RC>
+static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u32 k, const uint8_t* d_skip, u64* d_records,
+                           hipStream_t stream) {
+    const u32 stride = (read_len + 3) / 4, W = read_len - k + 1;
+    const u64 total = n_reads * (u64)W;
+    if (total == 0) return KATOME_OK;
+    const bool lds_ok = stride <= 256 && (u64)TILE_READS * W < 65536 && ((uintptr_t)d_packed % 16 == 0) &&
+                        ((uintptr_t)d_records % 16 == 0);
+    if (lds_ok) {
+        const u32 tile_dwords = ((TILE_READS * stride + 15) / 16) * 4;
+        const size_t lds_bytes = (tile_dwords + 8) * 4 + TILE_READS;
+        const u32 magicW = (u32)((1ull << 32) / W) + 1;
+        const u64 n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
+        unsigned grid = (unsigned)(n_tiles < 256u * 8u ? n_tiles : 256u * 8u);
+        hipLaunchKernelGGL((extract_fixed_kernel<NW, RC>), dim3(grid), dim3(BLOCK), lds_bytes, stream, d_packed, n_reads,
+                           stride, k, W, magicW, d_skip, d_records);
+    } else {
+        FixedAddr a{stride, W, d_skip, 0};
+        hipLaunchKernelGGL((extract_general_kernel<NW, RC, FixedAddr>), dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, stream,
+                           d_packed, n_reads * (u64)stride, a, total, k, d_records);
+    }
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream) {
+    if (read_len < k) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }   // pt_graph.rs:278
+    const int nw = key_words_for_k(k);
+    if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, k, d_skip, d_records, stream)
+                           : extract_fixed_t<1, false>(d_packed, n_reads, read_len, k, d_skip, d_records, stream);
+    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, k, d_skip, d_records, stream)
+              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, k, d_skip, d_records, stream);
+}
+
+int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
+                       const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
+                       uint64_t* d_records, hipStream_t stream) {
+    if (total_windows == 0 || n_reads == 0) return KATOME_OK;
+    ArrayAddr a{d_byte_off, d_len, d_win_prefix, n_reads};
+    const int nw = key_words_for_k(k);
+    dim3 grid(grid_for(total_windows, BLOCK)), block(BLOCK);
+    if (nw == 1) {
+        if (rc) hipLaunchKernelGGL((extract_general_kernel<1, true, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
+        else    hipLaunchKernelGGL((extract_general_kernel<1, false, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
+    } else {
+        if (rc) hipLaunchKernelGGL((extract_general_kernel<2, true, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
+        else    hipLaunchKernelGGL((extract_general_kernel<2, false, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
+    }
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+}  // namespace katome

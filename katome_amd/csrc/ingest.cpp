@@ -1,0 +1,179 @@
+// ingest.cpp -- host ingest in front of the GPU build: file checks, FASTQ/FASTA record scan,
+// the ACGT-only read filter and 2-bit packing.
+//
+// Restates reference src/katome/algorithms/builder.rs: check_files (57-77), create_fastq (142-165),
+// create_fasta (118-140); packing follows compress_node's bit order (compress.rs:55-73) with the
+// symbol code of encode_fasta_symbol (compress.rs:347-378).  Record framing follows bio 0.10.0's
+// io::fastq / io::fasta readers as published (crate not vendored in the reference): FASTQ = 4
+// lines per record, header starts with '@', sequence = the 2nd line right-trimmed; FASTA =
+// '>' header, sequence = following lines up to the next '>' right-trimmed and joined.
+#include <fcntl.h>
+#include <limits.h>
+#include <stdlib.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace katome {
+
+static thread_local char g_error[1024];
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+const char* get_error() { return g_error; }
+
+HostReads::~HostReads() { free(packed); free(byte_off); free(len); }
+
+namespace {
+
+struct Mapped {
+    const uint8_t* p = nullptr; size_t n = 0; int fd = -1;
+    ~Mapped() { if (p && n) munmap((void*)p, n); if (fd >= 0) close(fd); }
+};
+
+// symbol -> 2-bit code, 0xFF for anything builder.rs:155 rejects (only upper-case ACGT pass)
+struct CodeTable {
+    uint8_t t[256];
+    CodeTable() { memset(t, 0xFF, sizeof t); t['A'] = 0; t['C'] = 1; t['G'] = 2; t['T'] = 3; }
+};
+const CodeTable CODE;
+
+inline size_t rtrim(const uint8_t* s, size_t n) {        // str::trim_right on ASCII
+    while (n && (s[n - 1] == ' ' || (s[n - 1] >= 9 && s[n - 1] <= 13))) --n;
+    return n;
+}
+
+struct LineReader {                                      // BufRead::read_line: includes the '\n'
+    const uint8_t* p; size_t n, pos = 0;
+    LineReader(const uint8_t* p_, size_t n_) : p(p_), n(n_) {}
+    bool next(const uint8_t*& s, size_t& len) {
+        if (pos >= n) { s = p + n; len = 0; return false; }
+        const uint8_t* nl = (const uint8_t*)memchr(p + pos, '\n', n - pos);
+        size_t end = nl ? (size_t)(nl - p) + 1 : n;
+        s = p + pos; len = end - pos; pos = end;
+        return true;
+    }
+};
+
+int reserve_reads(HostReads& r, uint64_t extra_bytes) {
+    if (r.n_reads + 2 > r.cap_reads) {
+        uint64_t nc = r.cap_reads ? r.cap_reads * 2 : 4096;
+        uint64_t* bo = (uint64_t*)realloc(r.byte_off, nc * sizeof(uint64_t));
+        if (!bo) { set_error("out of host memory"); return KATOME_E_OOM; }
+        r.byte_off = bo;
+        uint32_t* ln = (uint32_t*)realloc(r.len, nc * sizeof(uint32_t));
+        if (!ln) { set_error("out of host memory"); return KATOME_E_OOM; }
+        r.len = ln;
+        r.cap_reads = nc;
+    }
+    if (r.packed_bytes + extra_bytes + 32 > r.packed_cap) {
+        uint64_t nc = (r.packed_bytes + extra_bytes + 32) * 2;
+        uint8_t* pk = (uint8_t*)realloc(r.packed, nc);
+        if (!pk) { set_error("out of host memory"); return KATOME_E_OOM; }
+        r.packed = pk; r.packed_cap = nc;
+    }
+    return KATOME_OK;
+}
+
+// builder.rs:152-160 loop body up to the hand-off to add_read_fastaq
+int accept_read(HostReads& r, const uint8_t* seq, size_t n, uint32_t k) {
+    ++r.n_records;
+    for (size_t i = 0; i < n; ++i) if (CODE.t[seq[i]] == 0xFF) return KATOME_OK;     // `continue` (155-157)
+    r.read_bytes += n;                                                             // total += seq.len() (158)
+    if (n < k) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }     // pt_graph.rs:278
+    if (n > 0xFFFFFFFFull) { set_error("read longer than 2^32 bases"); return KATOME_E_UNSUPPORTED; }
+    const size_t nb = (n + 3) / 4;
+    KCHECK(reserve_reads(r, nb));
+    uint8_t* out = r.packed + r.packed_bytes;
+    size_t i = 0, o = 0;
+    for (; i + 4 <= n; i += 4)
+        out[o++] = (uint8_t)((CODE.t[seq[i]] << 6) | (CODE.t[seq[i + 1]] << 4) | (CODE.t[seq[i + 2]] << 2) | CODE.t[seq[i + 3]]);
+    if (i < n) {
+        uint8_t c = 0; size_t rem = n - i;
+        for (size_t j = 0; j < rem; ++j) c = (uint8_t)((c << 2) | CODE.t[seq[i + j]]);
+        out[o++] = (uint8_t)(c << (2 * (4 - rem)));       // last byte left-aligned (compress.rs:64-72)
+    }
+    if (r.n_reads == 0) r.fixed_len = (uint32_t)n;
+    else if (r.fixed_len != (uint32_t)n) r.all_fixed = false;
+    r.byte_off[r.n_reads] = r.packed_bytes;
+    r.len[r.n_reads] = (uint32_t)n;
+    r.packed_bytes += nb;
+    r.byte_off[++r.n_reads] = r.packed_bytes;
+    r.total_windows += n - k + 1;
+    return KATOME_OK;
+}
+
+int scan_fastq(const uint8_t* p, size_t n, HostReads& r, uint32_t k) {
+    LineReader lr(p, n);
+    const uint8_t *h, *s, *sep, *q; size_t hn, sn, sepn, qn;
+    while (lr.next(h, hn)) {
+        if (h[0] != '@') { set_error("Expected @ at record start."); return KATOME_E_PARSE; }
+        lr.next(s, sn); lr.next(sep, sepn); lr.next(q, qn);
+        if (qn == 0) { set_error("Incomplete record. Each FastQ record has to consist of 4 lines: header, sequence, separator and qualities."); return KATOME_E_PARSE; }
+        KCHECK(accept_read(r, s, rtrim(s, sn), k));
+    }
+    return KATOME_OK;
+}
+
+int scan_fasta(const uint8_t* p, size_t n, HostReads& r, uint32_t k) {
+    LineReader lr(p, n);
+    const uint8_t* line; size_t ln;
+    std::vector<uint8_t> seq;
+    bool have = lr.next(line, ln);
+    while (have) {
+        if (line[0] != '>') { set_error("Expected > at record start."); return KATOME_E_PARSE; }
+        seq.clear();
+        while ((have = lr.next(line, ln)) && line[0] != '>') seq.insert(seq.end(), line, line + rtrim(line, ln));
+        KCHECK(accept_read(r, seq.data(), seq.size(), k));
+    }
+    return KATOME_OK;
+}
+
+}  // namespace
+
+int ingest_files(const katome_settings* s, const char* const* paths, size_t n_paths, HostReads& out) {
+    KCHECK(check_k(s->k));
+    if (s->file_type == 2) { set_error("BFCounter input is not supported by the GPU build yet"); return KATOME_E_UNSUPPORTED; }
+    if (s->file_type > 2) { set_error("unknown input file type %u", s->file_type); return KATOME_E_ARG; }
+    // check_files (builder.rs:57-77): every path is vetted before any file is opened
+    std::vector<std::string> files;
+    for (size_t i = 0; i < n_paths; ++i) {
+        char resolved[PATH_MAX];
+        if (!realpath(paths[i], resolved)) { set_error("Coulndt resolve path: %s", paths[i]); return KATOME_E_PATH; }
+        struct stat st;
+        if (stat(resolved, &st) != 0) { set_error("%s does not exist", resolved); return KATOME_E_NOT_EXIST; }
+        if (S_ISDIR(st.st_mode)) { set_error("%s is a directory", resolved); return KATOME_E_IS_DIR; }
+        files.push_back(resolved);
+    }
+    KCHECK(reserve_reads(out, 0));
+    out.byte_off[0] = 0;
+    std::vector<Mapped> maps(files.size());
+    for (size_t i = 0; i < files.size(); ++i) {            // Reader::from_file for all inputs first (builder.rs:146-149)
+        Mapped& m = maps[i];
+        m.fd = open(files[i].c_str(), O_RDONLY);
+        struct stat st;
+        if (m.fd < 0 || fstat(m.fd, &st) != 0) { set_error("Couldn't open all files: %s", files[i].c_str()); return KATOME_E_OPEN; }
+        m.n = (size_t)st.st_size;
+        if (m.n) {
+            void* p = mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
+            if (p == MAP_FAILED) { m.n = 0; set_error("Couldn't open all files: %s", files[i].c_str()); return KATOME_E_OPEN; }
+            m.p = (const uint8_t*)p;
+            madvise(p, m.n, MADV_SEQUENTIAL);
+        }
+    }
+    for (size_t i = 0; i < files.size(); ++i)
+        KCHECK(s->file_type == 1 ? scan_fastq(maps[i].p, maps[i].n, out, s->k) : scan_fasta(maps[i].p, maps[i].n, out, s->k));
+    if (!out.all_fixed || out.n_reads == 0) out.fixed_len = 0;
+    memset(out.packed + out.packed_bytes, 0, 32);          // slack for vector loads
+    return KATOME_OK;
+}
+
+}  // namespace katome

@@ -1,0 +1,160 @@
+// kmer_bits.h -- bit-level k-mer arithmetic shared by every kernel (and compiled for the host
+// by tests/hostshim so the same code is checked against the oracle without a GPU).
+//
+// Formats (all restating src/katome/compress.rs of the reference):
+//   * a base is 2 bits, A=0 C=1 G=2 T=3                      (encode_fasta_symbol, compress.rs:347-378)
+//   * packed reads: 4 bases per byte, first base in the two MOST significant bits, last byte
+//     left-aligned                                            (compress_node, compress.rs:55-73)
+//   * a k-mer KEY is the 2k bits of the window, right-aligned in NW 64-bit words, w[0] the most
+//     significant word; NW = 1 for k <= 31, 2 for k <= 63.  Key order == lexicographic order of
+//     the ACGT string, and the key's top 2(k-1) bits / low 2(k-1) bits are the source / target
+//     node of the edge, i.e. the two halves of compress_kmer  (compress.rs:18-28).
+//   * the reverse complement of a key is what compress_kmer_with_rev_compl builds out of
+//     reverse_compressed_node (compress.rs:34-48,153-169): reverse the 2-bit groups, complement.
+//   * an edge LABEL is compress_edge format: [pad][ceil(k/4) bytes, left-aligned] (compress.rs:250-271)
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define KD __host__ __device__ __forceinline__
+#else
+#define KD inline
+#endif
+
+namespace katome {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+constexpr u64 INVALID_WORD = ~0ull;   // w[0] of a record that carries no k-mer
+
+template <int NW> struct Key { u64 w[NW]; };
+
+KD int key_words_for_k(u32 k) { return 2 * k <= 62 ? 1 : 2; }
+
+// ---- hashing ------------------------------------------------------------------------------
+KD u64 mix64(u64 x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+KD u64 hash_key(const Key<1>& k) { return mix64(k.w[0]); }
+KD u64 hash_key(const Key<2>& k) { return mix64(k.w[1] ^ mix64(k.w[0] + 0x9E3779B97F4A7C15ull)); }
+
+KD u64 mulhi64(u64 a, u64 b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (u64)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+// owner / slot of a hash in [0, n)
+KD u64 hash_to_range(u64 h, u64 n) { return mulhi64(h, n); }
+
+// ---- comparisons --------------------------------------------------------------------------
+KD bool key_eq(const Key<1>& a, const Key<1>& b) { return a.w[0] == b.w[0]; }
+KD bool key_eq(const Key<2>& a, const Key<2>& b) { return a.w[0] == b.w[0] && a.w[1] == b.w[1]; }
+KD bool key_lt(const Key<1>& a, const Key<1>& b) { return a.w[0] < b.w[0]; }
+KD bool key_lt(const Key<2>& a, const Key<2>& b) { return a.w[0] < b.w[0] || (a.w[0] == b.w[0] && a.w[1] < b.w[1]); }
+template <int NW> KD bool key_valid(const Key<NW>& a) { return a.w[0] != INVALID_WORD; }
+template <int NW> KD Key<NW> key_invalid() { Key<NW> r; for (int i = 0; i < NW; ++i) r.w[i] = INVALID_WORD; return r; }
+
+// ---- shifts -------------------------------------------------------------------------------
+// (hi:lo) << s, top 64 bits; s in [0,63]
+KD u64 shl_fill(u64 hi, u64 lo, u32 s) { return s ? (hi << s) | (lo >> (64 - s)) : hi; }
+
+KD Key<1> key_shr(const Key<1>& a, u32 s) { Key<1> r; r.w[0] = s >= 64 ? 0 : a.w[0] >> s; return r; }
+KD Key<2> key_shr(const Key<2>& a, u32 s) {
+    Key<2> r;
+    if (s == 0) return a;
+    if (s >= 128) { r.w[0] = 0; r.w[1] = 0; }
+    else if (s >= 64) { r.w[0] = 0; r.w[1] = a.w[0] >> (s - 64); }
+    else { r.w[0] = a.w[0] >> s; r.w[1] = (a.w[1] >> s) | (a.w[0] << (64 - s)); }
+    return r;
+}
+// keep the low `bits` bits
+KD Key<1> key_low_bits(const Key<1>& a, u32 bits) { Key<1> r; r.w[0] = bits >= 64 ? a.w[0] : a.w[0] & ((1ull << bits) - 1); return r; }
+KD Key<2> key_low_bits(const Key<2>& a, u32 bits) {
+    Key<2> r = a;
+    if (bits >= 128) return r;
+    if (bits >= 64) r.w[0] = bits == 64 ? 0 : a.w[0] & ((1ull << (bits - 64)) - 1);
+    else { r.w[0] = 0; r.w[1] = a.w[1] & ((1ull << bits) - 1); }
+    return r;
+}
+// bits [shift, shift+nbits) of the key, nbits <= 32
+KD u32 key_digit(const Key<1>& a, u32 shift, u32 nbits) { return (u32)(shift >= 64 ? 0 : (a.w[0] >> shift)) & ((1u << nbits) - 1); }
+KD u32 key_digit(const Key<2>& a, u32 shift, u32 nbits) { return (u32)key_shr(a, shift).w[1] & ((1u << nbits) - 1); }
+
+// ---- window extraction --------------------------------------------------------------------
+// `d` holds 2*NW+1 consecutive 32-bit words of the packed read, each already byte-swapped so
+// that its numeric value reads the 16 bases most-significant-first; the window starts `sh`
+// bits (even, < 32) into d[0].  Returns the 2k-bit key, right-aligned.
+KD Key<1> extract_window(const u32* d, u32 sh, u32 k, Key<1>*) {
+    u64 w0 = ((u64)d[0] << 32) | d[1], w1 = (u64)d[2] << 32;
+    Key<1> r; r.w[0] = shl_fill(w0, w1, sh) >> (64 - 2 * k);
+    return r;
+}
+KD Key<2> extract_window(const u32* d, u32 sh, u32 k, Key<2>*) {
+    u64 w0 = ((u64)d[0] << 32) | d[1], w1 = ((u64)d[2] << 32) | d[3], w2 = (u64)d[4] << 32;
+    Key<2> x; x.w[0] = shl_fill(w0, w1, sh); x.w[1] = shl_fill(w1, w2, sh);
+    return key_shr(x, 128 - 2 * k);
+}
+
+// ---- reverse complement -------------------------------------------------------------------
+KD u64 brev64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brevll(x);
+#else
+    x = ((x >> 1) & 0x5555555555555555ull) | ((x & 0x5555555555555555ull) << 1);
+    x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+    return __builtin_bswap64(x);
+#endif
+}
+// reverse the order of the 32 two-bit groups of a word
+KD u64 rev_groups64(u64 x) {
+    u64 y = brev64(x);
+    return ((y >> 1) & 0x5555555555555555ull) | ((y & 0x5555555555555555ull) << 1);
+}
+KD Key<1> revcomp(const Key<1>& a, u32 k) {
+    Key<1> r; r.w[0] = (~rev_groups64(a.w[0])) >> (64 - 2 * k);
+    return r;
+}
+KD Key<2> revcomp(const Key<2>& a, u32 k) {
+    Key<2> x; x.w[0] = ~rev_groups64(a.w[1]); x.w[1] = ~rev_groups64(a.w[0]);
+    return key_shr(x, 128 - 2 * k);
+}
+template <int NW> KD Key<NW> canonical(const Key<NW>& a, u32 k) {
+    Key<NW> rc = revcomp(a, k);
+    return key_lt(rc, a) ? rc : a;
+}
+
+// ---- edge endpoints (the two halves of compress_kmer, compress.rs:23-26) --------------------
+template <int NW> KD Key<NW> source_node(const Key<NW>& kmer) { return key_shr(kmer, 2); }
+template <int NW> KD Key<NW> target_node(const Key<NW>& kmer, u32 k) { return key_low_bits(kmer, 2 * (k - 1)); }
+
+// ---- compress_edge label (compress.rs:250-271) ----------------------------------------------
+KD u32 label_stride_for_k(u32 k) { return 1 + (k + 3) / 4; }
+KD u32 label_pad_for_k(u32 k) { return (4 - k % 4) % 4; }
+// byte i (0-based, i < ceil(k/4)) of the left-aligned packed k-mer
+KD uint8_t label_byte(const Key<1>& a, u32 k, u32 i) {
+    u32 nb = (k + 3) / 4;
+    u64 v = a.w[0] << (2 * label_pad_for_k(k));      // now exactly 8*nb bits, right-aligned
+    return (uint8_t)(v >> (8 * (nb - 1 - i)));
+}
+KD uint8_t label_byte(const Key<2>& a, u32 k, u32 i) {
+    u32 nb = (k + 3) / 4, pad2 = 2 * label_pad_for_k(k);
+    Key<2> v; v.w[0] = shl_fill(a.w[0], a.w[1], pad2); v.w[1] = a.w[1] << pad2;
+    return (uint8_t)key_shr(v, 8 * (nb - 1 - i)).w[1];
+}
+
+// ---- synthetic workload (DESIGN.md "Synthetic workload"; same definition as the oracle's) ----
+KD u64 splitmix64(u64 x) {
+    u64 z = x + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace katome

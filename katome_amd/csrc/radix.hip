@@ -1,0 +1,467 @@
+// radix.hip -- hand-written device primitives for gfx950 wave64: LSD radix sort (keys, optional
+// u32 values, 64- or 128-bit keys), partition-by-owner (the same pass with a different digit),
+// unique, rank-in-sorted-array, and the edge -> endpoints / label transforms.
+//
+// These build the graph out of the k-mer table: PtGraph node numbering (reference
+// collections/graphs/pt_graph.rs:142-154), the endpoints of each edge (compress_kmer halves,
+// compress.rs:23-26) and the compress_edge labels (compress.rs:250-271; post-pass
+// pt_graph.rs:339-343).  All streaming, HBM-bound passes; no MFMA (integer keys).
+#include "common.h"
+
+namespace katome {
+
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int SORT_ITEMS = 16;
+constexpr int SORT_TILE = BLOCK * SORT_ITEMS;      // 4096 keys per workgroup
+constexpr int CHUNK_BLOCKS = 1024;                 // workgroups per offset chunk (4M keys < 2^32)
+static_assert(BLOCK == RADIX, "one thread per digit in the offset kernels");
+
+template <int NW> struct RadixDigit {
+    u32 shift, bits;
+    __device__ __forceinline__ u32 operator()(const Key<NW>& k) const { return key_digit(k, shift, bits); }
+};
+template <int NW> struct OwnerDigit {
+    u64 n_parts;
+    __device__ __forceinline__ u32 operator()(const Key<NW>& k) const {
+        return key_valid(k) ? (u32)hash_to_range(hash_key(k), n_parts) : (u32)n_parts;
+    }
+};
+
+template <int NW> __device__ __forceinline__ Key<NW> load_key(const u64* p, u64 i) {
+    Key<NW> k;
+    if (NW == 1) { k.w[0] = p[i]; }
+    else { ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + 2 * i); k.w[0] = v.x; k.w[NW - 1] = v.y; }
+    return k;
+}
+template <int NW> __device__ __forceinline__ void store_key(u64* p, u64 i, const Key<NW>& k) {
+    if (NW == 1) p[i] = k.w[0];
+    else *reinterpret_cast<ulonglong2*>(p + 2 * i) = make_ulonglong2(k.w[0], k.w[NW - 1]);
+}
+
+// ---- pass 1: per-workgroup digit histogram -> counts[block][digit] ----------------------------
+template <int NW, class Digit>
+__global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const u64* __restrict__ keys, u64 n, Digit dg, u32* __restrict__ counts) {
+    __shared__ u32 h[RADIX];
+    const u32 tid = threadIdx.x;
+    h[tid] = 0;
+    __syncthreads();
+    const u64 base = (u64)blockIdx.x * SORT_TILE;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        u64 i = base + (u64)j * BLOCK + tid;
+        if (i < n) atomicAdd(&h[dg(load_key<NW>(keys, i))], 1u);
+    }
+    __syncthreads();
+    counts[(u64)blockIdx.x * RADIX + tid] = h[tid];
+}
+
+// ---- pass 2a: per chunk of workgroups, per digit: sum; counts become exclusive prefixes inside
+// the chunk (u32), chunk_sum[chunk][digit] holds the chunk totals ---------------------------------
+__global__ __launch_bounds__(BLOCK) void radix_chunk_kernel(u32* __restrict__ counts, u64 nblocks, u64* __restrict__ chunk_sum) {
+    const u32 d = threadIdx.x;
+    const u64 b0 = (u64)blockIdx.x * CHUNK_BLOCKS;
+    const u64 b1 = b0 + CHUNK_BLOCKS < nblocks ? b0 + CHUNK_BLOCKS : nblocks;
+    u32 run = 0;
+    for (u64 b = b0; b < b1; ++b) {
+        u32 c = counts[b * RADIX + d];
+        counts[b * RADIX + d] = run;
+        run += c;
+    }
+    chunk_sum[(u64)blockIdx.x * RADIX + d] = run;
+}
+
+// ---- pass 2b: one workgroup turns chunk sums into global exclusive offsets, digit-major --------
+// chunk_sum[chunk][digit] -> chunk_off[chunk][digit]; digit_total[digit] gets each digit's count
+__global__ __launch_bounds__(BLOCK) void radix_offsets_kernel(u64* __restrict__ chunk_sum, u64 nchunks, u64* __restrict__ digit_total) {
+    __shared__ u64 tot[RADIX];
+    const u32 d = threadIdx.x;
+    u64 t = 0;
+    for (u64 c = 0; c < nchunks; ++c) t += chunk_sum[c * RADIX + d];
+    tot[d] = t;
+    if (digit_total) digit_total[d] = t;
+    __syncthreads();
+    u64 start = 0;
+    for (u32 e = 0; e < d; ++e) start += tot[e];
+    for (u64 c = 0; c < nchunks; ++c) {
+        u64 v = chunk_sum[c * RADIX + d];
+        chunk_sum[c * RADIX + d] = start;
+        start += v;
+    }
+}
+
+// ---- pass 3: stable scatter ----------------------------------------------------------------------
+// Each wave owns 1024 consecutive keys of the tile and ranks them 64 at a time with ballot-built
+// match masks (rank = keys of the same digit earlier in the wave); a cross-wave prefix gives the
+// key's place in the tile's digit-sorted order, the tile is reordered through LDS and written out
+// so that consecutive lanes store consecutive addresses of each digit's run.
+template <int NW, bool HAS_VAL, class Digit>
+__global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
+                                                               u64 n, Digit dg, const u32* __restrict__ rel,
+                                                               const u64* __restrict__ chunk_off, u64* __restrict__ keys_out,
+                                                               u32* __restrict__ vals_out) {
+    extern __shared__ u64 smem[];
+    u64* skeys = smem;                                            // [SORT_TILE * NW]
+    u32* svals = reinterpret_cast<u32*>(smem + SORT_TILE * NW);   // [SORT_TILE] when HAS_VAL
+    __shared__ u32 whist[BLOCK / 64][RADIX];
+    __shared__ u32 dstart[RADIX];
+    __shared__ u64 gbase[RADIX];
+    __shared__ u32 wsum[BLOCK / 64];
+
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = (u64)blockIdx.x * SORT_TILE;
+    const u32 cnt = (u32)((n - base) < (u64)SORT_TILE ? (n - base) : (u64)SORT_TILE);
+    for (u32 i = tid; i < (BLOCK / 64) * RADIX; i += BLOCK) (&whist[0][0])[i] = 0;
+    __syncthreads();
+
+    Key<NW> key[SORT_ITEMS]; u32 val[SORT_ITEMS]; u32 dig[SORT_ITEMS]; u32 rnk[SORT_ITEMS];
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const u32 idx = wave * (64 * SORT_ITEMS) + j * 64 + lane;
+        const bool valid = idx < cnt;
+        u32 d = 0;
+        if (valid) {
+            key[j] = load_key<NW>(keys_in, base + idx);
+            if (HAS_VAL) val[j] = vals_in[base + idx];
+            d = dg(key[j]);
+        }
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RADIX_BITS; ++b) {
+            const bool bit = (d >> b) & 1;
+            const u64 vote = __ballot(bit);
+            m &= bit ? vote : ~vote;
+        }
+        const u32 prior = __popcll(m & lt_mask);
+        u32 old = 0;
+        if (valid) old = whist[wave][d];
+        if (valid && prior == 0) whist[wave][d] = old + __popcll(m);
+        dig[j] = d;
+        rnk[j] = old + prior;
+    }
+    __syncthreads();
+
+    {   // thread = digit: wave-exclusive prefixes, tile-wide digit starts, global run bases
+        const u32 d = tid;
+        u32 run = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) { u32 c = whist[w][d]; whist[w][d] = run; run += c; }
+        u32 incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u32 woff = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) if (w < (int)wave) woff += wsum[w];
+        dstart[d] = woff + incl - run;
+        gbase[d] = chunk_off[(u64)(blockIdx.x / CHUNK_BLOCKS) * RADIX + d] + rel[(u64)blockIdx.x * RADIX + d];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const u32 idx = wave * (64 * SORT_ITEMS) + j * 64 + lane;
+        if (idx < cnt) {
+            const u32 pos = dstart[dig[j]] + whist[wave][dig[j]] + rnk[j];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) skeys[pos * NW + q] = key[j].w[q];
+            if (HAS_VAL) svals[pos] = val[j];
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; ++j) {
+        const u32 i = j * BLOCK + tid;
+        if (i < cnt) {
+            Key<NW> k;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) k.w[q] = skeys[i * NW + q];
+            const u32 d = dg(k);
+            const u64 o = gbase[d] + (i - dstart[d]);
+            store_key<NW>(keys_out, o, k);
+            if (HAS_VAL) vals_out[o] = svals[i];
+        }
+    }
+}
+
+struct PassBuffers {
+    DevBuf counts, chunk, totals;
+    u64 nblocks = 0, nchunks = 0;
+    int init(u64 n) {
+        nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+        nchunks = (nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+        KCHECK(counts.alloc(nblocks * RADIX * sizeof(u32)));
+        KCHECK(chunk.alloc(nchunks * RADIX * sizeof(u64)));
+        KCHECK(totals.alloc(RADIX * sizeof(u64)));
+        return KATOME_OK;
+    }
+};
+
+template <int NW, bool HAS_VAL, class Digit>
+static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout, u32* vout, PassBuffers& pb, hipStream_t stream) {
+    if (pb.nblocks > 0x7fffffffull) { set_error("radix pass: %llu keys exceed the grid limit", (unsigned long long)n); return KATOME_E_ARG; }
+    dim3 block(BLOCK);
+    hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
+    hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>());
+    hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
+    const size_t lds = (size_t)SORT_TILE * NW * 8 + (HAS_VAL ? (size_t)SORT_TILE * 4 : 0);
+    hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
+                       pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+template <int NW, bool HAS_VAL>
+static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream) {
+    if (n < 2) return KATOME_OK;
+    PassBuffers pb;
+    KCHECK(pb.init(n));
+    DevBuf tk, tv;
+    KCHECK(tk.alloc(n * 8 * NW));
+    if (HAS_VAL) KCHECK(tv.alloc(n * 4));
+    u64* kin = d_keys; u64* kout = tk.as<u64>();
+    u32* vin = d_vals; u32* vout = tv.as<u32>();
+    for (u32 shift = 0; shift < key_bits; shift += RADIX_BITS) {
+        RadixDigit<NW> dg{shift, (key_bits - shift) < (u32)RADIX_BITS ? (key_bits - shift) : (u32)RADIX_BITS};
+        KCHECK((radix_pass<NW, HAS_VAL>(kin, vin, n, dg, kout, vout, pb, stream)));
+        u64* t = kin; kin = kout; kout = t;
+        u32* tv2 = vin; vin = vout; vout = tv2;
+    }
+    if (kin != d_keys) {
+        KCHECK_HIP(hipMemcpyAsync(d_keys, kin, n * 8 * NW, hipMemcpyDeviceToDevice, stream));
+        if (HAS_VAL) KCHECK_HIP(hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));    // temporaries are freed on return
+    return KATOME_OK;
+}
+
+int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream) {
+    if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
+    if (key_bits == 0 || key_bits > 64 * nw) { set_error("key_bits out of range"); return KATOME_E_ARG; }
+    if (nw == 1) return d_vals ? sort_t<1, true>(d_keys, d_vals, n, key_bits, stream) : sort_t<1, false>(d_keys, nullptr, n, key_bits, stream);
+    return d_vals ? sort_t<2, true>(d_keys, d_vals, n, key_bits, stream) : sort_t<2, false>(d_keys, nullptr, n, key_bits, stream);
+}
+
+// group records by owner rank; invalid records go last (part n_parts) and are not counted
+int dev_partition(const uint64_t* d_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out, uint64_t* h_counts,
+                  hipStream_t stream) {
+    if (n_parts == 0 || n_parts >= (u32)RADIX) { set_error("n_parts must be 1..255"); return KATOME_E_ARG; }
+    for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
+    if (n == 0) return KATOME_OK;
+    PassBuffers pb;
+    KCHECK(pb.init(n));
+    if (nw == 1) { OwnerDigit<1> dg{n_parts}; KCHECK((radix_pass<1, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream))); }
+    else         { OwnerDigit<2> dg{n_parts}; KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream))); }
+    u64 totals[RADIX];
+    KCHECK_HIP(hipMemcpyAsync(totals, pb.totals.p, sizeof totals, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    for (u32 p = 0; p < n_parts; ++p) h_counts[p] = totals[p];
+    return KATOME_OK;
+}
+
+// ---- unique -------------------------------------------------------------------------------------
+constexpr int UNIQ_ITEMS = 8;
+constexpr int UNIQ_TILE = BLOCK * UNIQ_ITEMS;
+
+template <int NW> __device__ __forceinline__ bool is_head(const u64* keys, u64 i) {
+    return i == 0 || !key_eq(load_key<NW>(keys, i), load_key<NW>(keys, i - 1));
+}
+
+__device__ __forceinline__ u32 block_excl_scan(u32 mine, u32* wsum /*[BLOCK/64]*/, u32& total) {
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 woff = 0; total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) woff += wsum[w]; total += wsum[w]; }
+    __syncthreads();
+    return woff + incl - mine;
+}
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void uniq_count_kernel(const u64* __restrict__ keys, u64 n, u32* __restrict__ block_counts) {
+    __shared__ u32 wsum[BLOCK / 64];
+    const u64 base = (u64)blockIdx.x * UNIQ_TILE + (u64)threadIdx.x * UNIQ_ITEMS;
+    u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < UNIQ_ITEMS; ++j) if (base + j < n && is_head<NW>(keys, base + j)) ++mine;
+    u32 total;
+    (void)block_excl_scan(mine, wsum, total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+
+// exclusive scan of m u32 counts into u64 offsets, one workgroup; offs[m] = grand total
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict__ counts, u64 m, u64* __restrict__ offs) {
+    __shared__ u64 wsum[16];
+    __shared__ u64 carry_s;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (u64 b0 = 0; b0 < m; b0 += 1024) {
+        u64 i = b0 + tid;
+        u64 v = i < m ? counts[i] : 0;
+        u64 incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u64 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        u64 woff = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) { if (w < (int)wave) woff += wsum[w]; tot += wsum[w]; }
+        const u64 carry = carry_s;
+        if (i < m) offs[i] = carry + woff + incl - v;
+        __syncthreads();
+        if (tid == 0) carry_s = carry + tot;
+        __syncthreads();
+    }
+    if (tid == 0) offs[m] = carry_s;
+}
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void uniq_write_kernel(const u64* __restrict__ keys, u64 n, const u64* __restrict__ block_offs,
+                                                            u64* __restrict__ out) {
+    __shared__ u32 wsum[BLOCK / 64];
+    const u64 base = (u64)blockIdx.x * UNIQ_TILE + (u64)threadIdx.x * UNIQ_ITEMS;
+    bool head[UNIQ_ITEMS]; u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < UNIQ_ITEMS; ++j) { head[j] = base + j < n && is_head<NW>(keys, base + j); mine += head[j]; }
+    u32 total;
+    u64 pos = block_offs[blockIdx.x] + block_excl_scan(mine, wsum, total);
+#pragma unroll
+    for (int j = 0; j < UNIQ_ITEMS; ++j) if (head[j]) { store_key<NW>(out, pos, load_key<NW>(keys, base + j)); ++pos; }
+}
+
+int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipStream_t stream) {
+    *n_out = n;
+    if (n < 2) return KATOME_OK;
+    const u64 nblocks = (n + UNIQ_TILE - 1) / UNIQ_TILE;
+    if (nblocks > 0x7fffffffull) { set_error("unique: too many keys"); return KATOME_E_ARG; }
+    DevBuf counts, offs, tmp;
+    KCHECK(counts.alloc(nblocks * 4));
+    KCHECK(offs.alloc((nblocks + 1) * 8));
+    KCHECK(tmp.alloc(n * 8 * nw));
+    if (nw == 1) hipLaunchKernelGGL(uniq_count_kernel<1>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_keys, n, counts.as<u32>());
+    else         hipLaunchKernelGGL(uniq_count_kernel<2>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_keys, n, counts.as<u32>());
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<u32>(), nblocks, offs.as<u64>());
+    if (nw == 1) hipLaunchKernelGGL(uniq_write_kernel<1>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_keys, n, offs.as<u64>(), tmp.as<u64>());
+    else         hipLaunchKernelGGL(uniq_write_kernel<2>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_keys, n, offs.as<u64>(), tmp.as<u64>());
+    KCHECK_HIP(hipGetLastError());
+    KCHECK_HIP(hipMemcpyAsync(n_out, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    KCHECK_HIP(hipMemcpyAsync(d_keys, tmp.p, *n_out * 8 * nw, hipMemcpyDeviceToDevice, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+// ---- rank of query keys in a sorted unique array ------------------------------------------------
+// A bucket index over the top B bits (index[b] = first position whose top bits are >= b) narrows
+// each lookup to a few consecutive keys; a binary search inside the bucket finishes it.
+template <int NW> __device__ __forceinline__ u32 top_bits(const Key<NW>& k, u32 key_bits, u32 B) { return key_digit(k, key_bits - B, B); }
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void bucket_index_kernel(const u64* __restrict__ sorted, u64 n, u32 key_bits, u32 B, u64* __restrict__ index) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i <= n; i += (u64)gridDim.x * BLOCK) {
+        long long prev = i > 0 ? (long long)top_bits(load_key<NW>(sorted, i - 1), key_bits, B) : -1ll;
+        long long cur = i < n ? (long long)top_bits(load_key<NW>(sorted, i), key_bits, B) : (1ll << B);
+        for (long long b = prev + 1; b <= cur; ++b) index[b] = i;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void rank_kernel(const u64* __restrict__ sorted, u64 n, u32 key_bits, u32 B,
+                                                      const u64* __restrict__ index, const u64* __restrict__ q, u64 nq,
+                                                      u64* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < nq; i += (u64)gridDim.x * BLOCK) {
+        Key<NW> key = load_key<NW>(q, i);
+        u32 b = top_bits(key, key_bits, B);
+        u64 lo = index[b], hi = index[b + 1];
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if (key_lt(load_key<NW>(sorted, mid), key)) lo = mid + 1; else hi = mid;
+        }
+        out[i] = (lo < n && key_eq(load_key<NW>(sorted, lo), key)) ? lo : ~0ull;
+    }
+}
+
+int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t key_bits, const uint64_t* d_q, uint64_t nq,
+             uint64_t* d_out, hipStream_t stream) {
+    if (nq == 0) return KATOME_OK;
+    u32 B = 1;
+    while ((2ull << B) <= n_sorted / 8 && B < 27) ++B;
+    if (B > key_bits) B = key_bits;
+    DevBuf index;
+    KCHECK(index.alloc(((1ull << B) + 2) * 8));
+    dim3 block(BLOCK);
+    if (nw == 1) {
+        hipLaunchKernelGGL(bucket_index_kernel<1>, dim3(grid_for(n_sorted + 1, BLOCK)), block, 0, stream, d_sorted, n_sorted, key_bits, B, index.as<u64>());
+        hipLaunchKernelGGL(rank_kernel<1>, dim3(grid_for(nq, BLOCK, 256u * 32u)), block, 0, stream, d_sorted, n_sorted, key_bits, B, index.as<u64>(), d_q, nq, d_out);
+    } else {
+        hipLaunchKernelGGL(bucket_index_kernel<2>, dim3(grid_for(n_sorted + 1, BLOCK)), block, 0, stream, d_sorted, n_sorted, key_bits, B, index.as<u64>());
+        hipLaunchKernelGGL(rank_kernel<2>, dim3(grid_for(nq, BLOCK, 256u * 32u)), block, 0, stream, d_sorted, n_sorted, key_bits, B, index.as<u64>(), d_q, nq, d_out);
+    }
+    KCHECK_HIP(hipGetLastError());
+    KCHECK_HIP(hipStreamSynchronize(stream));     // index is freed on return
+    return KATOME_OK;
+}
+
+// ---- edge -> endpoints, labels ----------------------------------------------------------------
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void endpoints_kernel(const u64* __restrict__ ek, u64 n, u32 k, u64* __restrict__ src, u64* __restrict__ dst) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Key<NW> key = load_key<NW>(ek, i);
+        store_key<NW>(src, i, source_node(key));
+        store_key<NW>(dst, i, target_node(key, k));
+    }
+}
+int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
+    if (key_words_for_k(k) == 1) hipLaunchKernelGGL(endpoints_kernel<1>, grid, block, 0, stream, d_edge_key, n, k, d_src, d_dst);
+    else                         hipLaunchKernelGGL(endpoints_kernel<2>, grid, block, 0, stream, d_edge_key, n, k, d_src, d_dst);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+// compress_edge format: [pad][ceil(k/4) bytes].  A workgroup builds the labels of 256 edges in
+// LDS and streams them out as whole dwords (the byte stride is odd for most k).
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void labels_kernel(const u64* __restrict__ ek, u64 n, u32 k, uint8_t* __restrict__ out) {
+    extern __shared__ u32 lbuf[];
+    uint8_t* lb = reinterpret_cast<uint8_t*>(lbuf);
+    const u32 stride = label_stride_for_k(k), nb = stride - 1, pad = label_pad_for_k(k);
+    const u64 ntiles = (n + BLOCK - 1) / BLOCK;
+    for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const u64 e0 = t * BLOCK;
+        const u32 cnt = (u32)((n - e0) < (u64)BLOCK ? (n - e0) : (u64)BLOCK);
+        if (threadIdx.x < cnt) {
+            Key<NW> key = load_key<NW>(ek, e0 + threadIdx.x);
+            uint8_t* p = lb + threadIdx.x * stride;
+            p[0] = (uint8_t)pad;
+            for (u32 i = 0; i < nb; ++i) p[1 + i] = label_byte(key, k, i);
+        }
+        __syncthreads();
+        const u64 byte0 = e0 * stride;                 // BLOCK*stride is a multiple of 4 -> dword aligned
+        const u32 nbytes = cnt * stride;
+        u32* o32 = reinterpret_cast<u32*>(out + byte0);
+        for (u32 i = threadIdx.x; i < nbytes / 4; i += BLOCK) o32[i] = lbuf[i];
+        for (u32 i = (nbytes / 4) * 4 + threadIdx.x; i < nbytes; i += BLOCK) out[byte0 + i] = lb[i];
+        __syncthreads();
+    }
+}
+int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    const size_t lds = (size_t)BLOCK * label_stride_for_k(k) + 16;
+    dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
+    if ((uintptr_t)d_label % 4) { set_error("label buffer must be 4-byte aligned"); return KATOME_E_ARG; }
+    if (key_words_for_k(k) == 1) hipLaunchKernelGGL(labels_kernel<1>, grid, block, lds, stream, d_edge_key, n, k, d_label);
+    else                         hipLaunchKernelGGL(labels_kernel<2>, grid, block, lds, stream, d_edge_key, n, k, d_label);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+}  // namespace katome

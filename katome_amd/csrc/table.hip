@@ -1,0 +1,271 @@
+// table.hip -- open-address k-mer -> weight table in HBM (gfx950).
+//
+// Restates, for a whole batch at once, PtGraphBuilder::add_single_edge_fastaq (reference
+// src/katome/collections/graphs/pt_graph.rs:172-198): "find the edge, else add it with weight 1,
+// else weight += 1".  An edge (source (k-1)-mer, target (k-1)-mer) IS its k-mer (compress_kmer,
+// compress.rs:18-28), so the table is keyed by the packed k-mer; the (k-1)-mer -> <=4 out-edges
+// shape of HmGIR (collections/girs/hm_gir.rs:22) falls out of the key order at finalize.
+// Weights are u32 and wrap like EdgeWeight (prelude.rs:9, pt_graph.rs:190).
+//
+// Random-access kernel: algorithmic traffic per insertion = 8*NW B record + 16*NW B slot
+// (key compare + weight read-modify-write).  Integer/atomic work, no MFMA.
+#include "common.h"
+
+namespace katome {
+
+constexpr u64 OCC = 1ull << 63;    // slot holds a published key
+constexpr u64 LOCK = 1ull << 62;   // NW=2 only: high word claimed, low word not yet visible
+constexpr u64 KEYBITS = ~(OCC | LOCK);
+
+struct Slot1 { u64 key; u32 count; u32 pad; };
+struct Slot2 { u64 hi; u64 lo; u32 count; u32 pad[3]; };
+static_assert(sizeof(Slot1) == 16 && sizeof(Slot2) == 32, "slot layout");
+
+__device__ __forceinline__ u64 ld_agent(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// find-or-insert `key`, add `add` to its weight; returns 1 if the key was new.
+// `err` is set if the probe sequence wraps the whole table (cannot happen under the host's
+// load-factor policy; bounds the loop all the same).
+__device__ __forceinline__ u32 upsert(Slot1* slots, u64 cap, Key<1> key, u32 add, u32* err) {
+    const u64 want = key.w[0] | OCC;
+    u64 s = hash_to_range(hash_key(key), cap);
+    for (u64 probes = 0; probes < cap; ++probes) {
+        u64 cur = slots[s].key;     // a stale 0 is caught by the CAS; a non-zero key never changes
+        u32 fresh = 0;
+        if (cur == 0) {
+            cur = atomicCAS(&slots[s].key, 0ull, want);
+            if (cur == 0) { cur = want; fresh = 1; }
+        }
+        if (cur == want) {
+            atomicAdd(&slots[s].count, add);
+            return fresh;
+        }
+        if (++s == cap) s = 0;
+    }
+    *err = 1;
+    return 0;
+}
+
+// 128-bit keys: there is no 128-bit CAS, so the high word is claimed with LOCK set, the low word
+// is stored, drained (s_waitcnt) and then the high word is re-published with OCC.  A lane never
+// waits while it holds a claim (claim and publication are one straight-line block), so lanes of
+// one wave cannot deadlock each other; a lane that meets a LOCKed slot with ITS high word simply
+// re-reads the slot on its next loop trip.
+__device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add, u32* err) {
+    u64 s = hash_to_range(hash_key(key), cap);
+    u64 spins = 0;
+    for (u64 probes = 0; probes < cap;) {
+        u64 cur = ld_agent(&slots[s].hi);
+        u32 fresh = 0;
+        if (cur == 0) {
+            cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
+            if (cur == 0) {
+                st_agent(&slots[s].lo, key.w[1]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_agent(&slots[s].hi, key.w[0] | OCC);
+                cur = key.w[0] | OCC;
+                fresh = 1;
+                atomicAdd(&slots[s].count, add);
+                return fresh;
+            }
+        }
+        if ((cur & KEYBITS) == key.w[0]) {
+            if (cur & LOCK) {                       // same high word, low word in flight: look again
+                if (++spins > (1ull << 24)) { *err = 2; return 0; }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            if (ld_agent(&slots[s].lo) == key.w[1]) {
+                atomicAdd(&slots[s].count, add);
+                return 0;
+            }
+        }
+        if (++s == cap) s = 0;
+        ++probes;
+    }
+    *err = 1;
+    return 0;
+}
+
+template <int NW> struct SlotOf;
+template <> struct SlotOf<1> { typedef Slot1 type; };
+template <> struct SlotOf<2> { typedef Slot2 type; };
+
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type* slots, u64 cap,
+                                                        const u64* __restrict__ rec, const u32* __restrict__ wts, u64 n,
+                                                        u64* occupied, u32* err) {
+    u32 fresh = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Key<NW> key;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) key.w[j] = rec[i * NW + j];
+        if (!key_valid(key)) continue;
+        fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err);
+    }
+    fresh = wave_sum(fresh);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(occupied, (u64)fresh);
+}
+
+// move every (key, weight) of an old table into a bigger one
+__device__ __forceinline__ bool slot_key(const Slot1& s, Key<1>& k) { k.w[0] = s.key & KEYBITS; return (s.key & OCC) != 0; }
+__device__ __forceinline__ bool slot_key(const Slot2& s, Key<2>& k) { k.w[0] = s.hi & KEYBITS; k.w[1] = s.lo; return (s.hi & OCC) != 0; }
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void rehash_kernel(const typename SlotOf<NW>::type* __restrict__ old_slots, u64 old_cap,
+                                                        typename SlotOf<NW>::type* slots, u64 cap, u64* occupied, u32* err) {
+    u32 fresh = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < old_cap; i += (u64)gridDim.x * BLOCK) {
+        typename SlotOf<NW>::type o = old_slots[i];
+        Key<NW> key;
+        if (!slot_key(o, key)) continue;
+        fresh += upsert(slots, cap, key, o.count, err);
+    }
+    fresh = wave_sum(fresh);
+    if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(occupied, (u64)fresh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Table -> distinct oriented edges.  With reverse_complement the table holds canonical k-mers;
+// the reference adds a read's forward windows and then the windows of its reverse complement
+// (pt_graph.rs:282-308), so both orientations are edges with the same weight, and a k-mer that is
+// its own reverse complement (even k only) was added twice per window.
+// ---------------------------------------------------------------------------------------------
+constexpr int EMIT_ITEMS = 8;
+
+template <int NW, bool RC>
+__global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf<NW>::type* __restrict__ slots, u64 cap, u32 k,
+                                                            u64* __restrict__ out_keys, u32* __restrict__ out_w, u64* cursor) {
+    __shared__ u32 wave_tot[BLOCK / 64];
+    __shared__ u64 block_base;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 tile = (u64)BLOCK * EMIT_ITEMS;
+    for (u64 t0 = (u64)blockIdx.x * tile; t0 < cap; t0 += (u64)gridDim.x * tile) {
+        Key<NW> key[EMIT_ITEMS]; u32 cnt[EMIT_ITEMS]; u32 nemit[EMIT_ITEMS]; u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < EMIT_ITEMS; ++j) {
+            u64 i = t0 + (u64)j * BLOCK + tid;
+            nemit[j] = 0; cnt[j] = 0;
+            if (i < cap) {
+                typename SlotOf<NW>::type s = slots[i];
+                if (slot_key(s, key[j])) {
+                    cnt[j] = s.count;
+                    nemit[j] = 1;
+                    if (RC && !key_eq(revcomp(key[j], k), key[j])) nemit[j] = 2;
+                }
+            }
+            mine += nemit[j];
+        }
+        // block exclusive scan of `mine`
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        u32 wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) wave_off += wave_tot[w]; total += wave_tot[w]; }
+        if (tid == 0) block_base = total ? atomicAdd(cursor, (u64)total) : 0;
+        __syncthreads();
+        u64 pos = block_base + wave_off + (incl - mine);
+#pragma unroll
+        for (int j = 0; j < EMIT_ITEMS; ++j) {
+            if (!nemit[j]) continue;
+            Key<NW> rc = RC ? revcomp(key[j], k) : key[j];
+            u32 w = (RC && nemit[j] == 1) ? cnt[j] * 2u : cnt[j];     // self-complementary k-mer
+#pragma unroll
+            for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = key[j].w[q];
+            out_w[pos] = w; ++pos;
+            if (nemit[j] == 2) {
+#pragma unroll
+                for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rc.w[q];
+                out_w[pos] = w; ++pos;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host side --------------------------------------------------------------------------------
+struct TableAux { u64 occupied; u32 err; u32 pad; };
+
+int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream) {
+    if (cap < 1024) cap = 1024;
+    t.nw = nw; t.cap = cap;
+    KCHECK(t.slots.alloc(cap * t.slot_bytes()));
+    KCHECK(t.counter.alloc(sizeof(TableAux)));
+    KCHECK_HIP(hipMemsetAsync(t.slots.p, 0, cap * t.slot_bytes(), stream));
+    KCHECK_HIP(hipMemsetAsync(t.counter.p, 0, sizeof(TableAux), stream));
+    return KATOME_OK;
+}
+
+int table_occupied(Table& t, uint64_t* out, hipStream_t stream) {
+    TableAux aux;
+    KCHECK_HIP(hipMemcpyAsync(&aux, t.counter.p, sizeof aux, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    if (aux.err) { set_error("k-mer table probe failure (code %u): table full or claim stuck", aux.err); return KATOME_E_DEVICE; }
+    *out = aux.occupied;
+    return KATOME_OK;
+}
+
+int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    TableAux* aux = t.counter.as<TableAux>();
+    dim3 grid(grid_for(n, BLOCK, 256u * 32u)), block(BLOCK);
+    if (t.nw == 1)
+        hipLaunchKernelGGL(insert_kernel<1>, grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err);
+    else
+        hipLaunchKernelGGL(insert_kernel<2>, grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
+    Table nt;
+    KCHECK(table_alloc(nt, t.nw, new_cap, stream));
+    TableAux* aux = nt.counter.as<TableAux>();
+    dim3 grid(grid_for(t.cap, BLOCK, 256u * 32u)), block(BLOCK);
+    if (t.nw == 1)
+        hipLaunchKernelGGL(rehash_kernel<1>, grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, nt.slots.as<Slot1>(), nt.cap, &aux->occupied, &aux->err);
+    else
+        hipLaunchKernelGGL(rehash_kernel<2>, grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, nt.slots.as<Slot2>(), nt.cap, &aux->occupied, &aux->err);
+    KCHECK_HIP(hipGetLastError());
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    t.slots.release(); t.counter.release();
+    t.slots.p = nt.slots.take(); t.slots.bytes = new_cap * t.slot_bytes();
+    t.counter.p = nt.counter.take(); t.counter.bytes = sizeof(TableAux);
+    t.cap = new_cap;
+    return KATOME_OK;
+}
+
+int table_emit_edges(Table& t, uint32_t k, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_edges, hipStream_t stream) {
+    uint64_t occ = 0;
+    KCHECK(table_occupied(t, &occ, stream));
+    const uint64_t upper = occ * (rc ? 2 : 1);
+    KCHECK(keys.alloc((upper + 1) * 8 * t.nw));
+    KCHECK(weights.alloc((upper + 1) * 4));
+    DevBuf cursor;
+    KCHECK(cursor.alloc(8));
+    KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    dim3 grid(grid_for(t.cap, BLOCK * EMIT_ITEMS, 256u * 16u)), block(BLOCK);
+    if (t.nw == 1) {
+        if (rc) hipLaunchKernelGGL((emit_edges_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        else    hipLaunchKernelGGL((emit_edges_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+    } else {
+        if (rc) hipLaunchKernelGGL((emit_edges_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        else    hipLaunchKernelGGL((emit_edges_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+    }
+    KCHECK_HIP(hipGetLastError());
+    KCHECK_HIP(hipMemcpyAsync(n_edges, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+}  // namespace katome

@@ -1,0 +1,193 @@
+"""Device-resident driver over the C ABI: PyTorch supplies device memory, streams and
+torch.distributed (plumbing); every kernel is in katome_amd/lib/libkatome_gpu.so.
+
+Used by bench.py (inputs resident in HBM before the timed region) and by katome_amd/dist.py
+(one process per GPU).  Mirrors the steps of `Build::create` (reference builder.rs:142-165 ->
+pt_graph.rs:277-315,172-198,333-345): extract -> insert -> finalize.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .build import KatomePanic, make_settings
+
+
+def _check(status):
+    if status != 0:
+        raise KatomePanic(status, _lib.last_error())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _DevArray:
+    """zero-copy view of library-owned device memory (kept alive by `owner`)"""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.owner = owner
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def _view(ptr, shape, typestr, owner, device):
+    n = 1
+    for s in shape:
+        n *= s
+    if n == 0 or not ptr:
+        dt = {"<i8": torch.int64, "<i4": torch.int32, "|u1": torch.uint8}[typestr]
+        return torch.empty(shape, dtype=dt, device=device)
+    return torch.as_tensor(_DevArray(ptr, shape, typestr, owner), device=device)
+
+
+def record_words(k):
+    return _lib.lib().katome_record_words(k)
+
+
+class DeviceGraph:
+    """finalized graph, arrays resident in HBM (int64/int32 views of the u64/u32 data)"""
+
+    def __init__(self, dg, builder, device):
+        self.n_nodes, self.n_edges = dg.n_nodes, dg.n_edges
+        self.key_words, self.label_stride = dg.key_words, dg.label_stride
+        nw, ne, nn = dg.key_words, dg.n_edges, dg.n_nodes
+        self.edge_key = _view(dg.d_edge_key, (ne, nw), "<i8", builder, device)
+        self.edge_weight = _view(dg.d_edge_weight, (ne,), "<i4", builder, device)
+        self.edge_src = _view(dg.d_edge_src, (ne,), "<i8", builder, device)
+        self.edge_dst = _view(dg.d_edge_dst, (ne,), "<i8", builder, device)
+        self.edge_label = _view(dg.d_edge_label, (ne, dg.label_stride), "|u1", builder, device)
+        self.node_key = _view(dg.d_node_key, (nn, nw), "<i8", builder, device)
+
+
+class Builder:
+    """one GPU's share of a build"""
+
+    def __init__(self, k, reverse_complement, device=0, table_slots_hint=0):
+        self.k, self.rc, self.device = k, bool(reverse_complement), device
+        self.nw = record_words(k)
+        self._settings = make_settings(k, reverse_complement=reverse_complement, device=device,
+                                       table_slots_hint=table_slots_hint)
+        self._h = C.c_void_p()
+        _check(_lib.lib().katome_builder_create(C.byref(self._settings), C.byref(self._h)))
+        self.tdev = torch.device("cuda", device)
+
+    def close(self):
+        if self._h:
+            _lib.lib().katome_builder_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- extraction (compress_kmer[_with_rev_compl] over read.windows(K)) -----------------------
+    def extract_fixed(self, packed, n_reads, read_len, skip=None, out=None, first_read=0):
+        stride = (read_len + 3) // 4
+        n_rec = n_reads * (read_len - self.k + 1) if read_len >= self.k else 0
+        if out is None:
+            out = torch.empty(max(n_rec, 1) * self.nw, dtype=torch.int64, device=self.tdev)
+        assert out.numel() >= n_rec * self.nw
+        p = C.c_void_p(packed.data_ptr() + first_read * stride)
+        sk = C.c_void_p(skip.data_ptr() + first_read) if skip is not None else None
+        _check(_lib.lib().katome_dev_extract_fixed(self._h, p, n_reads, read_len, sk, _ptr(out), _stream()))
+        return out[:n_rec * self.nw]
+
+    def extract_var(self, packed, byte_off, lens, win_prefix, total_windows, out=None):
+        n_reads = lens.numel()
+        if out is None:
+            out = torch.empty(max(total_windows, 1) * self.nw, dtype=torch.int64, device=self.tdev)
+        _check(_lib.lib().katome_dev_extract_var(self._h, _ptr(packed), packed.numel(), _ptr(byte_off), _ptr(lens),
+                                                 _ptr(win_prefix), n_reads, total_windows, _ptr(out), _stream()))
+        return out[:total_windows * self.nw]
+
+    # ---- routing for the multi-GPU exchange -----------------------------------------------------
+    def partition(self, records, n_parts, out=None):
+        n = records.numel() // self.nw
+        if out is None:
+            out = torch.empty_like(records)
+        counts = (C.c_uint64 * n_parts)()
+        _check(_lib.lib().katome_dev_partition(self._h, _ptr(records), n, n_parts, _ptr(out), counts, _stream()))
+        return out, [int(c) for c in counts]
+
+    # ---- add_single_edge_fastaq for a batch ------------------------------------------------------
+    def insert(self, records, weights=None):
+        n = records.numel() // self.nw
+        if weights is None:
+            _check(_lib.lib().katome_dev_insert(self._h, _ptr(records), n, _stream()))
+        else:
+            _check(_lib.lib().katome_dev_insert_weighted(self._h, _ptr(records), _ptr(weights), n, _stream()))
+
+    def table_count(self):
+        out = C.c_uint64()
+        _check(_lib.lib().katome_dev_table_count(self._h, C.byref(out)))
+        return out.value
+
+    # ---- PtGraph::create post-pass -----------------------------------------------------------------
+    def edges(self):
+        """sorted distinct oriented edges of this builder's table: (keys [n, nw] int64 view, weights [n] int32 view)"""
+        pk, pw, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(_lib.lib().katome_dev_edges(self._h, C.byref(pk), C.byref(pw), C.byref(n), _stream()))
+        return (_view(pk.value, (n.value, self.nw), "<i8", self, self.tdev),
+                _view(pw.value, (n.value,), "<i4", self, self.tdev))
+
+    def finalize(self):
+        dg = _lib.DevGraph()
+        _check(_lib.lib().katome_dev_finalize(self._h, C.byref(dg), _stream()))
+        return DeviceGraph(dg, self, self.tdev)
+
+
+# ---- primitives ------------------------------------------------------------------------------------
+def sort_keys(keys, key_bits, key_words, values=None, device=0):
+    n = keys.numel() // key_words
+    _check(_lib.lib().katome_dev_sort(device, _ptr(keys), _ptr(values), n, key_words, key_bits, _stream()))
+    return keys, values
+
+
+def unique_sorted(keys, key_words, device=0):
+    n = keys.numel() // key_words
+    out = C.c_uint64()
+    _check(_lib.lib().katome_dev_unique(device, _ptr(keys), n, key_words, C.byref(out), _stream()))
+    return keys.view(-1)[:out.value * key_words]
+
+
+def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
+    ns, nq = sorted_keys.numel() // key_words, queries.numel() // key_words
+    out = torch.empty(max(nq, 1), dtype=torch.int64, device=queries.device)
+    _check(_lib.lib().katome_dev_rank(device, _ptr(sorted_keys), ns, key_words, key_bits, _ptr(queries), nq, _ptr(out),
+                                      _stream()))
+    return out[:nq]
+
+
+def endpoints(edge_keys, k, device=0):
+    nw = record_words(k)
+    n = edge_keys.numel() // nw
+    src, dst = torch.empty_like(edge_keys), torch.empty_like(edge_keys)
+    _check(_lib.lib().katome_dev_endpoints(device, _ptr(edge_keys), n, k, _ptr(src), _ptr(dst), _stream()))
+    return src, dst
+
+
+def labels(edge_keys, k, device=0):
+    nw = record_words(k)
+    n = edge_keys.numel() // nw
+    stride = 1 + (k + 3) // 4
+    out = torch.empty((max(n, 1) * stride + 3) // 4 * 4, dtype=torch.uint8, device=edge_keys.device)
+    _check(_lib.lib().katome_dev_labels(device, _ptr(edge_keys), n, k, _ptr(out), _stream()))
+    return out[:n * stride].view(n, stride)
+
+
+def synth_reads(first_read, n_reads, read_len, genome_len, err_rate, n_inject_percent=0, device=0):
+    """deterministic synthetic workload, generated in HBM (DESIGN.md 'Synthetic workload')"""
+    tdev = torch.device("cuda", device)
+    stride = (read_len + 3) // 4
+    packed = torch.empty(n_reads * stride + 32, dtype=torch.uint8, device=tdev)
+    skip = torch.empty(max(n_reads, 1), dtype=torch.uint8, device=tdev)
+    _check(_lib.lib().katome_dev_synth_reads(device, first_read, n_reads, read_len, genome_len, float(err_rate),
+                                             n_inject_percent, _ptr(packed), _ptr(skip), _stream()))
+    return packed, skip

@@ -1,0 +1,119 @@
+"""No-GPU checks of the C-ABI library: it loads, exports every symbol include/katome_gpu.h declares,
+its host ingest agrees with the oracle, error statuses mirror the reference's panics, and the
+device entry points fail loudly (no CPU fallback) when there is no GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import katome_amd
+from katome_amd import _lib
+from katome_amd.build import GpuGraph, InputFileType, KatomePanic, ingest_files, make_settings, set_global_k_sizes
+
+from helpers import ROOT
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "katome_gpu.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(katome_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(_lib.lib_path())
+    names = declared_symbols()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SYMBOLS) == names          # the Python binding covers the whole header
+    assert katome_amd.lib().katome_abi_version() == 1
+
+
+def test_record_words():
+    L = katome_amd.lib()
+    assert [L.katome_record_words(k) for k in (3, 31, 32, 40, 63)] == [1, 1, 2, 2, 2]
+
+
+@pytest.mark.parametrize("name,k", [("data1.txt", 40), ("data2.txt", 40), ("data3.txt", 31), ("data2.txt", 63)])
+def test_ingest_matches_oracle(oracle, golden_dir, name, k):
+    path = os.path.join(golden_dir, name)
+    got = ingest_files([path], InputFileType.Fastq, k)
+    want = oracle.scan_files([path], file_type=1)
+    assert got["n_records"] == want["n_records"]
+    assert got["n_reads"] == want["n_accepted"]
+    assert got["read_bytes"] == want["read_bytes"]
+    assert got["fixed_len"] == 100
+    oracle.set_k(k)
+    for r in range(got["n_reads"]):
+        seq = bytes(want["seq"][want["off"][r]:want["off"][r + 1]])
+        assert bytes(got["packed"][got["byte_off"][r]:got["byte_off"][r + 1]]) == oracle.compress_node(seq)
+        assert got["len"][r] == len(seq)
+    assert got["total_windows"] == sum(int(l) - k + 1 for l in got["len"])
+
+
+def test_ingest_variable_length_and_fasta(tmp_path, oracle):
+    fq = tmp_path / "v.fq"
+    fq.write_text("@a\nACGTACGTAC\n+\nIIIIIIIIII\n@b\nACGTNACGT\n+\nIIIIIIIII\n@c\nTTTTGGGGCCCCAAAA  \n+\nIIIIIIIIIIIIIIII\n")
+    got = ingest_files([str(fq)], InputFileType.Fastq, 5)
+    assert (got["n_records"], got["n_reads"], got["read_bytes"], got["fixed_len"]) == (3, 2, 26, 0)
+    want = oracle.scan_files([str(fq)], file_type=1)
+    assert got["read_bytes"] == want["read_bytes"] and got["n_reads"] == want["n_accepted"]
+    fa = tmp_path / "v.fa"
+    fa.write_text(">x desc\nACGTAC\nGGTT\n>y\nACNT\n>z\nCCCCCCC\n")
+    got = ingest_files([str(fa)], InputFileType.Fasta, 4)
+    want = oracle.scan_files([str(fa)], file_type=0)
+    assert (got["n_records"], got["n_reads"], got["read_bytes"]) == (3, 2, 17)
+    assert (want["n_records"], want["n_accepted"], want["read_bytes"]) == (3, 2, 17)
+    oracle.set_k(4)
+    assert bytes(got["packed"][:3]) == oracle.compress_node(b"ACGTACGGTT")
+
+
+def test_error_statuses_mirror_reference_panics(golden_dir, tmp_path):
+    def status(paths, k=40, ft=InputFileType.Fastq):
+        with pytest.raises(KatomePanic) as e:
+            ingest_files(paths, ft, k)
+        return e.value.name, e.value.message
+    # tests/build.rs:33,129-139 -- a path that does not exist
+    assert status([os.path.join(golden_dir, "data_too_short_reads")])[0] == "E_PATH"
+    assert status([golden_dir])[0] == "E_IS_DIR"                                    # builder.rs:67
+    name, msg = status([os.path.join(golden_dir, "data_too_short_read.txt")])        # pt_graph.rs:278
+    assert (name, msg) == ("E_SHORT_READ", "Read is too short!")
+    bad = tmp_path / "bad.fq"
+    bad.write_text("ACGT\nACGT\n+\nIIII\n")
+    assert status([str(bad)], k=3)[0] == "E_PARSE"                                  # builder.rs:153
+    trunc = tmp_path / "trunc.fq"
+    trunc.write_text("@a\nACGT\n+\n")
+    assert status([str(trunc)], k=3)[0] == "E_PARSE"
+    assert status([os.path.join(golden_dir, "data1.txt")], k=1)[0] == "E_ARG"       # prelude.rs:35
+    assert status([os.path.join(golden_dir, "data1.txt")], k=64)[0] == "E_ARG"
+    # errors are found in input order: the bad path wins over the good one before it (builder.rs:46)
+    assert status([os.path.join(golden_dir, "data1.txt"), os.path.join(golden_dir, "nope")])[0] == "E_PATH"
+
+
+def test_no_gpu_means_loud_failure(golden_dir):
+    """On a box without a GPU the build must fail with E_DEVICE -- never fall back to a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    set_global_k_sizes(40)
+    with pytest.raises(KatomePanic) as e:
+        GpuGraph.create([os.path.join(golden_dir, "data1.txt")], InputFileType.Fastq, False, 0)
+    assert e.value.name == "E_DEVICE"
+    s = make_settings(31)
+    h = C.c_void_p()
+    assert katome_amd.lib().katome_builder_create(C.byref(s), C.byref(h)) == -8
+    packed = np.zeros(38, np.uint8)
+    with pytest.raises(KatomePanic) as e:
+        GpuGraph.create_from_packed(packed, 1, 150, k=31)
+    assert e.value.name == "E_DEVICE"
+
+
+def test_product_never_touches_the_oracle():
+    """nothing under katome_amd/ may import, link or call oracle/"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "katome_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "katome_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f

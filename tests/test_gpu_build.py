@@ -1,0 +1,278 @@
+"""GPU parity tests proper: the HIP build path, through the C ABI, against the oracle and against the
+constants the reference's own tests pin (tests/golden/pinned.json).  Integer work: bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+from helpers import kmer_to_int, pack_reads_ascii, windows_multiset  # noqa: E402
+
+
+def _build_files(paths, k, rc, ft=None):
+    from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
+    set_global_k_sizes(k)
+    return GpuGraph.create(paths, ft if ft is not None else InputFileType.Fastq, rc, 0)
+
+
+def _check_graph_consistency(g, k):
+    """structure every build must have, whatever the input"""
+    nw = g.key_words
+    ek = g.key_ints("edge")
+    nk = g.key_ints("node")
+    assert ek == sorted(ek) and len(set(ek)) == len(ek)              # ascending distinct k-mers
+    assert nk == sorted(nk) and len(set(nk)) == len(nk)              # ascending distinct (k-1)-mers
+    mask = (1 << (2 * (k - 1))) - 1
+    for e in range(0, g.n_edges, max(1, g.n_edges // 500)):
+        assert nk[int(g.edge_src[e])] == ek[e] >> 2                   # compress_kmer halves
+        assert nk[int(g.edge_dst[e])] == ek[e] & mask
+    used = set(g.edge_src.tolist()) | set(g.edge_dst.tolist())
+    assert used == set(range(g.n_nodes))                             # every node is an endpoint
+    assert nw == (1 if 2 * k <= 62 else 2)
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_reference_pinned_constants(golden_dir, i):
+    """tests/build.rs:27-28,44-90 through the GPU path (k=40 -> 128-bit keys)"""
+    from katome_amd.build import CollectionStats
+    pinned = json.load(open(os.path.join(golden_dir, "pinned.json")))
+    g, read_bytes = _build_files([os.path.join(golden_dir, pinned["fixtures"][i])], pinned["k"], False)
+    assert read_bytes == pinned["read_bytes"]["values"][i]
+    want = pinned["pt_graph_stats"]["values"][i]
+    n, e = pinned["counts"]["values"][i]
+    assert g.stats() == CollectionStats(node_count=n, edge_count=e, **want)
+    _check_graph_consistency(g, 40)
+
+
+@pytest.mark.parametrize("k", [3, 5, 16, 31, 32, 33, 40, 63])
+@pytest.mark.parametrize("rc", [False, True])
+def test_fixture_multiset_equals_oracle(oracle, golden_dir, k, rc):
+    """bit-exact (k-mer, weight) multiset, labels and CollectionStats vs the oracle"""
+    path = os.path.join(golden_dir, "data2.txt")
+    g, read_bytes = _build_files([path], k, rc)
+    ref = oracle.build_files([path], k, rc)
+    assert read_bytes == ref.read_bytes
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    assert g.multiset() == ref.multiset()
+    # labels: same bytes as the oracle's compress_edge-format slots, edge for edge
+    ref_by_label = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
+    got_by_label = {bytes(row): int(w) for row, w in zip(g.edge_label, g.edge_weight)}
+    assert got_by_label == ref_by_label
+    st, rs = g.stats(), ref.stats
+    assert (st.max_edge_weight, st.max_in_degree, st.max_out_degree, st.incoming_vert_count, st.outgoing_vert_count) == \
+        (rs["max_edge_weight"], rs["max_in_degree"], rs["max_out_degree"], rs["incoming_vert_count"], rs["outgoing_vert_count"])
+    assert abs(st.avg_edge_weight - rs["avg_edge_weight"]) < 1e-12 and abs(st.avg_out_degree - rs["avg_out_degree"]) < 1e-12
+    _check_graph_consistency(g, k)
+
+
+def test_derived_goldens(golden_dir):
+    derived = json.load(open(os.path.join(golden_dir, "derived.json")))
+    for case in derived["cases"]:
+        g, _ = _build_files([os.path.join(golden_dir, case["fixture"])], case["k"], case["rc"])
+        assert [g.n_nodes, g.n_edges] == case["counts"], case
+        assert int(g.edge_weight.astype(np.uint64).sum()) == case["weight_sum"]
+
+
+def test_multifile_and_graph_topology_vs_oracle(oracle, golden_dir):
+    """multi-file = concatenation (builder.rs:152); node/edge incidence isomorphic to the oracle's graph"""
+    paths = [os.path.join(golden_dir, f) for f in ("data1.txt", "data3.txt")]
+    g, rb = _build_files(paths, 40, True)
+    ref = oracle.build_files(paths, 40, True)
+    assert rb == ref.read_bytes and g.multiset() == ref.multiset()
+    # edges as (source (k-1)-mer, target (k-1)-mer) pairs must agree with the oracle's node ids up to renaming
+    nk = g.key_ints("node")
+    ours = sorted((nk[int(s)], nk[int(d)]) for s, d in zip(g.edge_src, g.edge_dst))
+    ref_kmers = ref.kmer_strings()
+    node_name = {}
+    for km, s, d in zip(ref_kmers, ref.edge_src, ref.edge_dst):
+        node_name.setdefault(int(s), kmer_to_int(km[:-1]))
+        node_name.setdefault(int(d), kmer_to_int(km[1:]))
+        assert node_name[int(s)] == kmer_to_int(km[:-1]) and node_name[int(d)] == kmer_to_int(km[1:])
+    theirs = sorted((node_name[int(s)], node_name[int(d)]) for s, d in zip(ref.edge_src, ref.edge_dst))
+    assert ours == theirs and len(node_name) == g.n_nodes
+
+
+def test_variable_length_reads_and_fasta(oracle, tmp_path):
+    rng = np.random.default_rng(5)
+    lines, fa = [], []
+    for i in range(300):
+        n = int(rng.integers(12, 400))
+        s = "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+        if i % 17 == 0:
+            s = s[:5] + "N" + s[6:]
+        lines += ["@r%d" % i, s, "+", "I" * n]
+        fa += [">r%d" % i] + [s[j:j + 60] for j in range(0, n, 60)]
+    fq = tmp_path / "var.fq"
+    fq.write_text("\n".join(lines) + "\n")
+    faf = tmp_path / "var.fa"
+    faf.write_text("\n".join(fa) + "\n")
+    from katome_amd.build import InputFileType
+    for k, rc in ((11, True), (12, False), (33, True)):
+        ref = oracle.build_files([str(fq)], k, rc) if k <= 12 else None
+        if ref is None:
+            continue
+        g, rb = _build_files([str(fq)], k, rc)
+        assert rb == ref.read_bytes and g.multiset() == ref.multiset()
+        g2, rb2 = _build_files([str(faf)], k, rc, InputFileType.Fasta)
+        ref2 = oracle.build_files([str(faf)], k, rc, file_type=0)
+        assert rb2 == ref2.read_bytes == rb and g2.multiset() == ref2.multiset() == g.multiset()
+        _check_graph_consistency(g, k)
+
+
+def test_error_paths_on_gpu_box(golden_dir):
+    from katome_amd.build import KatomePanic
+    with pytest.raises(KatomePanic) as e:      # tests/build.rs:33,129-139 (fails3)
+        _build_files([os.path.join(golden_dir, "data_too_short_reads")], 40, False)
+    assert e.value.name == "E_PATH"
+    with pytest.raises(KatomePanic) as e:      # pt_graph.rs:278
+        _build_files([os.path.join(golden_dir, "data_too_short_read.txt")], 40, False)
+    assert e.value.name == "E_SHORT_READ" and e.value.message == "Read is too short!"
+    g, rb = _build_files([os.path.join(golden_dir, "data_too_short_read.txt")], 7, False)
+    assert (rb, g.n_edges, g.n_nodes) == (7, 1, 2)
+
+
+def test_empty_and_all_skipped_inputs(tmp_path):
+    from katome_amd.build import GpuGraph
+    empty = tmp_path / "e.fq"
+    empty.write_text("")
+    g, rb = _build_files([str(empty)], 31, True)
+    assert (rb, g.n_edges, g.n_nodes) == (0, 0, 0)
+    alln = tmp_path / "n.fq"
+    alln.write_text("@a\nACGTNNNN\n+\nIIIIIIII\n")
+    g, rb = _build_files([str(alln)], 5, True)
+    assert (rb, g.n_edges, g.n_nodes) == (0, 0, 0)
+    packed = np.zeros((4, 38), np.uint8)
+    g, rb = GpuGraph.create_from_packed(packed, 4, 150, skip=np.ones(4, np.uint8), reverse_complement=True, k=31)
+    assert (rb, g.n_edges) == (0, 0)
+
+
+@pytest.mark.parametrize("k,rc", [(31, True), (31, False), (63, True), (4, True), (6, True)])
+def test_extraction_kernel_records(oracle, k, rc):
+    """extract_fixed (LDS path) record for record vs the string-level windows"""
+    from katome_amd import device as kd
+    from helpers import revcomp_str, words_to_int
+    n, L = 777, 150
+    ascii_reads = oracle.synth_reads(5, n, L, 40000, 2e-2, 3)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("A")
+    packed = torch.from_numpy(np.ascontiguousarray(pack_reads_ascii(clean)).reshape(-1)).cuda()
+    skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+    b = kd.Builder(k, rc)
+    rec = b.extract_fixed(packed, n, L, skip)
+    torch.cuda.synchronize()
+    nw = b.nw
+    got = rec.cpu().numpy().view(np.uint64).reshape(n, L - k + 1, nw)
+    for r in range(0, n, 13):
+        s = bytes(clean[r]).decode()
+        for w in range(L - k + 1):
+            v = words_to_int(got[r, w])
+            if has_n[r]:
+                assert got[r, w, 0] == np.uint64(0xFFFFFFFFFFFFFFFF)
+                continue
+            km = s[w:w + k]
+            want = kmer_to_int(km)
+            if rc:
+                want = min(want, kmer_to_int(revcomp_str(km)))
+            assert v == want, (r, w)
+    b.close()
+
+
+@pytest.mark.parametrize("k,rc,n,L", [(31, True, 20000, 150), (31, False, 20000, 150), (40, True, 6000, 100),
+                                      (6, True, 3000, 64), (63, True, 5000, 150), (32, True, 4000, 75)])
+def test_synthetic_build_equals_oracle(oracle, k, rc, n, L):
+    """SURVEY 8d workload shape (N-injection included) at a size the oracle finishes in seconds"""
+    from katome_amd.build import GpuGraph
+    ascii_reads = oracle.synth_reads(0, n, L, 200000, 1e-3, 1)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("C")
+    g, rb = GpuGraph.create_from_packed(pack_reads_ascii(clean).reshape(-1), n, L, skip=has_n.astype(np.uint8),
+                                        reverse_complement=rc, k=k)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert rb == ref.read_bytes == int((~has_n).sum()) * L
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    ref_keys = np.array(sorted(kmer_to_int(s) for s in ref.kmer_strings()), dtype=object)
+    assert g.key_ints("edge") == list(ref_keys)
+    assert g.multiset() == ref.multiset()
+    _check_graph_consistency(g, k)
+
+
+def test_high_multiplicity_and_table_growth(oracle):
+    """many duplicate reads -> heavy contention on few slots; tiny table hint -> the table must grow"""
+    from katome_amd import device as kd
+    n, L, k = 64, 150, 31
+    base = oracle.synth_reads(0, n, L, 5000, 0.0, 0)
+    reps = 300
+    ascii_reads = np.tile(base, (reps, 1))
+    packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1)).cuda()
+    b = kd.Builder(k, True, table_slots_hint=2048)
+    rec = b.extract_fixed(packed, n * reps, L)
+    step = (n * (L - k + 1)) * 7
+    for off in range(0, rec.numel(), step):
+        b.insert(rec[off:off + step])
+    dg = b.finalize()
+    want = windows_multiset(base, k, True)
+    assert dg.n_edges == len(want)
+    w = dg.edge_weight.cpu().numpy().view(np.uint32)
+    keys = dg.edge_key.cpu().numpy().view(np.uint64)[:, 0]
+    want_sorted = sorted((kmer_to_int(s), c * reps) for s, c in want.items())
+    assert [int(x) for x in keys] == [x for x, _ in want_sorted]
+    assert [int(x) for x in w] == [c for _, c in want_sorted]
+    b.close()
+    # 128-bit keys under the same contention (claim/publish protocol of the two-word slots)
+    b = kd.Builder(40, True, table_slots_hint=2048)
+    rec = b.extract_fixed(packed, n * reps, L)
+    for off in range(0, rec.numel(), step * 2):
+        b.insert(rec[off:off + step * 2])
+    dg = b.finalize()
+    want = windows_multiset(base, 40, True)
+    assert dg.n_edges == len(want)
+    assert int(dg.edge_weight.cpu().numpy().view(np.uint32).astype(np.uint64).sum()) == sum(want.values()) * reps
+    got = {(int(h) << 64) | int(l): int(c) for (h, l), c in zip(dg.edge_key.cpu().numpy().view(np.uint64), dg.edge_weight.cpu().numpy().view(np.uint32))}
+    assert got == {kmer_to_int(s): c * reps for s, c in want.items()}
+    b.close()
+
+
+def test_properties_at_scale():
+    """1M reads x 150 bp, k=31, rc (BASELINE config 2 size): size-independent invariants"""
+    from katome_amd import device as kd
+    n, L, k = 1_000_000, 150, 31
+    packed, skip = kd.synth_reads(0, n, L, 1_000_000, 1e-3, 1)
+    b = kd.Builder(k, True)
+    rec = b.extract_fixed(packed, n, L, skip)
+    b.insert(rec)
+    dg = b.finalize()
+    W = L - k + 1
+    accepted = n - int(skip[:n].sum().item())
+    assert 0 < n - accepted < n // 50
+    # every window was counted on both strands: sum of weights = 2 * accepted * W (odd k: no self-complement)
+    assert int(dg.edge_weight.to(torch.int64).sum().item()) == 2 * accepted * W
+    keys = dg.edge_key[:, 0]
+    assert bool((keys[1:] > keys[:-1]).all())                        # sorted, distinct
+    nodes = dg.node_key[:, 0]
+    assert bool((nodes[1:] > nodes[:-1]).all())
+    assert bool((nodes[dg.edge_src] == (keys >> 2)).all())
+    assert bool((nodes[dg.edge_dst] == (keys & ((1 << 60) - 1))).all())
+    # strand symmetry: the reverse complement of every edge is an edge with the same weight
+    from katome_amd.device import rank_in_sorted
+    def rc64(x):
+        y = torch.zeros_like(x)
+        for i in range(k):
+            y |= (3 - ((x >> (2 * i)) & 3)) << (2 * (k - 1 - i))
+        return y
+    r = rank_in_sorted(dg.edge_key.reshape(-1), rc64(keys).contiguous(), 62, 1)
+    assert bool((r >= 0).all()) and bool((dg.edge_weight[r] == dg.edge_weight).all())
+    # idempotence: a second build of the same input gives the same arrays
+    b2 = kd.Builder(k, True)
+    b2.insert(b2.extract_fixed(packed, n, L, skip))
+    dg2 = b2.finalize()
+    assert dg2.n_edges == dg.n_edges and dg2.n_nodes == dg.n_nodes
+    assert torch.equal(dg2.edge_key, dg.edge_key) and torch.equal(dg2.edge_weight, dg.edge_weight)
+    assert torch.equal(dg2.edge_src, dg.edge_src) and torch.equal(dg2.edge_dst, dg.edge_dst)
+    assert torch.equal(dg2.edge_label, dg.edge_label)
+    b.close(); b2.close()

@@ -1,0 +1,176 @@
+"""GPU: each hand-written device primitive against numpy on the same seeded inputs."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+def _keys(rng, n, nw, bits):
+    """random keys of `bits` bits as [n, nw] uint64 (most significant word first)"""
+    a = np.zeros((n, nw), np.uint64)
+    lo_bits = min(bits, 64)
+    lo = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=n, dtype=np.uint64)
+    if lo_bits < 64:
+        lo &= np.uint64((1 << lo_bits) - 1)
+    a[:, nw - 1] = lo
+    if nw == 2 and bits > 64:
+        hi = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64)
+        hi &= np.uint64((1 << (bits - 64)) - 1)
+        a[:, 0] = hi
+    return a
+
+
+def _to_dev(a):
+    return torch.from_numpy(a.view(np.int64).copy()).cuda()
+
+
+def _from_dev(t, nw):
+    return t.cpu().numpy().view(np.uint64).reshape(-1, nw)
+
+
+def _lexsort(a):
+    return np.lexsort(tuple(a[:, j] for j in range(a.shape[1] - 1, -1, -1)))
+
+
+@pytest.mark.parametrize("nw,bits", [(1, 62), (1, 60), (1, 13), (2, 126), (2, 80), (2, 64)])
+@pytest.mark.parametrize("n", [0, 1, 2, 4095, 4096, 4097, 100003, 1 << 20])
+def test_radix_sort_keys(nw, bits, n):
+    from katome_amd import device as kd
+    rng = np.random.default_rng(n * 7 + bits)
+    a = _keys(rng, n, nw, bits)
+    if n > 1000:                       # duplicates exercise stability-independent equality
+        a[n // 2:n // 2 + 500] = a[:500]
+    d = _to_dev(a)
+    kd.sort_keys(d, bits, nw)
+    torch.cuda.synchronize()
+    got = _from_dev(d, nw)
+    want = a[_lexsort(a)]
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("nw,bits", [(1, 62), (2, 126)])
+def test_radix_sort_with_values_is_stable(nw, bits):
+    from katome_amd import device as kd
+    n = 300001
+    rng = np.random.default_rng(3)
+    a = _keys(rng, n, nw, bits)
+    a[:, nw - 1] &= np.uint64(0xFFFF)          # many equal keys: stability is observable through the values
+    if nw == 2:
+        a[:, 0] &= np.uint64(0x3)
+    v = np.arange(n, dtype=np.uint32)
+    d, dv = _to_dev(a), torch.from_numpy(v.view(np.int32).copy()).cuda()
+    kd.sort_keys(d, bits, nw, dv)
+    torch.cuda.synchronize()
+    order = np.lexsort((v,) + tuple(a[:, j] for j in range(nw - 1, -1, -1)))
+    assert np.array_equal(_from_dev(d, nw), a[order])
+    assert np.array_equal(dv.cpu().numpy().view(np.uint32), v[order])
+
+
+@pytest.mark.parametrize("nw", [1, 2])
+@pytest.mark.parametrize("n", [1, 2, 2047, 2048, 2049, 500000])
+def test_unique(nw, n):
+    from katome_amd import device as kd
+    rng = np.random.default_rng(n + nw)
+    a = _keys(rng, n, nw, 62 if nw == 1 else 100)
+    a[:, nw - 1] %= np.uint64(max(n // 3, 1))
+    if nw == 2:
+        a[:, 0] %= np.uint64(2)
+    a = a[_lexsort(a)]
+    d = _to_dev(a)
+    out = kd.unique_sorted(d, nw)
+    torch.cuda.synchronize()
+    want = np.unique(a, axis=0)
+    assert np.array_equal(_from_dev(out, nw), want)
+
+
+@pytest.mark.parametrize("nw,bits", [(1, 60), (1, 10), (2, 124)])
+def test_rank_in_sorted(nw, bits):
+    from katome_amd import device as kd
+    rng = np.random.default_rng(11)
+    a = np.unique(_keys(rng, 200000, nw, bits), axis=0)
+    q_idx = rng.integers(0, len(a), size=50000)
+    d, q = _to_dev(a), _to_dev(a[q_idx])
+    r = kd.rank_in_sorted(d, q, bits, nw)
+    torch.cuda.synchronize()
+    assert np.array_equal(r.cpu().numpy(), q_idx)
+    # absent keys -> all ones
+    missing = a[:10].copy()
+    missing[:, nw - 1] ^= np.uint64(1)
+    present = {tuple(x) for x in a.tolist()}
+    r = kd.rank_in_sorted(d, _to_dev(missing), bits, nw).cpu().numpy()
+    for row, rr in zip(missing.tolist(), r):
+        assert (rr == -1) == (tuple(row) not in present)
+
+
+@pytest.mark.parametrize("k", [31, 40])
+@pytest.mark.parametrize("n_parts", [1, 2, 8])
+def test_partition_by_owner(k, n_parts):
+    """records grouped by owner = mulhi(mix(key), n_parts); invalid records dropped; multiset kept"""
+    import ctypes as C
+    from katome_amd import device as kd
+    from helpers import hostshim
+    nw = kd.record_words(k)
+    rng = np.random.default_rng(k + n_parts)
+    n = 70001
+    a = _keys(rng, n, nw, 2 * k)
+    inv = rng.random(n) < 0.01
+    a[inv] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    b = kd.Builder(k, True)
+    out, counts = b.partition(_to_dev(a).view(-1), n_parts)
+    torch.cuda.synchronize()
+    got = _from_dev(out, nw)
+    L = hostshim()
+    owners = np.array([L.hs_owner((C.c_uint64 * nw)(*[int(x) for x in row]), nw, n_parts) for row in a[~inv]])
+    assert counts == [int((owners == p).sum()) for p in range(n_parts)]
+    assert sum(counts) == int((~inv).sum())
+    pos = 0
+    valid = a[~inv]
+    for p in range(n_parts):
+        seg = got[pos:pos + counts[p]]
+        want = valid[owners == p]
+        assert np.array_equal(seg, want)           # the pass is stable
+        pos += counts[p]
+    b.close()
+
+
+@pytest.mark.parametrize("k", [3, 31, 32, 40, 63])
+def test_endpoints_and_labels(oracle, k):
+    from katome_amd import device as kd
+    from helpers import int_to_kmer, words_to_int
+    nw = kd.record_words(k)
+    rng = np.random.default_rng(k)
+    n = 1000
+    a = _keys(rng, n, nw, 2 * k)
+    d = _to_dev(a)
+    src, dst = kd.endpoints(d.view(-1), k)
+    lab = kd.labels(d.view(-1), k)
+    torch.cuda.synchronize()
+    src, dst, lab = _from_dev(src, nw), _from_dev(dst, nw), lab.cpu().numpy()
+    oracle.set_k(k)
+    for i in range(0, n, 7):
+        v = words_to_int(a[i])
+        s = int_to_kmer(v, k)
+        assert words_to_int(src[i]) == v >> 2
+        assert words_to_int(dst[i]) == v & ((1 << (2 * (k - 1))) - 1)
+        assert bytes(lab[i]) == oracle.compress_edge(s.encode())
+
+
+@pytest.mark.parametrize("L,npct", [(150, 0), (150, 1), (101, 5), (33, 0)])
+def test_synth_reads_match_cpu_definition(oracle, L, npct):
+    from katome_amd import device as kd
+    from helpers import pack_reads_ascii
+    n, G, e, first = 3000, 100000, 1e-2, 12345
+    packed, skip = kd.synth_reads(first, n, L, G, e, npct)
+    torch.cuda.synchronize()
+    ascii_reads = oracle.synth_reads(first, n, L, G, e, npct)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    assert np.array_equal(skip.cpu().numpy()[:n].astype(bool), has_n)
+    clean = ascii_reads.copy()
+    stride = (L + 3) // 4
+    got = packed.cpu().numpy()[:n * stride].reshape(n, stride)
+    ok = ~has_n
+    assert np.array_equal(got[ok], pack_reads_ascii(clean[ok]))
+    if npct:
+        assert 0 < has_n.sum() < n

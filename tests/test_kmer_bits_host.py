@@ -1,0 +1,110 @@
+"""The kernels' bit arithmetic (katome_amd/csrc/kmer_bits.h, compiled for the host) against the
+oracle's restatement of compress.rs -- runs without a GPU."""
+import ctypes as C
+import random
+
+import pytest
+
+from helpers import hostshim, int_to_kmer, kmer_to_int, revcomp_str, shim_words, words_to_int
+
+KS = [3, 4, 5, 7, 16, 30, 31, 32, 33, 40, 47, 62, 63]
+
+
+def nw_of(k):
+    return 1 if 2 * k <= 62 else 2
+
+
+@pytest.mark.parametrize("k", KS)
+def test_window_extraction_matches_compress_kmer(oracle, k):
+    """key of window w == the ASCII k-mer; its halves == the two nodes of compress_kmer (compress.rs:18-28)"""
+    L = hostshim()
+    rng = random.Random(k)
+    oracle.set_k(k)
+    nw = nw_of(k)
+    for _ in range(20):
+        n = rng.randrange(k, k + 70)
+        read = "".join(rng.choice("ACGT") for _ in range(n))
+        packed = oracle.compress_node(read.encode())          # compress_node bit order == packed read
+        for w in range(0, n - k + 1):
+            out = (C.c_uint64 * nw)()
+            L.hs_extract(packed, len(packed), 0, w, k, out)
+            key = words_to_int(out)
+            assert key == kmer_to_int(read[w:w + k]), (k, w)
+            out2 = (C.c_uint64 * nw)()
+            L.hs_extract_aligned(packed, len(packed), 2 * w, k, out2)
+            assert words_to_int(out2) == key
+            src, dst = (C.c_uint64 * nw)(), (C.c_uint64 * nw)()
+            L.hs_endpoints(out, k, src, dst)
+            ck = oracle.compress_kmer(read[w:w + k].encode())
+            half = len(ck) // 2
+            pad = 2 * ((4 - (k - 1) % 4) % 4)
+            assert words_to_int(src) << pad == int.from_bytes(ck[:half], "big")
+            assert words_to_int(dst) << pad == int.from_bytes(ck[half:], "big")
+
+
+@pytest.mark.parametrize("k", KS)
+def test_revcomp_matches_compress_kmer_with_rev_compl(oracle, k):
+    L = hostshim()
+    rng = random.Random(100 + k)
+    oracle.set_k(k)
+    nw = nw_of(k)
+    for _ in range(200):
+        s = "".join(rng.choice("ACGT") for _ in range(k))
+        out = (C.c_uint64 * nw)()
+        L.hs_revcomp(shim_words(kmer_to_int(s), nw), k, out)
+        rc = words_to_int(out)
+        assert int_to_kmer(rc, k) == revcomp_str(s)
+        # oracle: rc k-mer in compress_kmer format decompresses to the same string
+        _, rev = oracle.compress_kmer_with_rev_compl(s.encode())
+        assert oracle.decompress_kmer(rev).decode() == int_to_kmer(rc, k)
+        can = (C.c_uint64 * nw)()
+        L.hs_canonical(shim_words(kmer_to_int(s), nw), k, can)
+        assert words_to_int(can) == min(kmer_to_int(s), rc)
+
+
+def test_palindromes_only_for_even_k():
+    L = hostshim()
+    for k in (4, 6, 32):
+        s = "ACGT" * (k // 4)
+        s = s[:k // 2]
+        pal = s + revcomp_str(s)
+        nw = nw_of(k)
+        out = (C.c_uint64 * nw)()
+        L.hs_revcomp(shim_words(kmer_to_int(pal), nw), k, out)
+        assert words_to_int(out) == kmer_to_int(pal)
+
+
+@pytest.mark.parametrize("k", KS)
+def test_label_matches_compress_edge(oracle, k):
+    """label == compress_edge(k-mer) == kmer_to_edge(compress_kmer(k-mer)) (pt_graph.rs:339-343)"""
+    L = hostshim()
+    rng = random.Random(200 + k)
+    oracle.set_k(k)
+    nw = nw_of(k)
+    stride = 1 + (k + 3) // 4
+    for _ in range(100):
+        s = "".join(rng.choice("ACGT") for _ in range(k))
+        buf = (C.c_uint8 * stride)()
+        L.hs_label(shim_words(kmer_to_int(s), nw), k, buf)
+        assert bytes(buf) == oracle.compress_edge(s.encode())
+        assert bytes(buf) == oracle.kmer_to_edge(oracle.compress_kmer(s.encode()))
+
+
+def test_digits_and_owner_ranges():
+    L = hostshim()
+    rng = random.Random(5)
+    for nw in (1, 2):
+        for _ in range(200):
+            v = rng.getrandbits(62 if nw == 1 else 126)
+            w = shim_words(v, nw)
+            for shift in range(0, 64 * nw - 8, 8):
+                assert L.hs_digit(w, nw, shift, 8) == (v >> shift) & 0xFF
+            assert L.hs_digit(w, nw, 3, 11) == (v >> 3) & 0x7FF
+            for n in (1, 2, 3, 8):
+                assert 0 <= L.hs_owner(w, nw, n) < n
+
+
+def test_splitmix_matches_oracle(oracle):
+    L = hostshim()
+    for x in (0, 1, 2 ** 63, 0x6B61746F6D650001, 2 ** 64 - 1):
+        assert L.hs_splitmix64(x) == oracle.splitmix64(x)
