@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- katome `build` stage on MI355X: k-mers/s (whole job) + distinct-edges/s.
+
+A "step" is one full build of the workload with the packed reads already resident in HBM:
+k-mer extraction -> k-mer table -> sorted distinct edges -> node numbering, endpoints, labels
+(everything `Build::create` + the PtGraph::create post-pass do in the reference), result left in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--reads R]
+
+N>1 is launched by torch.distributed.run, one rank per GPU; reads shard by index and k-mers are
+redistributed by hash with an RCCL all-to-all before insertion (katome_amd/dist.py).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="c3")
+    ap.add_argument("--reads", type=int, default=0, help="override the workload's read count (same coverage)")
+    ap.add_argument("--batch-reads", type=int, default=4 * 1024 * 1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
+    return ap.parse_args()
+
+
+class PhaseTimer:
+    """HIP events on the stream the kernels are launched on (torch's current stream)"""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.pairs = {}
+        self.launches = {}
+
+    def time(self, name):
+        t = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.a = t.torch.cuda.Event(enable_timing=True)
+                self.b = t.torch.cuda.Event(enable_timing=True)
+                self.a.record()
+
+            def __exit__(self, *exc):
+                self.b.record()
+                t.pairs.setdefault(name, []).append((self.a, self.b))
+        return _Ctx()
+
+    def collect(self):
+        self.torch.cuda.synchronize()
+        out = {}
+        for name, pairs in self.pairs.items():
+            ms = [a.elapsed_time(b) for a, b in pairs]
+            out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
+        self.pairs = {}
+        return out
+
+
+def one_build_single(wl, packed, skip, recbuf, batch_reads, timer):
+    """one step on one GPU; returns (n_edges, n_nodes)"""
+    from katome_amd import device as kd
+    hint = int(wl.expected_distinct_canonical() * 2.2)
+    b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint)
+    try:
+        for r0 in range(0, wl.reads, batch_reads):
+            nr = min(batch_reads, wl.reads - r0)
+            with timer.time("extract"):
+                rec = b.extract_fixed(packed, nr, wl.read_len, skip, out=recbuf, first_read=r0)
+            with timer.time("insert"):
+                b.insert(rec)
+        with timer.time("edges"):
+            b.edges()
+        with timer.time("finalize"):
+            dg = b.finalize()
+        return dg.n_edges, dg.n_nodes
+    finally:
+        b.close()
+
+
+def cpu_baseline(wl, sample_reads):
+    """the oracle (C restatement of katome's PtGraph::create) on 1 host core, on a bounded sample"""
+    from oracle import oracle as o
+    n = min(sample_reads, wl.reads)
+    reads = o.synth_reads(0, n, wl.read_len, wl.genome_len, wl.err_rate, wl.n_inject_percent)
+    t0 = time.perf_counter()
+    g = o.build_ascii(reads, wl.k, wl.reverse_complement)
+    dt = time.perf_counter() - t0
+    accepted = g.read_bytes // wl.read_len
+    return {"value": accepted * wl.windows_per_read / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
+            "sample": "first %d reads of workload %s (k=%d, rc=%s): %.1f s on one core of %d; %d distinct edges"
+                      % (n, wl.name, wl.k, wl.reverse_complement, dt, os.cpu_count() or 0, g.n_edges),
+            "distinct_edges_per_s": g.n_edges / dt}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from katome_amd.workloads import WORKLOADS
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the build has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    wl = WORKLOADS[args.workload]
+    if args.reads:
+        wl = wl.scaled(args.reads)
+
+    from katome_amd import device as kd
+    timer = PhaseTimer()
+    W = wl.windows_per_read
+    batch_reads = max(64, (args.batch_reads // 64) * 64)
+
+    if world == 1:
+        packed, skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, wl.n_inject_percent,
+                                      device=local_rank)
+        skip_arg = skip if wl.n_inject_percent else None
+        accepted = wl.reads - (int(skip[:wl.reads].sum().item()) if wl.n_inject_percent else 0)
+        recbuf = torch.empty(min(batch_reads, wl.reads) * W * kd.record_words(wl.k), dtype=torch.int64,
+                             device=packed.device)
+
+        def step():
+            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer)
+    else:
+        from katome_amd import dist as kdist
+        job = kdist.DistBuild(wl, batch_reads=batch_reads, timer=timer)
+        accepted = job.accepted_total
+
+        def step():
+            return job.build()
+
+    for _ in range(args.warmup):
+        step()
+    timer.collect()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_edges = n_nodes = 0
+    for _ in range(args.steps):
+        n_edges, n_nodes = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    phases = timer.collect()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        cnt = torch.tensor([n_edges, n_nodes], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt)
+        n_edges, n_nodes = int(cnt[0].item()), int(cnt[1].item())
+
+    if rank == 0:
+        ms_per_step = dt * 1e3 / args.steps
+        kmers = accepted * W
+        nw = kd.record_words(wl.k)
+        # algorithmic bytes: extraction = ceil(L/4) B read + 8*NW*W B written per read;
+        # insertion = 8*NW B record + 16*NW B slot per insertion
+        alg = {"extract": lambda launches, reads: reads * (wl.stride + 8 * nw * W),
+               "insert": lambda launches, reads: reads * W * (8 * nw + 16 * nw)}
+        kernels = {}
+        reads_per_rank_step = wl.reads / world
+        for name, ph in phases.items():
+            entry = {"launches_per_step": ph["launches"] / args.steps, "avg_ms": ph["avg_ms"],
+                     "ms_per_step": ph["total_ms"] / args.steps}
+            if name in alg:
+                by = alg[name](ph["launches"], reads_per_rank_step * args.steps) / ph["launches"]
+                entry["alg_bytes_per_launch"] = by
+                entry["achieved_GBs"] = by / (ph["avg_ms"] * 1e-3) / 1e9
+                entry["frac_of_hbm_peak"] = entry["achieved_GBs"] / HBM_PEAK_GBS
+            kernels[name] = entry
+        dom = max((n for n in kernels if n in alg), key=lambda n: kernels[n]["ms_per_step"])
+        roofline = {"kernel": {"extract": "extract_fixed_kernel", "insert": "insert_kernel"}[dom], "bound": "hbm",
+                    "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
+                    "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"],
+                    "avg_launch_ms": kernels[dom]["avg_ms"]}
+        line = {
+            "metric": "k-mers/s", "value": kmers / (ms_per_step * 1e-3), "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u64" if nw == 1 else "u128",
+            "data": "synthetic",
+            "config": {"workload": "%s: %d synthetic %d bp reads, k=%d, reverse_complement=%s, genome %d, err %.0e"
+                                   % (wl.name, wl.reads, wl.read_len, wl.k, wl.reverse_complement, wl.genome_len,
+                                      wl.err_rate),
+                       "reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads,
+                       "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
+                       if world > 1 else "1 GPU"},
+            "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
