@@ -37,35 +37,21 @@ def parse_args():
 
 
 class PhaseTimer:
-    """HIP events on the stream the kernels are launched on (torch's current stream)"""
+    """accumulates the library's per-phase HIP-event timings (events are recorded by the library on
+    the stream its kernels are launched on; katome_builder_profile_read)"""
 
     def __init__(self):
-        import torch
-        self.torch = torch
-        self.pairs = {}
-        self.launches = {}
+        self.acc = {}
 
-    def time(self, name):
-        t = self
-
-        class _Ctx:
-            def __enter__(self):
-                self.a = t.torch.cuda.Event(enable_timing=True)
-                self.b = t.torch.cuda.Event(enable_timing=True)
-                self.a.record()
-
-            def __exit__(self, *exc):
-                self.b.record()
-                t.pairs.setdefault(name, []).append((self.a, self.b))
-        return _Ctx()
+    def add(self, prof):
+        for name, (ms, launches) in prof.items():
+            a = self.acc.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += launches
 
     def collect(self):
-        self.torch.cuda.synchronize()
-        out = {}
-        for name, pairs in self.pairs.items():
-            ms = [a.elapsed_time(b) for a, b in pairs]
-            out[name] = {"launches": len(ms), "total_ms": sum(ms), "avg_ms": sum(ms) / len(ms)}
-        self.pairs = {}
+        out = {n: {"launches": c, "total_ms": ms, "avg_ms": ms / c} for n, (ms, c) in self.acc.items() if c}
+        self.acc = {}
         return out
 
 
@@ -74,17 +60,14 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer):
     from katome_amd import device as kd
     hint = int(wl.expected_distinct_canonical() * 2.2)
     b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint)
+    b.profile(True)
     try:
         for r0 in range(0, wl.reads, batch_reads):
             nr = min(batch_reads, wl.reads - r0)
-            with timer.time("extract"):
-                rec = b.extract_fixed(packed, nr, wl.read_len, skip, out=recbuf, first_read=r0)
-            with timer.time("insert"):
-                b.insert(rec)
-        with timer.time("edges"):
-            b.edges()
-        with timer.time("finalize"):
-            dg = b.finalize()
+            rec = b.extract_fixed(packed, nr, wl.read_len, skip, out=recbuf, first_read=r0)
+            b.insert(rec)
+        dg = b.finalize()
+        timer.add(b.profile_read())
         return dg.n_edges, dg.n_nodes
     finally:
         b.close()
@@ -180,11 +163,16 @@ def main():
         # insertion = 8*NW B record + 16*NW B slot per insertion
         alg = {"extract": lambda launches, reads: reads * (wl.stride + 8 * nw * W),
                "insert": lambda launches, reads: reads * W * (8 * nw + 16 * nw)}
+        kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",
+                        "region_order": "radix_hist_kernel+radix_scatter_kernel (HashDigit)",
+                        "emit_edges": "emit_edges_kernel", "sort_edges": "radix sort (edges)",
+                        "node_set": "endpoints + radix sort + unique", "rank": "bucket_index + rank_kernel",
+                        "labels": "labels_kernel"}
         kernels = {}
         reads_per_rank_step = wl.reads / world
         for name, ph in phases.items():
-            entry = {"launches_per_step": ph["launches"] / args.steps, "avg_ms": ph["avg_ms"],
-                     "ms_per_step": ph["total_ms"] / args.steps}
+            entry = {"kernel": kernel_names.get(name, name), "launches_per_step": ph["launches"] / args.steps,
+                     "avg_ms": ph["avg_ms"], "ms_per_step": ph["total_ms"] / args.steps}
             if name in alg:
                 by = alg[name](ph["launches"], reads_per_rank_step * args.steps) / ph["launches"]
                 entry["alg_bytes_per_launch"] = by

@@ -138,6 +138,15 @@ typedef struct katome_builder katome_builder;
 int  katome_builder_create(const katome_settings *s, katome_builder **out);
 void katome_builder_destroy(katome_builder *b);
 
+/* optional per-phase timing with HIP events recorded on the caller's stream (bench.py's roofline
+ * figures).  total_ms / launches have katome_phase_count() entries, named by katome_phase_name():
+ * extract, region_order, insert, emit_edges, sort_edges, node_set, rank, labels.  Reading
+ * synchronises the device and clears the record.                                            */
+int  katome_builder_profile(katome_builder *b, int enable);
+int  katome_builder_profile_read(katome_builder *b, double *total_ms, uint64_t *launches);
+uint32_t katome_phase_count(void);
+const char *katome_phase_name(uint32_t phase);
+
 /* u64 words per k-mer record for this k (1 or 2) */
 uint32_t katome_record_words(uint32_t k);
 

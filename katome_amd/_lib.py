@@ -60,6 +60,10 @@ SYMBOLS = {
     "katome_builder_create": (_i, [C.POINTER(Settings), C.POINTER(_vp)]),
     "katome_builder_destroy": (None, [_vp]),
     "katome_record_words": (_u32, [_u32]),
+    "katome_builder_profile": (_i, [_vp, _i]),
+    "katome_builder_profile_read": (_i, [_vp, C.POINTER(_dbl), u64p]),
+    "katome_phase_count": (_u32, []),
+    "katome_phase_name": (C.c_char_p, [_u32]),
     "katome_dev_extract_fixed": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
     "katome_dev_extract_var": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
     "katome_dev_partition": (_i, [_vp, _vp, _u64, _u32, _vp, u64p, _vp]),

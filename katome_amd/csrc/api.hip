@@ -13,8 +13,28 @@
 
 using namespace katome;
 
+// optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
+enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS, PH_COUNT };
+static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
+                                                  "rank", "labels"};
+struct Profiler {
+    bool on = false;
+    struct Ev { int phase; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    ~Profiler() { clear(); }
+    void clear() { for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } evs.clear(); }
+};
+struct PhaseScope {
+    Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase;
+    PhaseScope(Profiler& prof, int ph, hipStream_t st) : p(prof.on ? &prof : nullptr), s(st), phase(ph) {
+        if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
+    }
+    ~PhaseScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b}); } }
+};
+
 struct katome_builder {
     katome_settings s;
+    Profiler prof;
     uint32_t nw = 1;
     bool rc = false;
     Table table;
@@ -23,6 +43,8 @@ struct katome_builder {
     bool edges_ready = false;
     DevBuf edge_key, edge_weight;
     uint64_t n_edges = 0;
+    // scratch for ordering a batch by table region before it is inserted
+    DevBuf scratch_k[2], scratch_w[2];
     // finalized graph
     DevBuf edge_src, edge_dst, edge_label, node_key;
     uint64_t n_nodes = 0;
@@ -57,6 +79,7 @@ void katome_builder_destroy(katome_builder* b) {
 int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
                              const uint8_t* d_skip, uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
+    PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream);
 }
 
@@ -64,6 +87,7 @@ int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t 
                            const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                            uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
+    PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     return launch_extract_var(b->s.k, b->rc, d_packed, packed_bytes, d_byte_off, d_len, d_win_prefix, n_reads, total_windows,
                               d_records, (hipStream_t)stream);
 }
@@ -101,6 +125,14 @@ static int ensure_table(katome_builder* b, uint64_t incoming, hipStream_t stream
     return table_grow(b->table, want, stream);
 }
 
+// how many 8-bit region passes to run in front of an insert, from the table size (KATOME_REGION_PASSES overrides)
+static int region_passes(uint64_t table_bytes) {
+    if (const char* e = getenv("KATOME_REGION_PASSES")) return std::max(0, std::min(2, atoi(e)));
+    if (table_bytes <= (64ull << 20)) return 0;           // lives in the Infinity Cache anyway
+    if (table_bytes <= (4ull << 30)) return 1;            // 256 regions of <= 16 MiB
+    return 2;                                             // 65536 regions
+}
+
 extern "C" {
 
 int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n_records,
@@ -108,6 +140,24 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
     KCHECK(ensure_table(b, n_records, (hipStream_t)stream));
+    // A table far larger than the on-die caches is hit at random by every record: order the batch by
+    // table region first (streaming passes), so that the insert kernel's working set stays cache-sized.
+    int passes = region_passes(b->table.cap * b->table.slot_bytes());
+    if (passes > 0 && n_records >= (1u << 16)) {
+        for (int i = 0; i < 2; ++i) {
+            if ((i == 0 || passes > 1) && b->scratch_k[i].bytes < n_records * 8 * b->nw) KCHECK(b->scratch_k[i].alloc(n_records * 8 * b->nw));
+            if (d_weights && (i == 0 || passes > 1) && b->scratch_w[i].bytes < n_records * 4) KCHECK(b->scratch_w[i].alloc(n_records * 4));
+        }
+        const uint64_t* k_ord = nullptr; const uint32_t* w_ord = nullptr;
+        {
+            PhaseScope ps(b->prof, PH_REGION_ORDER, (hipStream_t)stream);
+            KCHECK(dev_region_order(d_records, d_weights, n_records, b->nw, passes, b->scratch_k[0].as<u64>(), b->scratch_k[1].as<u64>(),
+                                    b->scratch_w[0].as<u32>(), b->scratch_w[1].as<u32>(), &k_ord, &w_ord, (hipStream_t)stream));
+        }
+        PhaseScope ps(b->prof, PH_INSERT, (hipStream_t)stream);
+        return table_insert(b->table, k_ord, w_ord, n_records, (hipStream_t)stream);
+    }
+    PhaseScope ps(b->prof, PH_INSERT, (hipStream_t)stream);
     return table_insert(b->table, d_records, d_weights, n_records, (hipStream_t)stream);
 }
 int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_records, void* stream) {
@@ -127,10 +177,15 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
     if (!b->edges_ready) {
         b->n_edges = 0;
         if (b->table_ready) {
-            KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->edge_key, b->edge_weight, &b->n_edges, stream));
+            {
+                PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
+                KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->edge_key, b->edge_weight, &b->n_edges, stream));
+            }
+            for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
             b->table.slots.release();                 // the table is spent; its memory serves the sort
             b->table.counter.release();
             b->table_ready = false;
+            PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
             KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
         } else {
             KCHECK(b->edge_key.alloc(16)); KCHECK(b->edge_weight.alloc(16));
@@ -152,23 +207,30 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
     // numbered by ascending packed key
     KCHECK(b->node_key.alloc((2 * E + 1) * 8 * nw));
     u64* cand = b->node_key.as<u64>();
-    KCHECK(dev_endpoints(b->edge_key.as<u64>(), E, k, cand, cand + E * nw, stream));
-    KCHECK(dev_sort(cand, nullptr, 2 * E, nw, node_bits, stream));
-    b->n_nodes = 2 * E;
-    KCHECK(dev_unique(cand, 2 * E, nw, &b->n_nodes, stream));
+    {
+        PhaseScope ps(b->prof, PH_NODE_SET, stream);
+        KCHECK(dev_endpoints(b->edge_key.as<u64>(), E, k, cand, cand + E * nw, stream));
+        KCHECK(dev_sort(cand, nullptr, 2 * E, nw, node_bits, stream));
+        b->n_nodes = 2 * E;
+        KCHECK(dev_unique(cand, 2 * E, nw, &b->n_nodes, stream));
+    }
     KCHECK(b->edge_src.alloc((E + 1) * 8));
     KCHECK(b->edge_dst.alloc((E + 1) * 8));
     {
         DevBuf sk, dk;
         KCHECK(sk.alloc((E + 1) * 8 * nw));
         KCHECK(dk.alloc((E + 1) * 8 * nw));
+        PhaseScope ps(b->prof, PH_RANK, stream);
         KCHECK(dev_endpoints(b->edge_key.as<u64>(), E, k, sk.as<u64>(), dk.as<u64>(), stream));
         KCHECK(dev_rank(cand, b->n_nodes, nw, node_bits, sk.as<u64>(), E, b->edge_src.as<u64>(), stream));
         KCHECK(dev_rank(cand, b->n_nodes, nw, node_bits, dk.as<u64>(), E, b->edge_dst.as<u64>(), stream));
     }
     const uint32_t stride = label_stride_for_k(k);
     KCHECK(b->edge_label.alloc((E + 1) * (size_t)stride + 16));
-    KCHECK(dev_labels(b->edge_key.as<u64>(), E, k, b->edge_label.as<uint8_t>(), stream));
+    {
+        PhaseScope ps(b->prof, PH_LABELS, stream);
+        KCHECK(dev_labels(b->edge_key.as<u64>(), E, k, b->edge_label.as<uint8_t>(), stream));
+    }
     KCHECK_HIP(hipStreamSynchronize(stream));
     if (out) {
         out->n_nodes = b->n_nodes; out->n_edges = E;
@@ -177,6 +239,27 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
         out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = cand;
     }
+    return KATOME_OK;
+}
+
+int katome_builder_profile(katome_builder* b, int enable) {
+    if (!b) { set_error("null argument"); return KATOME_E_ARG; }
+    b->prof.on = enable != 0;
+    b->prof.clear();
+    return KATOME_OK;
+}
+uint32_t katome_phase_count(void) { return PH_COUNT; }
+const char* katome_phase_name(uint32_t phase) { return phase < PH_COUNT ? PHASE_NAMES[phase] : ""; }
+int katome_builder_profile_read(katome_builder* b, double* total_ms, uint64_t* launches) {
+    if (!b || !total_ms || !launches) { set_error("null argument"); return KATOME_E_ARG; }
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    KCHECK_HIP(hipDeviceSynchronize());
+    for (int i = 0; i < PH_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; }
+    for (auto& e : b->prof.evs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { total_ms[e.phase] += ms; launches[e.phase] += 1; }
+    }
+    b->prof.clear();
     return KATOME_OK;
 }
 

@@ -28,6 +28,13 @@ template <int NW> struct OwnerDigit {
     }
 };
 
+// table-region digit: the table slot is mulhi(hash, capacity), monotone in the hash, so the top bits of
+// the hash name the region of the table a record will land in
+template <int NW> struct HashDigit {
+    u32 shift;
+    __device__ __forceinline__ u32 operator()(const Key<NW>& k) const { return (u32)(hash_key(k) >> shift) & (RADIX - 1); }
+};
+
 template <int NW> __device__ __forceinline__ Key<NW> load_key(const u64* p, u64 i) {
     Key<NW> k;
     if (NW == 1) { k.w[0] = p[i]; }
@@ -260,6 +267,32 @@ int dev_partition(const uint64_t* d_in, uint64_t n, uint32_t nw, uint32_t n_part
     KCHECK_HIP(hipStreamSynchronize(stream));
     for (u32 p = 0; p < n_parts; ++p) h_counts[p] = totals[p];
     return KATOME_OK;
+}
+
+// order records by the table region they hash to (1 or 2 stable 8-bit passes over the top hash bits), so
+// that the insert kernel that follows works through the table one cache-sized region at a time.
+// Result lands in `bufs[passes & 1]` where bufs = {scratch_a, scratch_b}; returns that pointer.
+template <int NW>
+static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u64* ka, u64* kb, u32* wa, u32* wb,
+                          const u64** k_out, const u32** w_out, hipStream_t stream) {
+    PassBuffers pb;
+    KCHECK(pb.init(n));
+    const u64* kin = d_in; const u32* win = w_in;
+    u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
+    for (int p = 0; p < passes; ++p) {
+        HashDigit<NW> dg{(u32)(64 - 8 * (passes - p))};     // least significant region byte first
+        if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
+        else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream)));
+        kin = kdst[p & 1]; win = w_in ? wdst[p & 1] : nullptr;
+    }
+    *k_out = kin; *w_out = win;
+    KCHECK_HIP(hipStreamSynchronize(stream));     // pass buffers are freed on return
+    return KATOME_OK;
+}
+int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
+                     uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream) {
+    if (nw == 1) return region_order_t<1>(d_in, w_in, n, passes, ka, kb, wa, wb, k_out, w_out, stream);
+    return region_order_t<2>(d_in, w_in, n, passes, ka, kb, wa, wb, k_out, w_out, stream);
 }
 
 // ---- unique -------------------------------------------------------------------------------------

@@ -76,6 +76,18 @@ class Builder:
         _check(_lib.lib().katome_builder_create(C.byref(self._settings), C.byref(self._h)))
         self.tdev = torch.device("cuda", device)
 
+    # ---- per-phase HIP-event timing (on the stream the kernels run on) ---------------------------
+    def profile(self, enable=True):
+        _check(_lib.lib().katome_builder_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """{phase: (total_ms, launches)} since the last read; synchronises"""
+        L = _lib.lib()
+        n = L.katome_phase_count()
+        ms, cnt = (C.c_double * n)(), (C.c_uint64 * n)()
+        _check(L.katome_builder_profile_read(self._h, ms, cnt))
+        return {L.katome_phase_name(i).decode(): (ms[i], int(cnt[i])) for i in range(n) if cnt[i]}
+
     def close(self):
         if self._h:
             _lib.lib().katome_builder_destroy(self._h)
