@@ -203,6 +203,10 @@ int katome_dev_finalize(katome_builder *b, katome_dev_graph *out, void *stream);
 int katome_dev_edges(katome_builder *b, uint64_t **d_edge_key, uint32_t **d_edge_weight,
                      uint64_t *n_edges, void *stream);
 
+/* The library keeps freed device blocks for reuse (hipMalloc/hipFree of multi-GiB buffers are slow);
+ * this hands them back to the driver.                                                         */
+int katome_dev_release_cache(int device);
+
 /* ---- device primitives the finalize is built from (exported for the multi-GPU driver and
  * for unit tests; each is a hand-written HIP kernel set) -------------------------------- */
 /* LSD radix sort of n keys of `key_words` u64 words on bits [0, key_bits); optional u32

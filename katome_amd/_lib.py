@@ -72,6 +72,7 @@ SYMBOLS = {
     "katome_dev_table_count": (_i, [_vp, u64p]),
     "katome_dev_finalize": (_i, [_vp, C.POINTER(DevGraph), _vp]),
     "katome_dev_edges": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
+    "katome_dev_release_cache": (_i, [_i]),
     "katome_dev_sort": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp]),
     "katome_dev_unique": (_i, [_i, _vp, _u64, _u32, u64p, _vp]),
     "katome_dev_rank": (_i, [_i, _vp, _u64, _u32, _u32, _vp, _u64, _vp, _vp]),

@@ -100,65 +100,88 @@ int katome_dev_partition(katome_builder* b, const uint64_t* d_records, uint64_t 
 
 }  // extern "C"
 
-// make room for `incoming` more distinct keys at load factor <= 0.7
-static int ensure_table(katome_builder* b, uint64_t incoming, hipStream_t stream) {
-    const size_t slot = b->nw == 1 ? 16 : 32;
+// Table capacity policy.  A chunk of records may only be handed to the insert kernel when even in the
+// worst case (every record a new key) the table stays below MAX_LOAD, which bounds every probe sequence;
+// the table is doubled when its real occupancy passes GROW_LOAD.  `room` returns how many records may go in now.
+static constexpr double MAX_LOAD = 0.9, GROW_LOAD = 0.6;
+
+static int table_budget(katome_builder* b, double frac, uint64_t* slots) {
     size_t free_b = 0, total_b = 0;
     KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+    free_b += dev_cached_bytes();           // cached blocks are handed back when an allocation needs them
+    *slots = (uint64_t)(free_b * frac) / (b->nw == 1 ? 16 : 32);
+    return KATOME_OK;
+}
+
+static int ensure_table(katome_builder* b, uint64_t incoming, uint64_t* room, hipStream_t stream) {
     if (!b->table_ready) {
-        uint64_t want = b->s.table_slots_hint ? b->s.table_slots_hint : incoming * 2;
-        want = std::max<uint64_t>(want, (uint64_t)((double)incoming / 0.7) + 1024);
-        const uint64_t budget = (uint64_t)(free_b * 0.6) / slot;
+        uint64_t want = b->s.table_slots_hint ? b->s.table_slots_hint : std::min<uint64_t>(incoming, 1ull << 28) * 2;
+        want = std::max<uint64_t>(want, 1u << 16);
+        uint64_t budget = 0;
+        KCHECK(table_budget(b, 0.6, &budget));
         if (want > budget) want = budget;
-        if ((double)incoming > 0.7 * (double)want) { set_error("k-mer table does not fit in device memory (%llu keys)", (unsigned long long)incoming); return KATOME_E_OOM; }
         KCHECK(table_alloc(b->table, b->nw, want, stream));
         b->table_ready = true;
-        return KATOME_OK;
     }
-    uint64_t occ = 0;
-    KCHECK(table_occupied(b->table, &occ, stream));
-    if ((double)(occ + incoming) <= 0.7 * (double)b->table.cap) return KATOME_OK;
-    uint64_t want = std::max<uint64_t>(b->table.cap * 2, (uint64_t)((double)(occ + incoming) / 0.5));
-    const uint64_t budget = (uint64_t)(free_b * 0.9) / slot;
-    if (want > budget) want = budget;
-    if ((double)(occ + incoming) > 0.7 * (double)want) { set_error("k-mer table cannot grow to %llu keys in device memory", (unsigned long long)(occ + incoming)); return KATOME_E_OOM; }
-    return table_grow(b->table, want, stream);
+    for (;;) {
+        uint64_t occ = 0;
+        KCHECK(table_occupied(b->table, &occ, stream));
+        const uint64_t limit = (uint64_t)(MAX_LOAD * (double)b->table.cap);
+        const uint64_t r = limit > occ ? limit - occ : 0;
+        const bool crowded = (double)occ > GROW_LOAD * (double)b->table.cap;
+        if (!crowded && r >= std::min<uint64_t>(incoming, 1u << 20)) { *room = r; return KATOME_OK; }
+        uint64_t want = b->table.cap * 2, budget = 0;
+        KCHECK(table_budget(b, 0.9, &budget));
+        if (want > budget) want = budget;
+        if (want <= b->table.cap + b->table.cap / 8) {
+            if (r > 0) { *room = r; return KATOME_OK; }      // cannot grow: run on, up to the hard limit
+            set_error("k-mer table is full (%llu keys in %llu slots) and cannot grow in device memory",
+                      (unsigned long long)occ, (unsigned long long)b->table.cap);
+            return KATOME_E_OOM;
+        }
+        KCHECK(table_grow(b->table, want, stream));
+    }
 }
 
 // how many 8-bit region passes to run in front of an insert, from the table size (KATOME_REGION_PASSES overrides)
 static int region_passes(uint64_t table_bytes) {
+    (void)table_bytes;
     if (const char* e = getenv("KATOME_REGION_PASSES")) return std::max(0, std::min(2, atoi(e)));
-    if (table_bytes <= (64ull << 20)) return 0;           // lives in the Infinity Cache anyway
-    if (table_bytes <= (4ull << 30)) return 1;            // 256 regions of <= 16 MiB
-    return 2;                                             // 65536 regions
+    return 0;
 }
 
 extern "C" {
 
 int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n_records,
-                               void* stream) {
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
-    KCHECK(ensure_table(b, n_records, (hipStream_t)stream));
-    // A table far larger than the on-die caches is hit at random by every record: order the batch by
-    // table region first (streaming passes), so that the insert kernel's working set stays cache-sized.
-    int passes = region_passes(b->table.cap * b->table.slot_bytes());
+    if (n_records == 0) return KATOME_OK;
+    uint64_t room = 0;
+    KCHECK(ensure_table(b, n_records, &room, stream));
+    // Optional: order the batch by table region first (streaming radix passes over the hash prefix), so
+    // that the insert kernel's working set stays cache-sized.  Off unless KATOME_REGION_PASSES says so:
+    // measured on MI355X the insert kernel is bound by atomic throughput, not by where the slots live.
+    const uint64_t* k_in = d_records; const uint32_t* w_in = d_weights;
+    const int passes = region_passes(b->table.cap * b->table.slot_bytes());
     if (passes > 0 && n_records >= (1u << 16)) {
         for (int i = 0; i < 2; ++i) {
-            if ((i == 0 || passes > 1) && b->scratch_k[i].bytes < n_records * 8 * b->nw) KCHECK(b->scratch_k[i].alloc(n_records * 8 * b->nw));
-            if (d_weights && (i == 0 || passes > 1) && b->scratch_w[i].bytes < n_records * 4) KCHECK(b->scratch_w[i].alloc(n_records * 4));
+            if ((i == 0 || passes > 1) && b->scratch_k[i].bytes < n_records * 8 * b->nw) KCHECK(b->scratch_k[i].alloc(n_records * 8 * b->nw, stream));
+            if (d_weights && (i == 0 || passes > 1) && b->scratch_w[i].bytes < n_records * 4) KCHECK(b->scratch_w[i].alloc(n_records * 4, stream));
         }
-        const uint64_t* k_ord = nullptr; const uint32_t* w_ord = nullptr;
-        {
-            PhaseScope ps(b->prof, PH_REGION_ORDER, (hipStream_t)stream);
-            KCHECK(dev_region_order(d_records, d_weights, n_records, b->nw, passes, b->scratch_k[0].as<u64>(), b->scratch_k[1].as<u64>(),
-                                    b->scratch_w[0].as<u32>(), b->scratch_w[1].as<u32>(), &k_ord, &w_ord, (hipStream_t)stream));
-        }
-        PhaseScope ps(b->prof, PH_INSERT, (hipStream_t)stream);
-        return table_insert(b->table, k_ord, w_ord, n_records, (hipStream_t)stream);
+        PhaseScope ps(b->prof, PH_REGION_ORDER, stream);
+        KCHECK(dev_region_order(d_records, d_weights, n_records, b->nw, passes, b->scratch_k[0].as<u64>(), b->scratch_k[1].as<u64>(),
+                                b->scratch_w[0].as<u32>(), b->scratch_w[1].as<u32>(), &k_in, &w_in, stream));
     }
-    PhaseScope ps(b->prof, PH_INSERT, (hipStream_t)stream);
-    return table_insert(b->table, d_records, d_weights, n_records, (hipStream_t)stream);
+    for (uint64_t done = 0; done < n_records;) {
+        if (done) KCHECK(ensure_table(b, n_records - done, &room, stream));
+        const uint64_t n = std::min(n_records - done, room);
+        PhaseScope ps(b->prof, PH_INSERT, stream);
+        KCHECK(table_insert(b->table, k_in + done * b->nw, w_in ? w_in + done : nullptr, n, stream));
+        done += n;
+    }
+    return KATOME_OK;
 }
 int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_records, void* stream) {
     return katome_dev_insert_weighted(b, d_records, nullptr, n_records, stream);
@@ -188,7 +211,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
             KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
         } else {
-            KCHECK(b->edge_key.alloc(16)); KCHECK(b->edge_weight.alloc(16));
+            KCHECK(b->edge_key.alloc(16, stream)); KCHECK(b->edge_weight.alloc(16, stream));
         }
         b->edges_ready = true;
     }
@@ -205,7 +228,7 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
     const uint32_t nw = b->nw, k = b->s.k, node_bits = 2 * (k - 1);
     // node set = every source and target (k-1)-mer (add_fasta_node, pt_graph.rs:142-154),
     // numbered by ascending packed key
-    KCHECK(b->node_key.alloc((2 * E + 1) * 8 * nw));
+    KCHECK(b->node_key.alloc((2 * E + 1) * 8 * nw, stream));
     u64* cand = b->node_key.as<u64>();
     {
         PhaseScope ps(b->prof, PH_NODE_SET, stream);
@@ -214,10 +237,10 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         b->n_nodes = 2 * E;
         KCHECK(dev_unique(cand, 2 * E, nw, &b->n_nodes, stream));
     }
-    KCHECK(b->edge_src.alloc((E + 1) * 8));
-    KCHECK(b->edge_dst.alloc((E + 1) * 8));
+    KCHECK(b->edge_src.alloc((E + 1) * 8, stream));
+    KCHECK(b->edge_dst.alloc((E + 1) * 8, stream));
     {
-        DevBuf sk, dk;
+        DevBuf sk(stream), dk(stream);
         KCHECK(sk.alloc((E + 1) * 8 * nw));
         KCHECK(dk.alloc((E + 1) * 8 * nw));
         PhaseScope ps(b->prof, PH_RANK, stream);
@@ -226,7 +249,7 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         KCHECK(dev_rank(cand, b->n_nodes, nw, node_bits, dk.as<u64>(), E, b->edge_dst.as<u64>(), stream));
     }
     const uint32_t stride = label_stride_for_k(k);
-    KCHECK(b->edge_label.alloc((E + 1) * (size_t)stride + 16));
+    KCHECK(b->edge_label.alloc((E + 1) * (size_t)stride + 16, stream));
     {
         PhaseScope ps(b->prof, PH_LABELS, stream);
         KCHECK(dev_labels(b->edge_key.as<u64>(), E, k, b->edge_label.as<uint8_t>(), stream));
@@ -260,6 +283,12 @@ int katome_builder_profile_read(katome_builder* b, double* total_ms, uint64_t* l
         if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { total_ms[e.phase] += ms; launches[e.phase] += 1; }
     }
     b->prof.clear();
+    return KATOME_OK;
+}
+
+int katome_dev_release_cache(int device) {
+    KCHECK(use_device(device));
+    dev_release_cache(device);
     return KATOME_OK;
 }
 
@@ -344,6 +373,7 @@ static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** 
 static uint64_t batch_records(uint32_t nw) {
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 1ull << 24;
+    free_b += dev_cached_bytes();
     uint64_t r = (uint64_t)(free_b / 8) / (8ull * nw);
     return std::min<uint64_t>(std::max<uint64_t>(r, 1ull << 20), 1ull << 30);
 }

@@ -31,32 +31,37 @@ const char* get_error();
         if (_rc != KATOME_OK) return _rc; \
     } while (0)
 
-// device buffer with RAII
+// caching allocator (mem.cpp): blocks are reused across phases and across builds
+int dev_malloc(void** out, size_t bytes, hipStream_t stream);
+void dev_free(void* p, hipStream_t stream);
+size_t dev_cached_bytes();
+void dev_release_cache(int device);
+
+// device buffer with RAII; `stream` is the stream the buffer's users are ordered on
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
+    hipStream_t stream = nullptr;
     DevBuf() {}
+    explicit DevBuf(hipStream_t s) : stream(s) {}
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() { release(); }
     int alloc(size_t n) {
         release();
         if (n == 0) n = 16;
-        hipError_t e = hipMalloc(&p, n);
-        if (e != hipSuccess) {
-            p = nullptr;
-            set_error("hipMalloc(%zu bytes) failed: %s", n, hipGetErrorString(e));
-            (void)hipGetLastError();
-            return KATOME_E_OOM;
-        }
+        int rc = dev_malloc(&p, n, stream);
+        if (rc != KATOME_OK) { p = nullptr; return rc; }
         bytes = n;
         return KATOME_OK;
     }
+    int alloc(size_t n, hipStream_t s) { stream = s; return alloc(n); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) dev_free(p, stream);
         p = nullptr; bytes = 0;
     }
     void* take() { void* q = p; p = nullptr; bytes = 0; return q; }
+    void adopt(void* q, size_t n) { release(); p = q; bytes = n; }
     template <class T> T* as() const { return (T*)p; }
 };
 

@@ -197,7 +197,8 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const u64* __restr
 struct PassBuffers {
     DevBuf counts, chunk, totals;
     u64 nblocks = 0, nchunks = 0;
-    int init(u64 n) {
+    int init(u64 n, hipStream_t stream) {
+        counts.stream = chunk.stream = totals.stream = stream;
         nblocks = (n + SORT_TILE - 1) / SORT_TILE;
         nchunks = (nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
         KCHECK(counts.alloc(nblocks * RADIX * sizeof(u32)));
@@ -225,8 +226,8 @@ template <int NW, bool HAS_VAL>
 static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream) {
     if (n < 2) return KATOME_OK;
     PassBuffers pb;
-    KCHECK(pb.init(n));
-    DevBuf tk, tv;
+    KCHECK(pb.init(n, stream));
+    DevBuf tk(stream), tv(stream);
     KCHECK(tk.alloc(n * 8 * NW));
     if (HAS_VAL) KCHECK(tv.alloc(n * 4));
     u64* kin = d_keys; u64* kout = tk.as<u64>();
@@ -241,8 +242,7 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
         KCHECK_HIP(hipMemcpyAsync(d_keys, kin, n * 8 * NW, hipMemcpyDeviceToDevice, stream));
         if (HAS_VAL) KCHECK_HIP(hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, stream));
     }
-    KCHECK_HIP(hipStreamSynchronize(stream));    // temporaries are freed on return
-    return KATOME_OK;
+    return KATOME_OK;      // temporaries go back to the stream-ordered cache
 }
 
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream) {
@@ -259,7 +259,7 @@ int dev_partition(const uint64_t* d_in, uint64_t n, uint32_t nw, uint32_t n_part
     for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
     if (n == 0) return KATOME_OK;
     PassBuffers pb;
-    KCHECK(pb.init(n));
+    KCHECK(pb.init(n, stream));
     if (nw == 1) { OwnerDigit<1> dg{n_parts}; KCHECK((radix_pass<1, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream))); }
     else         { OwnerDigit<2> dg{n_parts}; KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream))); }
     u64 totals[RADIX];
@@ -276,7 +276,7 @@ template <int NW>
 static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u64* ka, u64* kb, u32* wa, u32* wb,
                           const u64** k_out, const u32** w_out, hipStream_t stream) {
     PassBuffers pb;
-    KCHECK(pb.init(n));
+    KCHECK(pb.init(n, stream));
     const u64* kin = d_in; const u32* win = w_in;
     u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
     for (int p = 0; p < passes; ++p) {
@@ -286,7 +286,6 @@ static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u
         kin = kdst[p & 1]; win = w_in ? wdst[p & 1] : nullptr;
     }
     *k_out = kin; *w_out = win;
-    KCHECK_HIP(hipStreamSynchronize(stream));     // pass buffers are freed on return
     return KATOME_OK;
 }
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
@@ -374,7 +373,7 @@ int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipSt
     if (n < 2) return KATOME_OK;
     const u64 nblocks = (n + UNIQ_TILE - 1) / UNIQ_TILE;
     if (nblocks > 0x7fffffffull) { set_error("unique: too many keys"); return KATOME_E_ARG; }
-    DevBuf counts, offs, tmp;
+    DevBuf counts(stream), offs(stream), tmp(stream);
     KCHECK(counts.alloc(nblocks * 4));
     KCHECK(offs.alloc((nblocks + 1) * 8));
     KCHECK(tmp.alloc(n * 8 * nw));
@@ -387,7 +386,6 @@ int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipSt
     KCHECK_HIP(hipMemcpyAsync(n_out, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     KCHECK_HIP(hipMemcpyAsync(d_keys, tmp.p, *n_out * 8 * nw, hipMemcpyDeviceToDevice, stream));
-    KCHECK_HIP(hipStreamSynchronize(stream));
     return KATOME_OK;
 }
 
@@ -427,7 +425,7 @@ int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t 
     u32 B = 1;
     while ((2ull << B) <= n_sorted / 8 && B < 27) ++B;
     if (B > key_bits) B = key_bits;
-    DevBuf index;
+    DevBuf index(stream);
     KCHECK(index.alloc(((1ull << B) + 2) * 8));
     dim3 block(BLOCK);
     if (nw == 1) {
@@ -438,7 +436,6 @@ int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t 
         hipLaunchKernelGGL(rank_kernel<2>, dim3(grid_for(nq, BLOCK, 256u * 32u)), block, 0, stream, d_sorted, n_sorted, key_bits, B, index.as<u64>(), d_q, nq, d_out);
     }
     KCHECK_HIP(hipGetLastError());
-    KCHECK_HIP(hipStreamSynchronize(stream));     // index is freed on return
     return KATOME_OK;
 }
 

@@ -199,8 +199,8 @@ struct TableAux { u64 occupied; u32 err; u32 pad; };
 int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream) {
     if (cap < 1024) cap = 1024;
     t.nw = nw; t.cap = cap;
-    KCHECK(t.slots.alloc(cap * t.slot_bytes()));
-    KCHECK(t.counter.alloc(sizeof(TableAux)));
+    KCHECK(t.slots.alloc(cap * t.slot_bytes(), stream));
+    KCHECK(t.counter.alloc(sizeof(TableAux), stream));
     KCHECK_HIP(hipMemsetAsync(t.slots.p, 0, cap * t.slot_bytes(), stream));
     KCHECK_HIP(hipMemsetAsync(t.counter.p, 0, sizeof(TableAux), stream));
     return KATOME_OK;
@@ -237,10 +237,8 @@ int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
     else
         hipLaunchKernelGGL(rehash_kernel<2>, grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, nt.slots.as<Slot2>(), nt.cap, &aux->occupied, &aux->err);
     KCHECK_HIP(hipGetLastError());
-    KCHECK_HIP(hipStreamSynchronize(stream));
-    t.slots.release(); t.counter.release();
-    t.slots.p = nt.slots.take(); t.slots.bytes = new_cap * t.slot_bytes();
-    t.counter.p = nt.counter.take(); t.counter.bytes = sizeof(TableAux);
+    t.slots.adopt(nt.slots.take(), new_cap * t.slot_bytes());
+    t.counter.adopt(nt.counter.take(), sizeof(TableAux));
     t.cap = new_cap;
     return KATOME_OK;
 }
@@ -249,9 +247,9 @@ int table_emit_edges(Table& t, uint32_t k, bool rc, DevBuf& keys, DevBuf& weight
     uint64_t occ = 0;
     KCHECK(table_occupied(t, &occ, stream));
     const uint64_t upper = occ * (rc ? 2 : 1);
-    KCHECK(keys.alloc((upper + 1) * 8 * t.nw));
-    KCHECK(weights.alloc((upper + 1) * 4));
-    DevBuf cursor;
+    KCHECK(keys.alloc((upper + 1) * 8 * t.nw, stream));
+    KCHECK(weights.alloc((upper + 1) * 4, stream));
+    DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     dim3 grid(grid_for(t.cap, BLOCK * EMIT_ITEMS, 256u * 16u)), block(BLOCK);

@@ -1,0 +1,206 @@
+"""Multi-GPU build: one process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).
+
+The reference's `Build::create` (builder.rs:42-54) is a single sequential loop; what shards is the
+read set (reads are independent until their k-mers meet in the graph), with ONE real exchange
+step per batch:
+
+  1. each rank extracts the k-mer records of its own reads (contiguous shard by read index);
+  2. records are routed to `owner = mulhi(mix(kmer), world)` -- a single all-to-all of fixed-size
+     records (RCCL has no alltoallv, so split sizes travel first in a tiny all-to-all);
+  3. each rank inserts what it received into its own table: every distinct k-mer lives on exactly
+     one rank, so the union of the ranks' edge lists IS the edge multiset of the whole input and
+     does not depend on the number of ranks;
+  4. node numbering needs a second, small exchange on distinct keys only: each (k-1)-mer is owned
+     by `mulhi(mix(node), world)`; owners number their nodes (rank offset + position in ascending
+     key order) and answer the id queries of the ranks that hold the incident edges.
+
+The 8 GPUs of an MI355X node are a full xGMI mesh, so the all-to-all runs on all 7 links of every
+GPU at once and is bound by the most loaded link; balanced hashing keeps the links even.
+
+`ops` is the set of device primitives; the product default is the HIP library (no CPU fallback).
+"""
+import torch
+import torch.distributed as dist
+
+
+class HipOps:
+    """device primitives of libkatome_gpu.so (katome_amd/device.py)"""
+
+    def __init__(self, k, rc, device, table_slots_hint=0):
+        from . import device as kd
+        self.kd = kd
+        self.k, self.rc = k, rc
+        self.nw = kd.record_words(k)
+        self.dev = device
+        self.b = kd.Builder(k, rc, device=device, table_slots_hint=table_slots_hint)
+        self.tdev = self.b.tdev
+
+    def extract_fixed(self, packed, n_reads, read_len, skip, out, first_read):
+        return self.b.extract_fixed(packed, n_reads, read_len, skip, out=out, first_read=first_read)
+
+    def partition(self, records, n_parts):
+        return self.b.partition(records, n_parts)
+
+    def insert(self, records):
+        self.b.insert(records)
+
+    def edges(self):
+        return self.b.edges()
+
+    def endpoints(self, keys):
+        return self.kd.endpoints(keys.reshape(-1), self.k, self.dev)
+
+    def sort_unique(self, keys, bits):
+        self.kd.sort_keys(keys, bits, self.nw, device=self.dev)
+        return self.kd.unique_sorted(keys, self.nw, device=self.dev)
+
+    def rank(self, sorted_keys, queries, bits):
+        return self.kd.rank_in_sorted(sorted_keys, queries, bits, self.nw, device=self.dev)
+
+    def labels(self, keys):
+        return self.kd.labels(keys.reshape(-1), self.k, self.dev)
+
+    def empty(self, n, dtype=torch.int64):
+        return torch.empty(n, dtype=dtype, device=self.tdev)
+
+    def close(self):
+        self.b.close()
+
+
+def _exchange(send, send_counts, nw, group):
+    """all-to-all of `send` (records grouped by destination rank, send_counts records each).
+    Returns (recv, recv_counts)."""
+    world = dist.get_world_size(group)
+    sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
+    rc = torch.empty(world, dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(rc, sc, group=group)
+    recv_counts = [int(x) for x in rc.tolist()]
+    recv = torch.empty(sum(recv_counts) * nw, dtype=send.dtype, device=send.device)
+    dist.all_to_all_single(recv, send[:sum(send_counts) * nw].contiguous(),
+                           output_split_sizes=[c * nw for c in recv_counts],
+                           input_split_sizes=[c * nw for c in send_counts], group=group)
+    return recv, recv_counts
+
+
+class RankGraph:
+    """this rank's share of the graph: its edges (disjoint from every other rank's) with GLOBAL node ids,
+    and the nodes it owns (global id = node_base + position)"""
+
+    def __init__(self, edge_key, edge_weight, edge_src, edge_dst, edge_label, node_key, node_base, total_nodes,
+                 total_edges):
+        self.edge_key, self.edge_weight = edge_key, edge_weight
+        self.edge_src, self.edge_dst, self.edge_label = edge_src, edge_dst, edge_label
+        self.node_key, self.node_base = node_key, node_base
+        self.n_edges = edge_weight.numel()
+        self.n_nodes = node_key.shape[0]
+        self.total_nodes, self.total_edges = total_nodes, total_edges
+
+
+def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, timer=None):
+    """Steps 1-3 for this rank's reads; afterwards ops' table holds the k-mers this rank owns."""
+    world = dist.get_world_size(group)
+    W = read_len - ops.k + 1
+    recbuf = ops.empty(max(1, min(batch_reads, max(n_reads, 1)) * W * ops.nw))
+    n_batches = (n_reads + batch_reads - 1) // batch_reads
+    # every rank must take part in every all-to-all: agree on the number of rounds
+    nb = torch.tensor([n_batches], dtype=torch.int64, device=recbuf.device)
+    dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=group)
+    for i in range(int(nb.item())):
+        r0 = i * batch_reads
+        nr = max(0, min(batch_reads, n_reads - r0))
+        if nr:
+            rec = ops.extract_fixed(packed, nr, read_len, skip, recbuf, r0)
+            part, counts = ops.partition(rec, world)
+        else:
+            part, counts = recbuf[:0], [0] * world
+        recv, _ = _exchange(part, counts, ops.nw, group)
+        if recv.numel():
+            ops.insert(recv)
+
+
+def finalize_distributed(ops, group=None):
+    """Step 4: sorted distinct edges of this rank + global node ids for their endpoints."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    nw, k = ops.nw, ops.k
+    node_bits = 2 * (k - 1)
+    keys, weights = ops.edges()                       # [E, nw], [E]
+    E = weights.numel()
+    src, dst = ops.endpoints(keys) if E else (keys.reshape(-1), keys.reshape(-1))
+    # distinct endpoint keys seen on this rank
+    cand = torch.cat([src.reshape(-1), dst.reshape(-1)]) if E else ops.empty(0)
+    U = ops.sort_unique(cand, node_bits) if E else cand
+    nU = U.numel() // nw
+    # route them to their owners
+    if nU:
+        P, counts = ops.partition(U, world)
+    else:
+        P, counts = U, [0] * world
+    R, recv_counts = _exchange(P, counts, nw, group)
+    # nodes this rank owns, in ascending key order
+    N = ops.sort_unique(R.clone(), node_bits) if R.numel() else R
+    n_owned = N.numel() // nw
+    all_n = torch.empty(world, dtype=torch.int64, device=keys.device if E else R.device)
+    pieces = [torch.empty(1, dtype=torch.int64, device=all_n.device) for _ in range(world)]
+    dist.all_gather(pieces, torch.tensor([n_owned], dtype=torch.int64, device=all_n.device), group=group)
+    all_n = torch.cat(pieces)
+    bases = torch.cumsum(all_n, 0) - all_n
+    base = int(bases[rank].item())
+    total_nodes = int(all_n.sum().item())
+    # answer the queries: global id of every key received, in the order received
+    ids_R = (ops.rank(N, R, node_bits) + base) if R.numel() else ops.empty(0)
+    ids_P, _ = _exchange(ids_R, recv_counts, 1, group)         # reverse route: same split sizes, mirrored
+    # ids_P is aligned with P (U grouped by owner); bring it back to U's order
+    if nU:
+        pos = ops.rank(U, P[:nU * nw], node_bits)
+        id_of_U = torch.empty(nU, dtype=torch.int64, device=ids_P.device)
+        id_of_U[pos] = ids_P
+        edge_src = id_of_U[ops.rank(U, src.reshape(-1), node_bits)]
+        edge_dst = id_of_U[ops.rank(U, dst.reshape(-1), node_bits)]
+        label = ops.labels(keys)
+    else:
+        edge_src = edge_dst = ops.empty(0)
+        label = torch.empty((0, 1 + (k + 3) // 4), dtype=torch.uint8, device=ids_P.device)
+    tot = torch.tensor([E], dtype=torch.int64, device=all_n.device)
+    dist.all_reduce(tot, group=group)
+    return RankGraph(keys, weights, edge_src, edge_dst, label, N.reshape(-1, nw), base, total_nodes, int(tot.item()))
+
+
+def shard_range(total_reads, world, rank):
+    """contiguous shard of reads for `rank`; starts are multiples of 64 reads (16-byte aligned in the packed buffer)"""
+    per = ((total_reads + world - 1) // world + 63) // 64 * 64
+    r0 = min(total_reads, rank * per)
+    r1 = min(total_reads, r0 + per)
+    return r0, r1
+
+
+class DistBuild:
+    """bench.py's N>1 job: the synthetic workload sharded over the ranks, resident in HBM"""
+
+    def __init__(self, wl, batch_reads, timer=None, group=None):
+        from . import device as kd
+        self.wl, self.batch_reads, self.timer, self.group = wl, batch_reads, timer, group
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.dev = torch.cuda.current_device()
+        r0, r1 = shard_range(wl.reads, self.world, self.rank)
+        self.n_local = r1 - r0
+        self.packed, skip = kd.synth_reads(r0, self.n_local, wl.read_len, wl.genome_len, wl.err_rate,
+                                           wl.n_inject_percent, device=self.dev)
+        self.skip = skip if wl.n_inject_percent else None
+        acc = torch.tensor([self.n_local - (int(skip[:self.n_local].sum().item()) if wl.n_inject_percent else 0)],
+                           dtype=torch.int64, device="cuda")
+        dist.all_reduce(acc, group=group)
+        self.accepted_total = int(acc.item())
+
+    def build(self):
+        wl = self.wl
+        hint = int(wl.expected_distinct_canonical() * 2.2 / self.world * 1.1)
+        ops = HipOps(wl.k, wl.reverse_complement, self.dev, table_slots_hint=hint)
+        ops.b.profile(self.timer is not None)
+        try:
+            build_shard(ops, self.packed, self.skip, self.n_local, wl.read_len, self.batch_reads, self.group)
+            g = finalize_distributed(ops, self.group)
+            if self.timer is not None:
+                self.timer.add(ops.b.profile_read())
+            return g.n_edges, g.n_nodes
+        finally:
+            ops.close()

@@ -1,0 +1,113 @@
+"""Test double for katome_amd.dist's `ops`: the device primitives restated with Python ints / numpy so
+that the multi-rank protocol (routing, split sizes, id resolution) can run under gloo on CPU.
+TEST INFRASTRUCTURE: lives in tests/, never imported by the product."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from helpers import hostshim, int_to_words, words_to_int
+
+INVALID = (1 << 64) - 1
+
+
+def _rc(v, k):
+    out = 0
+    for i in range(k):
+        out |= (3 - ((v >> (2 * i)) & 3)) << (2 * (k - 1 - i))
+    return out
+
+
+class NumpyOps:
+    def __init__(self, k, rc):
+        self.k, self.rc = k, rc
+        self.nw = 1 if 2 * k <= 62 else 2
+        self.table = {}
+        self.L = hostshim()
+
+    # -- conversions -------------------------------------------------------------------------------
+    def _to_tensor(self, ints):
+        a = np.array([w for v in ints for w in (int_to_words(v, self.nw) if v != INVALID else [INVALID] * self.nw)],
+                     dtype=np.uint64)
+        return torch.from_numpy(a.view(np.int64).copy())
+
+    def _to_ints(self, t):
+        a = t.numpy().view(np.uint64).reshape(-1, self.nw)
+        return [INVALID if int(r[0]) == INVALID else words_to_int(r) for r in a]
+
+    def empty(self, n, dtype=torch.int64):
+        return torch.empty(n, dtype=dtype)
+
+    # -- primitives --------------------------------------------------------------------------------
+    def extract_fixed(self, packed, n_reads, read_len, skip, out, first_read):
+        stride = (read_len + 3) // 4
+        p = packed.numpy()
+        recs = []
+        for r in range(first_read, first_read + n_reads):
+            row = p[r * stride:(r + 1) * stride]
+            bases = [(int(b) >> s) & 3 for b in row for s in (6, 4, 2, 0)][:read_len]
+            for w in range(read_len - self.k + 1):
+                if skip is not None and int(skip[r]):
+                    recs.append(INVALID)
+                    continue
+                v = 0
+                for c in bases[w:w + self.k]:
+                    v = (v << 2) | c
+                recs.append(min(v, _rc(v, self.k)) if self.rc else v)
+        return self._to_tensor(recs)
+
+    def _owner(self, v, n_parts):
+        return self.L.hs_owner((C.c_uint64 * self.nw)(*int_to_words(v, self.nw)), self.nw, n_parts)
+
+    def partition(self, records, n_parts):
+        ints = [v for v in self._to_ints(records) if v != INVALID]
+        parts = [[] for _ in range(n_parts)]
+        for v in ints:
+            parts[self._owner(v, n_parts)].append(v)
+        flat = [v for p in parts for v in p]
+        return self._to_tensor(flat), [len(p) for p in parts]
+
+    def insert(self, records):
+        for v in self._to_ints(records):
+            if v != INVALID:
+                self.table[v] = (self.table.get(v, 0) + 1) & 0xFFFFFFFF
+
+    def edges(self):
+        out = {}
+        for v, c in self.table.items():
+            if self.rc:
+                r = _rc(v, self.k)
+                if r == v:
+                    out[v] = (2 * c) & 0xFFFFFFFF
+                else:
+                    out[v] = c
+                    out[r] = c
+            else:
+                out[v] = c
+        keys = sorted(out)
+        return (self._to_tensor(keys).reshape(-1, self.nw),
+                torch.tensor([out[v] for v in keys], dtype=torch.int64).to(torch.int32))
+
+    def endpoints(self, keys):
+        ints = self._to_ints(keys.reshape(-1))
+        mask = (1 << (2 * (self.k - 1))) - 1
+        return self._to_tensor([v >> 2 for v in ints]), self._to_tensor([v & mask for v in ints])
+
+    def sort_unique(self, keys, bits):
+        return self._to_tensor(sorted(set(self._to_ints(keys))))
+
+    def rank(self, sorted_keys, queries, bits):
+        pos = {v: i for i, v in enumerate(self._to_ints(sorted_keys))}
+        return torch.tensor([pos.get(v, -1) for v in self._to_ints(queries)], dtype=torch.int64)
+
+    def labels(self, keys):
+        stride = 1 + (self.k + 3) // 4
+        rows = []
+        for v in self._to_ints(keys.reshape(-1)):
+            buf = (C.c_uint8 * stride)()
+            self.L.hs_label((C.c_uint64 * self.nw)(*int_to_words(v, self.nw)), self.k, buf)
+            rows.append(bytes(buf))
+        return torch.from_numpy(np.frombuffer(b"".join(rows), dtype=np.uint8).reshape(-1, stride).copy())
+
+    def close(self):
+        pass

@@ -1,0 +1,99 @@
+"""world_size-2 (and 3) runs of the multi-GPU protocol (katome_amd/dist.py) on CPU with gloo.
+The device primitives are replaced by a numpy test double (tests/numpy_ops.py); what is under test is
+the host logic: read sharding, routing by owner, variable-size all-to-all, global node numbering.
+The merged result of all ranks must equal the oracle's single-process build, whatever the world size."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    from helpers import pack_reads_ascii, words_to_int
+    from numpy_ops import NumpyOps
+    from katome_amd import dist as kdist
+    from oracle import oracle as o
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        ascii_reads = o.synth_reads(0, n_reads, read_len, 3000, 2e-2, 4)
+        has_n = (ascii_reads == ord("N")).any(axis=1)
+        clean = ascii_reads.copy()
+        clean[clean == ord("N")] = ord("A")
+        r0, r1 = kdist.shard_range(n_reads, world, rank)
+        # every rank packs only its own shard
+        packed = torch.from_numpy(pack_reads_ascii(clean[r0:r1]).reshape(-1).copy()) if r1 > r0 else torch.zeros(0, dtype=torch.uint8)
+        skip = torch.from_numpy(has_n[r0:r1].astype(np.uint8))
+        ops = NumpyOps(k, rc)
+        kdist.build_shard(ops, packed, skip, r1 - r0, read_len, batch_reads)
+        g = kdist.finalize_distributed(ops)
+        nw = ops.nw
+        ek = g.edge_key.numpy().view(np.uint64).reshape(-1, nw)
+        nk = g.node_key.numpy().view(np.uint64).reshape(-1, nw)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
+                 edge_key=np.array([words_to_int(r) for r in ek], dtype=object),
+                 weight=g.edge_weight.numpy(), src=g.edge_src.numpy(), dst=g.edge_dst.numpy(),
+                 label=g.edge_label.numpy(), node_key=np.array([words_to_int(r) for r in nk], dtype=object),
+                 node_base=g.node_base, total_nodes=g.total_nodes, total_edges=g.total_edges)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,k,rc,n_reads,batch", [(2, 11, True, 260, 64), (2, 33, True, 130, 1000), (3, 12, False, 200, 64),
+                                                       (2, 6, True, 70, 64)])
+def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads, batch):
+    read_len = 50
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, k, rc, n_reads, read_len, batch, str(tmp_path)), nprocs=world, join=True)
+    ref = oracle.build_ascii(oracle.synth_reads(0, n_reads, read_len, 3000, 2e-2, 4), k, rc)
+    from helpers import int_to_kmer
+    merged, node_of_id = {}, {}
+    total_nodes = total_edges = None
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
+    for p in parts:
+        total_nodes, total_edges = int(p["total_nodes"]), int(p["total_edges"])
+        for i, key in enumerate(p["node_key"]):
+            gid = int(p["node_base"]) + i
+            assert gid not in node_of_id
+            node_of_id[gid] = int(key)
+    mask = (1 << (2 * (k - 1))) - 1
+    for p in parts:
+        for key, w, s, d, lab in zip(p["edge_key"], p["weight"], p["src"], p["dst"], p["label"]):
+            key = int(key)
+            assert key not in merged                           # every k-mer lives on exactly one rank
+            merged[key] = int(np.uint32(w))
+            assert node_of_id[int(s)] == key >> 2 and node_of_id[int(d)] == key & mask
+            oracle.set_k(k)
+            assert bytes(lab) == oracle.compress_edge(int_to_kmer(key, k).encode())
+    assert sorted((int_to_kmer(v, k), w) for v, w in merged.items()) == ref.multiset()
+    assert (total_nodes, total_edges) == (ref.n_nodes, ref.n_edges)
+    assert sorted(node_of_id) == list(range(ref.n_nodes))       # dense global numbering
+    assert len(set(node_of_id.values())) == ref.n_nodes
+
+
+def test_shard_range_covers_all_reads():
+    from katome_amd.dist import shard_range
+    for total in (0, 1, 63, 64, 65, 1000, 200_000_000):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert all(s[0] % 64 == 0 or s[0] == total for s in spans)

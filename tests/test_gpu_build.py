@@ -276,3 +276,42 @@ def test_properties_at_scale():
     assert torch.equal(dg2.edge_src, dg.edge_src) and torch.equal(dg2.edge_dst, dg.edge_dst)
     assert torch.equal(dg2.edge_label, dg.edge_label)
     b.close(); b2.close()
+
+
+def test_dist_path_on_one_gpu(oracle):
+    """katome_amd/dist.py with the HIP ops (RCCL backend, world size 1 on this box): same graph as the oracle"""
+    import socket
+    import torch.distributed as dist
+    from katome_amd import dist as kdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        for k, rc in ((31, True), (40, True)):
+            n, L = 5000, 150
+            ascii_reads = oracle.synth_reads(0, n, L, 100000, 1e-3, 1)
+            has_n = (ascii_reads == ord("N")).any(axis=1)
+            clean = ascii_reads.copy()
+            clean[clean == ord("N")] = ord("G")
+            packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+            skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+            ops = kdist.HipOps(k, rc, 0)
+            kdist.build_shard(ops, packed, skip, n, L, 1024)
+            g = kdist.finalize_distributed(ops)
+            ref = oracle.build_ascii(ascii_reads, k, rc)
+            assert (g.total_nodes, g.total_edges, g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges, ref.n_nodes, ref.n_edges)
+            nw = ops.nw
+            ek = g.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
+            keys = [int(r[0]) if nw == 1 else (int(r[0]) << 64) | int(r[1]) for r in ek]
+            assert keys == sorted(kmer_to_int(s) for s in ref.kmer_strings())
+            w = dict(zip(keys, g.edge_weight.cpu().numpy().view(np.uint32).tolist()))
+            assert w == {kmer_to_int(s): c for s, c in ref.multiset()}
+            nk = g.node_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
+            nodes = [int(r[0]) if nw == 1 else (int(r[0]) << 64) | int(r[1]) for r in nk]
+            src, dst = g.edge_src.cpu().numpy(), g.edge_dst.cpu().numpy()
+            mask = (1 << (2 * (k - 1))) - 1
+            for e in range(0, len(keys), 97):
+                assert nodes[src[e]] == keys[e] >> 2 and nodes[dst[e]] == keys[e] & mask
+            ops.close()
+    finally:
+        dist.destroy_process_group()
