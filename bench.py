@@ -21,6 +21,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # written from tools/profile_round.sh output
+
+
+def pmc_traffic(kernel_prefix, streaming):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, KiB).  gfx950 correction from the MI355X guide: FETCH_SIZE reads half the bytes of a wide
+    coalesced stream, so it is doubled for streaming kernels; random-access kernels are left uncorrected."""
+    try:
+        pmc = json.load(open(PMC_FILE))
+    except Exception:
+        return None
+    for name, v in pmc.get("kernels", {}).items():
+        if kernel_prefix in name:
+            return {"bytes_per_launch": (v["fetch_kib"] * (2 if streaming else 1) + v["write_kib"]) * 1024.0,
+                    "fetch_kib": v["fetch_kib"], "write_kib": v["write_kib"], "fetch_x2": bool(streaming),
+                    "records_per_launch": v.get("records_per_launch"), "source": pmc.get("source")}
+    return None
 
 
 def parse_args():
@@ -179,12 +196,20 @@ def main():
                 entry["achieved_GBs"] = by / (ph["avg_ms"] * 1e-3) / 1e9
                 entry["frac_of_hbm_peak"] = entry["achieved_GBs"] / HBM_PEAK_GBS
             kernels[name] = entry
+        def roof(name):
+            t = pmc_traffic(kernel_names[name], streaming=(name == "extract")) if world == 1 else None
+            traffic = None
+            if t and t.get("records_per_launch"):
+                # counters were taken per launch of the profiled run; scale to this run's launch size
+                per_rec = t["bytes_per_launch"] / t["records_per_launch"]
+                recs = reads_per_rank_step * W / kernels[name]["launches_per_step"]
+                traffic = per_rec * recs
+            return {"kernel": kernel_names[name], "bound": "hbm", "achieved": kernels[name]["achieved_GBs"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[name]["frac_of_hbm_peak"], "traffic": traffic,
+                    "traffic_detail": t, "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"],
+                    "avg_launch_ms": kernels[name]["avg_ms"]}
         dom = max((n for n in kernels if n in alg), key=lambda n: kernels[n]["ms_per_step"])
-        roofline = {"kernel": {"extract": "extract_fixed_kernel", "insert": "insert_kernel"}[dom], "bound": "hbm",
-                    "achieved": kernels[dom]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": kernels[dom]["frac_of_hbm_peak"], "traffic": None,
-                    "alg_bytes_per_launch": kernels[dom]["alg_bytes_per_launch"],
-                    "avg_launch_ms": kernels[dom]["avg_ms"]}
+        roofline = roof(dom)
         line = {
             "metric": "k-mers/s", "value": kmers / (ms_per_step * 1e-3), "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -197,7 +222,7 @@ def main():
                        "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
                        if world > 1 else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
-            "roofline": roofline, "kernels": kernels,
+            "roofline": roofline, "roofline_extract": roof("extract"), "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
