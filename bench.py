@@ -78,11 +78,16 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer):
     hint = int(wl.expected_distinct_canonical() * 2.2)
     b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint)
     b.profile(True)
+    span = b.tile_span(wl.read_len)
     try:
         for r0 in range(0, wl.reads, batch_reads):
             nr = min(batch_reads, wl.reads - r0)
-            rec = b.extract_fixed(packed, nr, wl.read_len, skip, out=recbuf, first_read=r0)
-            b.insert(rec)
+            if span > 1:      # tiled counting: (L-k+1)/span tile records per read, expanded before the edges are read out
+                rec = b.extract_tiles(packed, nr, wl.read_len, span, skip, out=recbuf, first_read=r0)
+                b.insert_tiles(rec, span)
+            else:
+                rec = b.extract_fixed(packed, nr, wl.read_len, skip, out=recbuf, first_read=r0)
+                b.insert(rec)
         dg = b.finalize()
         timer.add(b.profile_read())
         return dg.n_edges, dg.n_nodes
@@ -178,9 +183,16 @@ def main():
         nw = kd.record_words(wl.k)
         # algorithmic bytes: extraction = ceil(L/4) B read + 8*NW*W B written per read;
         # insertion = 8*NW B record + 16*NW B slot per insertion
-        alg = {"extract": lambda launches, reads: reads * (wl.stride + 8 * nw * W),
-               "insert": lambda launches, reads: reads * W * (8 * nw + 16 * nw)}
+        from katome_amd._lib import lib as _katome_lib
+        span = _katome_lib().katome_tile_span(wl.k, wl.read_len) if world == 1 else 1
+        nwt = _katome_lib().katome_tile_words(wl.k, span)
+        # extraction writes one record per tile of `span` windows (span = 1: one per window);
+        # an insertion moves a record (8*NW B) and touches a slot (16*NW B)
+        alg = {"extract": lambda launches, reads: reads * (wl.stride + 8 * nwt * (W // span)),
+               "insert": lambda launches, reads: reads * W * (8 * nw + 16 * nw),
+               "insert_tiles": lambda launches, reads: reads * (W // span) * (8 * nwt + 16 * nwt)}
         kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",
+                        "insert_tiles": "insert_kernel", "expand_tiles": "expand_tiles_kernel",
                         "region_order": "radix_hist_kernel+radix_scatter_kernel (HashDigit)",
                         "emit_edges": "emit_edges_kernel", "sort_edges": "radix sort (edges)",
                         "node_set": "endpoints + radix sort + unique", "rank": "bucket_index + rank_kernel",
@@ -219,6 +231,7 @@ def main():
                                    % (wl.name, wl.reads, wl.read_len, wl.k, wl.reverse_complement, wl.genome_len,
                                       wl.err_rate),
                        "reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads,
+                       "tile_span": span,
                        "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
                        if world > 1 else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),

@@ -140,7 +140,8 @@ void katome_builder_destroy(katome_builder *b);
 
 /* optional per-phase timing with HIP events recorded on the caller's stream (bench.py's roofline
  * figures).  total_ms / launches have katome_phase_count() entries, named by katome_phase_name():
- * extract, region_order, insert, emit_edges, sort_edges, node_set, rank, labels.  Reading
+ * extract, region_order, insert, emit_edges, sort_edges, node_set, rank, labels, insert_tiles,
+ * expand_tiles.  Reading
  * synchronises the device and clears the record.                                            */
 int  katome_builder_profile(katome_builder *b, int enable);
 int  katome_builder_profile_read(katome_builder *b, double *total_ms, uint64_t *launches);
@@ -178,6 +179,24 @@ int katome_dev_insert(katome_builder *b, const uint64_t *d_records, uint64_t n_r
  * pre-aggregated partial tables)                                                           */
 int katome_dev_insert_weighted(katome_builder *b, const uint64_t *d_records, const uint32_t *d_weights,
                                uint64_t n_records, void *stream);
+
+/* Tiled counting.  The insert kernel is bound by the rate of device-scope atomics, one per window.  For
+ * fixed-length reads the windows can instead be counted in TILES -- the (k+span-1)-mers that cover `span`
+ * consecutive windows, (read_len-k+1)/span per read -- and every distinct tile then adds its count to its
+ * span k-mers at once (same sums as `weight += 1` per window, pt_graph.rs:186-191; ~span x fewer atomics).
+ * katome_tile_span: the span the library would use for these reads (1 = plain counting).
+ * Records of katome_dev_extract_tiles: [n_reads*(read_len-k+1)/span][katome_tile_words(k, span)] u64.
+ * Tiles are expanded into the k-mer table by katome_dev_edges / katome_dev_finalize; the multi-GPU
+ * driver takes them out with katome_dev_expand_tiles as (k-mer, weight) records (library-owned, valid until
+ * the next insert) and routes those to the k-mers' owners (katome_dev_insert_weighted).            */
+uint32_t katome_tile_span(uint32_t k, uint32_t read_len);
+uint32_t katome_tile_words(uint32_t k, uint32_t span);
+int katome_dev_extract_tiles(katome_builder *b, const uint8_t *d_packed, uint64_t n_reads, uint32_t read_len,
+                             uint32_t span, const uint8_t *d_skip, uint64_t *d_records, void *stream);
+int katome_dev_insert_tiles(katome_builder *b, const uint64_t *d_records, uint64_t n_records, uint32_t span,
+                            void *stream);
+int katome_dev_expand_tiles(katome_builder *b, uint64_t **d_keys, uint32_t **d_weights, uint64_t *n_records,
+                            void *stream);
 
 /* number of distinct keys in the table so far (synchronises) */
 int katome_dev_table_count(katome_builder *b, uint64_t *out);

@@ -14,9 +14,10 @@
 using namespace katome;
 
 // optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
-enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS, PH_COUNT };
+enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
+             PH_INSERT_TILES, PH_EXPAND_TILES, PH_COUNT };
 static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
-                                                  "rank", "labels"};
+                                                  "rank", "labels", "insert_tiles", "expand_tiles"};
 struct Profiler {
     bool on = false;
     struct Ev { int phase; hipEvent_t a, b; };
@@ -39,6 +40,10 @@ struct katome_builder {
     bool rc = false;
     Table table;
     bool table_ready = false;
+    // tiled counting: (k+span-1)-mers counted first, expanded into `table` before the edges are read out
+    Table tiles;
+    bool tiles_ready = false;
+    uint32_t span = 1;
     // sorted distinct oriented edges
     bool edges_ready = false;
     DevBuf edge_key, edge_weight;
@@ -83,6 +88,23 @@ int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream);
 }
 
+// Tiled counting (table.hip): largest span in 2..8 that divides the windows per read and keeps the tile in 128 bits
+uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
+    if (getenv("KATOME_NO_TILES") || read_len < k) return 1;
+    const uint32_t W = read_len - k + 1;
+    for (uint32_t s = 8; s >= 2; --s) if (W % s == 0 && k + s - 1 <= 63) return s;
+    return 1;
+}
+uint32_t katome_tile_words(uint32_t k, uint32_t span) { return (uint32_t)key_words_for_k(k + span - 1); }
+
+int katome_dev_extract_tiles(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len, uint32_t span,
+                             const uint8_t* d_skip, uint64_t* d_records, void* stream) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (span < 1 || b->s.k + span - 1 > 63) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
+    return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, span);
+}
+
 int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                            const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                            uint64_t* d_records, void* stream) {
@@ -113,34 +135,64 @@ static int table_budget(katome_builder* b, double frac, uint64_t* slots) {
     return KATOME_OK;
 }
 
-static int ensure_table(katome_builder* b, uint64_t incoming, uint64_t* room, hipStream_t stream) {
-    if (!b->table_ready) {
-        uint64_t want = b->s.table_slots_hint ? b->s.table_slots_hint : std::min<uint64_t>(incoming, 1ull << 28) * 2;
+static int ensure_table(katome_builder* b, Table& table, bool& ready, uint32_t nw, uint64_t hint, uint64_t incoming,
+                        uint64_t* room, hipStream_t stream) {
+    if (!ready) {
+        uint64_t want = hint ? hint : std::min<uint64_t>(incoming, 1ull << 28) * 2;
         want = std::max<uint64_t>(want, 1u << 16);
         uint64_t budget = 0;
-        KCHECK(table_budget(b, 0.6, &budget));
+        KCHECK(table_budget(b, 0.5, &budget));
+        budget = budget * 16 / (nw == 1 ? 16 : 32) * (b->nw == 1 ? 1 : 2);     // table_budget counts b->nw-sized slots
         if (want > budget) want = budget;
-        KCHECK(table_alloc(b->table, b->nw, want, stream));
-        b->table_ready = true;
+        KCHECK(table_alloc(table, nw, want, stream));
+        ready = true;
     }
     for (;;) {
         uint64_t occ = 0;
-        KCHECK(table_occupied(b->table, &occ, stream));
-        const uint64_t limit = (uint64_t)(MAX_LOAD * (double)b->table.cap);
+        KCHECK(table_occupied(table, &occ, stream));
+        const uint64_t limit = (uint64_t)(MAX_LOAD * (double)table.cap);
         const uint64_t r = limit > occ ? limit - occ : 0;
-        const bool crowded = (double)occ > GROW_LOAD * (double)b->table.cap;
+        const bool crowded = (double)occ > GROW_LOAD * (double)table.cap;
         if (!crowded && r >= std::min<uint64_t>(incoming, 1u << 20)) { *room = r; return KATOME_OK; }
-        uint64_t want = b->table.cap * 2, budget = 0;
+        uint64_t want = table.cap * 2, budget = 0;
         KCHECK(table_budget(b, 0.9, &budget));
+        budget = budget * 16 / (nw == 1 ? 16 : 32) * (b->nw == 1 ? 1 : 2);
         if (want > budget) want = budget;
-        if (want <= b->table.cap + b->table.cap / 8) {
+        if (want <= table.cap + table.cap / 8) {
             if (r > 0) { *room = r; return KATOME_OK; }      // cannot grow: run on, up to the hard limit
             set_error("k-mer table is full (%llu keys in %llu slots) and cannot grow in device memory",
-                      (unsigned long long)occ, (unsigned long long)b->table.cap);
+                      (unsigned long long)occ, (unsigned long long)table.cap);
             return KATOME_E_OOM;
         }
-        KCHECK(table_grow(b->table, want, stream));
+        KCHECK(table_grow(table, want, stream));
     }
+}
+static int ensure_table(katome_builder* b, uint64_t incoming, uint64_t* room, hipStream_t stream) {
+    return ensure_table(b, b->table, b->table_ready, b->nw, b->s.table_slots_hint, incoming, room, stream);
+}
+
+// every distinct tile adds its count to its `span` k-mers; afterwards the tile table is released
+static int expand_tiles(katome_builder* b, hipStream_t stream) {
+    if (!b->tiles_ready) return KATOME_OK;
+    uint64_t n_tiles = 0, room = 0;
+    KCHECK(table_occupied(b->tiles, &n_tiles, stream));
+    if (n_tiles) {
+        const uint64_t incoming = n_tiles * b->span;              // worst case: every k-mer new
+        for (;;) {                                                // the whole expansion is one launch: make room for all of it
+            KCHECK(ensure_table(b, incoming, &room, stream));
+            if (room >= incoming) break;
+            uint64_t budget = 0;
+            KCHECK(table_budget(b, 0.9, &budget));
+            const uint64_t want = std::min<uint64_t>(budget, std::max<uint64_t>(b->table.cap * 2, (uint64_t)((double)incoming / 0.5)));
+            if (want <= b->table.cap) { set_error("k-mer table cannot hold the expanded tiles in device memory"); return KATOME_E_OOM; }
+            KCHECK(table_grow(b->table, want, stream));
+        }
+        PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+        KCHECK(table_expand_tiles(b->tiles, b->table, b->s.k, b->span, b->rc, stream));
+    }
+    b->tiles.slots.release(); b->tiles.counter.release();
+    b->tiles_ready = false;
+    return KATOME_OK;
 }
 
 // how many 8-bit region passes to run in front of an insert, from the table size (KATOME_REGION_PASSES overrides)
@@ -187,6 +239,41 @@ int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_r
     return katome_dev_insert_weighted(b, d_records, nullptr, n_records, stream);
 }
 
+int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64_t n_records, uint32_t span, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
+    if (span < 2 || b->s.k + span - 1 > 63 || (b->tiles_ready && span != b->span)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    if (n_records == 0) return KATOME_OK;
+    b->span = span;
+    const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
+    for (uint64_t done = 0; done < n_records;) {
+        uint64_t room = 0;
+        KCHECK(ensure_table(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 2, n_records - done, &room, stream));
+        const uint64_t n = std::min(n_records - done, room);
+        PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+        KCHECK(table_insert(b->tiles, d_records + done * nwt, nullptr, n, stream));
+        done += n;
+    }
+    return KATOME_OK;
+}
+
+/* multi-GPU: the (k-mer, weight) records of this rank's tiles, to be routed to the k-mers' owners */
+int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_weights, uint64_t* n_records, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    *n_records = 0; *d_keys = nullptr; *d_weights = nullptr;
+    if (!b->tiles_ready) return KATOME_OK;
+    {
+        PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+        KCHECK(table_expand_tiles_to_records(b->tiles, b->s.k, b->span, b->rc, b->scratch_k[0], b->scratch_w[0], n_records, stream));
+    }
+    b->tiles.slots.release(); b->tiles.counter.release();
+    b->tiles_ready = false;
+    *d_keys = b->scratch_k[0].as<u64>(); *d_weights = b->scratch_w[0].as<u32>();
+    return KATOME_OK;
+}
+
 int katome_dev_table_count(katome_builder* b, uint64_t* out) {
     KCHECK_HIP(hipSetDevice(b->s.device));
     *out = 0;
@@ -199,6 +286,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (!b->edges_ready) {
         b->n_edges = 0;
+        KCHECK(expand_tiles(b, stream));
         if (b->table_ready) {
             {
                 PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
@@ -410,11 +498,18 @@ int katome_build_packed(const katome_settings* s, const uint8_t* packed, uint64_
             uint64_t reads_per_batch = std::max<uint64_t>(batch_records(b->nw) / W, 64);
             reads_per_batch = (reads_per_batch / 64) * 64;       // keeps batch starts 16-byte aligned
             if ((rc = d_rec.alloc(std::min(reads_per_batch, n_reads) * W * 8 * b->nw + 16))) break;
+            const uint32_t span = katome_tile_span(s->k, read_len);
             for (uint64_t r0 = 0; r0 < n_reads && !rc; r0 += reads_per_batch) {
                 const uint64_t nr = std::min(reads_per_batch, n_reads - r0);
-                rc = katome_dev_extract_fixed(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len,
-                                              skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);
-                if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), nr * W, nullptr);
+                if (span > 1) {       // tiled counting: W/span tile records per read
+                    rc = katome_dev_extract_tiles(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len, span,
+                                                  skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);
+                    if (!rc) rc = katome_dev_insert_tiles(b, d_rec.as<u64>(), nr * (W / span), span, nullptr);
+                } else {
+                    rc = katome_dev_extract_fixed(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len,
+                                                  skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);
+                    if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), nr * W, nullptr);
+                }
             }
             if (rc) break;
         }

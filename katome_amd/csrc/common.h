@@ -94,7 +94,7 @@ inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap =
 
 // ---- launchers implemented in the .hip files (all asynchronous on `stream`) -----------------
 int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
-                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream);
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span = 1);
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                        const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                        uint64_t* d_records, hipStream_t stream);
@@ -123,6 +123,11 @@ int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream);
 int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream);
 int table_occupied(Table& t, uint64_t* out, hipStream_t stream);
 int table_grow(Table& t, uint64_t new_cap, hipStream_t stream);
+// tiled counting: every tile (key of k+span-1 bases, weight n) adds n to each of its `span` k-mers
+int table_expand_tiles(Table& tiles, Table& kmers, uint32_t k, uint32_t span, bool rc, hipStream_t stream);
+// same, but the (k-mer, weight) records are written out instead (multi-GPU: they travel to their owners)
+int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
+                                  uint64_t* n_records, hipStream_t stream);
 // distinct oriented edges (unsorted): allocates d_keys/d_weights
 int table_emit_edges(Table& t, uint32_t k, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_edges, hipStream_t stream);
 

@@ -24,9 +24,9 @@ constexpr int TILE_READS = 64;
 
 template <int NW, bool RC>
 __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t* lds_skip, u32 i, u32 W, u32 magicW,
-                                                    u32 stride_bytes, u32 k) {
+                                                    u32 stride_bytes, u32 k, u32 step) {
     u32 r = __umulhi(i, magicW);           // i / W, exact for i, W < 2^16
-    u32 w = i - r * W;
+    u32 w = (i - r * W) * step;
     if (lds_skip[r]) return key_invalid<NW>();
     u32 bit = r * stride_bytes * 8 + 2 * w;
     u32 di = bit >> 5, sh = bit & 31;
@@ -40,7 +40,7 @@ __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t
 
 template <int NW, bool RC>
 __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __restrict__ packed, u64 n_reads,
-                                                               u32 stride_bytes, u32 k, u32 W, u32 magicW,
+                                                               u32 stride_bytes, u32 k, u32 W, u32 magicW, u32 step,
                                                                const uint8_t* __restrict__ skip, u64* __restrict__ out) {
     extern __shared__ u32 lds[];
     const u32 tile_bytes_max = TILE_READS * stride_bytes;
@@ -79,9 +79,9 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
         if (NW == 1) {
             for (u32 p = tid; 2 * p < nrec; p += BLOCK) {
                 u32 i0 = 2 * p;
-                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i0, W, magicW, stride_bytes, k);
+                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i0, W, magicW, stride_bytes, k, step);
                 if (i0 + 1 < nrec) {
-                    Key<NW> b = record_from_lds<NW, RC>(lds, lds_skip, i0 + 1, W, magicW, stride_bytes, k);
+                    Key<NW> b = record_from_lds<NW, RC>(lds, lds_skip, i0 + 1, W, magicW, stride_bytes, k, step);
                     *reinterpret_cast<ulonglong2*>(out + out0 + i0) = make_ulonglong2(a.w[0], b.w[0]);
                 } else {
                     out[out0 + i0] = a.w[0];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
             }
         } else {
             for (u32 i = tid; i < nrec; i += BLOCK) {
-                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i, W, magicW, stride_bytes, k);
+                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i, W, magicW, stride_bytes, k, step);
                 *reinterpret_cast<ulonglong2*>(out + (out0 + i) * 2) = make_ulonglong2(a.w[0], a.w[NW - 1]);
             }
         }
@@ -115,11 +115,11 @@ struct ArrayAddr {
     __device__ __forceinline__ bool skipped(u64) const { return false; }
 };
 struct FixedAddr {
-    u64 stride_bytes; u64 W; const uint8_t* skip; u64 r;
+    u64 stride_bytes; u64 W; const uint8_t* skip; u64 r; u32 step;
     __device__ __forceinline__ void locate(u64 i, u64& boff, u32& w) {
         r = i / W;
         boff = r * stride_bytes;
-        w = (u32)(i - r * W);
+        w = (u32)(i - r * W) * step;
     }
     __device__ __forceinline__ bool skipped(u64) const { return skip && skip[r]; }
 };
@@ -157,10 +157,13 @@ __global__ __launch_bounds__(BLOCK) void extract_general_kernel(const uint8_t* _
     }
 }
 
+// `k` is the length of the window that becomes a record; `step` the distance between consecutive window
+// starts and W the records per read (step 1, W = L-k+1: every k-mer; step = span, W = (L-k0+1)/span with
+// k = k0+span-1: the tiles of `span` consecutive k0-mers that the tiled counting path stores).
 template <int NW, bool RC>
-static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u32 k, const uint8_t* d_skip, u64* d_records,
-                           hipStream_t stream) {
-    const u32 stride = (read_len + 3) / 4, W = read_len - k + 1;
+static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u32 k, u32 step, u32 W, const uint8_t* d_skip,
+                           u64* d_records, hipStream_t stream) {
+    const u32 stride = (read_len + 3) / 4;
     const u64 total = n_reads * (u64)W;
     if (total == 0) return KATOME_OK;
     const bool lds_ok = stride <= 256 && (u64)TILE_READS * W < 65536 && ((uintptr_t)d_packed % 16 == 0) &&
@@ -172,9 +175,9 @@ static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u
         const u64 n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
         unsigned grid = (unsigned)(n_tiles < 256u * 8u ? n_tiles : 256u * 8u);
         hipLaunchKernelGGL((extract_fixed_kernel<NW, RC>), dim3(grid), dim3(BLOCK), lds_bytes, stream, d_packed, n_reads,
-                           stride, k, W, magicW, d_skip, d_records);
+                           stride, k, W, magicW, step, d_skip, d_records);
     } else {
-        FixedAddr a{stride, W, d_skip, 0};
+        FixedAddr a{stride, W, d_skip, 0, step};
         hipLaunchKernelGGL((extract_general_kernel<NW, RC, FixedAddr>), dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, stream,
                            d_packed, n_reads * (u64)stride, a, total, k, d_records);
     }
@@ -183,13 +186,15 @@ static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u
 }
 
 int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
-                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream) {
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span) {
     if (read_len < k) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }   // pt_graph.rs:278
-    const int nw = key_words_for_k(k);
-    if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, k, d_skip, d_records, stream)
-                           : extract_fixed_t<1, false>(d_packed, n_reads, read_len, k, d_skip, d_records, stream);
-    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, k, d_skip, d_records, stream)
-              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, k, d_skip, d_records, stream);
+    if (span == 0 || (read_len - k + 1) % span) { set_error("tile span %u does not divide the windows per read", span); return KATOME_E_ARG; }
+    const u32 kk = k + span - 1, W = (read_len - k + 1) / span;
+    const int nw = key_words_for_k(kk);
+    if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream)
+                           : extract_fixed_t<1, false>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream);
+    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream)
+              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream);
 }
 
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,

@@ -134,6 +134,15 @@ template <int NW> KD Key<NW> canonical(const Key<NW>& a, u32 k) {
 template <int NW> KD Key<NW> source_node(const Key<NW>& kmer) { return key_shr(kmer, 2); }
 template <int NW> KD Key<NW> target_node(const Key<NW>& kmer, u32 k) { return key_low_bits(kmer, 2 * (k - 1)); }
 
+// ---- tiles: a tile is the (k+span-1)-mer covering `span` consecutive k-mers of a read ------------
+KD Key<1> narrow_key(const Key<1>& a, Key<1>*) { return a; }
+KD Key<2> narrow_key(const Key<2>& a, Key<2>*) { return a; }
+KD Key<1> narrow_key(const Key<2>& a, Key<1>*) { Key<1> r; r.w[0] = a.w[1]; return r; }
+// the o-th k-mer (o = 0 is the leftmost) of a tile of span k-mers
+template <int NWT, int NWK> KD Key<NWK> sub_kmer(const Key<NWT>& tile, u32 k, u32 span, u32 o) {
+    return narrow_key(key_low_bits(key_shr(tile, 2 * (span - 1 - o)), 2 * k), (Key<NWK>*)nullptr);
+}
+
 // ---- compress_edge label (compress.rs:250-271) ----------------------------------------------
 KD u32 label_stride_for_k(u32 k) { return 1 + (k + 3) / 4; }
 KD u32 label_pad_for_k(u32 k) { return (4 - k % 4) % 4; }

@@ -88,6 +88,8 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
     return 0;
 }
 
+struct TableAux { u64 occupied; u32 err; u32 pad; };
+
 template <int NW> struct SlotOf;
 template <> struct SlotOf<1> { typedef Slot1 type; };
 template <> struct SlotOf<2> { typedef Slot2 type; };
@@ -130,6 +132,59 @@ __global__ __launch_bounds__(BLOCK) void rehash_kernel(const typename SlotOf<NW>
     }
     fresh = wave_sum(fresh);
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(occupied, (u64)fresh);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Tiled counting.  Adding 1 to the weight of each of the W k-mers of a read costs W device-scope atomics,
+// and the atomic rate (~2.5e10/s on MI355X, wherever the slots live) bounds the whole build.  The reads are
+// therefore first counted as TILES -- the (k+span-1)-mers that cover `span` consecutive windows, W/span per
+// read -- and each distinct tile then adds its count to its `span` k-mers at once.  The weights are the
+// same sums (pt_graph.rs:186-191 is `+= 1` per window; addition commutes), with ~span x fewer atomics.
+// ---------------------------------------------------------------------------------------------
+template <int NWT, int NWK, bool RC, bool TO_TABLE>
+__global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename SlotOf<NWT>::type* __restrict__ tiles, u64 tile_cap,
+                                                              u32 k, u32 span, typename SlotOf<NWK>::type* kmers, u64 kmer_cap,
+                                                              u64* occupied, u32* err, u64* __restrict__ out_keys,
+                                                              u32* __restrict__ out_w, u64* cursor) {
+    u32 fresh = 0;
+    const u32 lane = threadIdx.x & 63;
+    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < tile_cap; i0 += (u64)gridDim.x * BLOCK) {
+        const u64 i = i0 + threadIdx.x;
+        Key<NWT> tile; u32 n = 0; bool have = false;
+        if (i < tile_cap) {
+            typename SlotOf<NWT>::type s = tiles[i];
+            have = slot_key(s, tile);
+            n = s.count;
+        }
+        if (TO_TABLE) {
+            if (have)
+                for (u32 o = 0; o < span; ++o) {
+                    Key<NWK> x = sub_kmer<NWT, NWK>(tile, k, span, o);
+                    if (RC) x = canonical(x, k);
+                    fresh += upsert(kmers, kmer_cap, x, n, err);
+                }
+        } else {
+            // wave-aggregated output cursor: span records per occupied tile
+            const u64 m = __ballot(have);
+            const u32 before = __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
+            u64 base = 0;
+            if (lane == 0 && m) base = atomicAdd(cursor, (u64)__popcll(m) * span);
+            base = __shfl(base, 0, 64);
+            if (have)
+                for (u32 o = 0; o < span; ++o) {
+                    Key<NWK> x = sub_kmer<NWT, NWK>(tile, k, span, o);
+                    if (RC) x = canonical(x, k);
+                    const u64 pos = base + (u64)before * span + o;
+#pragma unroll
+                    for (int q = 0; q < NWK; ++q) out_keys[pos * NWK + q] = x.w[q];
+                    out_w[pos] = n;
+                }
+        }
+    }
+    if (TO_TABLE) {
+        fresh = wave_sum(fresh);
+        if (lane == 0 && fresh) atomicAdd(occupied, (u64)fresh);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -194,7 +249,6 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
 }
 
 // ---- host side --------------------------------------------------------------------------------
-struct TableAux { u64 occupied; u32 err; u32 pad; };
 
 int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream) {
     if (cap < 1024) cap = 1024;
@@ -240,6 +294,44 @@ int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
     t.slots.adopt(nt.slots.take(), new_cap * t.slot_bytes());
     t.counter.adopt(nt.counter.take(), sizeof(TableAux));
     t.cap = new_cap;
+    return KATOME_OK;
+}
+
+template <bool TO_TABLE>
+static int expand_launch(Table& tiles, Table* kmers, uint32_t k, uint32_t span, bool rc, u64* out_keys, u32* out_w, u64* cursor,
+                         hipStream_t stream) {
+    const uint32_t nwk = (uint32_t)key_words_for_k(k);
+    TableAux* aux = kmers ? kmers->counter.as<TableAux>() : nullptr;
+    dim3 grid(grid_for(tiles.cap, BLOCK, 256u * 32u)), block(BLOCK);
+#define KATOME_EXPAND(NWT, NWK, RCV)                                                                                          \
+    hipLaunchKernelGGL((expand_tiles_kernel<NWT, NWK, RCV, TO_TABLE>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), \
+                       tiles.cap, k, span, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
+                       aux ? &aux->occupied : nullptr, aux ? &aux->err : nullptr, out_keys, out_w, cursor)
+    if (tiles.nw == 1) { if (rc) KATOME_EXPAND(1, 1, true); else KATOME_EXPAND(1, 1, false); }
+    else if (nwk == 1) { if (rc) KATOME_EXPAND(2, 1, true); else KATOME_EXPAND(2, 1, false); }
+    else               { if (rc) KATOME_EXPAND(2, 2, true); else KATOME_EXPAND(2, 2, false); }
+#undef KATOME_EXPAND
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+int table_expand_tiles(Table& tiles, Table& kmers, uint32_t k, uint32_t span, bool rc, hipStream_t stream) {
+    return expand_launch<true>(tiles, &kmers, k, span, rc, nullptr, nullptr, nullptr, stream);
+}
+
+int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
+                                  uint64_t* n_records, hipStream_t stream) {
+    uint64_t occ = 0;
+    KCHECK(table_occupied(tiles, &occ, stream));
+    const uint32_t nwk = (uint32_t)key_words_for_k(k);
+    KCHECK(keys.alloc((occ * span + 1) * 8 * nwk, stream));
+    KCHECK(weights.alloc((occ * span + 1) * 4, stream));
+    DevBuf cursor(stream);
+    KCHECK(cursor.alloc(8));
+    KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    KCHECK(expand_launch<false>(tiles, nullptr, k, span, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream));
+    KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
     return KATOME_OK;
 }
 

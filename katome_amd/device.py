@@ -111,6 +111,36 @@ class Builder:
         _check(_lib.lib().katome_dev_extract_fixed(self._h, p, n_reads, read_len, sk, _ptr(out), _stream()))
         return out[:n_rec * self.nw]
 
+    # ---- tiled counting: (k+span-1)-mers covering `span` consecutive windows ---------------------------
+    def tile_span(self, read_len):
+        return _lib.lib().katome_tile_span(self.k, read_len)
+
+    def tile_words(self, span):
+        return _lib.lib().katome_tile_words(self.k, span)
+
+    def extract_tiles(self, packed, n_reads, read_len, span, skip=None, out=None, first_read=0):
+        stride = (read_len + 3) // 4
+        nwt = self.tile_words(span)
+        n_rec = n_reads * ((read_len - self.k + 1) // span)
+        if out is None:
+            out = torch.empty(max(n_rec, 1) * nwt, dtype=torch.int64, device=self.tdev)
+        assert out.numel() >= n_rec * nwt
+        p = C.c_void_p(packed.data_ptr() + first_read * stride)
+        sk = C.c_void_p(skip.data_ptr() + first_read) if skip is not None else None
+        _check(_lib.lib().katome_dev_extract_tiles(self._h, p, n_reads, read_len, span, sk, _ptr(out), _stream()))
+        return out[:n_rec * nwt]
+
+    def insert_tiles(self, records, span):
+        n = records.numel() // self.tile_words(span)
+        _check(_lib.lib().katome_dev_insert_tiles(self._h, _ptr(records), n, span, _stream()))
+
+    def expand_tiles(self):
+        """(k-mer keys [n*nw] int64 view, weights [n] int32 view) of this builder's tiles; the tile table is released"""
+        pk, pw, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(_lib.lib().katome_dev_expand_tiles(self._h, C.byref(pk), C.byref(pw), C.byref(n), _stream()))
+        return (_view(pk.value, (n.value * self.nw,), "<i8", self, self.tdev),
+                _view(pw.value, (n.value,), "<i4", self, self.tdev))
+
     def extract_var(self, packed, byte_off, lens, win_prefix, total_windows, out=None):
         n_reads = lens.numel()
         if out is None:

@@ -315,3 +315,51 @@ def test_dist_path_on_one_gpu(oracle):
             ops.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,L,rc", [(31, 150, True), (31, 150, False), (31, 100, True), (32, 75, True), (12, 51, True),
+                                    (40, 103, True), (5, 20, True)])
+def test_tiled_counting_equals_plain_counting(oracle, k, L, rc):
+    """tiles of `span` consecutive windows, counted and expanded, give the same table as one insert per window"""
+    from katome_amd import device as kd
+    n = 4000
+    ascii_reads = oracle.synth_reads(3, n, L, 30000, 5e-3, 2)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("T")
+    packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+    skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+    plain = kd.Builder(k, rc)
+    plain.insert(plain.extract_fixed(packed, n, L, skip))
+    ek0, ew0 = plain.edges()
+    tiled = kd.Builder(k, rc, table_slots_hint=4096)
+    span = tiled.tile_span(L)
+    W = L - k + 1
+    assert span == max([s for s in range(2, 9) if W % s == 0 and k + s - 1 <= 63] + [1])
+    if span == 1:
+        pytest.skip("no span divides the windows of this read length")
+    half = (n // 2 // 64) * 64
+    for first, cnt in ((0, half), (half, n - half)):
+        tiled.insert_tiles(tiled.extract_tiles(packed, cnt, L, span, skip, first_read=first), span)
+    ek1, ew1 = tiled.edges()
+    torch.cuda.synchronize()
+    assert torch.equal(ek0, ek1) and torch.equal(ew0, ew1)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert ek1.shape[0] == ref.n_edges
+    # the multi-GPU route: tiles -> (k-mer, weight) records -> weighted insert
+    t2 = kd.Builder(k, rc)
+    t2.insert_tiles(t2.extract_tiles(packed, n, L, span, skip), span)
+    keys, weights = t2.expand_tiles()
+    t3 = kd.Builder(k, rc)
+    t3.insert(keys.clone(), weights.clone())
+    ek2, ew2 = t3.edges()
+    assert torch.equal(ek0, ek2) and torch.equal(ew0, ew2)
+    for b in (plain, tiled, t2, t3):
+        b.close()
+
+
+def test_plain_path_when_tiles_disabled(oracle, golden_dir, monkeypatch):
+    monkeypatch.setenv("KATOME_NO_TILES", "1")
+    path = os.path.join(golden_dir, "data3.txt")
+    g, _ = _build_files([path], 31, True)
+    assert g.multiset() == oracle.build_files([path], 31, True).multiset()
