@@ -56,7 +56,8 @@ typedef struct {
  * What `Convert<GpuGIR> for PtGraph` needs (pt_graph.rs:33): node count, and per edge
  * (source, target, weight, label) with the label in compress_edge format (compress.rs:250-271),
  * i.e. what SEQUENCES[EdgeSlice.idx()] holds after PtGraph::create (pt_graph.rs:339-343).
- * Edge order = ascending packed k-mer; node ids = rank of the packed (k-1)-mer (deterministic). */
+ * Edge order = ascending packed k-mer.  Node ids (deterministic): the nodes that have out-edges in
+ * ascending packed-(k-1)-mer order, then the nodes without out-edges in ascending order.          */
 typedef struct {
     uint64_t n_nodes, n_edges;
     uint64_t read_bytes;          /* sum of accepted read lengths (builder.rs:158)              */
@@ -209,7 +210,7 @@ typedef struct {
     uint32_t *d_edge_weight;
     uint64_t *d_edge_src, *d_edge_dst;
     uint8_t  *d_edge_label;
-    uint64_t *d_node_key;     /* [n_nodes][key_words], ascending */
+    uint64_t *d_node_key;     /* [n_nodes][key_words]: sources ascending, then out-edge-less nodes ascending */
 } katome_dev_graph;
 
 /* Table -> distinct oriented edges, sorted by packed k-mer (both strands when

@@ -313,29 +313,16 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
     hipStream_t stream = (hipStream_t)stream_;
     KCHECK(katome_dev_edges(b, nullptr, nullptr, nullptr, stream_));
     const uint64_t E = b->n_edges;
-    const uint32_t nw = b->nw, k = b->s.k, node_bits = 2 * (k - 1);
-    // node set = every source and target (k-1)-mer (add_fasta_node, pt_graph.rs:142-154),
-    // numbered by ascending packed key
-    KCHECK(b->node_key.alloc((2 * E + 1) * 8 * nw, stream));
-    u64* cand = b->node_key.as<u64>();
-    {
-        PhaseScope ps(b->prof, PH_NODE_SET, stream);
-        KCHECK(dev_endpoints(b->edge_key.as<u64>(), E, k, cand, cand + E * nw, stream));
-        KCHECK(dev_sort(cand, nullptr, 2 * E, nw, node_bits, stream));
-        b->n_nodes = 2 * E;
-        KCHECK(dev_unique(cand, 2 * E, nw, &b->n_nodes, stream));
-    }
+    const uint32_t nw = b->nw, k = b->s.k;
+    // node set = every source and target (k-1)-mer (add_fasta_node, pt_graph.rs:142-154): read off the
+    // sorted edge list (radix.hip, dev_node_ids)
     KCHECK(b->edge_src.alloc((E + 1) * 8, stream));
     KCHECK(b->edge_dst.alloc((E + 1) * 8, stream));
     {
-        DevBuf sk(stream), dk(stream);
-        KCHECK(sk.alloc((E + 1) * 8 * nw));
-        KCHECK(dk.alloc((E + 1) * 8 * nw));
-        PhaseScope ps(b->prof, PH_RANK, stream);
-        KCHECK(dev_endpoints(b->edge_key.as<u64>(), E, k, sk.as<u64>(), dk.as<u64>(), stream));
-        KCHECK(dev_rank(cand, b->n_nodes, nw, node_bits, sk.as<u64>(), E, b->edge_src.as<u64>(), stream));
-        KCHECK(dev_rank(cand, b->n_nodes, nw, node_bits, dk.as<u64>(), E, b->edge_dst.as<u64>(), stream));
+        PhaseScope ps(b->prof, PH_NODE_SET, stream);
+        KCHECK(dev_node_ids(b->edge_key.as<u64>(), E, k, b->node_key, b->edge_src.as<u64>(), b->edge_dst.as<u64>(), &b->n_nodes, stream));
     }
+    u64* cand = b->node_key.as<u64>();
     const uint32_t stride = label_stride_for_k(k);
     KCHECK(b->edge_label.alloc((E + 1) * (size_t)stride + 16, stream));
     {

@@ -439,6 +439,164 @@ int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t 
     return KATOME_OK;
 }
 
+// ---- node numbering straight from the sorted edge list --------------------------------------------
+// Edges are sorted by packed k-mer, so their source (k-1)-mers (key >> 2) are sorted too: the nodes
+// that have out-edges are the run heads of that sequence -- no sort needed.  Targets are looked up in
+// that list; the few that are absent (nodes without out-edges: read ends nothing continues) are
+// collected, sorted and appended.  Node ids: sources in ascending key order, then the out-edge-less
+// nodes in ascending key order (add_fasta_node, pt_graph.rs:142-154, numbers in first-seen order; no
+// order is pinned by the reference -- DESIGN.md section 1).
+template <int NW> __device__ __forceinline__ bool is_src_head(const u64* keys, u64 i) {
+    return i == 0 || !key_eq(key_shr(load_key<NW>(keys, i), 2), key_shr(load_key<NW>(keys, i - 1), 2));
+}
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void src_count_kernel(const u64* __restrict__ keys, u64 n, u32* __restrict__ block_counts) {
+    __shared__ u32 wsum[BLOCK / 64];
+    const u64 base = (u64)blockIdx.x * UNIQ_TILE + (u64)threadIdx.x * UNIQ_ITEMS;
+    u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < UNIQ_ITEMS; ++j) if (base + j < n && is_src_head<NW>(keys, base + j)) ++mine;
+    u32 total;
+    (void)block_excl_scan(mine, wsum, total);
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
+}
+// writes the distinct sources (= node keys) and every edge's source id
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void src_write_kernel(const u64* __restrict__ keys, u64 n, const u64* __restrict__ block_offs,
+                                                           u64* __restrict__ nodes, u64* __restrict__ edge_src) {
+    __shared__ u32 wsum[BLOCK / 64];
+    const u64 base = (u64)blockIdx.x * UNIQ_TILE + (u64)threadIdx.x * UNIQ_ITEMS;
+    bool head[UNIQ_ITEMS]; u32 mine = 0;
+#pragma unroll
+    for (int j = 0; j < UNIQ_ITEMS; ++j) { head[j] = base + j < n && is_src_head<NW>(keys, base + j); mine += head[j]; }
+    u32 total;
+    u64 pos = block_offs[blockIdx.x] + block_excl_scan(mine, wsum, total);     // heads before this thread's items
+#pragma unroll
+    for (int j = 0; j < UNIQ_ITEMS; ++j) {
+        if (base + j >= n) break;
+        if (head[j]) { store_key<NW>(nodes, pos, key_shr(load_key<NW>(keys, base + j), 2)); ++pos; }
+        edge_src[base + j] = pos - 1;
+    }
+}
+// edge_dst[e] = position of the edge's target in `nodes`, or ~0 when it is not a source of any edge
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void dst_rank_kernel(const u64* __restrict__ nodes, u64 n_nodes, u32 key_bits, u32 B,
+                                                          const u64* __restrict__ index, const u64* __restrict__ keys, u64 n,
+                                                          u32 k, u64* __restrict__ edge_dst, u64* __restrict__ n_missing) {
+    u32 miss = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Key<NW> key = target_node(load_key<NW>(keys, i), k);
+        u32 b = top_bits(key, key_bits, B);
+        u64 lo = index[b], hi = index[b + 1];
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if (key_lt(load_key<NW>(nodes, mid), key)) lo = mid + 1; else hi = mid;
+        }
+        const bool found = lo < n_nodes && key_eq(load_key<NW>(nodes, lo), key);
+        edge_dst[i] = found ? lo : ~0ull;
+        miss += !found;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) miss += __shfl_down(miss, o, 64);
+    if ((threadIdx.x & 63) == 0 && miss) atomicAdd((unsigned long long*)n_missing, (unsigned long long)miss);
+}
+// gather the targets that were not found (unordered; they are sorted afterwards)
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void missing_gather_kernel(const u64* __restrict__ keys, u64 n, u32 k, const u64* __restrict__ edge_dst,
+                                                                u64* __restrict__ out, u64* cursor) {
+    const u32 lane = threadIdx.x & 63;
+    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < n; i0 += (u64)gridDim.x * BLOCK) {
+        const u64 i = i0 + threadIdx.x;
+        const bool miss = i < n && edge_dst[i] == ~0ull;
+        const u64 m = __ballot(miss);
+        if (!m) continue;
+        u64 base = 0;
+        if (lane == 0) base = atomicAdd((unsigned long long*)cursor, (unsigned long long)__popcll(m));
+        base = __shfl(base, 0, 64);
+        if (miss) store_key<NW>(out, base + __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull)), target_node(load_key<NW>(keys, i), k));
+    }
+}
+// second lookup, only for the edges whose target was not a source: id = n_sources + rank among the extra nodes
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restrict__ keys, u64 n, u32 k, const u64* __restrict__ extra,
+                                                              u64 n_extra, u64 n_sources, u64* __restrict__ edge_dst) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        if (edge_dst[i] != ~0ull) continue;
+        Key<NW> key = target_node(load_key<NW>(keys, i), k);
+        u64 lo = 0, hi = n_extra;
+        while (lo < hi) {
+            u64 mid = (lo + hi) >> 1;
+            if (key_lt(load_key<NW>(extra, mid), key)) lo = mid + 1; else hi = mid;
+        }
+        edge_dst[i] = n_sources + lo;
+    }
+}
+
+template <int NW>
+static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64* edge_src, u64* edge_dst, u64* n_nodes,
+                      hipStream_t stream) {
+    *n_nodes = 0;
+    if (E == 0) { KCHECK(node_key.alloc(16, stream)); return KATOME_OK; }
+    const u32 node_bits = 2 * (k - 1);
+    const u64 nblocks = (E + UNIQ_TILE - 1) / UNIQ_TILE;
+    if (nblocks > 0x7fffffffull) { set_error("node numbering: too many edges"); return KATOME_E_ARG; }
+    DevBuf counts(stream), offs(stream), aux(stream);
+    KCHECK(counts.alloc(nblocks * 4));
+    KCHECK(offs.alloc((nblocks + 1) * 8));
+    KCHECK(aux.alloc(16));
+    KCHECK_HIP(hipMemsetAsync(aux.p, 0, 16, stream));
+    hipLaunchKernelGGL(src_count_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, counts.as<u32>());
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<u32>(), nblocks, offs.as<u64>());
+    u64 n_src = 0;
+    KCHECK_HIP(hipMemcpyAsync(&n_src, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    KCHECK(node_key.alloc((n_src + 1) * 8 * NW, stream));
+    u64* nodes = node_key.as<u64>();
+    hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), nodes, edge_src);
+    // targets -> positions among the sources
+    u32 B = 1;
+    while ((2ull << B) <= n_src / 8 && B < 27) ++B;
+    if (B > node_bits) B = node_bits;
+    DevBuf index(stream);
+    KCHECK(index.alloc(((1ull << B) + 2) * 8));
+    hipLaunchKernelGGL(bucket_index_kernel<NW>, dim3(grid_for(n_src + 1, BLOCK)), dim3(BLOCK), 0, stream, nodes, n_src, node_bits, B, index.as<u64>());
+    hipLaunchKernelGGL(dst_rank_kernel<NW>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, nodes, n_src, node_bits, B,
+                       index.as<u64>(), d_edge_key, E, k, edge_dst, aux.as<u64>());
+    KCHECK_HIP(hipGetLastError());
+    u64 n_missing = 0;
+    KCHECK_HIP(hipMemcpyAsync(&n_missing, aux.p, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    u64 n_extra = 0;
+    if (n_missing) {
+        DevBuf extra(stream);
+        KCHECK(extra.alloc(n_missing * 8 * NW + 16));
+        hipLaunchKernelGGL(missing_gather_kernel<NW>, dim3(grid_for(E, BLOCK, 256u * 16u)), dim3(BLOCK), 0, stream, d_edge_key, E, k,
+                           edge_dst, extra.as<u64>(), aux.as<u64>() + 1);
+        KCHECK_HIP(hipGetLastError());
+        KCHECK(dev_sort(extra.as<u64>(), nullptr, n_missing, NW, node_bits, stream));
+        n_extra = n_missing;
+        KCHECK(dev_unique(extra.as<u64>(), n_missing, NW, &n_extra, stream));
+        hipLaunchKernelGGL(missing_rank_kernel<NW>, dim3(grid_for(E, BLOCK, 256u * 16u)), dim3(BLOCK), 0, stream, d_edge_key, E, k,
+                           extra.as<u64>(), n_extra, n_src, edge_dst);
+        KCHECK_HIP(hipGetLastError());
+        // node_key = sources ++ extra
+        DevBuf all(stream);
+        KCHECK(all.alloc((n_src + n_extra + 1) * 8 * NW));
+        KCHECK_HIP(hipMemcpyAsync(all.p, nodes, n_src * 8 * NW, hipMemcpyDeviceToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(all.as<u64>() + n_src * NW, extra.p, n_extra * 8 * NW, hipMemcpyDeviceToDevice, stream));
+        const size_t bytes = all.bytes;
+        node_key.adopt(all.take(), bytes);
+    }
+    *n_nodes = n_src + n_extra;
+    return KATOME_OK;
+}
+
+int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src,
+                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream) {
+    if (key_words_for_k(k) == 1) return node_ids_t<1>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream);
+    return node_ids_t<2>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream);
+}
+
 // ---- edge -> endpoints, labels ----------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void endpoints_kernel(const u64* __restrict__ ek, u64 n, u32 k, u64* __restrict__ src, u64* __restrict__ dst) {

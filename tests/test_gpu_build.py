@@ -25,7 +25,10 @@ def _check_graph_consistency(g, k):
     ek = g.key_ints("edge")
     nk = g.key_ints("node")
     assert ek == sorted(ek) and len(set(ek)) == len(ek)              # ascending distinct k-mers
-    assert nk == sorted(nk) and len(set(nk)) == len(nk)              # ascending distinct (k-1)-mers
+    assert len(set(nk)) == len(nk)                                   # distinct (k-1)-mers
+    n_src = len(set(g.edge_src.tolist()))                            # nodes with out-edges come first, ascending,
+    assert nk[:n_src] == sorted(nk[:n_src]) and nk[n_src:] == sorted(nk[n_src:])   # then the out-edge-less ones, ascending
+    assert set(g.edge_src.tolist()) == set(range(n_src))
     mask = (1 << (2 * (k - 1))) - 1
     for e in range(0, g.n_edges, max(1, g.n_edges // 500)):
         assert nk[int(g.edge_src[e])] == ek[e] >> 2                   # compress_kmer halves
@@ -255,7 +258,9 @@ def test_properties_at_scale():
     keys = dg.edge_key[:, 0]
     assert bool((keys[1:] > keys[:-1]).all())                        # sorted, distinct
     nodes = dg.node_key[:, 0]
-    assert bool((nodes[1:] > nodes[:-1]).all())
+    n_src = int(dg.edge_src.max().item()) + 1
+    assert bool((nodes[1:n_src] > nodes[:n_src - 1]).all()) and bool((nodes[n_src + 1:] > nodes[n_src:-1]).all())
+    assert int(torch.unique(nodes).numel()) == dg.n_nodes
     assert bool((nodes[dg.edge_src] == (keys >> 2)).all())
     assert bool((nodes[dg.edge_dst] == (keys & ((1 << 60) - 1))).all())
     # strand symmetry: the reverse complement of every edge is an edge with the same weight
