@@ -500,20 +500,33 @@ __global__ __launch_bounds__(BLOCK) void dst_rank_kernel(const u64* __restrict__
     for (int o = 32; o > 0; o >>= 1) miss += __shfl_down(miss, o, 64);
     if ((threadIdx.x & 63) == 0 && miss) atomicAdd((unsigned long long*)n_missing, (unsigned long long)miss);
 }
-// gather the targets that were not found (unordered; they are sorted afterwards)
+// gather the targets that were not found (unordered; they are sorted afterwards).  One cursor atomic per
+// workgroup tile: the misses are sparse, and one atomic per wave on a single address serialises.
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void missing_gather_kernel(const u64* __restrict__ keys, u64 n, u32 k, const u64* __restrict__ edge_dst,
                                                                 u64* __restrict__ out, u64* cursor) {
-    const u32 lane = threadIdx.x & 63;
-    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < n; i0 += (u64)gridDim.x * BLOCK) {
-        const u64 i = i0 + threadIdx.x;
-        const bool miss = i < n && edge_dst[i] == ~0ull;
-        const u64 m = __ballot(miss);
-        if (!m) continue;
-        u64 base = 0;
-        if (lane == 0) base = atomicAdd((unsigned long long*)cursor, (unsigned long long)__popcll(m));
-        base = __shfl(base, 0, 64);
-        if (miss) store_key<NW>(out, base + __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull)), target_node(load_key<NW>(keys, i), k));
+    __shared__ u32 wsum[BLOCK / 64];
+    __shared__ u64 block_base;
+    const u64 tile = (u64)BLOCK * UNIQ_ITEMS;
+    for (u64 t0 = (u64)blockIdx.x * tile; t0 < n; t0 += (u64)gridDim.x * tile) {
+        bool miss[UNIQ_ITEMS]; u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < UNIQ_ITEMS; ++j) {
+            const u64 i = t0 + (u64)j * BLOCK + threadIdx.x;
+            miss[j] = i < n && edge_dst[i] == ~0ull;
+            mine += miss[j];
+        }
+        u32 total;
+        const u32 excl = block_excl_scan(mine, wsum, total);
+        if (threadIdx.x == 0 && total) block_base = atomicAdd((unsigned long long*)cursor, (unsigned long long)total);
+        __syncthreads();
+        if (total) {
+            u64 pos = block_base + excl;
+#pragma unroll
+            for (int j = 0; j < UNIQ_ITEMS; ++j)
+                if (miss[j]) { store_key<NW>(out, pos, target_node(load_key<NW>(keys, t0 + (u64)j * BLOCK + threadIdx.x), k)); ++pos; }
+        }
+        __syncthreads();
     }
 }
 // second lookup, only for the edges whose target was not a source: id = n_sources + rank among the extra nodes
