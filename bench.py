@@ -24,20 +24,22 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E p
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # written from tools/profile_round.sh output
 
 
-def pmc_traffic(kernel_prefix, streaming):
+def pmc_traffic(kernel_name, streaming, config):
     """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
-    separate runs, KiB).  gfx950 correction from the MI355X guide: FETCH_SIZE reads half the bytes of a wide
-    coalesced stream, so it is doubled for streaming kernels; random-access kernels are left uncorrected."""
+    separate runs, KiB per dispatch) -- only when they were taken on this very configuration.  gfx950 correction
+    from the MI355X guide: FETCH_SIZE reads half the bytes of a wide coalesced stream, so it is doubled for
+    streaming kernels; random-access kernels are left uncorrected (uncalibrated there)."""
     try:
         pmc = json.load(open(PMC_FILE))
     except Exception:
         return None
-    for name, v in pmc.get("kernels", {}).items():
-        if kernel_prefix in name:
-            return {"bytes_per_launch": (v["fetch_kib"] * (2 if streaming else 1) + v["write_kib"]) * 1024.0,
-                    "fetch_kib": v["fetch_kib"], "write_kib": v["write_kib"], "fetch_x2": bool(streaming),
-                    "records_per_launch": v.get("records_per_launch"), "source": pmc.get("source")}
-    return None
+    if any(pmc.get("config", {}).get(k) != config.get(k) for k in ("reads", "read_len", "k", "batch_reads", "tile_span")):
+        return None
+    v = pmc.get("kernels", {}).get(kernel_name)
+    if not v:
+        return None
+    return {"bytes_per_launch": (v["fetch_kib"] * (2 if streaming else 1) + v["write_kib"]) * 1024.0,
+            "fetch_kib": v["fetch_kib"], "write_kib": v["write_kib"], "fetch_x2": bool(streaming), "source": pmc.get("source")}
 
 
 def parse_args():
@@ -49,6 +51,7 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=0, help="override the workload's read count (same coverage)")
     ap.add_argument("--batch-reads", type=int, default=4 * 1024 * 1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     return ap.parse_args()
 
@@ -124,8 +127,11 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the build has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
     if args.reads:
@@ -136,7 +142,7 @@ def main():
     W = wl.windows_per_read
     batch_reads = max(64, (args.batch_reads // 64) * 64)
 
-    if world == 1:
+    if not use_dist:
         packed, skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, wl.n_inject_percent,
                                       device=local_rank)
         skip_arg = skip if wl.n_inject_percent else None
@@ -157,7 +163,7 @@ def main():
     for _ in range(args.warmup):
         step()
     timer.collect()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -165,11 +171,11 @@ def main():
     for _ in range(args.steps):
         n_edges, n_nodes = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     dt = time.perf_counter() - t0
     phases = timer.collect()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -184,7 +190,7 @@ def main():
         # algorithmic bytes: extraction = ceil(L/4) B read + 8*NW*W B written per read;
         # insertion = 8*NW B record + 16*NW B slot per insertion
         from katome_amd._lib import lib as _katome_lib
-        span = _katome_lib().katome_tile_span(wl.k, wl.read_len) if world == 1 else 1
+        span = _katome_lib().katome_tile_span(wl.k, wl.read_len)
         nwt = _katome_lib().katome_tile_words(wl.k, span)
         # extraction writes one record per tile of `span` windows (span = 1: one per window);
         # an insertion moves a record (8*NW B) and touches a slot (16*NW B)
@@ -208,18 +214,17 @@ def main():
                 entry["achieved_GBs"] = by / (ph["avg_ms"] * 1e-3) / 1e9
                 entry["frac_of_hbm_peak"] = entry["achieved_GBs"] / HBM_PEAK_GBS
             kernels[name] = entry
+        cfg_now = {"reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads, "tile_span": span}
+        rcs = "true" if wl.reverse_complement else "false"
+        exact = {"extract": "void extract_fixed_kernel<%d, %s>" % (nwt, rcs), "insert": "void insert_kernel<%d>" % nw,
+                 "insert_tiles": "void insert_kernel<%d>" % nwt}
+
         def roof(name):
-            t = pmc_traffic(kernel_names[name], streaming=(name == "extract")) if world == 1 else None
-            traffic = None
-            if t and t.get("records_per_launch"):
-                # counters were taken per launch of the profiled run; scale to this run's launch size
-                per_rec = t["bytes_per_launch"] / t["records_per_launch"]
-                recs = reads_per_rank_step * W / kernels[name]["launches_per_step"]
-                traffic = per_rec * recs
-            return {"kernel": kernel_names[name], "bound": "hbm", "achieved": kernels[name]["achieved_GBs"],
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[name]["frac_of_hbm_peak"], "traffic": traffic,
-                    "traffic_detail": t, "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"],
-                    "avg_launch_ms": kernels[name]["avg_ms"]}
+            t = pmc_traffic(exact[name], streaming=(name == "extract"), config=cfg_now) if not use_dist else None
+            return {"kernel": exact[name].replace("void ", ""), "bound": "hbm", "achieved": kernels[name]["achieved_GBs"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[name]["frac_of_hbm_peak"],
+                    "traffic": t["bytes_per_launch"] if t else None, "traffic_detail": t,
+                    "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"], "avg_launch_ms": kernels[name]["avg_ms"]}
         dom = max((n for n in kernels if n in alg), key=lambda n: kernels[n]["ms_per_step"])
         roofline = roof(dom)
         line = {
@@ -233,14 +238,14 @@ def main():
                        "reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads,
                        "tile_span": span,
                        "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
-                       if world > 1 else "1 GPU"},
+                       if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
             "roofline": roofline, "roofline_extract": roof("extract"), "kernels": kernels,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -167,10 +167,12 @@ int katome_dev_extract_var(katome_builder *b, const uint8_t *d_packed, uint64_t 
                            const uint64_t *d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                            uint64_t *d_records, void *stream);
 
-/* group records by owner rank = mulhi(mix(key), n_parts) (invalid records are dropped);
- * d_out: same size as d_records; h_counts[n_parts] receives the records per part (synchronises) */
-int katome_dev_partition(katome_builder *b, const uint64_t *d_records, uint64_t n_records,
-                         uint32_t n_parts, uint64_t *d_out, uint64_t *h_counts, void *stream);
+/* group records of `key_words` u64 words by owner rank = mulhi(mix(key), n_parts) (stable; invalid records are
+ * dropped); optional u32 values travel with their records (both d_values and d_values_out, or neither).
+ * d_out: same size as d_records; h_counts[n_parts] receives the records per part (synchronises)       */
+int katome_dev_partition(int device, const uint64_t *d_records, const uint32_t *d_values, uint64_t n_records,
+                         uint32_t key_words, uint32_t n_parts, uint64_t *d_out, uint32_t *d_values_out,
+                         uint64_t *h_counts, void *stream);
 
 /* add_single_edge_fastaq (pt_graph.rs:172-198) for a batch: find-or-insert each record's
  * k-mer in the open-address table and add 1 to its weight (u32, wrapping).  Grows the table
@@ -241,6 +243,12 @@ int katome_dev_unique(int device, uint64_t *d_keys, uint64_t n, uint32_t key_wor
 int katome_dev_rank(int device, const uint64_t *d_sorted, uint64_t n_sorted, uint32_t key_words,
                     uint32_t key_bits, const uint64_t *d_queries, uint64_t n_queries,
                     uint64_t *d_rank_out, void *stream);
+/* node numbering of a sorted distinct edge list (what katome_dev_finalize does): d_node_key receives the
+ * node keys (capacity [2*n_edges][key_words]: the sources in ascending order, then the out-edge-less
+ * targets in ascending order), d_edge_src/d_edge_dst [n_edges] the positions of each edge's endpoints in
+ * it; *n_nodes the node count (synchronises)                                                    */
+int katome_dev_node_ids(int device, const uint64_t *d_edge_key, uint64_t n_edges, uint32_t k, uint64_t *d_node_key,
+                        uint64_t *d_edge_src, uint64_t *d_edge_dst, uint64_t *n_nodes, void *stream);
 /* derive (k-1)-mer endpoint keys of each edge: d_src/d_dst [n][key_words]                  */
 int katome_dev_endpoints(int device, const uint64_t *d_edge_key, uint64_t n, uint32_t k,
                          uint64_t *d_src_key, uint64_t *d_dst_key, void *stream);

@@ -66,7 +66,7 @@ SYMBOLS = {
     "katome_phase_name": (C.c_char_p, [_u32]),
     "katome_dev_extract_fixed": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
     "katome_dev_extract_var": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
-    "katome_dev_partition": (_i, [_vp, _vp, _u64, _u32, _vp, u64p, _vp]),
+    "katome_dev_partition": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp, _vp, u64p, _vp]),
     "katome_dev_insert": (_i, [_vp, _vp, _u64, _vp]),
     "katome_dev_insert_weighted": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "katome_dev_table_count": (_i, [_vp, u64p]),
@@ -81,6 +81,7 @@ SYMBOLS = {
     "katome_dev_sort": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp]),
     "katome_dev_unique": (_i, [_i, _vp, _u64, _u32, u64p, _vp]),
     "katome_dev_rank": (_i, [_i, _vp, _u64, _u32, _u32, _vp, _u64, _vp, _vp]),
+    "katome_dev_node_ids": (_i, [_i, _vp, _u64, _u32, _vp, _vp, _vp, u64p, _vp]),
     "katome_dev_endpoints": (_i, [_i, _vp, _u64, _u32, _vp, _vp, _vp]),
     "katome_dev_labels": (_i, [_i, _vp, _u64, _u32, _vp, _vp]),
     "katome_dev_synth_reads": (_i, [_i, _u64, _u64, _u32, _u64, _dbl, _u32, _vp, _vp, _vp]),

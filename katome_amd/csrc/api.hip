@@ -114,10 +114,10 @@ int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t 
                               d_records, (hipStream_t)stream);
 }
 
-int katome_dev_partition(katome_builder* b, const uint64_t* d_records, uint64_t n_records, uint32_t n_parts, uint64_t* d_out,
-                         uint64_t* h_counts, void* stream) {
-    KCHECK_HIP(hipSetDevice(b->s.device));
-    return dev_partition(d_records, n_records, b->nw, n_parts, d_out, h_counts, (hipStream_t)stream);
+int katome_dev_partition(int device, const uint64_t* d_records, const uint32_t* d_values, uint64_t n_records, uint32_t key_words,
+                         uint32_t n_parts, uint64_t* d_out, uint32_t* d_values_out, uint64_t* h_counts, void* stream) {
+    KCHECK(use_device(device));
+    return dev_partition(d_records, d_values, n_records, key_words, n_parts, d_out, d_values_out, h_counts, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -382,6 +382,17 @@ int katome_dev_rank(int device, const uint64_t* d_sorted, uint64_t n_sorted, uin
     if (key_words != 1 && key_words != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
     return dev_rank(d_sorted, n_sorted, key_words, key_bits, d_queries, n_queries, d_rank_out, (hipStream_t)stream);
 }
+int katome_dev_node_ids(int device, const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, uint64_t* d_node_key,
+                        uint64_t* d_edge_src, uint64_t* d_edge_dst, uint64_t* n_nodes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK(use_device(device));
+    KCHECK(check_k(k));
+    DevBuf nodes(stream);
+    KCHECK(dev_node_ids(d_edge_key, n_edges, k, nodes, d_edge_src, d_edge_dst, n_nodes, stream));
+    if (*n_nodes) KCHECK_HIP(hipMemcpyAsync(d_node_key, nodes.p, *n_nodes * 8 * key_words_for_k(k), hipMemcpyDeviceToDevice, stream));
+    return KATOME_OK;
+}
+
 int katome_dev_endpoints(int device, const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src_key, uint64_t* d_dst_key, void* stream) {
     KCHECK(use_device(device));
     KCHECK(check_k(k));

@@ -252,16 +252,26 @@ int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32
     return d_vals ? sort_t<2, true>(d_keys, d_vals, n, key_bits, stream) : sort_t<2, false>(d_keys, nullptr, n, key_bits, stream);
 }
 
-// group records by owner rank; invalid records go last (part n_parts) and are not counted
-int dev_partition(const uint64_t* d_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out, uint64_t* h_counts,
-                  hipStream_t stream) {
+// group records by owner rank; invalid records go last (part n_parts) and are not counted.
+// Optional u32 values travel with their records.
+int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
+                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream) {
     if (n_parts == 0 || n_parts >= (u32)RADIX) { set_error("n_parts must be 1..255"); return KATOME_E_ARG; }
+    if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
+    if ((v_in == nullptr) != (v_out == nullptr)) { set_error("partition: values in and out must both be given"); return KATOME_E_ARG; }
     for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
     if (n == 0) return KATOME_OK;
     PassBuffers pb;
     KCHECK(pb.init(n, stream));
-    if (nw == 1) { OwnerDigit<1> dg{n_parts}; KCHECK((radix_pass<1, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream))); }
-    else         { OwnerDigit<2> dg{n_parts}; KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream))); }
+    if (nw == 1) {
+        OwnerDigit<1> dg{n_parts};
+        if (v_in) KCHECK((radix_pass<1, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
+        else      KCHECK((radix_pass<1, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
+    } else {
+        OwnerDigit<2> dg{n_parts};
+        if (v_in) KCHECK((radix_pass<2, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
+        else      KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
+    }
     u64 totals[RADIX];
     KCHECK_HIP(hipMemcpyAsync(totals, pb.totals.p, sizeof totals, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));

@@ -150,13 +150,17 @@ class Builder:
         return out[:total_windows * self.nw]
 
     # ---- routing for the multi-GPU exchange -----------------------------------------------------
-    def partition(self, records, n_parts, out=None):
-        n = records.numel() // self.nw
-        if out is None:
-            out = torch.empty_like(records)
+    def partition(self, records, n_parts, key_words=None, values=None):
+        """records grouped by owner rank (stable, invalid dropped); -> (records_out, counts[, values_out])"""
+        nw = key_words or self.nw
+        n = records.numel() // nw
+        out = torch.empty_like(records)
+        vout = torch.empty_like(values) if values is not None else None
         counts = (C.c_uint64 * n_parts)()
-        _check(_lib.lib().katome_dev_partition(self._h, _ptr(records), n, n_parts, _ptr(out), counts, _stream()))
-        return out, [int(c) for c in counts]
+        _check(_lib.lib().katome_dev_partition(self.device, _ptr(records), _ptr(values), n, nw, n_parts, _ptr(out), _ptr(vout),
+                                               counts, _stream()))
+        counts = [int(c) for c in counts]
+        return (out, counts) if values is None else (out, counts, vout)
 
     # ---- add_single_edge_fastaq for a batch ------------------------------------------------------
     def insert(self, records, weights=None):
@@ -205,6 +209,18 @@ def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
     _check(_lib.lib().katome_dev_rank(device, _ptr(sorted_keys), ns, key_words, key_bits, _ptr(queries), nq, _ptr(out),
                                       _stream()))
     return out[:nq]
+
+
+def node_ids(edge_keys, k, device=0):
+    """local node numbering of sorted distinct edges -> (node_keys [n_nodes*nw], edge_src [E], edge_dst [E])"""
+    nw = record_words(k)
+    n = edge_keys.numel() // nw
+    nodes = torch.empty(max(2 * n, 1) * nw, dtype=torch.int64, device=edge_keys.device)
+    src = torch.empty(max(n, 1), dtype=torch.int64, device=edge_keys.device)
+    dst = torch.empty(max(n, 1), dtype=torch.int64, device=edge_keys.device)
+    nn = C.c_uint64()
+    _check(_lib.lib().katome_dev_node_ids(device, _ptr(edge_keys), n, k, _ptr(nodes), _ptr(src), _ptr(dst), C.byref(nn), _stream()))
+    return nodes[:nn.value * nw], src[:n], dst[:n]
 
 
 def endpoints(edge_keys, k, device=0):

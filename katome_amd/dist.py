@@ -38,17 +38,33 @@ class HipOps:
     def extract_fixed(self, packed, n_reads, read_len, skip, out, first_read):
         return self.b.extract_fixed(packed, n_reads, read_len, skip, out=out, first_read=first_read)
 
-    def partition(self, records, n_parts):
-        return self.b.partition(records, n_parts)
+    def partition(self, records, n_parts, key_words=None, values=None):
+        return self.b.partition(records, n_parts, key_words=key_words, values=values)
 
-    def insert(self, records):
-        self.b.insert(records)
+    def insert(self, records, weights=None):
+        self.b.insert(records, weights)
+
+    # tiled counting (table.hip): (k+span-1)-mers covering `span` consecutive windows
+    def tile_span(self, read_len):
+        return self.b.tile_span(read_len)
+
+    def tile_words(self, span):
+        return self.b.tile_words(span)
+
+    def extract_tiles(self, packed, n_reads, read_len, span, skip, out, first_read):
+        return self.b.extract_tiles(packed, n_reads, read_len, span, skip, out=out, first_read=first_read)
+
+    def insert_tiles(self, records, span):
+        self.b.insert_tiles(records, span)
+
+    def expand_tiles(self):
+        return self.b.expand_tiles()
 
     def edges(self):
         return self.b.edges()
 
-    def endpoints(self, keys):
-        return self.kd.endpoints(keys.reshape(-1), self.k, self.dev)
+    def node_ids(self, keys):
+        return self.kd.node_ids(keys.reshape(-1), self.k, self.dev)
 
     def sort_unique(self, keys, bits):
         self.kd.sort_keys(keys, bits, self.nw, device=self.dev)
@@ -97,10 +113,19 @@ class RankGraph:
 
 
 def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, timer=None):
-    """Steps 1-3 for this rank's reads; afterwards ops' table holds the k-mers this rank owns."""
+    """Steps 1-3 for this rank's reads; afterwards ops' table holds the k-mers this rank owns.
+
+    When a tile span divides the windows per read, what travels and is counted first are TILES (the
+    (k+span-1)-mers covering `span` consecutive windows: span x fewer records on the links and span x fewer
+    atomics); each rank then turns its distinct tiles into (k-mer, weight) records and a second, much
+    smaller all-to-all brings those to the k-mers' owners."""
     world = dist.get_world_size(group)
     W = read_len - ops.k + 1
-    recbuf = ops.empty(max(1, min(batch_reads, max(n_reads, 1)) * W * ops.nw))
+    span = ops.tile_span(read_len)
+    # the span must be the same on every rank (it is a function of k and the read length)
+    nwr = ops.tile_words(span) if span > 1 else ops.nw
+    per_read = W // span
+    recbuf = ops.empty(max(1, min(batch_reads, max(n_reads, 1)) * per_read * nwr))
     n_batches = (n_reads + batch_reads - 1) // batch_reads
     # every rank must take part in every all-to-all: agree on the number of rounds
     nb = torch.tensor([n_batches], dtype=torch.int64, device=recbuf.device)
@@ -109,13 +134,29 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, t
         r0 = i * batch_reads
         nr = max(0, min(batch_reads, n_reads - r0))
         if nr:
-            rec = ops.extract_fixed(packed, nr, read_len, skip, recbuf, r0)
-            part, counts = ops.partition(rec, world)
+            if span > 1:
+                rec = ops.extract_tiles(packed, nr, read_len, span, skip, recbuf, r0)
+            else:
+                rec = ops.extract_fixed(packed, nr, read_len, skip, recbuf, r0)
+            part, counts = ops.partition(rec, world, key_words=nwr)
         else:
             part, counts = recbuf[:0], [0] * world
-        recv, _ = _exchange(part, counts, ops.nw, group)
+        recv, _ = _exchange(part, counts, nwr, group)
         if recv.numel():
-            ops.insert(recv)
+            if span > 1:
+                ops.insert_tiles(recv, span)
+            else:
+                ops.insert(recv)
+    if span > 1:
+        keys, weights = ops.expand_tiles()               # this rank's distinct tiles as (k-mer, weight) records
+        if weights.numel():
+            pk, counts, pw = ops.partition(keys, world, key_words=ops.nw, values=weights)
+        else:
+            pk, counts, pw = keys, [0] * world, weights
+        rk, rcounts = _exchange(pk, counts, ops.nw, group)
+        rw, _ = _exchange(pw, counts, 1, group)
+        if rw.numel():
+            ops.insert(rk, rw)
 
 
 def finalize_distributed(ops, group=None):
@@ -123,25 +164,27 @@ def finalize_distributed(ops, group=None):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nw, k = ops.nw, ops.k
     node_bits = 2 * (k - 1)
-    keys, weights = ops.edges()                       # [E, nw], [E]
+    keys, weights = ops.edges()                       # [E, nw] ascending, [E]
     E = weights.numel()
-    src, dst = ops.endpoints(keys) if E else (keys.reshape(-1), keys.reshape(-1))
-    # distinct endpoint keys seen on this rank
-    cand = torch.cat([src.reshape(-1), dst.reshape(-1)]) if E else ops.empty(0)
-    U = ops.sort_unique(cand, node_bits) if E else cand
-    nU = U.numel() // nw
-    # route them to their owners
-    if nU:
-        P, counts = ops.partition(U, world)
+    dev = weights.device
+    # the distinct endpoint keys seen on this rank and the edges' positions in that list (read off the
+    # sorted edge list, no sort)
+    if E:
+        U, lsrc, ldst = ops.node_ids(keys)
     else:
-        P, counts = U, [0] * world
+        U, lsrc, ldst = ops.empty(0), ops.empty(0), ops.empty(0)
+    nU = U.numel() // nw
+    # route them to their owners, remembering where each came from
+    if nU:
+        P, counts, origin = ops.partition(U, world, key_words=nw, values=torch.arange(nU, dtype=torch.int32, device=dev))
+    else:
+        P, counts, origin = U, [0] * world, torch.empty(0, dtype=torch.int32, device=dev)
     R, recv_counts = _exchange(P, counts, nw, group)
     # nodes this rank owns, in ascending key order
     N = ops.sort_unique(R.clone(), node_bits) if R.numel() else R
     n_owned = N.numel() // nw
-    all_n = torch.empty(world, dtype=torch.int64, device=keys.device if E else R.device)
-    pieces = [torch.empty(1, dtype=torch.int64, device=all_n.device) for _ in range(world)]
-    dist.all_gather(pieces, torch.tensor([n_owned], dtype=torch.int64, device=all_n.device), group=group)
+    pieces = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(pieces, torch.tensor([n_owned], dtype=torch.int64, device=dev), group=group)
     all_n = torch.cat(pieces)
     bases = torch.cumsum(all_n, 0) - all_n
     base = int(bases[rank].item())
@@ -149,18 +192,15 @@ def finalize_distributed(ops, group=None):
     # answer the queries: global id of every key received, in the order received
     ids_R = (ops.rank(N, R, node_bits) + base) if R.numel() else ops.empty(0)
     ids_P, _ = _exchange(ids_R, recv_counts, 1, group)         # reverse route: same split sizes, mirrored
-    # ids_P is aligned with P (U grouped by owner); bring it back to U's order
     if nU:
-        pos = ops.rank(U, P[:nU * nw], node_bits)
-        id_of_U = torch.empty(nU, dtype=torch.int64, device=ids_P.device)
-        id_of_U[pos] = ids_P
-        edge_src = id_of_U[ops.rank(U, src.reshape(-1), node_bits)]
-        edge_dst = id_of_U[ops.rank(U, dst.reshape(-1), node_bits)]
+        id_of_U = torch.empty(nU, dtype=torch.int64, device=dev)
+        id_of_U[origin[:nU].to(torch.int64)] = ids_P           # ids_P is aligned with P; origin says which U entry that was
+        edge_src, edge_dst = id_of_U[lsrc], id_of_U[ldst]
         label = ops.labels(keys)
     else:
         edge_src = edge_dst = ops.empty(0)
-        label = torch.empty((0, 1 + (k + 3) // 4), dtype=torch.uint8, device=ids_P.device)
-    tot = torch.tensor([E], dtype=torch.int64, device=all_n.device)
+        label = torch.empty((0, 1 + (k + 3) // 4), dtype=torch.uint8, device=dev)
+    tot = torch.tensor([E], dtype=torch.int64, device=dev)
     dist.all_reduce(tot, group=group)
     return RankGraph(keys, weights, edge_src, edge_dst, label, N.reshape(-1, nw), base, total_nodes, int(tot.item()))
 

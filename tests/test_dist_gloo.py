@@ -56,10 +56,12 @@ def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,rc,n_reads,batch", [(2, 11, True, 260, 64), (2, 33, True, 130, 1000), (3, 12, False, 200, 64),
-                                                       (2, 6, True, 70, 64)])
-def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads, batch):
-    read_len = 50
+# read_len 50: k=11 -> 40 windows, tiles of 8; k=33 -> 18 windows, tiles of 6 (128-bit); k=12 -> 39 windows, tiles of 3;
+# k=6 -> 45 windows, tiles of 5; read_len 53 with k=11: 43 windows (prime) -> the plain, untiled route
+@pytest.mark.parametrize("world,k,rc,n_reads,batch,read_len", [(2, 11, True, 260, 64, 50), (2, 33, True, 130, 1000, 50),
+                                                                (3, 12, False, 200, 64, 50), (2, 6, True, 70, 64, 50),
+                                                                (2, 11, True, 130, 64, 53)])
+def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads, batch, read_len):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, k, rc, n_reads, read_len, batch, str(tmp_path)), nprocs=world, join=True)
     ref = oracle.build_ascii(oracle.synth_reads(0, n_reads, read_len, 3000, 2e-2, 4), k, rc)

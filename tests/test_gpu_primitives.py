@@ -118,9 +118,16 @@ def test_partition_by_owner(k, n_parts):
     inv = rng.random(n) < 0.01
     a[inv] = np.uint64(0xFFFFFFFFFFFFFFFF)
     b = kd.Builder(k, True)
-    out, counts = b.partition(_to_dev(a).view(-1), n_parts)
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    out, counts, vout = b.partition(_to_dev(a).view(-1), n_parts, values=vals)
+    out2, counts2 = b.partition(_to_dev(a).view(-1), n_parts)
     torch.cuda.synchronize()
+    assert counts2 == counts and torch.equal(out2[:sum(counts) * nw], out[:sum(counts) * nw])
+    assert np.array_equal(vout.cpu().numpy()[:sum(counts)] >= 0, np.ones(sum(counts), bool))
+    # values follow their records
+    src_rows = a[vout.cpu().numpy()[:sum(counts)]]
     got = _from_dev(out, nw)
+    assert np.array_equal(got[:sum(counts)], src_rows)
     L = hostshim()
     owners = np.array([L.hs_owner((C.c_uint64 * nw)(*[int(x) for x in row]), nw, n_parts) for row in a[~inv]])
     assert counts == [int((owners == p).sum()) for p in range(n_parts)]
