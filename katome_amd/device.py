@@ -211,6 +211,11 @@ def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
     return out[:nq]
 
 
+def release_cache(device=0):
+    """hand the library's cached device blocks back to the driver"""
+    _check(_lib.lib().katome_dev_release_cache(device))
+
+
 def node_ids(edge_keys, k, device=0):
     """local node numbering of sorted distinct edges -> (node_keys [n_nodes*nw], edge_src [E], edge_dst [E])"""
     nw = record_words(k)

@@ -83,6 +83,18 @@ class HipOps:
         self.b.close()
 
 
+def _empty(n, dtype, device):
+    """torch.empty that, when HBM is short, first hands the library's cached blocks back to the driver"""
+    try:
+        return torch.empty(n, dtype=dtype, device=device)
+    except torch.OutOfMemoryError:
+        if device.type == "cuda":
+            from . import device as kd
+            kd.release_cache(device.index if device.index is not None else torch.cuda.current_device())
+            torch.cuda.empty_cache()
+        return torch.empty(n, dtype=dtype, device=device)
+
+
 def _exchange(send, send_counts, nw, group):
     """all-to-all of `send` (records grouped by destination rank, send_counts records each).
     Returns (recv, recv_counts)."""
@@ -91,7 +103,7 @@ def _exchange(send, send_counts, nw, group):
     rc = torch.empty(world, dtype=torch.int64, device=send.device)
     dist.all_to_all_single(rc, sc, group=group)
     recv_counts = [int(x) for x in rc.tolist()]
-    recv = torch.empty(sum(recv_counts) * nw, dtype=send.dtype, device=send.device)
+    recv = _empty(sum(recv_counts) * nw, send.dtype, send.device)
     dist.all_to_all_single(recv, send[:sum(send_counts) * nw].contiguous(),
                            output_split_sizes=[c * nw for c in recv_counts],
                            input_split_sizes=[c * nw for c in send_counts], group=group)
@@ -193,7 +205,8 @@ def finalize_distributed(ops, group=None):
     ids_R = (ops.rank(N, R, node_bits) + base) if R.numel() else ops.empty(0)
     ids_P, _ = _exchange(ids_R, recv_counts, 1, group)         # reverse route: same split sizes, mirrored
     if nU:
-        id_of_U = torch.empty(nU, dtype=torch.int64, device=dev)
+        del P, R, ids_R
+        id_of_U = _empty(nU, torch.int64, dev)
         id_of_U[origin[:nU].to(torch.int64)] = ids_P           # ids_P is aligned with P; origin says which U entry that was
         edge_src, edge_dst = id_of_U[lsrc], id_of_U[ldst]
         label = ops.labels(keys)
