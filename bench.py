@@ -115,6 +115,11 @@ def cpu_baseline(wl, sample_reads):
 
 def main():
     args = parse_args()
+    # libraries (RCCL) print banners on fd 1; the contract is ONE JSON line on stdout, so the real stdout is
+    # set aside for that line and fd 1 points at stderr for everything else
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     from katome_amd.workloads import WORKLOADS
@@ -244,7 +249,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
 

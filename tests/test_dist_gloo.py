@@ -90,6 +90,32 @@ def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads
     assert len(set(node_of_id.values())) == ref.n_nodes
 
 
+def _exchange_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    from katome_amd import dist as kdist
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        kdist.MAX_MESSAGE_BYTES = 64                      # force the multi-round path: 4 records of 2 words per round
+        nw = 2
+        counts = [(7 * rank + 5 * p + 3) % 23 for p in range(world)]          # records for each destination
+        send = torch.cat([torch.arange(c * nw, dtype=torch.int64) + 1000 * p + 100000 * rank for p, c in enumerate(counts)])
+        recv, rcounts = kdist._exchange(send, counts, nw, None)
+        want_counts = [(7 * src + 5 * rank + 3) % 23 for src in range(world)]
+        assert rcounts == want_counts
+        want = torch.cat([torch.arange(c * nw, dtype=torch.int64) + 1000 * rank + 100000 * src for src, c in enumerate(want_counts)])
+        assert torch.equal(recv, want)
+        open(os.path.join(out_dir, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_exchange_in_rounds(tmp_path, world):
+    """messages above the per-pair limit are cut into rounds and reassembled in place"""
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d" % r)) for r in range(world))
+
+
 def test_shard_range_covers_all_reads():
     from katome_amd.dist import shard_range
     for total in (0, 1, 63, 64, 65, 1000, 200_000_000):
