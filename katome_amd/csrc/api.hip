@@ -92,6 +92,10 @@ int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_
 uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
     if (getenv("KATOME_NO_TILES") || read_len < k) return 1;
     const uint32_t W = read_len - k + 1;
+    if (const char* e = getenv("KATOME_TILE_SPAN")) {        // experiments: any span that divides W and fits 128 bits
+        const uint32_t s = (uint32_t)atoi(e);
+        if (s >= 1 && W % s == 0 && k + s - 1 <= 63) return s;
+    }
     for (uint32_t s = 8; s >= 2; --s) if (W % s == 0 && k + s - 1 <= 63) return s;
     return 1;
 }

@@ -56,18 +56,20 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
     u64 s = hash_to_range(hash_key(key), cap);
     u64 spins = 0;
     for (u64 probes = 0; probes < cap;) {
-        u64 cur = ld_agent(&slots[s].hi);
-        u32 fresh = 0;
+        // Fast path: a plain (L1/L2-cached) read.  A slot only ever moves 0 -> hi|LOCK -> hi|OCC, so a cached
+        // view can lag but never lie: if it shows OCC the key is final and its low word is in the same line;
+        // if it shows empty or LOCK the slot is re-read coherently (agent scope) before anything is decided.
+        u64 cur = slots[s].hi;
+        bool cached_view = true;
+        if (!(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
         if (cur == 0) {
             cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
             if (cur == 0) {
                 st_agent(&slots[s].lo, key.w[1]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&slots[s].hi, key.w[0] | OCC);
-                cur = key.w[0] | OCC;
-                fresh = 1;
                 atomicAdd(&slots[s].count, add);
-                return fresh;
+                return 1;
             }
         }
         if ((cur & KEYBITS) == key.w[0]) {
@@ -76,7 +78,8 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
                 __builtin_amdgcn_s_sleep(1);
                 continue;
             }
-            if (ld_agent(&slots[s].lo) == key.w[1]) {
+            const u64 lo = cached_view ? slots[s].lo : ld_agent(&slots[s].lo);
+            if (lo == key.w[1]) {
                 atomicAdd(&slots[s].count, add);
                 return 0;
             }
@@ -164,21 +167,30 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
                     fresh += upsert(kmers, kmer_cap, x, n, err);
                 }
         } else {
-            // wave-aggregated output cursor: span records per occupied tile
+            // one cursor atomic per workgroup iteration: span records per occupied tile
+            __shared__ u32 wtot[BLOCK / 64];
+            __shared__ u64 bbase;
+            const u32 wave = threadIdx.x >> 6;
             const u64 m = __ballot(have);
             const u32 before = __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
-            u64 base = 0;
-            if (lane == 0 && m) base = atomicAdd(cursor, (u64)__popcll(m) * span);
-            base = __shfl(base, 0, 64);
-            if (have)
+            if (lane == 0) wtot[wave] = __popcll(m);
+            __syncthreads();
+            u32 woff = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) woff += wtot[w]; total += wtot[w]; }
+            if (threadIdx.x == 0 && total) bbase = atomicAdd(cursor, (u64)total * span);
+            __syncthreads();
+            if (have) {
+                const u64 first = bbase + (u64)(woff + before) * span;
                 for (u32 o = 0; o < span; ++o) {
                     Key<NWK> x = sub_kmer<NWT, NWK>(tile, k, span, o);
                     if (RC) x = canonical(x, k);
-                    const u64 pos = base + (u64)before * span + o;
 #pragma unroll
-                    for (int q = 0; q < NWK; ++q) out_keys[pos * NWK + q] = x.w[q];
-                    out_w[pos] = n;
+                    for (int q = 0; q < NWK; ++q) out_keys[(first + o) * NWK + q] = x.w[q];
+                    out_w[first + o] = n;
                 }
+            }
+            __syncthreads();
         }
     }
     if (TO_TABLE) {

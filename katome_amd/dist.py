@@ -83,6 +83,43 @@ class HipOps:
         self.b.close()
 
 
+class _Phases:
+    """per-phase timing of the driver's own steps (HIP events on the current stream; no-op on CPU)"""
+
+    def __init__(self, enabled):
+        self.enabled = enabled and torch.cuda.is_available()
+        self.pairs = []
+
+    def __call__(self, name):
+        ph = self
+
+        class _Ctx:
+            def __enter__(self):
+                if ph.enabled:
+                    self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    self.a.record()
+
+            def __exit__(self, *exc):
+                if ph.enabled:
+                    self.b.record()
+                    ph.pairs.append((name, self.a, self.b))
+        return _Ctx()
+
+    def read(self):
+        if not self.enabled:
+            return {}
+        torch.cuda.synchronize()
+        out = {}
+        for name, a, b in self.pairs:
+            ms, n = out.get(name, (0.0, 0))
+            out[name] = (ms + a.elapsed_time(b), n + 1)
+        self.pairs = []
+        return out
+
+
+_NO_PHASES = _Phases(False)
+
+
 def _empty(n, dtype, device):
     """torch.empty that, when HBM is short, first hands the library's cached blocks back to the driver"""
     try:
@@ -151,7 +188,7 @@ class RankGraph:
         self.total_nodes, self.total_edges = total_nodes, total_edges
 
 
-def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, timer=None):
+def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, phases=_NO_PHASES):
     """Steps 1-3 for this rank's reads; afterwards ops' table holds the k-mers this rank owns.
 
     When a tile span divides the windows per read, what travels and is counted first are TILES (the
@@ -177,10 +214,12 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, t
                 rec = ops.extract_tiles(packed, nr, read_len, span, skip, recbuf, r0)
             else:
                 rec = ops.extract_fixed(packed, nr, read_len, skip, recbuf, r0)
-            part, counts = ops.partition(rec, world, key_words=nwr)
+            with phases("route_records"):
+                part, counts = ops.partition(rec, world, key_words=nwr)
         else:
             part, counts = recbuf[:0], [0] * world
-        recv, _ = _exchange(part, counts, nwr, group)
+        with phases("exchange_records"):
+            recv, _ = _exchange(part, counts, nwr, group)
         if recv.numel():
             if span > 1:
                 ops.insert_tiles(recv, span)
@@ -188,17 +227,19 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, t
                 ops.insert(recv)
     if span > 1:
         keys, weights = ops.expand_tiles()               # this rank's distinct tiles as (k-mer, weight) records
-        if weights.numel():
-            pk, counts, pw = ops.partition(keys, world, key_words=ops.nw, values=weights)
-        else:
-            pk, counts, pw = keys, [0] * world, weights
-        rk, rcounts = _exchange(pk, counts, ops.nw, group)
-        rw, _ = _exchange(pw, counts, 1, group)
+        with phases("route_kmers"):
+            if weights.numel():
+                pk, counts, pw = ops.partition(keys, world, key_words=ops.nw, values=weights)
+            else:
+                pk, counts, pw = keys, [0] * world, weights
+        with phases("exchange_kmers"):
+            rk, rcounts = _exchange(pk, counts, ops.nw, group)
+            rw, _ = _exchange(pw, counts, 1, group)
         if rw.numel():
             ops.insert(rk, rw)
 
 
-def finalize_distributed(ops, group=None):
+def finalize_distributed(ops, group=None, phases=_NO_PHASES):
     """Step 4: sorted distinct edges of this rank + global node ids for their endpoints."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nw, k = ops.nw, ops.k
@@ -209,18 +250,22 @@ def finalize_distributed(ops, group=None):
     # the distinct endpoint keys seen on this rank and the edges' positions in that list (read off the
     # sorted edge list, no sort)
     if E:
-        U, lsrc, ldst = ops.node_ids(keys)
+        with phases("local_node_ids"):
+            U, lsrc, ldst = ops.node_ids(keys)
     else:
         U, lsrc, ldst = ops.empty(0), ops.empty(0), ops.empty(0)
     nU = U.numel() // nw
     # route them to their owners, remembering where each came from
-    if nU:
-        P, counts, origin = ops.partition(U, world, key_words=nw, values=torch.arange(nU, dtype=torch.int32, device=dev))
-    else:
-        P, counts, origin = U, [0] * world, torch.empty(0, dtype=torch.int32, device=dev)
-    R, recv_counts = _exchange(P, counts, nw, group)
+    with phases("route_nodes"):
+        if nU:
+            P, counts, origin = ops.partition(U, world, key_words=nw, values=torch.arange(nU, dtype=torch.int32, device=dev))
+        else:
+            P, counts, origin = U, [0] * world, torch.empty(0, dtype=torch.int32, device=dev)
+    with phases("exchange_nodes"):
+        R, recv_counts = _exchange(P, counts, nw, group)
     # nodes this rank owns, in ascending key order
-    N = ops.sort_unique(R.clone(), node_bits) if R.numel() else R
+    with phases("own_nodes_sort"):
+        N = ops.sort_unique(R.clone(), node_bits) if R.numel() else R
     n_owned = N.numel() // nw
     pieces = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(pieces, torch.tensor([n_owned], dtype=torch.int64, device=dev), group=group)
@@ -229,13 +274,16 @@ def finalize_distributed(ops, group=None):
     base = int(bases[rank].item())
     total_nodes = int(all_n.sum().item())
     # answer the queries: global id of every key received, in the order received
-    ids_R = (ops.rank(N, R, node_bits) + base) if R.numel() else ops.empty(0)
-    ids_P, _ = _exchange(ids_R, recv_counts, 1, group)         # reverse route: same split sizes, mirrored
+    with phases("answer_ids"):
+        ids_R = (ops.rank(N, R, node_bits) + base) if R.numel() else ops.empty(0)
+    with phases("exchange_ids"):
+        ids_P, _ = _exchange(ids_R, recv_counts, 1, group)     # reverse route: same split sizes, mirrored
     if nU:
         del P, R, ids_R
-        id_of_U = _empty(nU, torch.int64, dev)
-        id_of_U[origin[:nU].to(torch.int64)] = ids_P           # ids_P is aligned with P; origin says which U entry that was
-        edge_src, edge_dst = id_of_U[lsrc], id_of_U[ldst]
+        with phases("apply_ids"):
+            id_of_U = _empty(nU, torch.int64, dev)
+            id_of_U[origin[:nU].to(torch.int64)] = ids_P       # ids_P is aligned with P; origin says which U entry that was
+            edge_src, edge_dst = id_of_U[lsrc], id_of_U[ldst]
         label = ops.labels(keys)
     else:
         edge_src = edge_dst = ops.empty(0)
@@ -276,11 +324,13 @@ class DistBuild:
         hint = int(wl.expected_distinct_canonical() * 2.2 / self.world * 1.1)
         ops = HipOps(wl.k, wl.reverse_complement, self.dev, table_slots_hint=hint)
         ops.b.profile(self.timer is not None)
+        phases = _Phases(self.timer is not None)
         try:
-            build_shard(ops, self.packed, self.skip, self.n_local, wl.read_len, self.batch_reads, self.group)
-            g = finalize_distributed(ops, self.group)
+            build_shard(ops, self.packed, self.skip, self.n_local, wl.read_len, self.batch_reads, self.group, phases)
+            g = finalize_distributed(ops, self.group, phases)
             if self.timer is not None:
                 self.timer.add(ops.b.profile_read())
+                self.timer.add(phases.read())
             return g.n_edges, g.n_nodes
         finally:
             ops.close()
