@@ -88,7 +88,7 @@ int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream);
 }
 
-// Tiled counting (table.hip): largest span in 2..8 that divides the windows per read and keeps the tile in 128 bits
+// Tiled counting (table.hip): largest span in 2..16 that divides the windows per read and keeps the tile in 128 bits
 uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
     if (getenv("KATOME_NO_TILES") || read_len < k) return 1;
     const uint32_t W = read_len - k + 1;
@@ -96,7 +96,7 @@ uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
         const uint32_t s = (uint32_t)atoi(e);
         if (s >= 1 && W % s == 0 && k + s - 1 <= 63) return s;
     }
-    for (uint32_t s = 8; s >= 2; --s) if (W % s == 0 && k + s - 1 <= 63) return s;
+    for (uint32_t s = 16; s >= 2; --s) if (W % s == 0 && k + s - 1 <= 63) return s;
     return 1;
 }
 uint32_t katome_tile_words(uint32_t k, uint32_t span) { return (uint32_t)key_words_for_k(k + span - 1); }
@@ -175,24 +175,20 @@ static int ensure_table(katome_builder* b, uint64_t incoming, uint64_t* room, hi
     return ensure_table(b, b->table, b->table_ready, b->nw, b->s.table_slots_hint, incoming, room, stream);
 }
 
-// every distinct tile adds its count to its `span` k-mers; afterwards the tile table is released
+// every distinct tile adds its count to its `span` k-mers; afterwards the tile table is released.
+// The tile table is walked in slot ranges small enough that even if every k-mer of the range were new the
+// k-mer table would stay under its load limit (so it keeps the size its hint gave it).
 static int expand_tiles(katome_builder* b, hipStream_t stream) {
     if (!b->tiles_ready) return KATOME_OK;
-    uint64_t n_tiles = 0, room = 0;
+    uint64_t n_tiles = 0;
     KCHECK(table_occupied(b->tiles, &n_tiles, stream));
-    if (n_tiles) {
-        const uint64_t incoming = n_tiles * b->span;              // worst case: every k-mer new
-        for (;;) {                                                // the whole expansion is one launch: make room for all of it
-            KCHECK(ensure_table(b, incoming, &room, stream));
-            if (room >= incoming) break;
-            uint64_t budget = 0;
-            KCHECK(table_budget(b, 0.9, &budget));
-            const uint64_t want = std::min<uint64_t>(budget, std::max<uint64_t>(b->table.cap * 2, (uint64_t)((double)incoming / 0.5)));
-            if (want <= b->table.cap) { set_error("k-mer table cannot hold the expanded tiles in device memory"); return KATOME_E_OOM; }
-            KCHECK(table_grow(b->table, want, stream));
-        }
+    for (uint64_t s0 = 0; n_tiles && s0 < b->tiles.cap;) {
+        uint64_t room = 0;
+        KCHECK(ensure_table(b, (uint64_t)b->span << 20, &room, stream));
+        const uint64_t slots = std::max<uint64_t>(std::min<uint64_t>(b->tiles.cap - s0, room / b->span), 1);
         PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-        KCHECK(table_expand_tiles(b->tiles, b->table, b->s.k, b->span, b->rc, stream));
+        KCHECK(table_expand_tiles(b->tiles, s0, s0 + slots, b->table, b->s.k, b->span, b->rc, stream));
+        s0 += slots;
     }
     b->tiles.slots.release(); b->tiles.counter.release();
     b->tiles_ready = false;

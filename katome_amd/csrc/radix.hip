@@ -514,7 +514,7 @@ __global__ __launch_bounds__(BLOCK) void dst_rank_kernel(const u64* __restrict__
 // workgroup tile: the misses are sparse, and one atomic per wave on a single address serialises.
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void missing_gather_kernel(const u64* __restrict__ keys, u64 n, u32 k, const u64* __restrict__ edge_dst,
-                                                                u64* __restrict__ out, u64* cursor) {
+                                                                u64* __restrict__ out, u64* __restrict__ out_edge, u64* cursor) {
     __shared__ u32 wsum[BLOCK / 64];
     __shared__ u64 block_base;
     const u64 tile = (u64)BLOCK * UNIQ_ITEMS;
@@ -534,24 +534,29 @@ __global__ __launch_bounds__(BLOCK) void missing_gather_kernel(const u64* __rest
             u64 pos = block_base + excl;
 #pragma unroll
             for (int j = 0; j < UNIQ_ITEMS; ++j)
-                if (miss[j]) { store_key<NW>(out, pos, target_node(load_key<NW>(keys, t0 + (u64)j * BLOCK + threadIdx.x), k)); ++pos; }
+                if (miss[j]) {
+                    const u64 e = t0 + (u64)j * BLOCK + threadIdx.x;
+                    store_key<NW>(out, pos, target_node(load_key<NW>(keys, e), k));
+                    out_edge[pos] = e;
+                    ++pos;
+                }
         }
         __syncthreads();
     }
 }
 // second lookup, only for the edges whose target was not a source: id = n_sources + rank among the extra nodes
 template <int NW>
-__global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restrict__ keys, u64 n, u32 k, const u64* __restrict__ extra,
-                                                              u64 n_extra, u64 n_sources, u64* __restrict__ edge_dst) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
-        if (edge_dst[i] != ~0ull) continue;
-        Key<NW> key = target_node(load_key<NW>(keys, i), k);
+__global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restrict__ miss_key, const u64* __restrict__ miss_edge, u64 n_miss,
+                                                              const u64* __restrict__ extra, u64 n_extra, u64 n_sources,
+                                                              u64* __restrict__ edge_dst) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n_miss; i += (u64)gridDim.x * BLOCK) {
+        Key<NW> key = load_key<NW>(miss_key, i);
         u64 lo = 0, hi = n_extra;
         while (lo < hi) {
             u64 mid = (lo + hi) >> 1;
             if (key_lt(load_key<NW>(extra, mid), key)) lo = mid + 1; else hi = mid;
         }
-        edge_dst[i] = n_sources + lo;
+        edge_dst[miss_edge[i]] = n_sources + lo;
     }
 }
 
@@ -591,16 +596,19 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
     KCHECK_HIP(hipStreamSynchronize(stream));
     u64 n_extra = 0;
     if (n_missing) {
-        DevBuf extra(stream);
+        DevBuf extra(stream), miss_key(stream), miss_edge(stream);
         KCHECK(extra.alloc(n_missing * 8 * NW + 16));
-        hipLaunchKernelGGL(missing_gather_kernel<NW>, dim3(grid_for(E, BLOCK, 256u * 16u)), dim3(BLOCK), 0, stream, d_edge_key, E, k,
-                           edge_dst, extra.as<u64>(), aux.as<u64>() + 1);
+        KCHECK(miss_key.alloc(n_missing * 8 * NW + 16));
+        KCHECK(miss_edge.alloc(n_missing * 8 + 16));
+        hipLaunchKernelGGL(missing_gather_kernel<NW>, dim3(grid_for(E, BLOCK * UNIQ_ITEMS, 256u * 16u)), dim3(BLOCK), 0, stream, d_edge_key, E, k,
+                           edge_dst, miss_key.as<u64>(), miss_edge.as<u64>(), aux.as<u64>() + 1);
         KCHECK_HIP(hipGetLastError());
+        KCHECK_HIP(hipMemcpyAsync(extra.p, miss_key.p, n_missing * 8 * NW, hipMemcpyDeviceToDevice, stream));
         KCHECK(dev_sort(extra.as<u64>(), nullptr, n_missing, NW, node_bits, stream));
         n_extra = n_missing;
         KCHECK(dev_unique(extra.as<u64>(), n_missing, NW, &n_extra, stream));
-        hipLaunchKernelGGL(missing_rank_kernel<NW>, dim3(grid_for(E, BLOCK, 256u * 16u)), dim3(BLOCK), 0, stream, d_edge_key, E, k,
-                           extra.as<u64>(), n_extra, n_src, edge_dst);
+        hipLaunchKernelGGL(missing_rank_kernel<NW>, dim3(grid_for(n_missing, BLOCK)), dim3(BLOCK), 0, stream, miss_key.as<u64>(),
+                           miss_edge.as<u64>(), n_missing, extra.as<u64>(), n_extra, n_src, edge_dst);
         KCHECK_HIP(hipGetLastError());
         // node_key = sources ++ extra
         DevBuf all(stream);

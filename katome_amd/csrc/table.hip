@@ -145,13 +145,13 @@ __global__ __launch_bounds__(BLOCK) void rehash_kernel(const typename SlotOf<NW>
 // same sums (pt_graph.rs:186-191 is `+= 1` per window; addition commutes), with ~span x fewer atomics.
 // ---------------------------------------------------------------------------------------------
 template <int NWT, int NWK, bool RC, bool TO_TABLE>
-__global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename SlotOf<NWT>::type* __restrict__ tiles, u64 tile_cap,
+__global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename SlotOf<NWT>::type* __restrict__ tiles, u64 slot0, u64 tile_cap,
                                                               u32 k, u32 span, typename SlotOf<NWK>::type* kmers, u64 kmer_cap,
                                                               u64* occupied, u32* err, u64* __restrict__ out_keys,
                                                               u32* __restrict__ out_w, u64* cursor) {
     u32 fresh = 0;
     const u32 lane = threadIdx.x & 63;
-    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < tile_cap; i0 += (u64)gridDim.x * BLOCK) {
+    for (u64 i0 = slot0 + (u64)blockIdx.x * BLOCK; i0 < tile_cap; i0 += (u64)gridDim.x * BLOCK) {
         const u64 i = i0 + threadIdx.x;
         Key<NWT> tile; u32 n = 0; bool have = false;
         if (i < tile_cap) {
@@ -309,15 +309,17 @@ int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
     return KATOME_OK;
 }
 
+// tile-table slots [slot0, slot1)
 template <bool TO_TABLE>
-static int expand_launch(Table& tiles, Table* kmers, uint32_t k, uint32_t span, bool rc, u64* out_keys, u32* out_w, u64* cursor,
-                         hipStream_t stream) {
+static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint32_t k, uint32_t span, bool rc, u64* out_keys,
+                         u32* out_w, u64* cursor, hipStream_t stream) {
     const uint32_t nwk = (uint32_t)key_words_for_k(k);
     TableAux* aux = kmers ? kmers->counter.as<TableAux>() : nullptr;
-    dim3 grid(grid_for(tiles.cap, BLOCK, 256u * 32u)), block(BLOCK);
+    if (slot1 <= slot0) return KATOME_OK;
+    dim3 grid(grid_for(slot1 - slot0, BLOCK, 256u * 32u)), block(BLOCK);
 #define KATOME_EXPAND(NWT, NWK, RCV)                                                                                          \
     hipLaunchKernelGGL((expand_tiles_kernel<NWT, NWK, RCV, TO_TABLE>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), \
-                       tiles.cap, k, span, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
+                       slot0, slot1, k, span, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
                        aux ? &aux->occupied : nullptr, aux ? &aux->err : nullptr, out_keys, out_w, cursor)
     if (tiles.nw == 1) { if (rc) KATOME_EXPAND(1, 1, true); else KATOME_EXPAND(1, 1, false); }
     else if (nwk == 1) { if (rc) KATOME_EXPAND(2, 1, true); else KATOME_EXPAND(2, 1, false); }
@@ -327,8 +329,9 @@ static int expand_launch(Table& tiles, Table* kmers, uint32_t k, uint32_t span, 
     return KATOME_OK;
 }
 
-int table_expand_tiles(Table& tiles, Table& kmers, uint32_t k, uint32_t span, bool rc, hipStream_t stream) {
-    return expand_launch<true>(tiles, &kmers, k, span, rc, nullptr, nullptr, nullptr, stream);
+int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmers, uint32_t k, uint32_t span, bool rc,
+                       hipStream_t stream) {
+    return expand_launch<true>(tiles, slot0, slot1, &kmers, k, span, rc, nullptr, nullptr, nullptr, stream);
 }
 
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
@@ -341,7 +344,7 @@ int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool 
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
-    KCHECK(expand_launch<false>(tiles, nullptr, k, span, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream));
+    KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream));
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     return KATOME_OK;
