@@ -25,7 +25,7 @@ constexpr int TILE_READS = 64;
 template <int NW, bool RC>
 __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t* lds_skip, u32 i, u32 W, u32 magicW,
                                                     u32 stride_bytes, u32 k, u32 step) {
-    u32 r = __umulhi(i, magicW);           // i / W, exact for i, W < 2^16
+    u32 r = W == 1 ? i : __umulhi(i, magicW);   // i / W (magic multiply, exact for i, W < 2^16; W = 1 has no 32-bit magic)
     u32 w = (i - r * W) * step;
     if (lds_skip[r]) return key_invalid<NW>();
     u32 bit = r * stride_bytes * 8 + 2 * w;
