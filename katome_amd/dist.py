@@ -306,7 +306,8 @@ class DistBuild:
 
     def __init__(self, wl, batch_reads, timer=None, group=None):
         from . import device as kd
-        self.wl, self.batch_reads, self.timer, self.group = wl, batch_reads, timer, group
+        # tile records are small (8-16 tiles of 16 B per read): larger batches mean fewer exchange rounds
+        self.wl, self.batch_reads, self.timer, self.group = wl, max(batch_reads, 16 * 1024 * 1024), timer, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.dev = torch.cuda.current_device()
         r0, r1 = shard_range(wl.reads, self.world, self.rank)
