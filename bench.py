@@ -24,22 +24,27 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E p
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # written from tools/profile_round.sh output
 
 
-def pmc_traffic(kernel_name, streaming, config):
-    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
-    separate runs, KiB per dispatch) -- only when they were taken on this very configuration.  gfx950 correction
-    from the MI355X guide: FETCH_SIZE reads half the bytes of a wide coalesced stream, so it is doubled for
-    streaming kernels; random-access kernels are left uncorrected (uncalibrated there)."""
+def pmc_traffic(parts, config):
+    """HBM bytes per launch of a phase from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs, KiB per dispatch) -- only when they were taken on this very configuration.
+    `parts` = [(kernel name, dispatches per phase launch, streaming)].  gfx950 correction from the MI355X guide:
+    FETCH_SIZE reads half the bytes of a wide coalesced stream, so it is doubled for streaming kernels;
+    random-access kernels are left uncorrected (uncalibrated there)."""
     try:
         pmc = json.load(open(PMC_FILE))
     except Exception:
         return None
     if any(pmc.get("config", {}).get(k) != config.get(k) for k in ("reads", "read_len", "k", "batch_reads", "tile_span")):
         return None
-    v = pmc.get("kernels", {}).get(kernel_name)
-    if not v:
-        return None
-    return {"bytes_per_launch": (v["fetch_kib"] * (2 if streaming else 1) + v["write_kib"]) * 1024.0,
-            "fetch_kib": v["fetch_kib"], "write_kib": v["write_kib"], "fetch_x2": bool(streaming), "source": pmc.get("source")}
+    total, detail = 0.0, []
+    for kernel_name, mult, streaming in parts:
+        v = pmc.get("kernels", {}).get(kernel_name)
+        if not v:
+            return None
+        total += mult * (v["fetch_kib"] * (2 if streaming else 1) + v["write_kib"]) * 1024.0
+        detail.append({"kernel": kernel_name, "dispatches": mult, "fetch_kib": v["fetch_kib"], "write_kib": v["write_kib"],
+                       "fetch_x2": bool(streaming)})
+    return {"bytes_per_launch": total, "parts": detail, "source": pmc.get("source")}
 
 
 def parse_args():
@@ -62,6 +67,7 @@ class PhaseTimer:
 
     def __init__(self):
         self.acc = {}
+        self.counts = {}
 
     def add(self, prof):
         for name, (ms, launches) in prof.items():
@@ -93,6 +99,7 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer):
                 b.insert(rec)
         dg = b.finalize()
         timer.add(b.profile_read())
+        timer.counts = b.counts()
         return dg.n_edges, dg.n_nodes
     finally:
         b.close()
@@ -199,9 +206,17 @@ def main():
         nwt = _katome_lib().katome_tile_words(wl.k, span)
         # extraction writes one record per tile of `span` windows (span = 1: one per window);
         # an insertion moves a record (8*NW B) and touches a slot (16*NW B)
+        cnt = timer.counts or {}
+        steps = args.steps
         alg = {"extract": lambda launches, reads: reads * (wl.stride + 8 * nwt * (W // span)),
                "insert": lambda launches, reads: reads * W * (8 * nw + 16 * nw),
                "insert_tiles": lambda launches, reads: reads * (W // span) * (8 * nwt + 16 * nwt)}
+        if not use_dist and cnt:
+            # expansion: one scan of the tile table + a 16*NW-byte slot touch per (distinct tile, k-mer) pair;
+            # edge sort: ceil(2k/8) passes, each reading and writing every (key, weight) pair once
+            alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
+            alg["sort_edges"] = lambda launches, reads: steps * n_edges * ((2 * wl.k + 7) // 8) * 2 * (8 * nw + 4)
+            alg["emit_edges"] = lambda launches, reads: steps * (cnt["kmer_slots"] * 16 * nw + n_edges * (8 * nw + 4))
         kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",
                         "insert_tiles": "insert_kernel", "expand_tiles": "expand_tiles_kernel",
                         "region_order": "radix_hist_kernel+radix_scatter_kernel (HashDigit)",
@@ -222,14 +237,24 @@ def main():
         cfg_now = {"reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads, "tile_span": span}
         rcs = "true" if wl.reverse_complement else "false"
         exact = {"extract": "void extract_fixed_kernel<%d, %s>" % (nwt, rcs), "insert": "void insert_kernel<%d>" % nw,
-                 "insert_tiles": "void insert_kernel<%d>" % nwt}
+                 "insert_tiles": "void insert_kernel<%d>" % nwt,
+                 "expand_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (nwt, nw, rcs),
+                 "sort_edges": "void radix_scatter_kernel<%d, true, RadixDigit<%d> >" % (nw, nw),
+                 "emit_edges": "void emit_edges_kernel<%d, %s>" % (nw, rcs)}
 
         def roof(name):
-            t = pmc_traffic(exact[name], streaming=(name == "extract"), config=cfg_now) if not use_dist else None
-            return {"kernel": exact[name].replace("void ", ""), "bound": "hbm", "achieved": kernels[name]["achieved_GBs"],
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[name]["frac_of_hbm_peak"],
-                    "traffic": t["bytes_per_launch"] if t else None, "traffic_detail": t,
-                    "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"], "avg_launch_ms": kernels[name]["avg_ms"]}
+            # phases made of several launches of one kernel (the 8 scatter passes of the edge sort, the slot
+            # ranges of the expansion) are priced per phase: bytes of the phase / time of the phase
+            passes = (2 * wl.k + 7) // 8
+            parts = {"sort_edges": [(exact["sort_edges"], passes, True),
+                                    ("void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw), passes, True),
+                                    ("radix_chunk_kernel", passes, True)]}.get(name, [(exact[name], 1, name == "extract")])
+            t = pmc_traffic(parts, cfg_now) if not use_dist else None
+            return {"kernel": exact[name].replace("void ", ""), "phase": name, "bound": "hbm",
+                    "achieved": kernels[name]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": kernels[name]["frac_of_hbm_peak"], "traffic": t["bytes_per_launch"] if t else None,
+                    "traffic_detail": t, "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"],
+                    "avg_launch_ms": kernels[name]["avg_ms"], "ms_per_step": kernels[name]["ms_per_step"]}
         dom = max((n for n in kernels if n in alg), key=lambda n: kernels[n]["ms_per_step"])
         roofline = roof(dom)
         line = {

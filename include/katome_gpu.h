@@ -149,6 +149,10 @@ int  katome_builder_profile_read(katome_builder *b, double *total_ms, uint64_t *
 uint32_t katome_phase_count(void);
 const char *katome_phase_name(uint32_t phase);
 
+/* sizes seen by the last katome_dev_edges/finalize: out4 = {distinct tiles, tile-table slots, distinct stored
+ * k-mers (one per strand pair when reverse_complement), k-mer-table slots}                        */
+int  katome_builder_counts(katome_builder *b, uint64_t *out4);
+
 /* u64 words per k-mer record for this k (1 or 2) */
 uint32_t katome_record_words(uint32_t k);
 

@@ -60,6 +60,7 @@ SYMBOLS = {
     "katome_builder_create": (_i, [C.POINTER(Settings), C.POINTER(_vp)]),
     "katome_builder_destroy": (None, [_vp]),
     "katome_record_words": (_u32, [_u32]),
+    "katome_builder_counts": (_i, [_vp, u64p]),
     "katome_builder_profile": (_i, [_vp, _i]),
     "katome_builder_profile_read": (_i, [_vp, C.POINTER(_dbl), u64p]),
     "katome_phase_count": (_u32, []),

@@ -44,6 +44,8 @@ struct katome_builder {
     Table tiles;
     bool tiles_ready = false;
     uint32_t span = 1;
+    // bookkeeping for katome_builder_counts: distinct tiles, tile-table slots, distinct stored k-mers, k-mer-table slots
+    uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
     // sorted distinct oriented edges
     bool edges_ready = false;
     DevBuf edge_key, edge_weight;
@@ -182,6 +184,7 @@ static int expand_tiles(katome_builder* b, hipStream_t stream) {
     if (!b->tiles_ready) return KATOME_OK;
     uint64_t n_tiles = 0;
     KCHECK(table_occupied(b->tiles, &n_tiles, stream));
+    b->stat_tiles = n_tiles; b->stat_tile_slots = b->tiles.cap;
     for (uint64_t s0 = 0; n_tiles && s0 < b->tiles.cap;) {
         uint64_t room = 0;
         KCHECK(ensure_table(b, (uint64_t)b->span << 20, &room, stream));
@@ -288,6 +291,8 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
         b->n_edges = 0;
         KCHECK(expand_tiles(b, stream));
         if (b->table_ready) {
+            KCHECK(table_occupied(b->table, &b->stat_kmers, stream));
+            b->stat_kmer_slots = b->table.cap;
             {
                 PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
                 KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->edge_key, b->edge_weight, &b->n_edges, stream));
@@ -337,6 +342,12 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
         out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = cand;
     }
+    return KATOME_OK;
+}
+
+int katome_builder_counts(katome_builder* b, uint64_t* out4) {
+    if (!b || !out4) { set_error("null argument"); return KATOME_E_ARG; }
+    out4[0] = b->stat_tiles; out4[1] = b->stat_tile_slots; out4[2] = b->stat_kmers; out4[3] = b->stat_kmer_slots;
     return KATOME_OK;
 }
 

@@ -88,6 +88,12 @@ class Builder:
         _check(L.katome_builder_profile_read(self._h, ms, cnt))
         return {L.katome_phase_name(i).decode(): (ms[i], int(cnt[i])) for i in range(n) if cnt[i]}
 
+    def counts(self):
+        """{distinct_tiles, tile_slots, distinct_kmers, kmer_slots} of the last edges()/finalize()"""
+        out = (C.c_uint64 * 4)()
+        _check(_lib.lib().katome_builder_counts(self._h, out))
+        return dict(distinct_tiles=out[0], tile_slots=out[1], distinct_kmers=out[2], kmer_slots=out[3])
+
     def close(self):
         if self._h:
             _lib.lib().katome_builder_destroy(self._h)
