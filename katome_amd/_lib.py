@@ -90,7 +90,7 @@ SYMBOLS = {
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libkatome_gpu.so")
+    return os.environ.get("KATOME_LIB") or os.path.join(_HERE, "lib", "libkatome_gpu.so")
 
 
 def lib():

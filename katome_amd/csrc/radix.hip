@@ -12,7 +12,10 @@ namespace katome {
 
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
-constexpr int SORT_ITEMS = 16;
+#ifndef KATOME_SORT_ITEMS
+#define KATOME_SORT_ITEMS 16
+#endif
+constexpr int SORT_ITEMS = KATOME_SORT_ITEMS;
 constexpr int SORT_TILE = BLOCK * SORT_ITEMS;      // 4096 keys per workgroup
 constexpr int CHUNK_BLOCKS = 1024;                 // workgroups per offset chunk (4M keys < 2^32)
 static_assert(BLOCK == RADIX, "one thread per digit in the offset kernels");
@@ -470,22 +473,37 @@ __global__ __launch_bounds__(BLOCK) void src_count_kernel(const u64* __restrict_
     (void)block_excl_scan(mine, wsum, total);
     if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
 }
-// writes the distinct sources (= node keys) and every edge's source id
+// writes the distinct sources (= node keys) and every edge's source id.  Rows of BLOCK consecutive edges are
+// taken one after the other (coalesced loads and stores); a ballot scan per row keeps the running head count.
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void src_write_kernel(const u64* __restrict__ keys, u64 n, const u64* __restrict__ block_offs,
                                                            u64* __restrict__ nodes, u64* __restrict__ edge_src) {
-    __shared__ u32 wsum[BLOCK / 64];
-    const u64 base = (u64)blockIdx.x * UNIQ_TILE + (u64)threadIdx.x * UNIQ_ITEMS;
-    bool head[UNIQ_ITEMS]; u32 mine = 0;
-#pragma unroll
-    for (int j = 0; j < UNIQ_ITEMS; ++j) { head[j] = base + j < n && is_src_head<NW>(keys, base + j); mine += head[j]; }
-    u32 total;
-    u64 pos = block_offs[blockIdx.x] + block_excl_scan(mine, wsum, total);     // heads before this thread's items
+    __shared__ u32 wtot[UNIQ_ITEMS][BLOCK / 64];
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 base = (u64)blockIdx.x * UNIQ_TILE;
+    bool head[UNIQ_ITEMS]; u32 before[UNIQ_ITEMS];
 #pragma unroll
     for (int j = 0; j < UNIQ_ITEMS; ++j) {
-        if (base + j >= n) break;
-        if (head[j]) { store_key<NW>(nodes, pos, key_shr(load_key<NW>(keys, base + j), 2)); ++pos; }
-        edge_src[base + j] = pos - 1;
+        const u64 e = base + (u64)j * BLOCK + threadIdx.x;
+        head[j] = e < n && is_src_head<NW>(keys, e);
+        const u64 m = __ballot(head[j]);
+        before[j] = __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        if (lane == 0) wtot[j][wave] = __popcll(m);
+    }
+    __syncthreads();
+    u64 carry = block_offs[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < UNIQ_ITEMS; ++j) {
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) woff += wtot[j][w]; total += wtot[j][w]; }
+        const u64 e = base + (u64)j * BLOCK + threadIdx.x;
+        if (e < n) {
+            const u64 pos = carry + woff + before[j];           // heads strictly before this edge
+            if (head[j]) store_key<NW>(nodes, pos, key_shr(load_key<NW>(keys, e), 2));
+            edge_src[e] = head[j] ? pos : pos - 1;
+        }
+        carry += total;
     }
 }
 // edge_dst[e] = position of the edge's target in `nodes`, or ~0 when it is not a source of any edge
