@@ -559,6 +559,29 @@ int katome_build_files(const katome_settings* s, const char* const* paths, size_
     *out = nullptr;
     HostReads hr;
     KCHECK(ingest_files(s, paths, n_paths, hr));           // path / parse / short-read errors surface before any GPU work
+    if (s->file_type == 2) {
+        // BFCounter (create_bfc, builder.rs:79-115; add_read_bfc, pt_graph.rs:317-330): every kept line is a k-mer
+        // with a weight -> one record per line (read length == k), added with its weight.  Lines naming the same
+        // k-mer (or, with reverse_complement, a k-mer and its reverse complement) add up here, where the reference
+        // keeps parallel edges: BFCounter output lists each k-mer once, so the two agree on such input.
+        katome_builder* b = nullptr;
+        KCHECK(katome_builder_create(s, &b));
+        int rc = KATOME_OK;
+        do {
+            if (hr.n_reads) {
+                DevBuf d_packed, d_w, d_rec;
+                if ((rc = d_packed.alloc(hr.packed_bytes + 32)) || (rc = d_w.alloc(hr.n_reads * 4)) || (rc = d_rec.alloc(hr.n_reads * 8 * b->nw + 16))) break;
+                if (hipMemcpy(d_packed.p, hr.packed, hr.packed_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(d_w.p, hr.weight, hr.n_reads * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+                if ((rc = katome_dev_extract_fixed(b, d_packed.as<uint8_t>(), hr.n_reads, s->k, nullptr, d_rec.as<u64>(), nullptr))) break;
+                if ((rc = katome_dev_insert_weighted(b, d_rec.as<u64>(), d_w.as<u32>(), hr.n_reads, nullptr))) break;
+                if (hipStreamSynchronize(nullptr) != hipSuccess) { set_error("device failure during build"); rc = KATOME_E_DEVICE; break; }
+            }
+            rc = graph_to_host(b, hr.read_bytes, out);
+        } while (0);
+        katome_builder_destroy(b);
+        return rc;
+    }
     if (hr.fixed_len) {
         katome_graph* g = nullptr;
         KCHECK(katome_build_packed(s, hr.packed, hr.n_reads, hr.fixed_len, nullptr, &g));

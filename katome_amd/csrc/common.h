@@ -145,6 +145,7 @@ struct HostReads {
     bool all_fixed = true;
     uint8_t* packed = nullptr; uint64_t packed_bytes = 0, packed_cap = 0;
     uint64_t* byte_off = nullptr; uint32_t* len = nullptr; uint64_t cap_reads = 0;
+    uint32_t* weight = nullptr;          // BFCounter input only: one weight per k-mer line (builder.rs:96-105)
     ~HostReads();
 };
 int ingest_files(const katome_settings* s, const char* const* paths, size_t n_paths, HostReads& out);

@@ -30,7 +30,7 @@ void set_error(const char* fmt, ...) {
 }
 const char* get_error() { return g_error; }
 
-HostReads::~HostReads() { free(packed); free(byte_off); free(len); }
+HostReads::~HostReads() { free(packed); free(byte_off); free(len); free(weight); }
 
 namespace {
 
@@ -137,11 +137,46 @@ int scan_fasta(const uint8_t* p, size_t n, HostReads& r, uint32_t k) {
     return KATOME_OK;
 }
 
+// create_bfc (builder.rs:79-115): one `kmer<TAB>weight` per line; lines with weight < minimal_weight_threshold are
+// dropped (106-108); every kept line is one k-mer with that weight (add_read_bfc, pt_graph.rs:317-330).
+// `BufRead::lines()` strips "\n" and "\r\n".  The reference encodes whatever bytes it is given
+// (encode_fasta_symbol is undefined outside ACGT, compress.rs:319-321); here a non-ACGT byte is a parse error.
+int scan_bfc(const uint8_t* p, size_t n, HostReads& r, uint32_t k, uint32_t min_weight) {
+    LineReader lr(p, n);
+    const uint8_t* line; size_t ln;
+    while (lr.next(line, ln)) {
+        if (ln && line[ln - 1] == '\n') --ln;
+        if (ln && line[ln - 1] == '\r') --ln;
+        const uint8_t* tab = (const uint8_t*)memchr(line, '\t', ln);
+        if (!tab) { set_error("called `Option::unwrap()` on a `None` value (BFCounter line without a tab)"); return KATOME_E_PARSE; }
+        const size_t klen = (size_t)(tab - line);
+        const uint8_t* w = tab + 1; size_t wn = ln - klen - 1;
+        if (const uint8_t* tab2 = (const uint8_t*)memchr(w, '\t', wn)) wn = (size_t)(tab2 - w);
+        uint64_t weight = 0;
+        size_t i = 0;
+        if (i < wn && w[i] == '+') ++i;                            // u32::from_str accepts a leading '+'
+        if (i == wn) { set_error("Parse int error (if the kind is overflow user should change type of EdgeWeight in prelude.rs): cannot parse integer from empty string"); return KATOME_E_PARSE; }
+        for (; i < wn; ++i) {
+            if (w[i] < '0' || w[i] > '9') { set_error("Parse int error (if the kind is overflow user should change type of EdgeWeight in prelude.rs): invalid digit found in string"); return KATOME_E_PARSE; }
+            weight = weight * 10 + (w[i] - '0');
+            if (weight > 0xFFFFFFFFull) { set_error("Parse int error (if the kind is overflow user should change type of EdgeWeight in prelude.rs): number too large to fit in target type"); return KATOME_E_PARSE; }
+        }
+        if (weight < min_weight) { ++r.n_records; continue; }       // builder.rs:106-108
+        for (size_t j = 0; j < klen; ++j) if (CODE.t[line[j]] == 0xFF) { set_error("BFCounter k-mer with a non-ACGT byte"); return KATOME_E_PARSE; }
+        if (klen > k) { set_error("BFCounter line holds %zu bases, k is %u", klen, k); return KATOME_E_ARG; }
+        KCHECK(accept_read(r, line, klen, k));                      // total += edge.len() (109); "Read is too short!" (pt_graph.rs:318)
+        uint32_t* nw = (uint32_t*)realloc(r.weight, (r.n_reads + 1) * sizeof(uint32_t));
+        if (!nw) { set_error("out of host memory"); return KATOME_E_OOM; }
+        r.weight = nw;
+        r.weight[r.n_reads - 1] = (uint32_t)weight;
+    }
+    return KATOME_OK;
+}
+
 }  // namespace
 
 int ingest_files(const katome_settings* s, const char* const* paths, size_t n_paths, HostReads& out) {
     KCHECK(check_k(s->k));
-    if (s->file_type == 2) { set_error("BFCounter input is not supported by the GPU build yet"); return KATOME_E_UNSUPPORTED; }
     if (s->file_type > 2) { set_error("unknown input file type %u", s->file_type); return KATOME_E_ARG; }
     // check_files (builder.rs:57-77): every path is vetted before any file is opened
     std::vector<std::string> files;
@@ -169,8 +204,10 @@ int ingest_files(const katome_settings* s, const char* const* paths, size_t n_pa
             madvise(p, m.n, MADV_SEQUENTIAL);
         }
     }
-    for (size_t i = 0; i < files.size(); ++i)
-        KCHECK(s->file_type == 1 ? scan_fastq(maps[i].p, maps[i].n, out, s->k) : scan_fasta(maps[i].p, maps[i].n, out, s->k));
+    for (size_t i = 0; i < files.size(); ++i) {
+        if (s->file_type == 2) KCHECK(scan_bfc(maps[i].p, maps[i].n, out, s->k, s->min_weight));
+        else KCHECK(s->file_type == 1 ? scan_fastq(maps[i].p, maps[i].n, out, s->k) : scan_fasta(maps[i].p, maps[i].n, out, s->k));
+    }
     if (!out.all_fixed || out.n_reads == 0) out.fixed_len = 0;
     memset(out.packed + out.packed_bytes, 0, 32);          // slack for vector loads
     return KATOME_OK;

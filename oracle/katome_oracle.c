@@ -525,6 +525,33 @@ static int add_read_fastaq(builder_t *b, const uint8_t *read, size_t len, int re
     return KO_OK;
 }
 
+/* pt_graph.rs:201-213 add_single_edge_bfc: push the slot, find-or-add both nodes (add_bfc_node 119-139: the
+ * fixedbitset/region arithmetic of get_node_idx 157-169 is just "index in first-seen order", which the map
+ * gives directly), and ALWAYS add an edge -- no find_edge, duplicates become parallel edges.              */
+static void add_single_edge_bfc(builder_t *b, const uint8_t *compressed, uint32_t weight)
+{
+    uint64_t offset = seqs_push(&b->seqs, compressed);
+    uint64_t s = add_fasta_node(b, 2 * offset);
+    uint64_t t = add_fasta_node(b, 2 * offset + 1);
+    pg_add_edge(&b->graph, s, t, offset, weight);
+}
+/* pt_graph.rs:317-330 */
+static int add_read_bfc(builder_t *b, const uint8_t *read, size_t len, uint32_t weight, int reverse_complement)
+{
+    if (len < K_SIZE) { snprintf(g_err, sizeof g_err, "Read is too short!"); return KO_E_SHORT_READ; }
+    if (len != K_SIZE) { snprintf(g_err, sizeof g_err, "oracle: BFCounter line of %zu bases with k=%zu is not restated", len, K_SIZE); return KO_E_ARG; }
+    uint8_t kbuf[64], rbuf[64];
+    if (reverse_complement) {
+        ko_compress_kmer_with_rev_compl(read, len, kbuf, rbuf);
+        add_single_edge_bfc(b, kbuf, weight);
+        add_single_edge_bfc(b, rbuf, weight);
+    } else {
+        ko_compress_kmer(read, len, kbuf);
+        add_single_edge_bfc(b, kbuf, weight);
+    }
+    return KO_OK;
+}
+
 /* ============ HmGIR (hm_gir.rs:22,39-153; hs_gir.rs:192-203) -- counts only ========= */
 typedef struct { uint64_t to; uint32_t w; uint8_t last_char; } gedge_t;
 typedef struct { gedge_t *e; uint32_t n; } outgoing_t;
@@ -707,6 +734,37 @@ static int scan_fasta(linebuf_t *lb, read_cb cb, void *ctx, uint64_t *n_records)
     return rc;
 }
 
+typedef int (*bfc_cb)(void *ctx, const uint8_t *kmer, size_t len, uint32_t weight);
+/* builder.rs:79-115 create_bfc: io::Lines (strips "\n" / "\r\n"), split('\t'), u32 parse, threshold */
+static int scan_bfc(linebuf_t *lb, uint32_t threshold, bfc_cb cb, void *ctx, uint64_t *total)
+{
+    for (;;) {
+        const uint8_t *line; size_t ln;
+        read_line(lb, &line, &ln);
+        if (ln == 0) return KO_OK;
+        if (line[ln - 1] == '\n') --ln;
+        if (ln && line[ln - 1] == '\r') --ln;
+        const uint8_t *tab = (const uint8_t *)memchr(line, '\t', ln);
+        if (!tab) { snprintf(g_err, sizeof g_err, "called `Option::unwrap()` on a `None` value"); return KO_E_PARSE; }
+        size_t klen = (size_t)(tab - line), wn = ln - klen - 1;
+        const uint8_t *w = tab + 1;
+        const uint8_t *tab2 = (const uint8_t *)memchr(w, '\t', wn);
+        if (tab2) wn = (size_t)(tab2 - w);
+        uint64_t weight = 0; size_t i = 0;
+        if (i < wn && w[i] == '+') ++i;
+        if (i == wn) { snprintf(g_err, sizeof g_err, "Parse int error"); return KO_E_PARSE; }
+        for (; i < wn; ++i) {
+            if (w[i] < '0' || w[i] > '9') { snprintf(g_err, sizeof g_err, "Parse int error"); return KO_E_PARSE; }
+            weight = weight * 10 + (uint64_t)(w[i] - '0');
+            if (weight > 0xFFFFFFFFull) { snprintf(g_err, sizeof g_err, "Parse int error"); return KO_E_PARSE; }
+        }
+        if (weight < threshold) continue;
+        *total += klen;
+        int rc = cb(ctx, line, klen, (uint32_t)weight);
+        if (rc) return rc;
+    }
+}
+
 static int scan_paths(const char *const *paths, size_t n_paths, int file_type, read_cb cb, void *ctx, uint64_t *n_records)
 {
     /* builder.rs:46 check_files runs over ALL inputs before any is opened */
@@ -825,6 +883,37 @@ int ko_build_files(const char *const *paths, size_t n_paths, int file_type, int 
     int rc = scan_paths(paths, n_paths, file_type, build_read_cb, &c, &n_records);
     if (!rc) *out = finish(&c);
     ctx_free(&c);
+    return rc;
+}
+
+static int build_bfc_cb(void *vctx, const uint8_t *kmer, size_t len, uint32_t weight)
+{
+    build_ctx *c = (build_ctx *)vctx;
+    return add_read_bfc(&c->b, kmer, len, weight, c->rc);
+}
+
+/* Build::create with InputFileType::BFCounter (builder.rs:50-52,79-115) */
+int ko_build_bfc(const char *const *paths, size_t n_paths, int reverse_complement, uint32_t threshold, size_t k, ko_graph **out)
+{
+    *out = NULL; g_err[0] = 0;
+    if (k < 3 || k > 128) { snprintf(g_err, sizeof g_err, "oracle: k out of range"); return KO_E_ARG; }
+    ko_set_global_k_sizes(k);
+    char (*resolved)[PATH_MAX] = (char (*)[PATH_MAX])xrealloc(NULL, (n_paths ? n_paths : 1) * PATH_MAX);
+    int rc = KO_OK;
+    for (size_t i = 0; i < n_paths && !rc; ++i) rc = check_file(paths[i], resolved[i]);
+    build_ctx c; ctx_init(&c, reverse_complement, 0);
+    uint64_t total = 0;
+    for (size_t i = 0; i < n_paths && !rc; ++i) {
+        linebuf_t lb;
+        rc = slurp(resolved[i], &lb);
+        if (rc) break;
+        rc = scan_bfc(&lb, threshold, build_bfc_cb, &c, &total);
+        free(lb.buf);
+    }
+    c.total = total;
+    if (!rc) *out = finish(&c);
+    ctx_free(&c);
+    free(resolved);
     return rc;
 }
 

@@ -89,6 +89,10 @@ enum {
 /* file_type: 0 Fasta, 1 Fastq (config.rs:5-14); BFCounter not restated (unpinned) */
 int  ko_build_files(const char *const *paths, size_t n_paths, int file_type,
                     int reverse_complement, size_t k, int with_gir, ko_graph **out);
+/* InputFileType::BFCounter (builder.rs:79-115; pt_graph.rs:201-213,317-330): `kmer\tweight` lines, lines below the
+ * threshold dropped, every kept line one edge (two with reverse_complement), duplicates kept as parallel edges */
+int  ko_build_bfc(const char *const *paths, size_t n_paths, int reverse_complement, uint32_t threshold, size_t k,
+                  ko_graph **out);
 /* reads given as fixed-length ASCII rows (the synthetic workloads); the ACGT filter
  * of builder.rs:155-157 is applied exactly as for file input                        */
 int  ko_build_ascii(const uint8_t *reads, size_t n_reads, size_t read_len,

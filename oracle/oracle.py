@@ -79,6 +79,8 @@ def lib():
         L.ko_decode_compressed_chunk.argtypes = [C.c_uint8, u8p]
         L.ko_build_files.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_int, C.c_size_t,
                                      C.c_int, C.POINTER(C.POINTER(KoGraph))]
+        L.ko_build_bfc.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint32, C.c_size_t,
+                                   C.POINTER(C.POINTER(KoGraph))]
         L.ko_build_ascii.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_int,
                                      C.POINTER(C.POINTER(KoGraph))]
         L.ko_graph_free.argtypes = [C.POINTER(KoGraph)]
@@ -238,6 +240,17 @@ def build_files(paths, k, reverse_complement=False, file_type=1, with_gir=False)
     gp = C.POINTER(KoGraph)()
     rc = lib().ko_build_files(_paths(paths), len(paths), file_type, int(reverse_complement), k, int(with_gir),
                               C.byref(gp))
+    if rc:
+        raise OracleError(rc, lib().ko_last_error().decode())
+    try:
+        return OracleGraph(gp, k)
+    finally:
+        lib().ko_graph_free(gp)
+
+
+def build_bfc(paths, k, reverse_complement=False, threshold=0):
+    gp = C.POINTER(KoGraph)()
+    rc = lib().ko_build_bfc(_paths(paths), len(paths), int(reverse_complement), threshold, k, C.byref(gp))
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:

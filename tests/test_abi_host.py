@@ -117,3 +117,24 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "katome_oracle" not in text and "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_bfcounter_ingest(tmp_path):
+    """`kmer<TAB>weight` lines (builder.rs:79-115): threshold, byte count, error statuses -- host side"""
+    f = tmp_path / "a.bfc"
+    f.write_text("ACGTA\t3\nCCCCC\t1\r\nGGGTT\t+7\textra\n")
+    from katome_amd.build import make_settings
+    import ctypes as C
+    s = make_settings(5, InputFileType.BFCounter, min_weight=2)
+    rp = C.POINTER(_lib.Reads)()
+    arr = (C.c_char_p * 1)(os.fsencode(str(f)))
+    assert katome_amd.lib().katome_ingest_files(C.byref(s), arr, 1, C.byref(rp)) == 0
+    r = rp.contents
+    assert (r.n_records, r.n_reads, r.read_bytes, r.fixed_len) == (3, 2, 10, 5)
+    katome_amd.lib().katome_reads_free(rp)
+    for text, k, want in (("ACGTA 3\n", 5, "E_PARSE"), ("ACGTA\tx\n", 5, "E_PARSE"), ("ACGTA\t99999999999\n", 5, "E_PARSE"),
+                          ("ACG\t1\n", 5, "E_SHORT_READ"), ("ACGTAC\t1\n", 5, "E_ARG"), ("ACNTA\t1\n", 5, "E_PARSE")):
+        f.write_text(text)
+        with pytest.raises(KatomePanic) as e:
+            ingest_files([str(f)], InputFileType.BFCounter, k)
+        assert e.value.name == want, text

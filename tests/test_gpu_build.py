@@ -368,3 +368,42 @@ def test_plain_path_when_tiles_disabled(oracle, golden_dir, monkeypatch):
     path = os.path.join(golden_dir, "data3.txt")
     g, _ = _build_files([path], 31, True)
     assert g.multiset() == oracle.build_files([path], 31, True).multiset()
+
+
+@pytest.mark.parametrize("k,rc", [(31, False), (31, True), (40, True), (6, True)])
+def test_bfcounter_input(oracle, golden_dir, tmp_path, k, rc):
+    """InputFileType::BFCounter through the GPU path vs the oracle's create_bfc restatement"""
+    from katome_amd.build import InputFileType
+    import random
+    path = os.path.join(golden_dir, "data3.txt")
+    base = oracle.build_files([path], k, False)
+    rng = random.Random(k)
+    comp = str.maketrans("ACGT", "TGCA")
+    lines = []
+    seen = set()
+    for km, w in base.multiset():            # one line per strand pair, orientation picked at random (as BFCounter does)
+        r = km.translate(comp)[::-1]
+        if min(km, r) in seen:
+            continue
+        seen.add(min(km, r))
+        lines.append("%s\t%d" % (km if rng.random() < 0.5 else r, w + rng.randrange(3)))
+    bfc = tmp_path / "kmers.bfc"
+    bfc.write_text("\n".join(lines) + "\n")
+    for thr in (0, 2):
+        g, rb = _build_files([str(bfc)], k, rc, InputFileType.BFCounter) if thr == 0 else (None, None)
+        if thr:
+            from katome_amd.build import GpuGraph, set_global_k_sizes
+            set_global_k_sizes(k)
+            g, rb = GpuGraph.create([str(bfc)], InputFileType.BFCounter, rc, thr)
+        ref = oracle.build_bfc([str(bfc)], k, rc, thr)
+        assert rb == ref.read_bytes
+        if rc and k % 2 == 0:
+            # a self-complementary k-mer is two parallel edges in the reference, one edge of twice the weight here
+            merged = {}
+            for km, w in ref.multiset():
+                merged[km] = merged.get(km, 0) + w
+            assert g.multiset() == sorted(merged.items())
+        else:
+            assert g.multiset() == ref.multiset()
+            assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+        _check_graph_consistency(g, k)

@@ -88,3 +88,26 @@ def test_derived_goldens(oracle, golden_dir):
         g = oracle.build_files([os.path.join(golden_dir, case["fixture"])], case["k"], case["rc"])
         assert [g.n_nodes, g.n_edges] == case["counts"]
         assert int(g.edge_weight.astype("uint64").sum()) == case["weight_sum"]
+
+
+def test_bfcounter_restatement(oracle, golden_dir, tmp_path):
+    """create_bfc (builder.rs:79-115): unpinned by the reference's tests; checked for self-consistency with the
+    FASTQ path: the distinct k-mers of a FASTQ build, written as a BFCounter file, rebuild the same graph."""
+    path = os.path.join(golden_dir, "data2.txt")
+    ref = oracle.build_files([path], 31, False)
+    bfc = tmp_path / "kmers.bfc"
+    bfc.write_text("".join("%s\t%d\n" % (km, w) for km, w in ref.multiset()))
+    g = oracle.build_bfc([str(bfc)], 31, False, 0)
+    assert g.multiset() == ref.multiset() and g.n_nodes == ref.n_nodes
+    assert g.read_bytes == 31 * ref.n_edges
+    # threshold drops lines before anything is added (builder.rs:106-108)
+    g2 = oracle.build_bfc([str(bfc)], 31, False, 2)
+    assert g2.multiset() == [(km, w) for km, w in ref.multiset() if w >= 2]
+    # reverse_complement adds the reverse complement of every line as a second edge (pt_graph.rs:321-324)
+    g3 = oracle.build_bfc([str(bfc)], 31, True, 0)
+    assert g3.n_edges == 2 * ref.n_edges
+    with pytest.raises(oracle.OracleError) as e:
+        bad = tmp_path / "bad.bfc"
+        bad.write_text("ACGT\n")
+        oracle.build_bfc([str(bad)], 4, False, 0)
+    assert e.value.name == "E_PARSE"
