@@ -205,6 +205,12 @@ int katome_dev_insert_tiles(katome_builder *b, const uint64_t *d_records, uint64
 int katome_dev_expand_tiles(katome_builder *b, uint64_t **d_keys, uint32_t **d_weights, uint64_t *n_records,
                             void *stream);
 
+/* Clean::remove_weak_edges(threshold) for PtGraph (pruner.rs:84-93): keep the edges with weight >= threshold,
+ * then drop the vertices left without neighbours.  Call before katome_dev_edges / katome_dev_finalize: the
+ * filter is applied when the edges are read out of the table, so the sort and the node numbering only see
+ * the surviving edges (and the nodes are exactly their endpoints).                                   */
+int katome_dev_remove_weak_edges(katome_builder *b, uint32_t threshold);
+
 /* number of distinct keys in the table so far (synchronises) */
 int katome_dev_table_count(katome_builder *b, uint64_t *out);
 

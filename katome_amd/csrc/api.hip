@@ -45,6 +45,7 @@ struct katome_builder {
     bool tiles_ready = false;
     uint32_t span = 1;
     // bookkeeping for katome_builder_counts: distinct tiles, tile-table slots, distinct stored k-mers, k-mer-table slots
+    uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
     uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
     // sorted distinct oriented edges
     bool edges_ready = false;
@@ -277,6 +278,13 @@ int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_w
     return KATOME_OK;
 }
 
+int katome_dev_remove_weak_edges(katome_builder* b, uint32_t threshold) {
+    if (!b) { set_error("null argument"); return KATOME_E_ARG; }
+    if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
+    b->prune_weight = threshold;
+    return KATOME_OK;
+}
+
 int katome_dev_table_count(katome_builder* b, uint64_t* out) {
     KCHECK_HIP(hipSetDevice(b->s.device));
     *out = 0;
@@ -295,7 +303,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             b->stat_kmer_slots = b->table.cap;
             {
                 PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
-                KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->edge_key, b->edge_weight, &b->n_edges, stream));
+                KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, stream));
             }
             for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
             b->table.slots.release();                 // the table is spent; its memory serves the sort

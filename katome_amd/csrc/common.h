@@ -132,7 +132,8 @@ int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmer
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
                                   uint64_t* n_records, hipStream_t stream);
 // distinct oriented edges (unsorted): allocates d_keys/d_weights
-int table_emit_edges(Table& t, uint32_t k, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_edges, hipStream_t stream);
+int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf& keys, DevBuf& weights, uint64_t* n_edges,
+                     hipStream_t stream);
 
 // synth.hip
 int launch_synth(uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, double err_rate,

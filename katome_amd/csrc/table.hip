@@ -209,7 +209,8 @@ constexpr int EMIT_ITEMS = 8;
 
 template <int NW, bool RC>
 __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf<NW>::type* __restrict__ slots, u64 cap, u32 k,
-                                                            u64* __restrict__ out_keys, u32* __restrict__ out_w, u64* cursor) {
+                                                            u32 min_weight, u64* __restrict__ out_keys, u32* __restrict__ out_w,
+                                                            u64* cursor) {
     __shared__ u32 wave_tot[BLOCK / 64];
     __shared__ u64 block_base;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -226,6 +227,8 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
                     cnt[j] = s.count;
                     nemit[j] = 1;
                     if (RC && !key_eq(revcomp(key[j], k), key[j])) nemit[j] = 2;
+                    // Clean::remove_weak_edges (pruner.rs:89-92): edges below the threshold are not emitted
+                    if (((RC && nemit[j] == 1) ? cnt[j] * 2u : cnt[j]) < min_weight) nemit[j] = 0;
                 }
             }
             mine += nemit[j];
@@ -350,7 +353,8 @@ int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool 
     return KATOME_OK;
 }
 
-int table_emit_edges(Table& t, uint32_t k, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_edges, hipStream_t stream) {
+int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf& keys, DevBuf& weights, uint64_t* n_edges,
+                     hipStream_t stream) {
     uint64_t occ = 0;
     KCHECK(table_occupied(t, &occ, stream));
     const uint64_t upper = occ * (rc ? 2 : 1);
@@ -361,11 +365,11 @@ int table_emit_edges(Table& t, uint32_t k, bool rc, DevBuf& keys, DevBuf& weight
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     dim3 grid(grid_for(t.cap, BLOCK * EMIT_ITEMS, 256u * 16u)), block(BLOCK);
     if (t.nw == 1) {
-        if (rc) hipLaunchKernelGGL((emit_edges_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-        else    hipLaunchKernelGGL((emit_edges_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        if (rc) hipLaunchKernelGGL((emit_edges_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        else    hipLaunchKernelGGL((emit_edges_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
     } else {
-        if (rc) hipLaunchKernelGGL((emit_edges_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-        else    hipLaunchKernelGGL((emit_edges_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        if (rc) hipLaunchKernelGGL((emit_edges_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        else    hipLaunchKernelGGL((emit_edges_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
     }
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_edges, cursor.p, 8, hipMemcpyDeviceToHost, stream));

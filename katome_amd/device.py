@@ -176,6 +176,10 @@ class Builder:
         else:
             _check(_lib.lib().katome_dev_insert_weighted(self._h, _ptr(records), _ptr(weights), n, _stream()))
 
+    def remove_weak_edges(self, threshold):
+        """Clean::remove_weak_edges (pruner.rs:84-93), applied when the edges are read out of the table"""
+        _check(_lib.lib().katome_dev_remove_weak_edges(self._h, threshold))
+
     def table_count(self):
         out = C.c_uint64()
         _check(_lib.lib().katome_dev_table_count(self._h, C.byref(out)))

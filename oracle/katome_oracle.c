@@ -1000,3 +1000,47 @@ void ko_synth_reads(uint64_t first_read, uint64_t n_reads, uint32_t read_len, ui
         if (n_inject_percent && (u % 100) < n_inject_percent) row[(u >> 32) % L] = 'N';
     }
 }
+
+/* ============================ pruner.rs:84-93 (PtGraph) ============================= */
+/* Clean::remove_weak_edges = retain_edges(weight >= threshold) then remove_single_vertices = retain_nodes(has a
+ * neighbour).  Only the surviving COUNTS and the edge multiset are observable in the reference's tests
+ * (tests/pruner.rs:37-169), so the restatement filters the result arrays instead of replaying petgraph's
+ * swap-remove index shuffling.  Node ids are renumbered densely in their old order.                    */
+void ko_remove_weak_edges(ko_graph *g, uint32_t threshold)
+{
+    uint64_t ne = 0;
+    for (uint64_t e = 0; e < g->n_edges; ++e) {
+        if (g->edge_weight[e] < threshold) continue;
+        g->edge_src[ne] = g->edge_src[e]; g->edge_dst[ne] = g->edge_dst[e];
+        g->edge_weight[ne] = g->edge_weight[e]; g->edge_slot[ne] = g->edge_slot[e];
+        memmove(g->edge_label + ne * (size_t)g->label_stride, g->edge_label + e * (size_t)g->label_stride, g->label_stride);
+        ++ne;
+    }
+    g->n_edges = ne;
+    uint64_t *remap = (uint64_t *)xrealloc(NULL, (g->n_nodes ? g->n_nodes : 1) * 8);
+    memset(remap, 0xFF, (g->n_nodes ? g->n_nodes : 1) * 8);
+    for (uint64_t e = 0; e < ne; ++e) { remap[g->edge_src[e]] = 0; remap[g->edge_dst[e]] = 0; }
+    uint64_t nn = 0;
+    for (uint64_t n = 0; n < g->n_nodes; ++n) if (remap[n] == 0) remap[n] = nn++;
+    for (uint64_t e = 0; e < ne; ++e) { g->edge_src[e] = remap[g->edge_src[e]]; g->edge_dst[e] = remap[g->edge_dst[e]]; }
+    g->n_nodes = nn;
+    free(remap);
+    /* stats of the pruned graph (stats/collections.rs:137-168) */
+    memset(&g->stats, 0, sizeof g->stats);
+    g->stats.node_count = nn; g->stats.edge_count = ne;
+    uint64_t *od = (uint64_t *)calloc(nn ? nn : 1, 8), *id = (uint64_t *)calloc(nn ? nn : 1, 8), sw = 0, so = 0;
+    for (uint64_t e = 0; e < ne; ++e) {
+        if (g->edge_weight[e] > g->stats.max_edge_weight) g->stats.max_edge_weight = g->edge_weight[e];
+        sw += g->edge_weight[e]; od[g->edge_src[e]]++; id[g->edge_dst[e]]++;
+    }
+    for (uint64_t n = 0; n < nn; ++n) {
+        if (od[n] > g->stats.max_out_degree) g->stats.max_out_degree = od[n];
+        if (id[n] > g->stats.max_in_degree) g->stats.max_in_degree = id[n];
+        so += od[n];
+        if (!id[n]) g->stats.incoming_vert_count++;
+        if (!od[n]) g->stats.outgoing_vert_count++;
+    }
+    g->stats.avg_edge_weight = (double)sw / (double)ne;
+    g->stats.avg_out_degree = (double)so / (double)nn;
+    free(od); free(id);
+}

@@ -84,6 +84,7 @@ def lib():
         L.ko_build_ascii.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_int,
                                      C.POINTER(C.POINTER(KoGraph))]
         L.ko_graph_free.argtypes = [C.POINTER(KoGraph)]
+        L.ko_remove_weak_edges.argtypes = [C.POINTER(KoGraph), C.c_uint32]
         L.ko_last_error.restype = C.c_char_p
         L.ko_scan_files.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.POINTER(C.POINTER(KoReads))]
         L.ko_reads_free.argtypes = [C.POINTER(KoReads)]
@@ -236,13 +237,15 @@ def _paths(paths):
     return arr
 
 
-def build_files(paths, k, reverse_complement=False, file_type=1, with_gir=False):
+def build_files(paths, k, reverse_complement=False, file_type=1, with_gir=False, remove_weak_edges=None):
     gp = C.POINTER(KoGraph)()
     rc = lib().ko_build_files(_paths(paths), len(paths), file_type, int(reverse_complement), k, int(with_gir),
                               C.byref(gp))
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:
+        if remove_weak_edges is not None:
+            lib().ko_remove_weak_edges(gp, remove_weak_edges)      # Clean::remove_weak_edges (pruner.rs:84-93)
         return OracleGraph(gp, k)
     finally:
         lib().ko_graph_free(gp)

@@ -407,3 +407,52 @@ def test_bfcounter_input(oracle, golden_dir, tmp_path, k, rc):
             assert g.multiset() == ref.multiset()
             assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
         _check_graph_consistency(g, k)
+
+
+def _fixture_on_device(golden_dir, name, k):
+    from katome_amd.build import InputFileType, ingest_files
+    r = ingest_files([os.path.join(golden_dir, name)], InputFileType.Fastq, k)
+    assert r["fixed_len"] == 100
+    return torch.from_numpy(r["packed"].copy()).cuda(), r["n_reads"], r["fixed_len"]
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_pinned_remove_weak_edges_on_gpu(golden_dir, i):
+    """tests/pruner.rs:37-169 through the GPU path: the threshold is applied when the edges leave the table"""
+    from katome_amd import device as kd
+    pinned = json.load(open(os.path.join(golden_dir, "pinned.json")))
+    p = pinned["remove_weak_edges"]
+    packed, n, L = _fixture_on_device(golden_dir, pinned["fixtures"][i], 40)
+    b = kd.Builder(40, False)
+    b.insert(b.extract_fixed(packed, n, L))
+    b.remove_weak_edges(p["thresholds"][i])
+    dg = b.finalize()
+    assert [dg.n_nodes, dg.n_edges] == p["counts"][i]
+    b.close()
+
+
+@pytest.mark.parametrize("k,rc,thr", [(31, True, 2), (31, True, 5), (12, False, 3), (40, True, 2), (6, True, 40)])
+def test_remove_weak_edges_equals_oracle(oracle, k, rc, thr):
+    from katome_amd import device as kd
+    n, L = 3000, 150
+    ascii_reads = oracle.synth_reads(0, n, L, 20000, 1e-2, 0)
+    packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc)
+    span = b.tile_span(L)
+    if span > 1:
+        b.insert_tiles(b.extract_tiles(packed, n, L, span), span)
+    else:
+        b.insert(b.extract_fixed(packed, n, L))
+    b.remove_weak_edges(thr)
+    dg = b.finalize()
+    # reference: build, then Clean::remove_weak_edges(thr) (edges kept iff weight >= thr; isolated vertices dropped)
+    full = oracle.build_ascii(ascii_reads, k, rc)
+    want = sorted((kmer_to_int(s), w) for s, w in full.multiset() if w >= thr)
+    nw = dg.key_words
+    ek = dg.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
+    keys = [int(r[0]) if nw == 1 else (int(r[0]) << 64) | int(r[1]) for r in ek]
+    assert list(zip(keys, dg.edge_weight.cpu().numpy().view(np.uint32).tolist())) == want
+    mask = (1 << (2 * (k - 1))) - 1
+    assert dg.n_nodes == len({x >> 2 for x, _ in want} | {x & mask for x, _ in want})
+    assert 0 < len(want) < full.n_edges
+    b.close()

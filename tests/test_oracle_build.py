@@ -111,3 +111,12 @@ def test_bfcounter_restatement(oracle, golden_dir, tmp_path):
         bad.write_text("ACGT\n")
         oracle.build_bfc([str(bad)], 4, False, 0)
     assert e.value.name == "E_PARSE"
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_pinned_remove_weak_edges(oracle, pinned, golden_dir, i):
+    """Clean::remove_weak_edges for PtGraph (pruner.rs:84-93) against tests/pruner.rs's constants"""
+    p = pinned["remove_weak_edges"]
+    g = oracle.build_files([os.path.join(golden_dir, pinned["fixtures"][i])], pinned["k"], False,
+                           remove_weak_edges=p["thresholds"][i])
+    assert [g.n_nodes, g.n_edges] == p["counts"][i]
