@@ -15,6 +15,7 @@
 #include <unistd.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -173,6 +174,129 @@ int scan_bfc(const uint8_t* p, size_t n, HostReads& r, uint32_t k, uint32_t min_
     return KATOME_OK;
 }
 
+int scan_range(const katome_settings* s, const uint8_t* p, size_t n, HostReads& r) {
+    if (s->file_type == 2) return scan_bfc(p, n, r, s->k, s->min_weight);
+    return s->file_type == 1 ? scan_fastq(p, n, r, s->k) : scan_fasta(p, n, r, s->k);
+}
+
+// One file, scanned by several host threads.  The file is cut at RECORD starts so that every thread sees whole
+// records in file order: FASTQ records are exactly four lines (bio 0.10.0), so a record starts at every line whose
+// index is a multiple of 4 (line indices come from a parallel newline count); FASTA records start at lines that
+// begin with '>'; BFCounter input is one record per line.  Results are appended in file order, and the error of
+// the first failing piece (in file order) is the error a sequential scan would have hit first.
+int scan_parallel(const katome_settings* s, const uint8_t* p, size_t n, HostReads& out) {
+    unsigned T = std::thread::hardware_concurrency();
+    if (const char* e = getenv("KATOME_INGEST_THREADS")) T = (unsigned)atoi(e);
+    size_t min_chunk = 4u << 20;
+    if (const char* e = getenv("KATOME_INGEST_MIN_CHUNK")) min_chunk = std::max<size_t>(1, (size_t)atoll(e));
+    T = std::max(1u, std::min({T, 32u, (unsigned)(n / min_chunk) + 1u}));
+    if (T == 1) return scan_range(s, p, n, out);
+    std::vector<size_t> raw(T + 1), cut(T + 1);
+    for (unsigned c = 0; c <= T; ++c) raw[c] = (size_t)((unsigned __int128)n * c / T);
+    std::vector<uint64_t> newlines(T, 0);
+    if (s->file_type == 1) {
+        std::vector<std::thread> th;
+        for (unsigned c = 0; c < T; ++c)
+            th.emplace_back([&, c] {
+                uint64_t cnt = 0;
+                const uint8_t* q = p + raw[c]; const uint8_t* end = p + raw[c + 1];
+                while (q < end && (q = (const uint8_t*)memchr(q, '\n', (size_t)(end - q)))) { ++cnt; ++q; }
+                newlines[c] = cnt;
+            });
+        for (auto& t : th) t.join();
+    }
+    cut[0] = 0; cut[T] = n;
+    uint64_t lines_before = 0;                                  // newlines in [0, raw[c])
+    for (unsigned c = 1; c < T; ++c) {
+        lines_before += newlines[c - 1];
+        size_t pos = raw[c];
+        uint64_t line = lines_before;                          // index of the line that contains byte `pos`
+        if (pos > 0 && p[pos - 1] != '\n') {                   // mid-line: go to the next line start
+            const uint8_t* nl = (const uint8_t*)memchr(p + pos, '\n', n - pos);
+            pos = nl ? (size_t)(nl - p) + 1 : n;
+            ++line;
+        }
+        if (s->file_type == 1) {
+            while (pos < n && line % 4 != 0) {
+                const uint8_t* nl = (const uint8_t*)memchr(p + pos, '\n', n - pos);
+                pos = nl ? (size_t)(nl - p) + 1 : n;
+                ++line;
+            }
+        } else if (s->file_type == 0) {
+            while (pos < n && p[pos] != '>') {
+                const uint8_t* nl = (const uint8_t*)memchr(p + pos, '\n', n - pos);
+                pos = nl ? (size_t)(nl - p) + 1 : n;
+            }
+        }
+        cut[c] = std::max(pos, cut[c - 1]);
+    }
+    struct Piece { HostReads r; int rc = KATOME_OK; std::string err; };
+    std::vector<Piece> pieces(T);
+    {
+        std::vector<std::thread> th;
+        for (unsigned c = 0; c < T; ++c)
+            th.emplace_back([&, c] {
+                Piece& pc = pieces[c];
+                if (cut[c + 1] <= cut[c]) return;
+                pc.rc = reserve_reads(pc.r, 0);
+                if (!pc.rc) { pc.r.byte_off[0] = 0; pc.rc = scan_range(s, p + cut[c], cut[c + 1] - cut[c], pc.r); }
+                if (pc.rc) pc.err = get_error();
+            });
+        for (auto& t : th) t.join();
+    }
+    for (unsigned c = 0; c < T; ++c) {
+        // everything before the first failing piece was accepted by the sequential scan too (byte totals included)
+        if (pieces[c].rc) {
+            for (unsigned d = 0; d <= c; ++d) { out.n_records += pieces[d].r.n_records; out.read_bytes += pieces[d].r.read_bytes; }
+            set_error("%s", pieces[c].err.c_str());
+            return pieces[c].rc;
+        }
+    }
+    // all pieces are good: size the output once and let every thread copy its own piece into place
+    std::vector<uint64_t> n0(T + 1, out.n_reads), b0(T + 1, out.packed_bytes);
+    for (unsigned c = 0; c < T; ++c) { n0[c + 1] = n0[c] + pieces[c].r.n_reads; b0[c + 1] = b0[c] + pieces[c].r.packed_bytes; }
+    const bool weighted = s->file_type == 2;
+    if (n0[T] + 2 > out.cap_reads) {
+        const uint64_t nc = n0[T] + 2;
+        uint64_t* bo = (uint64_t*)realloc(out.byte_off, nc * sizeof(uint64_t));
+        if (!bo) { set_error("out of host memory"); return KATOME_E_OOM; }
+        out.byte_off = bo;
+        uint32_t* ln = (uint32_t*)realloc(out.len, nc * sizeof(uint32_t));
+        if (!ln) { set_error("out of host memory"); return KATOME_E_OOM; }
+        out.len = ln;
+        out.cap_reads = nc;
+    }
+    KCHECK(reserve_reads(out, b0[T] - out.packed_bytes));
+    if (weighted) {
+        uint32_t* nw = (uint32_t*)realloc(out.weight, (n0[T] + 1) * sizeof(uint32_t));
+        if (!nw) { set_error("out of host memory"); return KATOME_E_OOM; }
+        out.weight = nw;
+    }
+    {
+        std::vector<std::thread> th;
+        for (unsigned c = 0; c < T; ++c)
+            th.emplace_back([&, c] {
+                const HostReads& part = pieces[c].r;
+                if (part.packed_bytes) memcpy(out.packed + b0[c], part.packed, part.packed_bytes);
+                for (uint64_t i = 0; i < part.n_reads; ++i) { out.byte_off[n0[c] + i] = b0[c] + part.byte_off[i]; out.len[n0[c] + i] = part.len[i]; }
+                if (weighted && part.n_reads) memcpy(out.weight + n0[c], part.weight, part.n_reads * sizeof(uint32_t));
+            });
+        for (auto& t : th) t.join();
+    }
+    for (unsigned c = 0; c < T; ++c) {
+        const HostReads& part = pieces[c].r;
+        if (part.n_reads) {
+            if (out.n_reads == 0) { out.fixed_len = part.fixed_len; out.all_fixed = part.all_fixed; }
+            else if (!part.all_fixed || part.fixed_len != out.fixed_len) out.all_fixed = false;
+        }
+        out.n_reads += part.n_reads;
+        out.n_records += part.n_records; out.read_bytes += part.read_bytes; out.total_windows += part.total_windows;
+    }
+    out.packed_bytes = b0[T];
+    out.byte_off[out.n_reads] = out.packed_bytes;
+    return KATOME_OK;
+}
+
 }  // namespace
 
 int ingest_files(const katome_settings* s, const char* const* paths, size_t n_paths, HostReads& out) {
@@ -204,10 +328,7 @@ int ingest_files(const katome_settings* s, const char* const* paths, size_t n_pa
             madvise(p, m.n, MADV_SEQUENTIAL);
         }
     }
-    for (size_t i = 0; i < files.size(); ++i) {
-        if (s->file_type == 2) KCHECK(scan_bfc(maps[i].p, maps[i].n, out, s->k, s->min_weight));
-        else KCHECK(s->file_type == 1 ? scan_fastq(maps[i].p, maps[i].n, out, s->k) : scan_fasta(maps[i].p, maps[i].n, out, s->k));
-    }
+    for (size_t i = 0; i < files.size(); ++i) KCHECK(scan_parallel(s, maps[i].p, maps[i].n, out));
     if (!out.all_fixed || out.n_reads == 0) out.fixed_len = 0;
     memset(out.packed + out.packed_bytes, 0, 32);          // slack for vector loads
     return KATOME_OK;

@@ -138,3 +138,46 @@ def test_bfcounter_ingest(tmp_path):
         with pytest.raises(KatomePanic) as e:
             ingest_files([str(f)], InputFileType.BFCounter, k)
         assert e.value.name == want, text
+
+
+def test_parallel_ingest_equals_sequential(tmp_path, monkeypatch, oracle):
+    """the multi-threaded scan (file cut at record starts) gives byte-identical output and the same first error"""
+    rng = np.random.default_rng(3)
+    fq_lines, fa_lines, bfc_lines = [], [], []
+    for i in range(3000):
+        n = int(rng.integers(20, 160))
+        s = "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+        if i % 11 == 0:
+            s = s[:3] + "N" + s[4:]
+        q = "".join(chr(int(c)) for c in rng.integers(33, 74, n))      # qualities may start with '@' or '+'
+        fq_lines += ["@r%d" % i, s, "+", "@" + q[1:] if i % 5 == 0 else q]
+        fa_lines += [">r%d" % i] + [s[j:j + 37] for j in range(0, n, 37)]
+        bfc_lines.append("%s\t%d" % ("".join("ACGT"[c] for c in rng.integers(0, 4, 21)), int(rng.integers(1, 9))))
+    files = {"fq": (tmp_path / "p.fq", "\n".join(fq_lines) + "\n", InputFileType.Fastq, 15),
+             "fa": (tmp_path / "p.fa", "\n".join(fa_lines) + "\n", InputFileType.Fasta, 15),
+             "bfc": (tmp_path / "p.bfc", "\n".join(bfc_lines) + "\n", InputFileType.BFCounter, 21)}
+    for name, (path, text, ft, k) in files.items():
+        path.write_text(text)
+        monkeypatch.setenv("KATOME_INGEST_THREADS", "1")
+        seq = ingest_files([str(path)], ft, k)
+        monkeypatch.setenv("KATOME_INGEST_MIN_CHUNK", "1000")
+        for threads in ("2", "5", "32"):
+            monkeypatch.setenv("KATOME_INGEST_THREADS", threads)
+            par = ingest_files([str(path)], ft, k)
+            for key in ("n_records", "n_reads", "read_bytes", "packed_bytes", "total_windows", "fixed_len"):
+                assert par[key] == seq[key], (name, threads, key)
+            for key in ("packed", "byte_off", "len"):
+                assert np.array_equal(par[key], seq[key]), (name, threads, key)
+        monkeypatch.delenv("KATOME_INGEST_MIN_CHUNK")
+    # first error in file order wins, whichever thread meets it: a short read late in the file, a broken record later still
+    path, text, ft, k = files["fq"]
+    lines = text.split("\n")
+    lines[4 * 2000 + 1] = "ACGTACG"                      # record 2000: accepted but shorter than k
+    lines[4 * 2500] = "broken header"                    # record 2500: parse error, never reached
+    path.write_text("\n".join(lines))
+    monkeypatch.setenv("KATOME_INGEST_MIN_CHUNK", "1000")
+    for threads in ("1", "7"):
+        monkeypatch.setenv("KATOME_INGEST_THREADS", threads)
+        with pytest.raises(KatomePanic) as e:
+            ingest_files([str(path)], ft, k)
+        assert e.value.name == "E_SHORT_READ", threads
