@@ -214,7 +214,14 @@ def main():
         if not use_dist and cnt:
             # expansion: one scan of the tile table + a 16*NW-byte slot touch per (distinct tile, k-mer) pair;
             # edge sort: ceil(2k/8) passes, each reading and writing every (key, weight) pair once
-            alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
+            ms2 = cnt.get("mid_span", 0)
+            if ms2:      # two levels: big tiles -> mid tiles (128-bit upserts) -> k-mers
+                nwm = _katome_lib().katome_tile_words(wl.k, ms2)
+                alg["expand_tiles"] = lambda launches, reads: steps * (
+                    cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * (span // ms2) * 16 * nwm +
+                    cnt["mid_tile_slots"] * 16 * nwm + cnt["distinct_mid_tiles"] * ms2 * 16 * nw)
+            else:
+                alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
             alg["sort_edges"] = lambda launches, reads: steps * n_edges * ((2 * wl.k + 7) // 8) * 2 * (8 * nw + 4)
             alg["emit_edges"] = lambda launches, reads: steps * (cnt["kmer_slots"] * 16 * nw + n_edges * (8 * nw + 4))
         kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",

@@ -149,9 +149,10 @@ int  katome_builder_profile_read(katome_builder *b, double *total_ms, uint64_t *
 uint32_t katome_phase_count(void);
 const char *katome_phase_name(uint32_t phase);
 
-/* sizes seen by the last katome_dev_edges/finalize: out4 = {distinct tiles, tile-table slots, distinct stored
- * k-mers (one per strand pair when reverse_complement), k-mer-table slots}                        */
-int  katome_builder_counts(katome_builder *b, uint64_t *out4);
+/* sizes seen by the last katome_dev_edges/finalize: out8 = {distinct tiles, tile-table slots, distinct stored
+ * k-mers (one per strand pair when reverse_complement), k-mer-table slots, distinct mid tiles, mid-tile-table
+ * slots, tile span, mid-tile span (0 = tiles expand straight into k-mers)}                          */
+int  katome_builder_counts(katome_builder *b, uint64_t *out8);
 
 /* u64 words per k-mer record for this k (1 or 2) */
 uint32_t katome_record_words(uint32_t k);
@@ -191,7 +192,8 @@ int katome_dev_insert_weighted(katome_builder *b, const uint64_t *d_records, con
  * fixed-length reads the windows can instead be counted in TILES -- the (k+span-1)-mers that cover `span`
  * consecutive windows, (read_len-k+1)/span per read -- and every distinct tile then adds its count to its
  * span k-mers at once (same sums as `weight += 1` per window, pt_graph.rs:186-191; ~span x fewer atomics).
- * katome_tile_span: the span the library would use for these reads (1 = plain counting).
+ * katome_tile_span: the span the library would use for these reads (1 = plain counting); spans above 16 are
+ * broken into mid tiles first (two levels of the same expansion).
  * Records of katome_dev_extract_tiles: [n_reads*(read_len-k+1)/span][katome_tile_words(k, span)] u64.
  * Tiles are expanded into the k-mer table by katome_dev_edges / katome_dev_finalize; the multi-GPU
  * driver takes them out with katome_dev_expand_tiles as (k-mer, weight) records (library-owned, valid until

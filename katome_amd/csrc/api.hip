@@ -44,6 +44,11 @@ struct katome_builder {
     Table tiles;
     bool tiles_ready = false;
     uint32_t span = 1;
+    // big tiles (span > 16) are first broken into mid tiles of span2 windows (a second tile table), those into k-mers
+    Table tiles2;
+    bool tiles2_ready = false;
+    uint32_t span2 = 0;
+    uint64_t stat_tiles2 = 0, stat_tile2_slots = 0;
     // bookkeeping for katome_builder_counts: distinct tiles, tile-table slots, distinct stored k-mers, k-mer-table slots
     uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
     uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
@@ -91,7 +96,7 @@ int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream);
 }
 
-// Tiled counting (table.hip): largest span in 2..16 that divides the windows per read and keeps the tile in 128 bits
+// Tiled counting (table.hip): largest span in 2..32 that divides the windows per read and keeps the tile in 128 bits
 uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
     if (getenv("KATOME_NO_TILES") || read_len < k) return 1;
     const uint32_t W = read_len - k + 1;
@@ -99,7 +104,7 @@ uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
         const uint32_t s = (uint32_t)atoi(e);
         if (s >= 1 && W % s == 0 && k + s - 1 <= 63) return s;
     }
-    for (uint32_t s = 16; s >= 2; --s) if (W % s == 0 && k + s - 1 <= 63) return s;
+    for (uint32_t s = 32; s >= 2; --s) if (W % s == 0 && k + s - 1 <= 63) return s;
     return 1;
 }
 uint32_t katome_tile_words(uint32_t k, uint32_t span) { return (uint32_t)key_words_for_k(k + span - 1); }
@@ -178,24 +183,57 @@ static int ensure_table(katome_builder* b, uint64_t incoming, uint64_t* room, hi
     return ensure_table(b, b->table, b->table_ready, b->nw, b->s.table_slots_hint, incoming, room, stream);
 }
 
-// every distinct tile adds its count to its `span` k-mers; afterwards the tile table is released.
-// The tile table is walked in slot ranges small enough that even if every k-mer of the range were new the
-// k-mer table would stay under its load limit (so it keeps the size its hint gave it).
-static int expand_tiles(katome_builder* b, hipStream_t stream) {
-    if (!b->tiles_ready) return KATOME_OK;
+// span of the mid tiles a big tile is broken into: the divisor of `span` in 2..8 closest to 6; 0 = expand directly
+static uint32_t mid_span(uint32_t span) {
+    if (span <= 16 || getenv("KATOME_ONE_LEVEL_TILES")) return 0;
+    static const uint32_t pref[] = {6, 5, 7, 4, 8, 3, 2};
+    for (uint32_t s : pref) if (span % s == 0) return s;
+    return 0;
+}
+
+// walk `from` in slot ranges small enough that even if every sub-window of the range were a new key, `to` stays
+// under its load limit (so it keeps the size its hint gave it); every tile adds its count to its n_sub sub-windows
+static int expand_level(katome_builder* b, Table& from, Table& to, bool& to_ready, uint32_t to_nw, uint64_t to_hint,
+                        uint32_t sub_len, uint32_t n_sub, uint32_t stride, hipStream_t stream) {
+    for (uint64_t s0 = 0; s0 < from.cap;) {
+        uint64_t room = 0;
+        KCHECK(ensure_table(b, to, to_ready, to_nw, to_hint, (uint64_t)n_sub << 20, &room, stream));
+        const uint64_t slots = std::max<uint64_t>(std::min<uint64_t>(from.cap - s0, room / n_sub), 1);
+        PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+        KCHECK(table_expand_tiles(from, s0, s0 + slots, to, sub_len, n_sub, stride, b->rc, stream));
+        s0 += slots;
+    }
+    return KATOME_OK;
+}
+
+// big tiles -> mid tiles (when the span is large); leaves the tiles that hold k-mers directly in `*last`
+static int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, hipStream_t stream) {
     uint64_t n_tiles = 0;
     KCHECK(table_occupied(b->tiles, &n_tiles, stream));
     b->stat_tiles = n_tiles; b->stat_tile_slots = b->tiles.cap;
-    for (uint64_t s0 = 0; n_tiles && s0 < b->tiles.cap;) {
-        uint64_t room = 0;
-        KCHECK(ensure_table(b, (uint64_t)b->span << 20, &room, stream));
-        const uint64_t slots = std::max<uint64_t>(std::min<uint64_t>(b->tiles.cap - s0, room / b->span), 1);
-        PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-        KCHECK(table_expand_tiles(b->tiles, s0, s0 + slots, b->table, b->s.k, b->span, b->rc, stream));
-        s0 += slots;
+    b->span2 = mid_span(b->span);
+    *last = &b->tiles; *last_span = b->span;
+    if (b->span2 && n_tiles) {
+        const uint32_t kk2 = b->s.k + b->span2 - 1;
+        KCHECK(expand_level(b, b->tiles, b->tiles2, b->tiles2_ready, (uint32_t)key_words_for_k(kk2), b->s.table_slots_hint / 2,
+                            kk2, b->span / b->span2, b->span2, stream));
+        b->tiles.slots.release(); b->tiles.counter.release();
+        KCHECK(table_occupied(b->tiles2, &b->stat_tiles2, stream));
+        b->stat_tile2_slots = b->tiles2.cap;
+        *last = &b->tiles2; *last_span = b->span2;
     }
+    return KATOME_OK;
+}
+
+// every distinct tile adds its count to its k-mers; afterwards the tile tables are released
+static int expand_tiles(katome_builder* b, hipStream_t stream) {
+    if (!b->tiles_ready) return KATOME_OK;
+    Table* last = nullptr; uint32_t last_span = 1;
+    KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+    if (b->stat_tiles) KCHECK(expand_level(b, *last, b->table, b->table_ready, b->nw, b->s.table_slots_hint, b->s.k, last_span, 1, stream));
     b->tiles.slots.release(); b->tiles.counter.release();
-    b->tiles_ready = false;
+    b->tiles2.slots.release(); b->tiles2.counter.release();
+    b->tiles_ready = false; b->tiles2_ready = false;
     return KATOME_OK;
 }
 
@@ -268,12 +306,15 @@ int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_w
     KCHECK_HIP(hipSetDevice(b->s.device));
     *n_records = 0; *d_keys = nullptr; *d_weights = nullptr;
     if (!b->tiles_ready) return KATOME_OK;
+    Table* last = nullptr; uint32_t last_span = 1;
+    KCHECK(expand_to_last_level(b, &last, &last_span, stream));
     {
         PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-        KCHECK(table_expand_tiles_to_records(b->tiles, b->s.k, b->span, b->rc, b->scratch_k[0], b->scratch_w[0], n_records, stream));
+        KCHECK(table_expand_tiles_to_records(*last, b->s.k, last_span, b->rc, b->scratch_k[0], b->scratch_w[0], n_records, stream));
     }
     b->tiles.slots.release(); b->tiles.counter.release();
-    b->tiles_ready = false;
+    b->tiles2.slots.release(); b->tiles2.counter.release();
+    b->tiles_ready = false; b->tiles2_ready = false;
     *d_keys = b->scratch_k[0].as<u64>(); *d_weights = b->scratch_w[0].as<u32>();
     return KATOME_OK;
 }
@@ -353,9 +394,10 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
     return KATOME_OK;
 }
 
-int katome_builder_counts(katome_builder* b, uint64_t* out4) {
-    if (!b || !out4) { set_error("null argument"); return KATOME_E_ARG; }
-    out4[0] = b->stat_tiles; out4[1] = b->stat_tile_slots; out4[2] = b->stat_kmers; out4[3] = b->stat_kmer_slots;
+int katome_builder_counts(katome_builder* b, uint64_t* out8) {
+    if (!b || !out8) { set_error("null argument"); return KATOME_E_ARG; }
+    out8[0] = b->stat_tiles; out8[1] = b->stat_tile_slots; out8[2] = b->stat_kmers; out8[3] = b->stat_kmer_slots;
+    out8[4] = b->stat_tiles2; out8[5] = b->stat_tile2_slots; out8[6] = b->span; out8[7] = b->span2;
     return KATOME_OK;
 }
 

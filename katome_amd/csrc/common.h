@@ -126,8 +126,8 @@ int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights,
 int table_occupied(Table& t, uint64_t* out, hipStream_t stream);
 int table_grow(Table& t, uint64_t new_cap, hipStream_t stream);
 // tiled counting: every tile (key of k+span-1 bases, weight n) adds n to each of its `span` k-mers
-int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmers, uint32_t k, uint32_t span, bool rc,
-                       hipStream_t stream);
+int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmers, uint32_t k, uint32_t span, uint32_t stride,
+                       bool rc, hipStream_t stream);
 // same, but the (k-mer, weight) records are written out instead (multi-GPU: they travel to their owners)
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
                                   uint64_t* n_records, hipStream_t stream);

@@ -138,9 +138,10 @@ template <int NW> KD Key<NW> target_node(const Key<NW>& kmer, u32 k) { return ke
 KD Key<1> narrow_key(const Key<1>& a, Key<1>*) { return a; }
 KD Key<2> narrow_key(const Key<2>& a, Key<2>*) { return a; }
 KD Key<1> narrow_key(const Key<2>& a, Key<1>*) { Key<1> r; r.w[0] = a.w[1]; return r; }
-// the o-th k-mer (o = 0 is the leftmost) of a tile of span k-mers
-template <int NWT, int NWK> KD Key<NWK> sub_kmer(const Key<NWT>& tile, u32 k, u32 span, u32 o) {
-    return narrow_key(key_low_bits(key_shr(tile, 2 * (span - 1 - o)), 2 * k), (Key<NWK>*)nullptr);
+// the o-th sub-window (o = 0 is the leftmost) of a tile made of n_sub windows of sub_len bases whose starts are
+// `stride` bases apart (k-mers of a tile: sub_len = k, stride = 1; the smaller tiles of a big tile: stride = their span)
+template <int NWT, int NWK> KD Key<NWK> sub_window(const Key<NWT>& tile, u32 sub_len, u32 n_sub, u32 stride, u32 o) {
+    return narrow_key(key_low_bits(key_shr(tile, 2 * stride * (n_sub - 1 - o)), 2 * sub_len), (Key<NWK>*)nullptr);
 }
 
 // ---- compress_edge label (compress.rs:250-271) ----------------------------------------------

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(BLOCK) void rehash_kernel(const typename SlotOf<NW>
 // ---------------------------------------------------------------------------------------------
 template <int NWT, int NWK, bool RC, bool TO_TABLE>
 __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename SlotOf<NWT>::type* __restrict__ tiles, u64 slot0, u64 tile_cap,
-                                                              u32 k, u32 span, typename SlotOf<NWK>::type* kmers, u64 kmer_cap,
+                                                              u32 k, u32 span, u32 stride, typename SlotOf<NWK>::type* kmers, u64 kmer_cap,
                                                               u64* occupied, u32* err, u64* __restrict__ out_keys,
                                                               u32* __restrict__ out_w, u64* cursor) {
     u32 fresh = 0;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
         if (TO_TABLE) {
             if (have)
                 for (u32 o = 0; o < span; ++o) {
-                    Key<NWK> x = sub_kmer<NWT, NWK>(tile, k, span, o);
+                    Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, stride, o);
                     if (RC) x = canonical(x, k);
                     fresh += upsert(kmers, kmer_cap, x, n, err);
                 }
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
             if (have) {
                 const u64 first = bbase + (u64)(woff + before) * span;
                 for (u32 o = 0; o < span; ++o) {
-                    Key<NWK> x = sub_kmer<NWT, NWK>(tile, k, span, o);
+                    Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, stride, o);
                     if (RC) x = canonical(x, k);
 #pragma unroll
                     for (int q = 0; q < NWK; ++q) out_keys[(first + o) * NWK + q] = x.w[q];
@@ -312,17 +312,17 @@ int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
     return KATOME_OK;
 }
 
-// tile-table slots [slot0, slot1)
+// tile-table slots [slot0, slot1); every tile holds `span` windows of `k` bases, `stride` bases apart
 template <bool TO_TABLE>
-static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint32_t k, uint32_t span, bool rc, u64* out_keys,
-                         u32* out_w, u64* cursor, hipStream_t stream) {
+static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint32_t k, uint32_t span, uint32_t stride, bool rc,
+                         u64* out_keys, u32* out_w, u64* cursor, hipStream_t stream) {
     const uint32_t nwk = (uint32_t)key_words_for_k(k);
     TableAux* aux = kmers ? kmers->counter.as<TableAux>() : nullptr;
     if (slot1 <= slot0) return KATOME_OK;
     dim3 grid(grid_for(slot1 - slot0, BLOCK, 256u * 32u)), block(BLOCK);
 #define KATOME_EXPAND(NWT, NWK, RCV)                                                                                          \
     hipLaunchKernelGGL((expand_tiles_kernel<NWT, NWK, RCV, TO_TABLE>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), \
-                       slot0, slot1, k, span, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
+                       slot0, slot1, k, span, stride, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
                        aux ? &aux->occupied : nullptr, aux ? &aux->err : nullptr, out_keys, out_w, cursor)
     if (tiles.nw == 1) { if (rc) KATOME_EXPAND(1, 1, true); else KATOME_EXPAND(1, 1, false); }
     else if (nwk == 1) { if (rc) KATOME_EXPAND(2, 1, true); else KATOME_EXPAND(2, 1, false); }
@@ -332,9 +332,9 @@ static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint3
     return KATOME_OK;
 }
 
-int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmers, uint32_t k, uint32_t span, bool rc,
-                       hipStream_t stream) {
-    return expand_launch<true>(tiles, slot0, slot1, &kmers, k, span, rc, nullptr, nullptr, nullptr, stream);
+int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmers, uint32_t k, uint32_t span, uint32_t stride,
+                       bool rc, hipStream_t stream) {
+    return expand_launch<true>(tiles, slot0, slot1, &kmers, k, span, stride, rc, nullptr, nullptr, nullptr, stream);
 }
 
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
@@ -347,7 +347,7 @@ int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool 
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
-    KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream));
+    KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, 1, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream));
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     return KATOME_OK;

@@ -90,9 +90,10 @@ class Builder:
 
     def counts(self):
         """{distinct_tiles, tile_slots, distinct_kmers, kmer_slots} of the last edges()/finalize()"""
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 8)()
         _check(_lib.lib().katome_builder_counts(self._h, out))
-        return dict(distinct_tiles=out[0], tile_slots=out[1], distinct_kmers=out[2], kmer_slots=out[3])
+        return dict(distinct_tiles=out[0], tile_slots=out[1], distinct_kmers=out[2], kmer_slots=out[3],
+                    distinct_mid_tiles=out[4], mid_tile_slots=out[5], span=out[6], mid_span=out[7])
 
     def close(self):
         if self._h:

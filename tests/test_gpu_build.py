@@ -340,7 +340,7 @@ def test_tiled_counting_equals_plain_counting(oracle, k, L, rc):
     tiled = kd.Builder(k, rc, table_slots_hint=4096)
     span = tiled.tile_span(L)
     W = L - k + 1
-    assert span == max([s for s in range(2, 17) if W % s == 0 and k + s - 1 <= 63] + [1])
+    assert span == max([s for s in range(2, 33) if W % s == 0 and k + s - 1 <= 63] + [1])
     if span == 1:
         pytest.skip("no span divides the windows of this read length")
     half = (n // 2 // 64) * 64
