@@ -277,7 +277,7 @@ def main():
                        "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
-            "roofline": roofline, "roofline_extract": roof("extract"), "kernels": kernels,
+            "roofline": roofline, "roofline_extract": roof("extract"), "kernels": kernels, "counts": cnt,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
