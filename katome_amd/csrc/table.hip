@@ -149,8 +149,15 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
                                                               u32 k, u32 span, u32 stride, typename SlotOf<NWK>::type* kmers, u64 kmer_cap,
                                                               u64* occupied, u32* err, u64* __restrict__ out_keys,
                                                               u32* __restrict__ out_w, u64* cursor) {
+    // The tile table is sparse (10-25 % occupied) and every tile has `span` sub-windows: the occupied tiles of
+    // each run of BLOCK slots are first compacted into LDS, then the (tile, sub-window) pairs are dealt out
+    // evenly over the lanes, so that every lane has an independent upsert in flight.
+    __shared__ u64 lkey[BLOCK * NWT];
+    __shared__ u32 lcnt[BLOCK];
+    __shared__ u32 wtot[BLOCK / 64];
+    __shared__ u64 bbase;
     u32 fresh = 0;
-    const u32 lane = threadIdx.x & 63;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (u64 i0 = slot0 + (u64)blockIdx.x * BLOCK; i0 < tile_cap; i0 += (u64)gridDim.x * BLOCK) {
         const u64 i = i0 + threadIdx.x;
         Key<NWT> tile; u32 n = 0; bool have = false;
@@ -159,39 +166,37 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
             have = slot_key(s, tile);
             n = s.count;
         }
-        if (TO_TABLE) {
-            if (have)
-                for (u32 o = 0; o < span; ++o) {
-                    Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, stride, o);
-                    if (RC) x = canonical(x, k);
-                    fresh += upsert(kmers, kmer_cap, x, n, err);
-                }
-        } else {
-            // one cursor atomic per workgroup iteration: span records per occupied tile
-            __shared__ u32 wtot[BLOCK / 64];
-            __shared__ u64 bbase;
-            const u32 wave = threadIdx.x >> 6;
-            const u64 m = __ballot(have);
-            const u32 before = __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
-            if (lane == 0) wtot[wave] = __popcll(m);
-            __syncthreads();
-            u32 woff = 0, total = 0;
+        const u64 m = __ballot(have);
+        const u32 before = __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        if (lane == 0) wtot[wave] = __popcll(m);
+        __syncthreads();
+        u32 woff = 0, total = 0;
 #pragma unroll
-            for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) woff += wtot[w]; total += wtot[w]; }
-            if (threadIdx.x == 0 && total) bbase = atomicAdd(cursor, (u64)total * span);
-            __syncthreads();
-            if (have) {
-                const u64 first = bbase + (u64)(woff + before) * span;
-                for (u32 o = 0; o < span; ++o) {
-                    Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, stride, o);
-                    if (RC) x = canonical(x, k);
+        for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) woff += wtot[w]; total += wtot[w]; }
+        if (have) {
 #pragma unroll
-                    for (int q = 0; q < NWK; ++q) out_keys[(first + o) * NWK + q] = x.w[q];
-                    out_w[first + o] = n;
-                }
-            }
-            __syncthreads();
+            for (int q = 0; q < NWT; ++q) lkey[(woff + before) * NWT + q] = tile.w[q];
+            lcnt[woff + before] = n;
         }
+        if (!TO_TABLE && threadIdx.x == 0 && total) bbase = atomicAdd(cursor, (u64)total * span);
+        __syncthreads();
+        const u32 pairs = total * span;
+        for (u32 p = threadIdx.x; p < pairs; p += BLOCK) {
+            const u32 t = p / span, o = p - t * span;
+            Key<NWT> tk;
+#pragma unroll
+            for (int q = 0; q < NWT; ++q) tk.w[q] = lkey[t * NWT + q];
+            Key<NWK> x = sub_window<NWT, NWK>(tk, k, span, stride, o);
+            if (RC) x = canonical(x, k);
+            if (TO_TABLE) {
+                fresh += upsert(kmers, kmer_cap, x, lcnt[t], err);
+            } else {
+#pragma unroll
+                for (int q = 0; q < NWK; ++q) out_keys[(bbase + p) * NWK + q] = x.w[q];
+                out_w[bbase + p] = lcnt[t];
+            }
+        }
+        __syncthreads();
     }
     if (TO_TABLE) {
         fresh = wave_sum(fresh);
