@@ -125,12 +125,7 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const u64* __restr
     __syncthreads();
 
     Key<NW> key[SORT_ITEMS]; u32 val[SORT_ITEMS]; u32 dig[SORT_ITEMS]; u32 rnk[SORT_ITEMS];
-    u32 lead[SORT_ITEMS]; u32 old[SORT_ITEMS];
     const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
-    // pass A: for every row of 64 keys, the lanes holding the same digit find each other with ballots; the lowest
-    // of them (the leader) bumps the wave's digit counter with an LDS atomic that returns the old value.  The 16
-    // atomics are issued back to back (LDS keeps a wave's operations in order, so row order = key order) and only
-    // waited for once, instead of a read-modify-write round trip per row.
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
         const u32 idx = wave * (64 * SORT_ITEMS) + j * 64 + lane;
@@ -149,15 +144,12 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const u64* __restr
             m &= bit ? vote : ~vote;
         }
         const u32 prior = __popcll(m & lt_mask);
+        u32 old = 0;
+        if (valid) old = whist[wave][d];
+        if (valid && prior == 0) whist[wave][d] = old + __popcll(m);
         dig[j] = d;
-        rnk[j] = prior;
-        lead[j] = valid ? (u32)__ffsll((unsigned long long)m) - 1 : lane;
-        old[j] = 0;
-        if (valid && prior == 0) old[j] = atomicAdd(&whist[wave][d], (u32)__popcll(m));
+        rnk[j] = old + prior;
     }
-    // pass B: everyone picks up its leader's base
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; ++j) rnk[j] += __shfl(old[j], (int)lead[j], 64);
     __syncthreads();
 
     {   // thread = digit: wave-exclusive prefixes, tile-wide digit starts, global run bases
