@@ -106,13 +106,12 @@ __global__ __launch_bounds__(BLOCK) void radix_offsets_kernel(u64* __restrict__ 
 // key's place in the tile's digit-sorted order, the tile is reordered through LDS and written out
 // so that consecutive lanes store consecutive addresses of each digit's run.
 template <int NW, bool HAS_VAL, class Digit>
-__global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
+__global__ __launch_bounds__(BLOCK, 4) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                u64 n, Digit dg, const u32* __restrict__ rel,
                                                                const u64* __restrict__ chunk_off, u64* __restrict__ keys_out,
                                                                u32* __restrict__ vals_out) {
     extern __shared__ u64 smem[];
-    u64* skeys = smem;                                            // [SORT_TILE * NW]
-    u32* svals = reinterpret_cast<u32*>(smem + SORT_TILE * NW);   // [SORT_TILE] when HAS_VAL
+    u64* skeys = smem;                                            // [SORT_TILE * NW]; reused for the values afterwards
     __shared__ u32 whist[BLOCK / 64][RADIX];
     __shared__ u32 dstart[RADIX];
     __shared__ u64 gbase[RADIX];
@@ -170,29 +169,46 @@ __global__ __launch_bounds__(BLOCK) void radix_scatter_kernel(const u64* __restr
     }
     __syncthreads();
 
+    // the tile goes through LDS twice, keys first and then the values through the same buffer: half the LDS per
+    // workgroup means twice the workgroups (and bytes in flight) per CU, which is what bounds this kernel
+    u32 pos[SORT_ITEMS];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
         const u32 idx = wave * (64 * SORT_ITEMS) + j * 64 + lane;
+        pos[j] = idx < cnt ? dstart[dig[j]] + whist[wave][dig[j]] + rnk[j] : 0;
         if (idx < cnt) {
-            const u32 pos = dstart[dig[j]] + whist[wave][dig[j]] + rnk[j];
 #pragma unroll
-            for (int q = 0; q < NW; ++q) skeys[pos * NW + q] = key[j].w[q];
-            if (HAS_VAL) svals[pos] = val[j];
+            for (int q = 0; q < NW; ++q) skeys[pos[j] * NW + q] = key[j].w[q];
         }
     }
     __syncthreads();
-
+    u32 dout[SORT_ITEMS];            // digit of the key this thread writes out in row j (needed again for its value)
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
         const u32 i = j * BLOCK + tid;
+        dout[j] = 0;
         if (i < cnt) {
             Key<NW> k;
 #pragma unroll
             for (int q = 0; q < NW; ++q) k.w[q] = skeys[i * NW + q];
             const u32 d = dg(k);
-            const u64 o = gbase[d] + (i - dstart[d]);
-            store_key<NW>(keys_out, o, k);
-            if (HAS_VAL) vals_out[o] = svals[i];
+            dout[j] = d;
+            store_key<NW>(keys_out, gbase[d] + (i - dstart[d]), k);
+        }
+    }
+    if (HAS_VAL) {
+        u32* svals = reinterpret_cast<u32*>(smem);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const u32 idx = wave * (64 * SORT_ITEMS) + j * 64 + lane;
+            if (idx < cnt) svals[pos[j]] = val[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; ++j) {
+            const u32 i = j * BLOCK + tid;
+            if (i < cnt) vals_out[gbase[dout[j]] + (i - dstart[dout[j]])] = svals[i];
         }
     }
 }
@@ -218,7 +234,7 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
     hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
     hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>());
     hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
-    const size_t lds = (size_t)SORT_TILE * NW * 8 + (HAS_VAL ? (size_t)SORT_TILE * 4 : 0);
+    const size_t lds = (size_t)SORT_TILE * NW * 8;
     hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
                        pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout);
     KCHECK_HIP(hipGetLastError());
