@@ -16,6 +16,9 @@ constexpr int RADIX = 1 << RADIX_BITS;
 #define KATOME_SORT_ITEMS 16
 #endif
 constexpr int SORT_ITEMS = KATOME_SORT_ITEMS;
+#ifndef KATOME_SORT_WAVES
+#define KATOME_SORT_WAVES 4      // workgroups per CU the scatter kernel is compiled for (register budget)
+#endif
 constexpr int SORT_TILE = BLOCK * SORT_ITEMS;      // 4096 keys per workgroup
 constexpr int CHUNK_BLOCKS = 1024;                 // workgroups per offset chunk (4M keys < 2^32)
 static_assert(BLOCK == RADIX, "one thread per digit in the offset kernels");
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(BLOCK) void radix_offsets_kernel(u64* __restrict__ 
 // key's place in the tile's digit-sorted order, the tile is reordered through LDS and written out
 // so that consecutive lanes store consecutive addresses of each digit's run.
 template <int NW, bool HAS_VAL, class Digit>
-__global__ __launch_bounds__(BLOCK, 4) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
+__global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                u64 n, Digit dg, const u32* __restrict__ rel,
                                                                const u64* __restrict__ chunk_off, u64* __restrict__ keys_out,
                                                                u32* __restrict__ vals_out) {
