@@ -217,8 +217,9 @@ def main():
             ms2 = cnt.get("mid_span", 0)
             if ms2:      # two levels: big tiles -> mid tiles (128-bit upserts) -> k-mers
                 nwm = _katome_lib().katome_tile_words(wl.k, ms2)
+                alg["expand_mid_tiles"] = lambda launches, reads: steps * (
+                    cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * (span // ms2) * 16 * nwm)
                 alg["expand_tiles"] = lambda launches, reads: steps * (
-                    cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * (span // ms2) * 16 * nwm +
                     cnt["mid_tile_slots"] * 16 * nwm + cnt["distinct_mid_tiles"] * ms2 * 16 * nw)
             else:
                 alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
@@ -226,6 +227,7 @@ def main():
             alg["emit_edges"] = lambda launches, reads: steps * (cnt["kmer_slots"] * 16 * nw + n_edges * (8 * nw + 4))
         kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",
                         "insert_tiles": "insert_kernel", "expand_tiles": "expand_tiles_kernel",
+                        "expand_mid_tiles": "expand_tiles_kernel (big tiles -> mid tiles)",
                         "region_order": "radix_hist_kernel+radix_scatter_kernel (HashDigit)",
                         "emit_edges": "emit_edges_kernel", "sort_edges": "radix sort (edges)",
                         "node_set": "endpoints + radix sort + unique", "rank": "bucket_index + rank_kernel",
@@ -245,7 +247,10 @@ def main():
         rcs = "true" if wl.reverse_complement else "false"
         exact = {"extract": "void extract_fixed_kernel<%d, %s>" % (nwt, rcs), "insert": "void insert_kernel<%d>" % nw,
                  "insert_tiles": "void insert_kernel<%d>" % nwt,
-                 "expand_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (nwt, nw, rcs),
+                 "expand_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (
+                     _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or span), nw, rcs),
+                 "expand_mid_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (
+                     nwt, _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or 1), rcs),
                  "sort_edges": "void radix_scatter_kernel<%d, true, RadixDigit<%d> >" % (nw, nw),
                  "emit_edges": "void emit_edges_kernel<%d, %s>" % (nw, rcs)}
 

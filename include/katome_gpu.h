@@ -142,7 +142,7 @@ void katome_builder_destroy(katome_builder *b);
 /* optional per-phase timing with HIP events recorded on the caller's stream (bench.py's roofline
  * figures).  total_ms / launches have katome_phase_count() entries, named by katome_phase_name():
  * extract, region_order, insert, emit_edges, sort_edges, node_set, rank, labels, insert_tiles,
- * expand_tiles.  Reading
+ * expand_tiles, expand_mid_tiles.  Reading
  * synchronises the device and clears the record.                                            */
 int  katome_builder_profile(katome_builder *b, int enable);
 int  katome_builder_profile_read(katome_builder *b, double *total_ms, uint64_t *launches);

@@ -15,9 +15,9 @@ using namespace katome;
 
 // optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
 enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
-             PH_INSERT_TILES, PH_EXPAND_TILES, PH_COUNT };
+             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_COUNT };
 static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
-                                                  "rank", "labels", "insert_tiles", "expand_tiles"};
+                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles"};
 struct Profiler {
     bool on = false;
     struct Ev { int phase; hipEvent_t a, b; };
@@ -194,12 +194,12 @@ static uint32_t mid_span(uint32_t span) {
 // walk `from` in slot ranges small enough that even if every sub-window of the range were a new key, `to` stays
 // under its load limit (so it keeps the size its hint gave it); every tile adds its count to its n_sub sub-windows
 static int expand_level(katome_builder* b, Table& from, Table& to, bool& to_ready, uint32_t to_nw, uint64_t to_hint,
-                        uint32_t sub_len, uint32_t n_sub, uint32_t stride, hipStream_t stream) {
+                        uint32_t sub_len, uint32_t n_sub, uint32_t stride, int phase, hipStream_t stream) {
     for (uint64_t s0 = 0; s0 < from.cap;) {
         uint64_t room = 0;
         KCHECK(ensure_table(b, to, to_ready, to_nw, to_hint, (uint64_t)n_sub << 20, &room, stream));
         const uint64_t slots = std::max<uint64_t>(std::min<uint64_t>(from.cap - s0, room / n_sub), 1);
-        PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+        PhaseScope ps(b->prof, phase, stream);
         KCHECK(table_expand_tiles(from, s0, s0 + slots, to, sub_len, n_sub, stride, b->rc, stream));
         s0 += slots;
     }
@@ -216,7 +216,7 @@ static int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_
     if (b->span2 && n_tiles) {
         const uint32_t kk2 = b->s.k + b->span2 - 1;
         KCHECK(expand_level(b, b->tiles, b->tiles2, b->tiles2_ready, (uint32_t)key_words_for_k(kk2), b->s.table_slots_hint / 2,
-                            kk2, b->span / b->span2, b->span2, stream));
+                            kk2, b->span / b->span2, b->span2, PH_EXPAND_MID, stream));
         b->tiles.slots.release(); b->tiles.counter.release();
         KCHECK(table_occupied(b->tiles2, &b->stat_tiles2, stream));
         b->stat_tile2_slots = b->tiles2.cap;
@@ -230,7 +230,7 @@ static int expand_tiles(katome_builder* b, hipStream_t stream) {
     if (!b->tiles_ready) return KATOME_OK;
     Table* last = nullptr; uint32_t last_span = 1;
     KCHECK(expand_to_last_level(b, &last, &last_span, stream));
-    if (b->stat_tiles) KCHECK(expand_level(b, *last, b->table, b->table_ready, b->nw, b->s.table_slots_hint, b->s.k, last_span, 1, stream));
+    if (b->stat_tiles) KCHECK(expand_level(b, *last, b->table, b->table_ready, b->nw, b->s.table_slots_hint, b->s.k, last_span, 1, PH_EXPAND_TILES, stream));
     b->tiles.slots.release(); b->tiles.counter.release();
     b->tiles2.slots.release(); b->tiles2.counter.release();
     b->tiles_ready = false; b->tiles2_ready = false;
