@@ -456,3 +456,28 @@ def test_remove_weak_edges_equals_oracle(oracle, k, rc, thr):
     assert dg.n_nodes == len({x >> 2 for x, _ in want} | {x & mask for x, _ in want})
     assert 0 < len(want) < full.n_edges
     b.close()
+
+
+@pytest.mark.parametrize("k,rc", [(4, True), (6, True), (7, False), (31, True), (32, True), (40, True)])
+def test_low_complexity_reads(oracle, tmp_path, k, rc):
+    """homopolymers, short tandem repeats and reverse-palindromes: self-loops (a (k-1)-mer that is its own
+    successor), k-mers equal to their reverse complement (even k), (k-1)-mers equal to their reverse complement
+    (odd k), heavy multiplicity -- against the oracle's restatement of the reference"""
+    L = 96
+    seqs = ["A" * L, "T" * L, "AC" * (L // 2), "ACGT" * (L // 4), "AATT" * (L // 4), "G" * 40 + "C" * 56,
+            ("ACGTTGCA" * 12)[:L], ("AAAAC" * 20)[:L], ("AT" * 48), ("GATC" * 24)]
+    lines = []
+    for rep in range(7):
+        for i, s in enumerate(seqs):
+            lines += ["@r%d_%d" % (rep, i), s, "+", "I" * L]
+    fq = tmp_path / "lowc.fq"
+    fq.write_text("\n".join(lines) + "\n")
+    g, rb = _build_files([str(fq)], k, rc)
+    ref = oracle.build_files([str(fq)], k, rc)
+    assert rb == ref.read_bytes
+    assert g.multiset() == ref.multiset()
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    st, rs = g.stats(), ref.stats
+    assert (st.max_edge_weight, st.max_in_degree, st.max_out_degree, st.incoming_vert_count, st.outgoing_vert_count) == \
+        (rs["max_edge_weight"], rs["max_in_degree"], rs["max_out_degree"], rs["incoming_vert_count"], rs["outgoing_vert_count"])
+    _check_graph_consistency(g, k)
