@@ -26,6 +26,13 @@ extern "C" {
 
 #define KATOME_ABI_VERSION 1
 
+/* settings.flags.  FIRST_SEEN_ORDER: number edges and nodes exactly as the reference's sequential loop does --
+ * petgraph edge indices in the order `add_edge` is first called for them, node indices in the order `add_node`
+ * is (pt_graph.rs:149,194) -- instead of by packed key.  Downstream stages that walk petgraph's adjacency
+ * (pruner.rs:241, collapser.rs:120) then see the same graph, index for index.  Costs two extra atomics per
+ * counted record and two more sorts at the end; fixed-length reads, one GPU.                            */
+#define KATOME_FLAG_FIRST_SEEN_ORDER 1u
+
 /* status codes: the reference's panics, one code each */
 enum {
     KATOME_OK = 0,
@@ -46,7 +53,7 @@ typedef struct {
     uint32_t k;                  /* k_mer_size; supported 3..63 (k<=31: 64-bit keys, else 128-bit) */
     uint8_t  file_type;          /* InputFileType (config.rs:5-14): 0 Fasta, 1 Fastq, 2 BFCounter   */
     uint8_t  reverse_complement; /* Config::reverse_complement                                     */
-    uint16_t _pad;
+    uint16_t flags;              /* KATOME_FLAG_*                                                   */
     uint32_t min_weight;         /* minimal_weight_threshold (BFCounter ingest only, builder.rs:106)*/
     int32_t  device;             /* HIP device ordinal of the MI355X to build on                     */
     uint64_t table_slots_hint;   /* 0 = size the (k-1)-mer/edge table automatically                 */
@@ -57,7 +64,8 @@ typedef struct {
  * (source, target, weight, label) with the label in compress_edge format (compress.rs:250-271),
  * i.e. what SEQUENCES[EdgeSlice.idx()] holds after PtGraph::create (pt_graph.rs:339-343).
  * Edge order = ascending packed k-mer.  Node ids (deterministic): the nodes that have out-edges in
- * ascending packed-(k-1)-mer order, then the nodes without out-edges in ascending order.          */
+ * ascending packed-(k-1)-mer order, then the nodes without out-edges in ascending order.
+ * With KATOME_FLAG_FIRST_SEEN_ORDER: edges and nodes in the reference's own (first-seen) order.    */
 typedef struct {
     uint64_t n_nodes, n_edges;
     uint64_t read_bytes;          /* sum of accepted read lengths (builder.rs:158)              */
@@ -142,7 +150,7 @@ void katome_builder_destroy(katome_builder *b);
 /* optional per-phase timing with HIP events recorded on the caller's stream (bench.py's roofline
  * figures).  total_ms / launches have katome_phase_count() entries, named by katome_phase_name():
  * extract, region_order, insert, emit_edges, sort_edges, node_set, rank, labels, insert_tiles,
- * expand_tiles, expand_mid_tiles.  Reading
+ * expand_tiles, expand_mid_tiles, first_seen_order.  Reading
  * synchronises the device and clears the record.                                            */
 int  katome_builder_profile(katome_builder *b, int enable);
 int  katome_builder_profile_read(katome_builder *b, double *total_ms, uint64_t *launches);

@@ -14,7 +14,7 @@ STATUS = {0: "OK", -1: "E_PATH", -2: "E_IS_DIR", -3: "E_NOT_EXIST", -4: "E_OPEN"
 
 
 class Settings(C.Structure):
-    _fields_ = [("k", C.c_uint32), ("file_type", C.c_uint8), ("reverse_complement", C.c_uint8), ("_pad", C.c_uint16),
+    _fields_ = [("k", C.c_uint32), ("file_type", C.c_uint8), ("reverse_complement", C.c_uint8), ("flags", C.c_uint16),
                 ("min_weight", C.c_uint32), ("device", C.c_int32), ("table_slots_hint", C.c_uint64)]
 
 

@@ -15,9 +15,9 @@ using namespace katome;
 
 // optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
 enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
-             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_COUNT };
+             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_COUNT };
 static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
-                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles"};
+                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles", "first_seen_order"};
 struct Profiler {
     bool on = false;
     struct Ev { int phase; hipEvent_t a, b; };
@@ -50,6 +50,11 @@ struct katome_builder {
     uint32_t span2 = 0;
     uint64_t stat_tiles2 = 0, stat_tile2_slots = 0;
     // bookkeeping for katome_builder_counts: distinct tiles, tile-table slots, distinct stored k-mers, k-mer-table slots
+    // first-seen-order mode (KATOME_FLAG_FIRST_SEEN_ORDER)
+    bool first_seen = false;
+    uint64_t reads_inserted = 0;       // reads whose records have been handed to an insert so far
+    uint32_t seen_read_len = 0;        // read length of the last extraction (records per read follow from it)
+    DevBuf edge_seq;                   // sequence number of each edge's first insertion, aligned with edge_key
     uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
     uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
     // sorted distinct oriented edges
@@ -79,6 +84,8 @@ int katome_builder_create(const katome_settings* s, katome_builder** out) {
     b->s = *s;
     b->nw = (uint32_t)key_words_for_k(s->k);
     b->rc = s->reverse_complement != 0;
+    b->first_seen = (s->flags & KATOME_FLAG_FIRST_SEEN_ORDER) != 0;
+    b->table.track_seen = b->tiles.track_seen = b->tiles2.track_seen = b->first_seen;
     *out = b;
     return KATOME_OK;
 }
@@ -93,7 +100,9 @@ int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_
                              const uint8_t* d_skip, uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
-    return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream);
+    b->seen_read_len = read_len;
+    return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, 1,
+                                b->first_seen && b->rc);
 }
 
 // Tiled counting (table.hip): largest span in 2..32 that divides the windows per read and keeps the tile in 128 bits
@@ -114,13 +123,16 @@ int katome_dev_extract_tiles(katome_builder* b, const uint8_t* d_packed, uint64_
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (span < 1 || b->s.k + span - 1 > 63) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
-    return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, span);
+    b->seen_read_len = read_len;
+    return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, span,
+                                b->first_seen && b->rc);
 }
 
 int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                            const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                            uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
+    if (b->first_seen) { set_error("first-seen order is implemented for fixed-length reads only"); return KATOME_E_UNSUPPORTED; }
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     return launch_extract_var(b->s.k, b->rc, d_packed, packed_bytes, d_byte_off, d_len, d_win_prefix, n_reads, total_windows,
                               d_records, (hipStream_t)stream);
@@ -217,7 +229,7 @@ static int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_
         const uint32_t kk2 = b->s.k + b->span2 - 1;
         KCHECK(expand_level(b, b->tiles, b->tiles2, b->tiles2_ready, (uint32_t)key_words_for_k(kk2), b->s.table_slots_hint / 2,
                             kk2, b->span / b->span2, b->span2, PH_EXPAND_MID, stream));
-        b->tiles.slots.release(); b->tiles.counter.release();
+        b->tiles.release();
         KCHECK(table_occupied(b->tiles2, &b->stat_tiles2, stream));
         b->stat_tile2_slots = b->tiles2.cap;
         *last = &b->tiles2; *last_span = b->span2;
@@ -231,8 +243,8 @@ static int expand_tiles(katome_builder* b, hipStream_t stream) {
     Table* last = nullptr; uint32_t last_span = 1;
     KCHECK(expand_to_last_level(b, &last, &last_span, stream));
     if (b->stat_tiles) KCHECK(expand_level(b, *last, b->table, b->table_ready, b->nw, b->s.table_slots_hint, b->s.k, last_span, 1, PH_EXPAND_TILES, stream));
-    b->tiles.slots.release(); b->tiles.counter.release();
-    b->tiles2.slots.release(); b->tiles2.counter.release();
+    b->tiles.release();
+    b->tiles2.release();
     b->tiles_ready = false; b->tiles2_ready = false;
     return KATOME_OK;
 }
@@ -258,7 +270,14 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
     // that the insert kernel's working set stays cache-sized.  Off unless KATOME_REGION_PASSES says so:
     // measured on MI355X the insert kernel is bound by atomic throughput, not by where the slots live.
     const uint64_t* k_in = d_records; const uint32_t* w_in = d_weights;
-    const int passes = region_passes(b->table.cap * b->table.slot_bytes());
+    SeenOrigin origin;
+    if (b->first_seen) {
+        if (b->seen_read_len < b->s.k) { set_error("first-seen order: extract the records with this builder first"); return KATOME_E_ARG; }
+        origin.windows = b->seen_read_len - b->s.k + 1; origin.per_read = origin.windows; origin.span = 1; origin.rc = b->rc;
+        origin.read0 = b->reads_inserted;
+        if (n_records % origin.per_read) { set_error("first-seen order: a batch must hold whole reads"); return KATOME_E_ARG; }
+    }
+    const int passes = b->first_seen ? 0 : region_passes(b->table.cap * b->table.slot_bytes());
     if (passes > 0 && n_records >= (1u << 16)) {
         for (int i = 0; i < 2; ++i) {
             if ((i == 0 || passes > 1) && b->scratch_k[i].bytes < n_records * 8 * b->nw) KCHECK(b->scratch_k[i].alloc(n_records * 8 * b->nw, stream));
@@ -272,9 +291,11 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
         if (done) KCHECK(ensure_table(b, n_records - done, &room, stream));
         const uint64_t n = std::min(n_records - done, room);
         PhaseScope ps(b->prof, PH_INSERT, stream);
-        KCHECK(table_insert(b->table, k_in + done * b->nw, w_in ? w_in + done : nullptr, n, stream));
+        origin.rec0 = done;
+        KCHECK(table_insert(b->table, k_in + done * b->nw, w_in ? w_in + done : nullptr, n, stream, b->first_seen ? &origin : nullptr));
         done += n;
     }
+    if (b->first_seen) b->reads_inserted += n_records / origin.per_read;
     return KATOME_OK;
 }
 int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_records, void* stream) {
@@ -289,14 +310,23 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     if (n_records == 0) return KATOME_OK;
     b->span = span;
     const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
+    SeenOrigin origin;
+    if (b->first_seen) {
+        if (b->seen_read_len < b->s.k) { set_error("first-seen order: extract the records with this builder first"); return KATOME_E_ARG; }
+        origin.windows = b->seen_read_len - b->s.k + 1; origin.per_read = origin.windows / span; origin.span = span; origin.rc = b->rc;
+        origin.read0 = b->reads_inserted;
+        if (origin.per_read == 0 || n_records % origin.per_read) { set_error("first-seen order: a batch must hold whole reads"); return KATOME_E_ARG; }
+    }
     for (uint64_t done = 0; done < n_records;) {
         uint64_t room = 0;
         KCHECK(ensure_table(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 2, n_records - done, &room, stream));
         const uint64_t n = std::min(n_records - done, room);
         PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
-        KCHECK(table_insert(b->tiles, d_records + done * nwt, nullptr, n, stream));
+        origin.rec0 = done;
+        KCHECK(table_insert(b->tiles, d_records + done * nwt, nullptr, n, stream, b->first_seen ? &origin : nullptr));
         done += n;
     }
+    if (b->first_seen) b->reads_inserted += n_records / origin.per_read;
     return KATOME_OK;
 }
 
@@ -305,6 +335,7 @@ int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_w
     hipStream_t stream = (hipStream_t)stream_;
     KCHECK_HIP(hipSetDevice(b->s.device));
     *n_records = 0; *d_keys = nullptr; *d_weights = nullptr;
+    if (b->first_seen) { set_error("first-seen order is not available on the multi-GPU route"); return KATOME_E_UNSUPPORTED; }
     if (!b->tiles_ready) return KATOME_OK;
     Table* last = nullptr; uint32_t last_span = 1;
     KCHECK(expand_to_last_level(b, &last, &last_span, stream));
@@ -312,8 +343,8 @@ int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_w
         PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
         KCHECK(table_expand_tiles_to_records(*last, b->s.k, last_span, b->rc, b->scratch_k[0], b->scratch_w[0], n_records, stream));
     }
-    b->tiles.slots.release(); b->tiles.counter.release();
-    b->tiles2.slots.release(); b->tiles2.counter.release();
+    b->tiles.release();
+    b->tiles2.release();
     b->tiles_ready = false; b->tiles2_ready = false;
     *d_keys = b->scratch_k[0].as<u64>(); *d_weights = b->scratch_w[0].as<u32>();
     return KATOME_OK;
@@ -342,16 +373,30 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
         if (b->table_ready) {
             KCHECK(table_occupied(b->table, &b->stat_kmers, stream));
             b->stat_kmer_slots = b->table.cap;
+            DevBuf raw_w(stream), raw_seq(stream);
             {
                 PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
-                KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, stream));
+                if (b->first_seen) KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->prune_weight, b->edge_key, raw_w, &b->n_edges, stream, &raw_seq));
+                else KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, stream));
             }
             for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
-            b->table.slots.release();                 // the table is spent; its memory serves the sort
-            b->table.counter.release();
+            b->table.release();                       // the table is spent; its memory serves the sort
             b->table_ready = false;
             PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
-            KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
+            if (b->first_seen) {
+                // sort (key, position) and bring weight and sequence number along through the positions
+                if (b->n_edges >= (1ull << 32)) { set_error("first-seen order: more than 2^32 edges on one GPU"); return KATOME_E_UNSUPPORTED; }
+                DevBuf idx(stream);
+                KCHECK(idx.alloc((b->n_edges + 1) * 4));
+                KCHECK(dev_iota(idx.as<u32>(), b->n_edges, stream));
+                KCHECK(dev_sort(b->edge_key.as<u64>(), idx.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
+                KCHECK(b->edge_weight.alloc((b->n_edges + 1) * 4, stream));
+                KCHECK(b->edge_seq.alloc((b->n_edges + 1) * 8, stream));
+                KCHECK(dev_gather_u32(raw_w.as<u32>(), idx.as<u32>(), b->n_edges, b->edge_weight.as<u32>(), stream));
+                KCHECK(dev_gather_u64(raw_seq.as<u64>(), idx.as<u32>(), b->n_edges, b->edge_seq.as<u64>(), stream));
+            } else {
+                KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
+            }
         } else {
             KCHECK(b->edge_key.alloc(16, stream)); KCHECK(b->edge_weight.alloc(16, stream));
         }
@@ -377,6 +422,44 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         KCHECK(dev_node_ids(b->edge_key.as<u64>(), E, k, b->node_key, b->edge_src.as<u64>(), b->edge_dst.as<u64>(), &b->n_nodes, stream));
     }
     u64* cand = b->node_key.as<u64>();
+    if (b->first_seen && E) {
+        // Re-number everything the way the reference's loop would have: edges by the sequence number of their first
+        // insertion, nodes by the first insertion that touches them (source of a strand's first window: 2*seq;
+        // target: 2*seq + 1).  petgraph hands out indices in exactly that order (pt_graph.rs:149,194).
+        PhaseScope ps(b->prof, PH_FIRST_SEEN, stream);
+        const uint64_t N = b->n_nodes;
+        if (N >= (1ull << 32)) { set_error("first-seen order: more than 2^32 nodes on one GPU"); return KATOME_E_UNSUPPORTED; }
+        const uint64_t max_seq = 2 * (b->reads_inserted + 1) * 2 * (uint64_t)(b->seen_read_len - k + 1) + 2;
+        uint32_t bits = 1;
+        while (bits < 64 && (max_seq >> bits)) ++bits;
+        DevBuf node_first(stream), nperm(stream), new_id(stream), eseq(stream), eperm(stream);
+        KCHECK(node_first.alloc((N + 1) * 8)); KCHECK(nperm.alloc((N + 1) * 4)); KCHECK(new_id.alloc((N + 1) * 8));
+        KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
+        KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
+        KCHECK(dev_iota(nperm.as<u32>(), N, stream));
+        KCHECK(dev_sort(node_first.as<u64>(), nperm.as<u32>(), N, 1, bits, stream));        // nperm[new] = old
+        KCHECK(dev_invert(nperm.as<u32>(), N, new_id.as<u64>(), stream));                   // new_id[old] = new
+        KCHECK(eseq.alloc((E + 1) * 8)); KCHECK(eperm.alloc((E + 1) * 4));
+        KCHECK_HIP(hipMemcpyAsync(eseq.p, b->edge_seq.p, E * 8, hipMemcpyDeviceToDevice, stream));
+        KCHECK(dev_iota(eperm.as<u32>(), E, stream));
+        KCHECK(dev_sort(eseq.as<u64>(), eperm.as<u32>(), E, 1, bits, stream));               // eperm[new] = old
+        DevBuf okey(stream), ow(stream), osrc(stream), odst(stream), onode(stream);
+        KCHECK(okey.alloc((E + 1) * 8 * nw)); KCHECK(ow.alloc((E + 1) * 4)); KCHECK(osrc.alloc((E + 1) * 8)); KCHECK(odst.alloc((E + 1) * 8));
+        KCHECK(onode.alloc((N + 1) * 8 * nw));
+        KCHECK(dev_gather_keys(b->edge_key.as<u64>(), eperm.as<u32>(), E, nw, okey.as<u64>(), stream));
+        KCHECK(dev_gather_u32(b->edge_weight.as<u32>(), eperm.as<u32>(), E, ow.as<u32>(), stream));
+        KCHECK(dev_gather_mapped(b->edge_src.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, osrc.as<u64>(), stream));
+        KCHECK(dev_gather_mapped(b->edge_dst.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, odst.as<u64>(), stream));
+        KCHECK(dev_gather_keys(b->node_key.as<u64>(), nperm.as<u32>(), N, nw, onode.as<u64>(), stream));
+        KCHECK_HIP(hipMemcpyAsync(b->edge_seq.p, eseq.p, E * 8, hipMemcpyDeviceToDevice, stream));
+        size_t n;
+        n = okey.bytes; b->edge_key.adopt(okey.take(), n);
+        n = ow.bytes; b->edge_weight.adopt(ow.take(), n);
+        n = osrc.bytes; b->edge_src.adopt(osrc.take(), n);
+        n = odst.bytes; b->edge_dst.adopt(odst.take(), n);
+        n = onode.bytes; b->node_key.adopt(onode.take(), n);
+        cand = b->node_key.as<u64>();
+    }
     const uint32_t stride = label_stride_for_k(k);
     KCHECK(b->edge_label.alloc((E + 1) * (size_t)stride + 16, stream));
     {

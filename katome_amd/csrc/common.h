@@ -94,7 +94,7 @@ inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap =
 
 // ---- launchers implemented in the .hip files (all asynchronous on `stream`) -----------------
 int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
-                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span = 1);
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span = 1, bool mark = false);
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                        const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                        uint64_t* d_records, hipStream_t stream);
@@ -110,6 +110,13 @@ int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t 
              uint64_t* d_out, hipStream_t stream);
 int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src,
                  uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream);
+int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream);
+int dev_gather_u32(const uint32_t* src, const uint32_t* idx, uint64_t n, uint32_t* dst, hipStream_t stream);
+int dev_gather_u64(const uint64_t* src, const uint32_t* idx, uint64_t n, uint64_t* dst, hipStream_t stream);
+int dev_gather_keys(const uint64_t* src, const uint32_t* idx, uint64_t n, uint32_t nw, uint64_t* dst, hipStream_t stream);
+int dev_gather_mapped(const uint64_t* src, const uint32_t* idx, const uint64_t* map, uint64_t n, uint64_t* dst, hipStream_t stream);
+int dev_invert(const uint32_t* perm, uint64_t n, uint64_t* inv, hipStream_t stream);
+int dev_node_first(const uint64_t* src, const uint64_t* dst, const uint64_t* seq, uint64_t n, uint64_t* node_first, hipStream_t stream);
 int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream);
 int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream);
 
@@ -117,12 +124,18 @@ int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_la
 struct Table {
     DevBuf slots;          // NW=1: {u64 key|OCC, u32 count, u32 pad}; NW=2: {u64 hi|flags, u64 lo, u32 count, u32 pad[3]}
     DevBuf counter;        // u64 occupied
+    DevBuf seen;           // first-seen-order mode: [cap][2] u64 earliest sequence base per strand (table.hip)
+    bool track_seen = false;
     uint64_t cap = 0;
     uint32_t nw = 1;
     size_t slot_bytes() const { return nw == 1 ? 16 : 32; }
+    void release() { slots.release(); counter.release(); seen.release(); }
 };
+// where a batch of records sits in the read-ordered stream (first-seen-order mode)
+struct SeenOrigin { uint64_t read0 = 0, rec0 = 0; uint32_t per_read = 1, span = 1, windows = 1; bool rc = false; };
 int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream);
-int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream);
+int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream,
+                 const SeenOrigin* origin = nullptr);
 int table_occupied(Table& t, uint64_t* out, hipStream_t stream);
 int table_grow(Table& t, uint64_t new_cap, hipStream_t stream);
 // tiled counting: every tile (key of k+span-1 bases, weight n) adds n to each of its `span` k-mers
@@ -133,7 +146,7 @@ int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool 
                                   uint64_t* n_records, hipStream_t stream);
 // distinct oriented edges (unsorted): allocates d_keys/d_weights
 int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf& keys, DevBuf& weights, uint64_t* n_edges,
-                     hipStream_t stream);
+                     hipStream_t stream, DevBuf* seqs = nullptr);
 
 // synth.hip
 int launch_synth(uint64_t first_read, uint64_t n_reads, uint32_t read_len, uint64_t genome_len, double err_rate,

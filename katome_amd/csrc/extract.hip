@@ -21,12 +21,13 @@ namespace katome {
 //      a record = 2*NW+1 LDS dwords -> funnel shift -> (canonical) key.
 // ---------------------------------------------------------------------------------------------
 constexpr int TILE_READS = 64;
+constexpr u32 MARK_FLAG = 1u << 31;     // or-ed into `step`: tag records with RC_MARK (first-seen-order mode)
 
 template <int NW, bool RC>
 __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t* lds_skip, u32 i, u32 W, u32 magicW,
                                                     u32 stride_bytes, u32 k, u32 step) {
     u32 r = W == 1 ? i : __umulhi(i, magicW);   // i / W (magic multiply, exact for i, W < 2^16; W = 1 has no 32-bit magic)
-    u32 w = (i - r * W) * step;
+    u32 w = (i - r * W) * (step & ~MARK_FLAG);
     if (lds_skip[r]) return key_invalid<NW>();
     u32 bit = r * stride_bytes * 8 + 2 * w;
     u32 di = bit >> 5, sh = bit & 31;
@@ -34,7 +35,11 @@ __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t
 #pragma unroll
     for (int j = 0; j < 2 * NW + 1; ++j) d[j] = lds[di + j];
     Key<NW> key = extract_window(d, sh, k, (Key<NW>*)nullptr);
-    if (RC) key = canonical(key, k);
+    if (RC) {
+        bool flipped;
+        key = canonical_flip(key, k, flipped);
+        if (step & MARK_FLAG) key.w[0] |= flipped ? RC_MARK : 0;     // first-seen-order mode: remember the orientation
+    }
     return key;
 }
 
@@ -113,14 +118,16 @@ struct ArrayAddr {
         w = (u32)(i - win_prefix[lo]);
     }
     __device__ __forceinline__ bool skipped(u64) const { return false; }
+    __device__ __forceinline__ bool mark() const { return false; }
 };
 struct FixedAddr {
     u64 stride_bytes; u64 W; const uint8_t* skip; u64 r; u32 step;
     __device__ __forceinline__ void locate(u64 i, u64& boff, u32& w) {
         r = i / W;
         boff = r * stride_bytes;
-        w = (u32)(i - r * W) * step;
+        w = (u32)(i - r * W) * (step & ~MARK_FLAG);
     }
+    __device__ __forceinline__ bool mark() const { return (step & MARK_FLAG) != 0; }
     __device__ __forceinline__ bool skipped(u64) const { return skip && skip[r]; }
 };
 
@@ -150,7 +157,11 @@ __global__ __launch_bounds__(BLOCK) void extract_general_kernel(const uint8_t* _
                 d[j] = v;
             }
             key = extract_window(d, sh, k, (Key<NW>*)nullptr);
-            if (RC) key = canonical(key, k);
+            if (RC) {
+                bool flipped;
+                key = canonical_flip(key, k, flipped);
+                if (addr.mark() && flipped) key.w[0] |= RC_MARK;
+            }
         }
 #pragma unroll
         for (int j = 0; j < NW; ++j) out[i * NW + j] = key.w[j];
@@ -186,15 +197,16 @@ static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u
 }
 
 int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
-                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span) {
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span, bool mark) {
     if (read_len < k) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }   // pt_graph.rs:278
     if (span == 0 || (read_len - k + 1) % span) { set_error("tile span %u does not divide the windows per read", span); return KATOME_E_ARG; }
     const u32 kk = k + span - 1, W = (read_len - k + 1) / span;
     const int nw = key_words_for_k(kk);
-    if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream)
-                           : extract_fixed_t<1, false>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream);
-    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream)
-              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, span, W, d_skip, d_records, stream);
+    const u32 step = span | (mark ? MARK_FLAG : 0u);
+    if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream)
+                           : extract_fixed_t<1, false>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream);
+    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream)
+              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream);
 }
 
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,

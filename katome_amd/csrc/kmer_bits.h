@@ -27,6 +27,9 @@ typedef uint64_t u64;
 typedef uint32_t u32;
 
 constexpr u64 INVALID_WORD = ~0ull;   // w[0] of a record that carries no k-mer
+// first-seen-order mode only: set in w[0] of a record whose stored (canonical) key is the reverse complement of
+// what the read holds; keys use at most 62 bits of w[0] (k <= 31: 2k bits; k <= 63: 2k-64 bits)
+constexpr u64 RC_MARK = 1ull << 62;
 
 template <int NW> struct Key { u64 w[NW]; };
 
@@ -128,6 +131,12 @@ KD Key<2> revcomp(const Key<2>& a, u32 k) {
 template <int NW> KD Key<NW> canonical(const Key<NW>& a, u32 k) {
     Key<NW> rc = revcomp(a, k);
     return key_lt(rc, a) ? rc : a;
+}
+// same, telling whether the reverse complement was taken
+template <int NW> KD Key<NW> canonical_flip(const Key<NW>& a, u32 k, bool& flipped) {
+    Key<NW> rc = revcomp(a, k);
+    flipped = key_lt(rc, a);
+    return flipped ? rc : a;
 }
 
 // ---- edge endpoints (the two halves of compress_kmer, compress.rs:23-26) --------------------

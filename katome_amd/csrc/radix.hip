@@ -665,6 +665,76 @@ int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBu
     return node_ids_t<2>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream);
 }
 
+// ---- first-seen order: small permutation helpers ---------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void iota_kernel(u32* __restrict__ out, u64 n) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) out[i] = (u32)i;
+}
+template <class T>
+__global__ __launch_bounds__(BLOCK) void gather_kernel(const T* __restrict__ src, const u32* __restrict__ idx, u64 n, T* __restrict__ dst) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) dst[i] = src[idx[i]];
+}
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void gather_keys_kernel(const u64* __restrict__ src, const u32* __restrict__ idx, u64 n, u64* __restrict__ dst) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) store_key<NW>(dst, i, load_key<NW>(src, idx[i]));
+}
+// dst[i] = map[src[idx[i]]]
+__global__ __launch_bounds__(BLOCK) void gather_mapped_kernel(const u64* __restrict__ src, const u32* __restrict__ idx, const u64* __restrict__ map,
+                                                               u64 n, u64* __restrict__ dst) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) dst[i] = map[src[idx[i]]];
+}
+// inverse of a permutation: inv[perm[i]] = i
+__global__ __launch_bounds__(BLOCK) void invert_kernel(const u32* __restrict__ perm, u64 n, u64* __restrict__ inv) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) inv[perm[i]] = i;
+}
+// a node is created by the first edge insertion that touches it: as the source of the first window of a strand
+// (2*seq) or as a target (2*seq + 1) -- add_single_edge_fastaq, pt_graph.rs:180-185
+__global__ __launch_bounds__(BLOCK) void node_first_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, const u64* __restrict__ seq,
+                                                            u64 n, u64* node_first) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        atomicMin((unsigned long long*)&node_first[src[i]], (unsigned long long)(2 * seq[i]));
+        atomicMin((unsigned long long*)&node_first[dst[i]], (unsigned long long)(2 * seq[i] + 1));
+    }
+}
+
+int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, d, n);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_gather_u32(const uint32_t* src, const uint32_t* idx, uint64_t n, uint32_t* dst, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(gather_kernel<u32>, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, idx, n, dst);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_gather_u64(const uint64_t* src, const uint32_t* idx, uint64_t n, uint64_t* dst, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(gather_kernel<u64>, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, idx, n, dst);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_gather_keys(const uint64_t* src, const uint32_t* idx, uint64_t n, uint32_t nw, uint64_t* dst, hipStream_t stream) {
+    if (n) {
+        if (nw == 1) hipLaunchKernelGGL(gather_keys_kernel<1>, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, idx, n, dst);
+        else         hipLaunchKernelGGL(gather_keys_kernel<2>, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, idx, n, dst);
+    }
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_gather_mapped(const uint64_t* src, const uint32_t* idx, const uint64_t* map, uint64_t n, uint64_t* dst, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(gather_mapped_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, idx, map, n, dst);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_invert(const uint32_t* perm, uint64_t n, uint64_t* inv, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(invert_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, perm, n, inv);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_node_first(const uint64_t* src, const uint64_t* dst, const uint64_t* seq, uint64_t n, uint64_t* node_first, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(node_first_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, seq, n, node_first);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
 // ---- edge -> endpoints, labels ----------------------------------------------------------------
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void endpoints_kernel(const u64* __restrict__ ek, u64 n, u32 k, u64* __restrict__ src, u64* __restrict__ dst) {

@@ -27,7 +27,7 @@ __device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, 
 // find-or-insert `key`, add `add` to its weight; returns 1 if the key was new.
 // `err` is set if the probe sequence wraps the whole table (cannot happen under the host's
 // load-factor policy; bounds the loop all the same).
-__device__ __forceinline__ u32 upsert(Slot1* slots, u64 cap, Key<1> key, u32 add, u32* err) {
+__device__ __forceinline__ u32 upsert(Slot1* slots, u64 cap, Key<1> key, u32 add, u32* err, u64* slot_out = nullptr) {
     const u64 want = key.w[0] | OCC;
     u64 s = hash_to_range(hash_key(key), cap);
     for (u64 probes = 0; probes < cap; ++probes) {
@@ -39,6 +39,7 @@ __device__ __forceinline__ u32 upsert(Slot1* slots, u64 cap, Key<1> key, u32 add
         }
         if (cur == want) {
             atomicAdd(&slots[s].count, add);
+            if (slot_out) *slot_out = s;
             return fresh;
         }
         if (++s == cap) s = 0;
@@ -52,7 +53,7 @@ __device__ __forceinline__ u32 upsert(Slot1* slots, u64 cap, Key<1> key, u32 add
 // waits while it holds a claim (claim and publication are one straight-line block), so lanes of
 // one wave cannot deadlock each other; a lane that meets a LOCKed slot with ITS high word simply
 // re-reads the slot on its next loop trip.
-__device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add, u32* err) {
+__device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add, u32* err, u64* slot_out = nullptr) {
     u64 s = hash_to_range(hash_key(key), cap);
     u64 spins = 0;
     for (u64 probes = 0; probes < cap;) {
@@ -69,6 +70,7 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&slots[s].hi, key.w[0] | OCC);
                 atomicAdd(&slots[s].count, add);
+                if (slot_out) *slot_out = s;
                 return 1;
             }
         }
@@ -81,6 +83,7 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
             const u64 lo = cached_view ? slots[s].lo : ld_agent(&slots[s].lo);
             if (lo == key.w[1]) {
                 atomicAdd(&slots[s].count, add);
+                if (slot_out) *slot_out = s;
                 return 0;
             }
         }
@@ -103,17 +106,50 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
     return v;
 }
 
-template <int NW>
+// First-seen-order mode.  The reference numbers edges and nodes in the order its sequential loop first meets them
+// (petgraph indices: pt_graph.rs:149,194).  Per read r it adds the forward windows i = 0..W-1 and then the windows of
+// the reverse complement, last window first (pt_graph.rs:282-308): window i goes in at sequence number r*2W + i and
+// rc(window i) at r*2W + 2W-1-i.  A tile covering windows i0..i0+s-1 therefore puts its o-th window in at P + o with
+// P = r*2W + i0, and its reverse complement puts ITS o-th window in at Q + o with Q = r*2W + 2W - i0 - s.  Beside every
+// table sits seen[slot] = {earliest base of the stored orientation, earliest base of its reverse complement}
+// (atomicMin); sub-windows inherit base + offset when tiles are expanded, so every k-mer ends up with the sequence
+// number of its first insertion, for each strand.
+struct SeenParams {
+    u64* seen;            // [cap][2]
+    u64 read0;            // index of the read the first record of this launch belongs to ...
+    u64 rec0;             // ... and that record's index within the read-ordered stream of this batch
+    u32 per_read;         // records per read (W / span)
+    u32 span;             // windows per record
+    u32 windows;          // W
+    u32 rc;
+};
+
+template <int NW, bool SEEN>
 __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type* slots, u64 cap,
                                                         const u64* __restrict__ rec, const u32* __restrict__ wts, u64 n,
-                                                        u64* occupied, u32* err) {
+                                                        u64* occupied, u32* err, SeenParams sp) {
     u32 fresh = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         Key<NW> key;
 #pragma unroll
         for (int j = 0; j < NW; ++j) key.w[j] = rec[i * NW + j];
         if (!key_valid(key)) continue;
-        fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err);
+        if (SEEN) {
+            const bool flipped = (key.w[0] & RC_MARK) != 0;
+            key.w[0] &= ~RC_MARK;
+            u64 slot;
+            fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err, &slot);
+            const u64 g = sp.rec0 + i, r = sp.read0 + g / sp.per_read, i0 = (g % sp.per_read) * sp.span;
+            const u64 P = r * 2 * sp.windows + i0, Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
+            if (sp.rc) {
+                atomicMin((unsigned long long*)&sp.seen[2 * slot + 0], (unsigned long long)(flipped ? Q : P));
+                atomicMin((unsigned long long*)&sp.seen[2 * slot + 1], (unsigned long long)(flipped ? P : Q));
+            } else {
+                atomicMin((unsigned long long*)&sp.seen[2 * slot + 0], (unsigned long long)P);
+            }
+        } else {
+            fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err);
+        }
     }
     fresh = wave_sum(fresh);
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(occupied, (u64)fresh);
@@ -125,13 +161,16 @@ __device__ __forceinline__ bool slot_key(const Slot2& s, Key<2>& k) { k.w[0] = s
 
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void rehash_kernel(const typename SlotOf<NW>::type* __restrict__ old_slots, u64 old_cap,
-                                                        typename SlotOf<NW>::type* slots, u64 cap, u64* occupied, u32* err) {
+                                                        typename SlotOf<NW>::type* slots, u64 cap, u64* occupied, u32* err,
+                                                        const u64* __restrict__ old_seen, u64* seen) {
     u32 fresh = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < old_cap; i += (u64)gridDim.x * BLOCK) {
         typename SlotOf<NW>::type o = old_slots[i];
         Key<NW> key;
         if (!slot_key(o, key)) continue;
-        fresh += upsert(slots, cap, key, o.count, err);
+        u64 slot;
+        fresh += upsert(slots, cap, key, o.count, err, &slot);
+        if (seen) { seen[2 * slot] = old_seen[2 * i]; seen[2 * slot + 1] = old_seen[2 * i + 1]; }   // one writer per key
     }
     fresh = wave_sum(fresh);
     if ((threadIdx.x & 63) == 0 && fresh) atomicAdd(occupied, (u64)fresh);
@@ -148,11 +187,13 @@ template <int NWT, int NWK, bool RC, bool TO_TABLE>
 __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename SlotOf<NWT>::type* __restrict__ tiles, u64 slot0, u64 tile_cap,
                                                               u32 k, u32 span, u32 stride, typename SlotOf<NWK>::type* kmers, u64 kmer_cap,
                                                               u64* occupied, u32* err, u64* __restrict__ out_keys,
-                                                              u32* __restrict__ out_w, u64* cursor) {
+                                                              u32* __restrict__ out_w, u64* cursor,
+                                                              const u64* __restrict__ tile_seen, u64* kmer_seen) {
     // The tile table is sparse (10-25 % occupied) and every tile has `span` sub-windows: the occupied tiles of
     // each run of BLOCK slots are first compacted into LDS, then the (tile, sub-window) pairs are dealt out
     // evenly over the lanes, so that every lane has an independent upsert in flight.
     __shared__ u64 lkey[BLOCK * NWT];
+    __shared__ u64 lseen[BLOCK * 2];      // first-seen-order mode: the tile's two sequence bases
     __shared__ u32 lcnt[BLOCK];
     __shared__ u32 wtot[BLOCK / 64];
     __shared__ u64 bbase;
@@ -177,6 +218,7 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
 #pragma unroll
             for (int q = 0; q < NWT; ++q) lkey[(woff + before) * NWT + q] = tile.w[q];
             lcnt[woff + before] = n;
+            if (tile_seen) { lseen[2 * (woff + before)] = tile_seen[2 * i]; lseen[2 * (woff + before) + 1] = tile_seen[2 * i + 1]; }
         }
         if (!TO_TABLE && threadIdx.x == 0 && total) bbase = atomicAdd(cursor, (u64)total * span);
         __syncthreads();
@@ -187,9 +229,20 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
 #pragma unroll
             for (int q = 0; q < NWT; ++q) tk.w[q] = lkey[t * NWT + q];
             Key<NWK> x = sub_window<NWT, NWK>(tk, k, span, stride, o);
-            if (RC) x = canonical(x, k);
+            bool flipped = false;
+            if (RC) x = canonical_flip(x, k, flipped);
             if (TO_TABLE) {
-                fresh += upsert(kmers, kmer_cap, x, lcnt[t], err);
+                if (kmer_seen) {
+                    // the o-th sub-window of the tile was first put in at base + o*stride; the reverse complement of
+                    // the tile holds its reverse complement as sub-window span-1-o
+                    u64 slot;
+                    fresh += upsert(kmers, kmer_cap, x, lcnt[t], err, &slot);
+                    const u64 fwd = lseen[2 * t] + (u64)o * stride, rev = lseen[2 * t + 1] + (u64)(span - 1 - o) * stride;
+                    atomicMin((unsigned long long*)&kmer_seen[2 * slot], (unsigned long long)(flipped ? rev : fwd));
+                    if (RC) atomicMin((unsigned long long*)&kmer_seen[2 * slot + 1], (unsigned long long)(flipped ? fwd : rev));
+                } else {
+                    fresh += upsert(kmers, kmer_cap, x, lcnt[t], err);
+                }
             } else {
 #pragma unroll
                 for (int q = 0; q < NWK; ++q) out_keys[(bbase + p) * NWK + q] = x.w[q];
@@ -215,7 +268,7 @@ constexpr int EMIT_ITEMS = 8;
 template <int NW, bool RC>
 __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf<NW>::type* __restrict__ slots, u64 cap, u32 k,
                                                             u32 min_weight, u64* __restrict__ out_keys, u32* __restrict__ out_w,
-                                                            u64* cursor) {
+                                                            u64* cursor, const u64* __restrict__ seen, u64* __restrict__ out_seq) {
     __shared__ u32 wave_tot[BLOCK / 64];
     __shared__ u64 block_base;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -255,13 +308,23 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
             if (!nemit[j]) continue;
             Key<NW> rc = RC ? revcomp(key[j], k) : key[j];
             u32 w = (RC && nemit[j] == 1) ? cnt[j] * 2u : cnt[j];     // self-complementary k-mer
+            u64 s0 = 0, s1 = 0;
+            if (seen) {
+                const u64 slot = t0 + (u64)j * BLOCK + tid;
+                s0 = seen[2 * slot]; s1 = seen[2 * slot + 1];
+                if (RC && nemit[j] == 1) s0 = s0 < s1 ? s0 : s1;      // both strands are the same edge
+            }
 #pragma unroll
             for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = key[j].w[q];
-            out_w[pos] = w; ++pos;
+            out_w[pos] = w;
+            if (seen) out_seq[pos] = s0;
+            ++pos;
             if (nemit[j] == 2) {
 #pragma unroll
                 for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rc.w[q];
-                out_w[pos] = w; ++pos;
+                out_w[pos] = w;
+                if (seen) out_seq[pos] = s1;
+                ++pos;
             }
         }
         __syncthreads();
@@ -275,6 +338,10 @@ int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream) {
     t.nw = nw; t.cap = cap;
     KCHECK(t.slots.alloc(cap * t.slot_bytes(), stream));
     KCHECK(t.counter.alloc(sizeof(TableAux), stream));
+    if (t.track_seen) {
+        KCHECK(t.seen.alloc(cap * 16, stream));
+        KCHECK_HIP(hipMemsetAsync(t.seen.p, 0xFF, cap * 16, stream));
+    }
     KCHECK_HIP(hipMemsetAsync(t.slots.p, 0, cap * t.slot_bytes(), stream));
     KCHECK_HIP(hipMemsetAsync(t.counter.p, 0, sizeof(TableAux), stream));
     return KATOME_OK;
@@ -289,30 +356,43 @@ int table_occupied(Table& t, uint64_t* out, hipStream_t stream) {
     return KATOME_OK;
 }
 
-int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream) {
+int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream,
+                 const SeenOrigin* origin) {
     if (n == 0) return KATOME_OK;
     TableAux* aux = t.counter.as<TableAux>();
     dim3 grid(grid_for(n, BLOCK, 256u * 32u)), block(BLOCK);
-    if (t.nw == 1)
-        hipLaunchKernelGGL(insert_kernel<1>, grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err);
+    SeenParams sp{};
+    if (t.track_seen) {
+        if (!origin) { set_error("first-seen order: records must come with their position in the read stream"); return KATOME_E_ARG; }
+        sp.seen = t.seen.as<u64>(); sp.read0 = origin->read0; sp.rec0 = origin->rec0; sp.per_read = origin->per_read;
+        sp.span = origin->span; sp.windows = origin->windows; sp.rc = origin->rc;
+        if (t.nw == 1)
+            hipLaunchKernelGGL((insert_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
+        else
+            hipLaunchKernelGGL((insert_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
+    } else if (t.nw == 1)
+        hipLaunchKernelGGL((insert_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
     else
-        hipLaunchKernelGGL(insert_kernel<2>, grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err);
+        hipLaunchKernelGGL((insert_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
 
 int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
     Table nt;
+    nt.track_seen = t.track_seen;
     KCHECK(table_alloc(nt, t.nw, new_cap, stream));
     TableAux* aux = nt.counter.as<TableAux>();
     dim3 grid(grid_for(t.cap, BLOCK, 256u * 32u)), block(BLOCK);
+    const u64* os = t.track_seen ? t.seen.as<u64>() : nullptr; u64* ns = t.track_seen ? nt.seen.as<u64>() : nullptr;
     if (t.nw == 1)
-        hipLaunchKernelGGL(rehash_kernel<1>, grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, nt.slots.as<Slot1>(), nt.cap, &aux->occupied, &aux->err);
+        hipLaunchKernelGGL(rehash_kernel<1>, grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, nt.slots.as<Slot1>(), nt.cap, &aux->occupied, &aux->err, os, ns);
     else
-        hipLaunchKernelGGL(rehash_kernel<2>, grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, nt.slots.as<Slot2>(), nt.cap, &aux->occupied, &aux->err);
+        hipLaunchKernelGGL(rehash_kernel<2>, grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, nt.slots.as<Slot2>(), nt.cap, &aux->occupied, &aux->err, os, ns);
     KCHECK_HIP(hipGetLastError());
     t.slots.adopt(nt.slots.take(), new_cap * t.slot_bytes());
     t.counter.adopt(nt.counter.take(), sizeof(TableAux));
+    if (t.track_seen) t.seen.adopt(nt.seen.take(), new_cap * 16);
     t.cap = new_cap;
     return KATOME_OK;
 }
@@ -328,7 +408,9 @@ static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint3
 #define KATOME_EXPAND(NWT, NWK, RCV)                                                                                          \
     hipLaunchKernelGGL((expand_tiles_kernel<NWT, NWK, RCV, TO_TABLE>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), \
                        slot0, slot1, k, span, stride, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
-                       aux ? &aux->occupied : nullptr, aux ? &aux->err : nullptr, out_keys, out_w, cursor)
+                       aux ? &aux->occupied : nullptr, aux ? &aux->err : nullptr, out_keys, out_w, cursor,                      \
+                       (kmers && kmers->track_seen) ? tiles.seen.as<u64>() : nullptr,                                          \
+                       (kmers && kmers->track_seen) ? kmers->seen.as<u64>() : nullptr)
     if (tiles.nw == 1) { if (rc) KATOME_EXPAND(1, 1, true); else KATOME_EXPAND(1, 1, false); }
     else if (nwk == 1) { if (rc) KATOME_EXPAND(2, 1, true); else KATOME_EXPAND(2, 1, false); }
     else               { if (rc) KATOME_EXPAND(2, 2, true); else KATOME_EXPAND(2, 2, false); }
@@ -359,22 +441,24 @@ int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool 
 }
 
 int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf& keys, DevBuf& weights, uint64_t* n_edges,
-                     hipStream_t stream) {
+                     hipStream_t stream, DevBuf* seqs) {
     uint64_t occ = 0;
     KCHECK(table_occupied(t, &occ, stream));
     const uint64_t upper = occ * (rc ? 2 : 1);
     KCHECK(keys.alloc((upper + 1) * 8 * t.nw, stream));
     KCHECK(weights.alloc((upper + 1) * 4, stream));
+    const u64* seen = nullptr; u64* out_seq = nullptr;
+    if (seqs && t.track_seen) { KCHECK(seqs->alloc((upper + 1) * 8, stream)); seen = t.seen.as<u64>(); out_seq = seqs->as<u64>(); }
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     dim3 grid(grid_for(t.cap, BLOCK * EMIT_ITEMS, 256u * 16u)), block(BLOCK);
     if (t.nw == 1) {
-        if (rc) hipLaunchKernelGGL((emit_edges_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-        else    hipLaunchKernelGGL((emit_edges_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        if (rc) hipLaunchKernelGGL((emit_edges_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
+        else    hipLaunchKernelGGL((emit_edges_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
     } else {
-        if (rc) hipLaunchKernelGGL((emit_edges_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-        else    hipLaunchKernelGGL((emit_edges_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        if (rc) hipLaunchKernelGGL((emit_edges_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
+        else    hipLaunchKernelGGL((emit_edges_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
     }
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_edges, cursor.p, 8, hipMemcpyDeviceToHost, stream));

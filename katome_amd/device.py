@@ -67,11 +67,11 @@ class DeviceGraph:
 class Builder:
     """one GPU's share of a build"""
 
-    def __init__(self, k, reverse_complement, device=0, table_slots_hint=0):
+    def __init__(self, k, reverse_complement, device=0, table_slots_hint=0, first_seen_order=False):
         self.k, self.rc, self.device = k, bool(reverse_complement), device
         self.nw = record_words(k)
         self._settings = make_settings(k, reverse_complement=reverse_complement, device=device,
-                                       table_slots_hint=table_slots_hint)
+                                       table_slots_hint=table_slots_hint, first_seen_order=first_seen_order)
         self._h = C.c_void_p()
         _check(_lib.lib().katome_builder_create(C.byref(self._settings), C.byref(self._h)))
         self.tdev = torch.device("cuda", device)

@@ -481,3 +481,67 @@ def test_low_complexity_reads(oracle, tmp_path, k, rc):
     assert (st.max_edge_weight, st.max_in_degree, st.max_out_degree, st.incoming_vert_count, st.outgoing_vert_count) == \
         (rs["max_edge_weight"], rs["max_in_degree"], rs["max_out_degree"], rs["incoming_vert_count"], rs["outgoing_vert_count"])
     _check_graph_consistency(g, k)
+
+
+def _assert_same_as_reference_order(g, ref):
+    """edge for edge, node id for node id: the arrays the reference's petgraph would hold"""
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    assert np.array_equal(g.edge_label, ref.edge_label)          # same edge at every index
+    assert np.array_equal(g.edge_weight, ref.edge_weight)
+    assert np.array_equal(g.edge_src, ref.edge_src) and np.array_equal(g.edge_dst, ref.edge_dst)
+
+
+@pytest.mark.parametrize("name,k,rc", [("data1.txt", 40, False), ("data2.txt", 40, False), ("data3.txt", 40, True),
+                                       ("data2.txt", 31, True), ("data3.txt", 31, False), ("data2.txt", 16, True),
+                                       ("data2.txt", 63, True), ("data3.txt", 6, True)])
+def test_first_seen_order_fixtures(oracle, golden_dir, name, k, rc):
+    """KATOME_FLAG_FIRST_SEEN_ORDER: petgraph's own edge and node numbering (pt_graph.rs:149,194), through plain
+    counting (k=40, 63), one-level tiles (k=31: span 14, k=16: span 17 -> ...) and low k with heavy multiplicity"""
+    from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
+    path = os.path.join(golden_dir, name)
+    set_global_k_sizes(k)
+    g, rb = GpuGraph.create([path], InputFileType.Fastq, rc, 0, first_seen_order=True)
+    ref = oracle.build_files([path], k, rc)
+    assert rb == ref.read_bytes
+    _assert_same_as_reference_order(g, ref)
+
+
+@pytest.mark.parametrize("k,rc,n,L,npct", [(31, True, 6000, 150, 1), (31, False, 6000, 150, 0), (12, True, 3000, 51, 2),
+                                           (40, True, 4000, 103, 1), (33, True, 2500, 92, 0), (5, True, 500, 36, 0)])
+def test_first_seen_order_synthetic(oracle, k, rc, n, L, npct):
+    """two-level tiles (L=150, k=31: span 30 -> 6), other spans, plain counting, skipped reads, several batches"""
+    from katome_amd import device as kd
+    ascii_reads = oracle.synth_reads(0, n, L, 40000, 3e-3, npct)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("A")
+    packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+    skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+    b = kd.Builder(k, rc, first_seen_order=True, table_slots_hint=1 << 16)      # small tables: growth on the way
+    span = b.tile_span(L)
+    step = 1024
+    for r0 in range(0, n, step):
+        nr = min(step, n - r0)
+        if span > 1:
+            b.insert_tiles(b.extract_tiles(packed, nr, L, span, skip, first_read=r0), span)
+        else:
+            b.insert(b.extract_fixed(packed, nr, L, skip, first_read=r0))
+    dg = b.finalize()
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
+    assert np.array_equal(dg.edge_label.cpu().numpy(), ref.edge_label)
+    assert np.array_equal(dg.edge_weight.cpu().numpy().view(np.uint32), ref.edge_weight)
+    assert np.array_equal(dg.edge_src.cpu().numpy().view(np.uint64), ref.edge_src)
+    assert np.array_equal(dg.edge_dst.cpu().numpy().view(np.uint64), ref.edge_dst)
+    b.close()
+
+
+def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
+    from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
+    base = oracle.build_files([os.path.join(golden_dir, "data1.txt")], 31, False)
+    bfc = tmp_path / "k.bfc"
+    bfc.write_text("".join("%s\t%d\n" % (km, w) for km, w in reversed(base.multiset())))
+    set_global_k_sizes(31)
+    for rc in (False, True):
+        g, _ = GpuGraph.create([str(bfc)], InputFileType.BFCounter, rc, 0, first_seen_order=True)
+        _assert_same_as_reference_order(g, oracle.build_bfc([str(bfc)], 31, rc, 0))
