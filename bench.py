@@ -56,6 +56,8 @@ def parse_args():
     ap.add_argument("--reads", type=int, default=0, help="override the workload's read count (same coverage)")
     ap.add_argument("--batch-reads", type=int, default=4 * 1024 * 1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--first-seen-order", action="store_true",
+                    help="number edges and nodes in the reference's first-seen (petgraph) order (single GPU)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     return ap.parse_args()
@@ -81,11 +83,12 @@ class PhaseTimer:
         return out
 
 
-def one_build_single(wl, packed, skip, recbuf, batch_reads, timer):
+def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=False):
     """one step on one GPU; returns (n_edges, n_nodes)"""
     from katome_amd import device as kd
     hint = int(wl.expected_distinct_canonical() * 2.2)
-    b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint)
+    b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint,
+                   first_seen_order=first_seen)
     b.profile(True)
     span = b.tile_span(wl.read_len)
     try:
@@ -163,7 +166,7 @@ def main():
                              device=packed.device)
 
         def step():
-            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer)
+            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer, args.first_seen_order)
     else:
         from katome_amd import dist as kdist
         job = kdist.DistBuild(wl, batch_reads=batch_reads, timer=timer)
@@ -278,7 +281,7 @@ def main():
                                    % (wl.name, wl.reads, wl.read_len, wl.k, wl.reverse_complement, wl.genome_len,
                                       wl.err_rate),
                        "reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads,
-                       "tile_span": span,
+                       "tile_span": span, "order": "first-seen (petgraph)" if args.first_seen_order else "by packed key",
                        "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
