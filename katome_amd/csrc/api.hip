@@ -227,7 +227,7 @@ static int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_
     *last = &b->tiles; *last_span = b->span;
     if (b->span2 && n_tiles) {
         const uint32_t kk2 = b->s.k + b->span2 - 1;
-        KCHECK(expand_level(b, b->tiles, b->tiles2, b->tiles2_ready, (uint32_t)key_words_for_k(kk2), b->s.table_slots_hint / 2,
+        KCHECK(expand_level(b, b->tiles, b->tiles2, b->tiles2_ready, (uint32_t)key_words_for_k(kk2), b->s.table_slots_hint / 4,
                             kk2, b->span / b->span2, b->span2, PH_EXPAND_MID, stream));
         b->tiles.release();
         KCHECK(table_occupied(b->tiles2, &b->stat_tiles2, stream));
@@ -319,7 +319,7 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     }
     for (uint64_t done = 0; done < n_records;) {
         uint64_t room = 0;
-        KCHECK(ensure_table(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 2, n_records - done, &room, stream));
+        KCHECK(ensure_table(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 4, n_records - done, &room, stream));
         const uint64_t n = std::min(n_records - done, room);
         PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
         origin.rec0 = done;
