@@ -432,32 +432,49 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         const uint64_t max_seq = 2 * (b->reads_inserted + 1) * 2 * (uint64_t)(b->seen_read_len - k + 1) + 2;
         uint32_t bits = 1;
         while (bits < 64 && (max_seq >> bits)) ++bits;
-        DevBuf node_first(stream), nperm(stream), new_id(stream), eseq(stream), eperm(stream);
-        KCHECK(node_first.alloc((N + 1) * 8)); KCHECK(nperm.alloc((N + 1) * 4)); KCHECK(new_id.alloc((N + 1) * 8));
-        KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
-        KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
-        KCHECK(dev_iota(nperm.as<u32>(), N, stream));
-        KCHECK(dev_sort(node_first.as<u64>(), nperm.as<u32>(), N, 1, bits, stream));        // nperm[new] = old
-        KCHECK(dev_invert(nperm.as<u32>(), N, new_id.as<u64>(), stream));                   // new_id[old] = new
-        KCHECK(eseq.alloc((E + 1) * 8)); KCHECK(eperm.alloc((E + 1) * 4));
-        KCHECK_HIP(hipMemcpyAsync(eseq.p, b->edge_seq.p, E * 8, hipMemcpyDeviceToDevice, stream));
+        // (buffers are taken and given back one at a time: at C3 every one of them is 6-13 GB)
+        DevBuf new_id(stream), eperm(stream);
+        KCHECK(new_id.alloc((N + 1) * 8));
+        {
+            DevBuf node_first(stream), nperm(stream), onode(stream);
+            KCHECK(node_first.alloc((N + 1) * 8)); KCHECK(nperm.alloc((N + 1) * 4));
+            KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
+            KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
+            KCHECK(dev_iota(nperm.as<u32>(), N, stream));
+            KCHECK(dev_sort(node_first.as<u64>(), nperm.as<u32>(), N, 1, bits, stream));        // nperm[new] = old
+            node_first.release();
+            KCHECK(dev_invert(nperm.as<u32>(), N, new_id.as<u64>(), stream));                   // new_id[old] = new
+            KCHECK(onode.alloc((N + 1) * 8 * nw));
+            KCHECK(dev_gather_keys(b->node_key.as<u64>(), nperm.as<u32>(), N, nw, onode.as<u64>(), stream));
+            const size_t n = onode.bytes; b->node_key.adopt(onode.take(), n);
+        }
+        KCHECK(eperm.alloc((E + 1) * 4));
         KCHECK(dev_iota(eperm.as<u32>(), E, stream));
-        KCHECK(dev_sort(eseq.as<u64>(), eperm.as<u32>(), E, 1, bits, stream));               // eperm[new] = old
-        DevBuf okey(stream), ow(stream), osrc(stream), odst(stream), onode(stream);
-        KCHECK(okey.alloc((E + 1) * 8 * nw)); KCHECK(ow.alloc((E + 1) * 4)); KCHECK(osrc.alloc((E + 1) * 8)); KCHECK(odst.alloc((E + 1) * 8));
-        KCHECK(onode.alloc((N + 1) * 8 * nw));
-        KCHECK(dev_gather_keys(b->edge_key.as<u64>(), eperm.as<u32>(), E, nw, okey.as<u64>(), stream));
-        KCHECK(dev_gather_u32(b->edge_weight.as<u32>(), eperm.as<u32>(), E, ow.as<u32>(), stream));
-        KCHECK(dev_gather_mapped(b->edge_src.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, osrc.as<u64>(), stream));
-        KCHECK(dev_gather_mapped(b->edge_dst.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, odst.as<u64>(), stream));
-        KCHECK(dev_gather_keys(b->node_key.as<u64>(), nperm.as<u32>(), N, nw, onode.as<u64>(), stream));
-        KCHECK_HIP(hipMemcpyAsync(b->edge_seq.p, eseq.p, E * 8, hipMemcpyDeviceToDevice, stream));
-        size_t n;
-        n = okey.bytes; b->edge_key.adopt(okey.take(), n);
-        n = ow.bytes; b->edge_weight.adopt(ow.take(), n);
-        n = osrc.bytes; b->edge_src.adopt(osrc.take(), n);
-        n = odst.bytes; b->edge_dst.adopt(odst.take(), n);
-        n = onode.bytes; b->node_key.adopt(onode.take(), n);
+        KCHECK(dev_sort(b->edge_seq.as<u64>(), eperm.as<u32>(), E, 1, bits, stream));           // eperm[new] = old; edge_seq now ascending
+        {
+            DevBuf o(stream);
+            KCHECK(o.alloc((E + 1) * 8 * nw));
+            KCHECK(dev_gather_keys(b->edge_key.as<u64>(), eperm.as<u32>(), E, nw, o.as<u64>(), stream));
+            const size_t n = o.bytes; b->edge_key.adopt(o.take(), n);
+        }
+        {
+            DevBuf o(stream);
+            KCHECK(o.alloc((E + 1) * 4));
+            KCHECK(dev_gather_u32(b->edge_weight.as<u32>(), eperm.as<u32>(), E, o.as<u32>(), stream));
+            const size_t n = o.bytes; b->edge_weight.adopt(o.take(), n);
+        }
+        {
+            DevBuf o(stream);
+            KCHECK(o.alloc((E + 1) * 8));
+            KCHECK(dev_gather_mapped(b->edge_src.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, o.as<u64>(), stream));
+            const size_t n = o.bytes; b->edge_src.adopt(o.take(), n);
+        }
+        {
+            DevBuf o(stream);
+            KCHECK(o.alloc((E + 1) * 8));
+            KCHECK(dev_gather_mapped(b->edge_dst.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, o.as<u64>(), stream));
+            const size_t n = o.bytes; b->edge_dst.adopt(o.take(), n);
+        }
         cand = b->node_key.as<u64>();
     }
     const uint32_t stride = label_stride_for_k(k);
