@@ -137,23 +137,41 @@ def _empty(n, dtype, device):
 MAX_MESSAGE_BYTES = 1 << 30
 
 
+def _a2a(out, inp, out_splits=None, in_splits=None, group=None):
+    """all_to_all_single; device tensors are staged through the host when the backend cannot move them itself
+    (gloo: used to rehearse several ranks on one GPU -- RCCL refuses two ranks on the same device)"""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group)
+
+
+def _all_reduce(t, op, group):
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, op=op, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
 def _exchange(send, send_counts, nw, group):
     """all-to-all of `send` (records of nw elements, grouped by destination rank, send_counts records each).
     Returns (recv, recv_counts), recv grouped by source rank."""
     world = dist.get_world_size(group)
     sc = torch.tensor(send_counts, dtype=torch.int64, device=send.device)
     rc = torch.empty(world, dtype=torch.int64, device=send.device)
-    dist.all_to_all_single(rc, sc, group=group)
+    _a2a(rc, sc, group=group)
     recv_counts = [int(x) for x in rc.tolist()]
     recv = _empty(sum(recv_counts) * nw, send.dtype, send.device)
     chunk = max(1, MAX_MESSAGE_BYTES // (nw * send.element_size()))
     biggest = torch.tensor([max(send_counts + recv_counts + [0])], dtype=torch.int64, device=send.device)
-    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(biggest, dist.ReduceOp.MAX, group)
     rounds = (int(biggest.item()) + chunk - 1) // chunk
     if rounds <= 1:
-        dist.all_to_all_single(recv, send[:sum(send_counts) * nw].contiguous(),
-                               output_split_sizes=[c * nw for c in recv_counts],
-                               input_split_sizes=[c * nw for c in send_counts], group=group)
+        _a2a(recv, send[:sum(send_counts) * nw].contiguous(), [c * nw for c in recv_counts], [c * nw for c in send_counts], group)
         return recv, recv_counts
     s_off = [0] * world
     r_off = [0] * world
@@ -165,8 +183,7 @@ def _exchange(send, send_counts, nw, group):
         r_n = [min(max(c - r * chunk, 0), chunk) for c in recv_counts]
         src = torch.cat([send[(s_off[p] + r * chunk) * nw:(s_off[p] + r * chunk + s_n[p]) * nw] for p in range(world)])
         dst = _empty(sum(r_n) * nw, send.dtype, send.device)
-        dist.all_to_all_single(dst, src, output_split_sizes=[c * nw for c in r_n], input_split_sizes=[c * nw for c in s_n],
-                               group=group)
+        _a2a(dst, src, [c * nw for c in r_n], [c * nw for c in s_n], group)
         o = 0
         for p in range(world):
             recv[(r_off[p] + r * chunk) * nw:(r_off[p] + r * chunk + r_n[p]) * nw] = dst[o:o + r_n[p] * nw]
@@ -205,7 +222,7 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
     n_batches = (n_reads + batch_reads - 1) // batch_reads
     # every rank must take part in every all-to-all: agree on the number of rounds
     nb = torch.tensor([n_batches], dtype=torch.int64, device=recbuf.device)
-    dist.all_reduce(nb, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(nb, dist.ReduceOp.MAX, group)
     for i in range(int(nb.item())):
         r0 = i * batch_reads
         nr = max(0, min(batch_reads, n_reads - r0))
@@ -267,9 +284,10 @@ def finalize_distributed(ops, group=None, phases=_NO_PHASES):
     with phases("own_nodes_sort"):
         N = ops.sort_unique(R.clone(), node_bits) if R.numel() else R
     n_owned = N.numel() // nw
-    pieces = [torch.empty(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(pieces, torch.tensor([n_owned], dtype=torch.int64, device=dev), group=group)
-    all_n = torch.cat(pieces)
+    cdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev      # gloo gathers on the host
+    pieces = [torch.empty(1, dtype=torch.int64, device=cdev) for _ in range(world)]
+    dist.all_gather(pieces, torch.tensor([n_owned], dtype=torch.int64, device=cdev), group=group)
+    all_n = torch.cat(pieces).to(dev)
     bases = torch.cumsum(all_n, 0) - all_n
     base = int(bases[rank].item())
     total_nodes = int(all_n.sum().item())
@@ -289,7 +307,7 @@ def finalize_distributed(ops, group=None, phases=_NO_PHASES):
         edge_src = edge_dst = ops.empty(0)
         label = torch.empty((0, 1 + (k + 3) // 4), dtype=torch.uint8, device=dev)
     tot = torch.tensor([E], dtype=torch.int64, device=dev)
-    dist.all_reduce(tot, group=group)
+    _all_reduce(tot, dist.ReduceOp.SUM, group)
     return RankGraph(keys, weights, edge_src, edge_dst, label, N.reshape(-1, nw), base, total_nodes, int(tot.item()))
 
 
@@ -317,7 +335,7 @@ class DistBuild:
         self.skip = skip if wl.n_inject_percent else None
         acc = torch.tensor([self.n_local - (int(skip[:self.n_local].sum().item()) if wl.n_inject_percent else 0)],
                            dtype=torch.int64, device="cuda")
-        dist.all_reduce(acc, group=group)
+        _all_reduce(acc, dist.ReduceOp.SUM, group)
         self.accepted_total = int(acc.item())
 
     def build(self):
