@@ -32,6 +32,11 @@ extern "C" {
  * (pruner.rs:241, collapser.rs:120) then see the same graph, index for index.  Costs two extra atomics per
  * counted record and two more sorts at the end; fixed-length reads, one GPU.                            */
 #define KATOME_FLAG_FIRST_SEEN_ORDER 1u
+/* REMOVE_DEAD_PATHS (host entries katome_build_*): run Prunable::remove_dead_paths (pruner.rs:36-82) on the built
+ * graph before it is handed back, as assemble() does right after the build (asm/basic_assembler.rs:58-62).  The reference's
+ * walks and swap-removes depend on petgraph's numbering, so this needs FIRST_SEEN_ORDER as well (KATOME_E_ARG
+ * otherwise); the result then equals the reference's pruned PtGraph index for index.                      */
+#define KATOME_FLAG_REMOVE_DEAD_PATHS 2u
 
 /* status codes: the reference's panics, one code each */
 enum {
@@ -239,6 +244,21 @@ typedef struct {
  * reverse_complement, pt_graph.rs:282-308); then node numbering, endpoints and labels
  * (the PtGraph::create post-pass, pt_graph.rs:339-343 -> kmer_to_edge compress.rs:231-233). */
 int katome_dev_finalize(katome_builder *b, katome_dev_graph *out, void *stream);
+
+/* Prunable::remove_dead_paths for PtGraph (pruner.rs:36-82; Externals 165-195, remove_paths 199-217,
+ * check_dead_path 229-257), in place on the finalized graph of a FIRST_SEEN_ORDER builder: call after
+ * katome_dev_finalize; `graph` is updated (counts shrink, labels are rewritten).  The walks, the degree
+ * bookkeeping and the array moves run on the device; the two sequential swap_remove replays that fix petgraph's
+ * re-numbering run on the host between them (see prune.hip).                                          */
+typedef struct {
+    uint64_t passes;                 /* iterations of the reference's outer loop, the last (empty) one included */
+    uint64_t walks, dead_walks;      /* walks started from vertices without incoming edges / walks found dead   */
+    uint64_t marked;                 /* edge indices collected, duplicates counted                              */
+    uint64_t removed_edges, removed_by_duplicates, removed_nodes;
+    double   host_ms;                /* time in the sequential replays                                          */
+    double   total_ms;
+} katome_prune_stats;
+int katome_dev_remove_dead_paths(katome_builder *b, katome_dev_graph *graph, katome_prune_stats *stats, void *stream);
 
 /* first half of finalize only: sorted distinct edges (key, weight); used by the multi-GPU
  * driver, which resolves node ids across ranks itself                                      */

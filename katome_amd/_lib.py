@@ -38,6 +38,12 @@ class Reads(C.Structure):
                 ("_pad", C.c_uint32), ("packed", u8p), ("byte_off", u64p), ("len", u32p)]
 
 
+class PruneStats(C.Structure):
+    _fields_ = [("passes", C.c_uint64), ("walks", C.c_uint64), ("dead_walks", C.c_uint64), ("marked", C.c_uint64),
+                ("removed_edges", C.c_uint64), ("removed_by_duplicates", C.c_uint64), ("removed_nodes", C.c_uint64),
+                ("host_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 class DevGraph(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("key_words", C.c_uint32),
                 ("label_stride", C.c_uint32), ("d_edge_key", C.c_void_p), ("d_edge_weight", C.c_void_p),
@@ -78,6 +84,7 @@ SYMBOLS = {
     "katome_dev_insert_tiles": (_i, [_vp, _vp, _u64, _u32, _vp]),
     "katome_dev_expand_tiles": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
     "katome_dev_finalize": (_i, [_vp, C.POINTER(DevGraph), _vp]),
+    "katome_dev_remove_dead_paths": (_i, [_vp, C.POINTER(DevGraph), C.POINTER(PruneStats), _vp]),
     "katome_dev_edges": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
     "katome_dev_release_cache": (_i, [_i]),
     "katome_dev_sort": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp]),

@@ -110,15 +110,16 @@ class CollectionStats:
 
 
 FLAG_FIRST_SEEN_ORDER = 1
+FLAG_REMOVE_DEAD_PATHS = 2
 
 
 def make_settings(k, file_type=InputFileType.Fastq, reverse_complement=False, min_weight=0, device=0,
-                  table_slots_hint=0, first_seen_order=False):
+                  table_slots_hint=0, first_seen_order=False, remove_dead_paths=False):
     s = _lib.Settings()
     s.k = k
     s.file_type = int(file_type)
     s.reverse_complement = 1 if reverse_complement else 0
-    s.flags = FLAG_FIRST_SEEN_ORDER if first_seen_order else 0
+    s.flags = (FLAG_FIRST_SEEN_ORDER if first_seen_order else 0) | (FLAG_REMOVE_DEAD_PATHS if remove_dead_paths else 0)
     s.min_weight = min_weight
     s.device = device
     s.table_slots_hint = table_slots_hint
@@ -166,11 +167,14 @@ class GpuGraph:
 
     # ---- Build::create (builder.rs:42-54) ----------------------------------------------------
     @classmethod
-    def create(cls, input_files, ft, reverse_complement, minimal_weight_threshold=0, device=0, first_seen_order=False):
+    def create(cls, input_files, ft, reverse_complement, minimal_weight_threshold=0, device=0, first_seen_order=False,
+               remove_dead_paths=False):
         """-> (GpuGraph, number_of_read_bytes); uses the global k set by set_global_k_sizes.
-        first_seen_order: number edges and nodes as the reference's petgraph does (order of first insertion)."""
+        first_seen_order: number edges and nodes as the reference's petgraph does (order of first insertion).
+        remove_dead_paths: also run Prunable::remove_dead_paths (pruner.rs:36-82) as assemble() does next
+        (asm/basic_assembler.rs:58-62); needs first_seen_order."""
         s = make_settings(K_SIZE, ft, reverse_complement, minimal_weight_threshold, device,
-                          first_seen_order=first_seen_order)
+                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths)
         gp = C.POINTER(_lib.Graph)()
         _check(_lib.lib().katome_build_files(C.byref(s), _paths(input_files), len(input_files), C.byref(gp)))
         try:
@@ -181,10 +185,10 @@ class GpuGraph:
 
     @classmethod
     def create_from_packed(cls, packed, n_reads, read_len, skip=None, reverse_complement=False, device=0, k=None,
-                           first_seen_order=False):
+                           first_seen_order=False, remove_dead_paths=False):
         """Same build from 2-bit packed reads (numpy uint8), the synthetic-workload entry."""
         s = make_settings(K_SIZE if k is None else k, InputFileType.Fastq, reverse_complement, 0, device,
-                          first_seen_order=first_seen_order)
+                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths)
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         skip_p = None
         if skip is not None:

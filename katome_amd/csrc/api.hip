@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -15,9 +16,9 @@ using namespace katome;
 
 // optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
 enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
-             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_COUNT };
+             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_COUNT };
 static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
-                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles", "first_seen_order"};
+                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles", "first_seen_order", "remove_dead_paths"};
 struct Profiler {
     bool on = false;
     struct Ev { int phase; hipEvent_t a, b; };
@@ -66,6 +67,7 @@ struct katome_builder {
     // finalized graph
     DevBuf edge_src, edge_dst, edge_label, node_key;
     uint64_t n_nodes = 0;
+    bool finalized = false;
 };
 
 extern "C" {
@@ -85,6 +87,11 @@ int katome_builder_create(const katome_settings* s, katome_builder** out) {
     b->nw = (uint32_t)key_words_for_k(s->k);
     b->rc = s->reverse_complement != 0;
     b->first_seen = (s->flags & KATOME_FLAG_FIRST_SEEN_ORDER) != 0;
+    if ((s->flags & KATOME_FLAG_REMOVE_DEAD_PATHS) && !b->first_seen) {
+        delete b;
+        set_error("KATOME_FLAG_REMOVE_DEAD_PATHS needs KATOME_FLAG_FIRST_SEEN_ORDER: the reference's pruning depends on petgraph's numbering");
+        return KATOME_E_ARG;
+    }
     b->table.track_seen = b->tiles.track_seen = b->tiles2.track_seen = b->first_seen;
     *out = b;
     return KATOME_OK;
@@ -484,12 +491,42 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         KCHECK(dev_labels(b->edge_key.as<u64>(), E, k, b->edge_label.as<uint8_t>(), stream));
     }
     KCHECK_HIP(hipStreamSynchronize(stream));
+    b->finalized = true;
     if (out) {
         out->n_nodes = b->n_nodes; out->n_edges = E;
         out->key_words = nw; out->label_stride = stride;
         out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
         out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = cand;
+    }
+    return KATOME_OK;
+}
+
+int katome_dev_remove_dead_paths(katome_builder* b, katome_dev_graph* out, katome_prune_stats* stats, void* stream_) {
+    if (!b) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (!b->first_seen) { set_error("remove_dead_paths needs a KATOME_FLAG_FIRST_SEEN_ORDER builder"); return KATOME_E_ARG; }
+    if (!b->finalized) { set_error("remove_dead_paths: call katome_dev_finalize first"); return KATOME_E_ARG; }
+    const auto t0 = std::chrono::steady_clock::now();
+    PruneGraph g{&b->edge_src, &b->edge_dst, &b->edge_weight, &b->edge_key, &b->node_key, b->n_edges, b->n_nodes, b->nw};
+    katome_prune_stats st;
+    {
+        PhaseScope ps(b->prof, PH_DEAD_PATHS, stream);
+        KCHECK(dev_remove_dead_paths(g, b->s.k, &st, stream));
+        b->n_edges = g.n_edges; b->n_nodes = g.n_nodes;
+        // the labels follow their edges: rewrite them from the keys (kmer_to_edge, compress.rs:231-233)
+        KCHECK(dev_labels(b->edge_key.as<u64>(), b->n_edges, b->s.k, b->edge_label.as<uint8_t>(), stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    st.total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = st;
+    if (out) {
+        out->n_nodes = b->n_nodes; out->n_edges = b->n_edges;
+        out->key_words = b->nw; out->label_stride = label_stride_for_k(b->s.k);
+        out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
+        out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
+        out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = b->node_key.as<u64>();
     }
     return KATOME_OK;
 }
@@ -597,6 +634,7 @@ template <class T> static int d2h(GraphOwner* o, const T** dst, const void* d_sr
 static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** out) {
     katome_dev_graph dg;
     KCHECK(katome_dev_finalize(b, &dg, nullptr));
+    if (b->s.flags & KATOME_FLAG_REMOVE_DEAD_PATHS) KCHECK(katome_dev_remove_dead_paths(b, &dg, nullptr, nullptr));
     GraphOwner* o = new (std::nothrow) GraphOwner();
     if (!o) { set_error("out of host memory"); return KATOME_E_OOM; }
     memset(&o->g, 0, sizeof o->g);

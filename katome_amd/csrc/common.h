@@ -119,6 +119,16 @@ int dev_invert(const uint32_t* perm, uint64_t n, uint64_t* inv, hipStream_t stre
 int dev_node_first(const uint64_t* src, const uint64_t* dst, const uint64_t* seq, uint64_t n, uint64_t* node_first, hipStream_t stream);
 int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream);
 int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream);
+// exclusive scan of m u32 counts into u64 offsets (offs[m] = total), one workgroup
+int dev_scan_counts(const uint32_t* d_counts, uint64_t m, uint64_t* d_offs, hipStream_t stream);
+
+// prune.hip: Prunable::remove_dead_paths on a first-seen-ordered graph, in place (counts shrink, buffers stay)
+struct PruneGraph {
+    DevBuf *edge_src, *edge_dst, *edge_weight, *edge_key, *node_key;
+    uint64_t n_edges, n_nodes;
+    uint32_t nw;
+};
+int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream);
 
 // table.hip
 struct Table {

@@ -1,0 +1,377 @@
+// prune.hip -- Prunable::remove_dead_paths for PtGraph (reference src/katome/algorithms/pruner.rs:36-82, with
+// Externals 165-195, remove_paths 199-217, remove_single_node 219-225, check_dead_path 229-257) on the
+// first-seen-ordered device graph, index for index.
+//
+// The reference repeats until nothing is found: (1) from every vertex without incoming edges follow
+// first_edge(Outgoing) for fewer than 2k steps; a walk that ends at a vertex without out-edges or at one with three
+// or more incoming edges is a dead path (walks from vertices without out-edges can never end that way, so they are
+// skipped here); (2) the collected petgraph edge indices are sorted descending and removed ONE BY ONE with
+// Graph::remove_edge, each followed by remove_node of the endpoints that became isolated.  petgraph 0.4.13 removes by
+// swap_remove, so every removal re-labels the last edge / node, and an index that two walks both collected removes
+// whatever edge was swapped in.  That bookkeeping decides the final numbering (and, through the duplicates, the
+// surviving set), so it is reproduced exactly:
+//   * device: degrees and first_edge(Outgoing) of every node (petgraph's list head = the live out-edge added last =
+//     largest first-seen index; swap_remove re-labels edges but never reorders the lists), the walks, the marks per
+//     edge index, which endpoints die with which removal, and applying the resulting moves to the arrays;
+//   * host: the two sequential swap_remove replays (edges: two descending streams; nodes: arrays over the dying tail).
+#include <chrono>
+#include <vector>
+
+#include "common.h"
+
+namespace katome {
+namespace {
+
+typedef uint32_t u32;
+constexpr u32 NONE32 = 0xFFFFFFFFu;
+constexpr int WALK_TILE = 2048;        // nodes per workgroup in the walk kernel
+constexpr int MARK_ITEMS = 8;          // edges per thread in the mark compaction
+
+// node_deg[v]: in-degree in the low half, out-degree in the high half.  first_out[v]: (first-seen index + 1) << 32 | position
+// of the out-edge with the largest first-seen index (0 = none).
+__global__ __launch_bounds__(BLOCK) void degree_kernel(const u64* __restrict__ src, const u64* __restrict__ dst,
+                                                       const u32* __restrict__ orig, u64 E, u64* __restrict__ node_deg,
+                                                       u64* __restrict__ first_out) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
+        const u64 a = src[e], b = dst[e];
+        atomicAdd((unsigned long long*)&node_deg[a], 1ull << 32);
+        atomicAdd((unsigned long long*)&node_deg[b], 1ull);
+        atomicMax((unsigned long long*)&first_out[a], ((unsigned long long)(orig[e] + 1u) << 32) | (unsigned long long)e);
+    }
+}
+
+// check_dead_path(vertex, Incoming, Outgoing) (pruner.rs:229-257): returns the number of edges of the dead path, 0 if
+// the walk is not dead; with MARK, adds one to mult[] of every edge on the way
+template <bool MARK>
+__device__ __forceinline__ u32 walk(u32 v, u32 two_k, const u64* __restrict__ first_out, const u64* __restrict__ dst,
+                                    const u64* __restrict__ node_deg, u32* __restrict__ mult, u32 len) {
+    u32 cur = v, cnt = 0, n = 0;
+    for (;;) {
+        cnt += 1;
+        if (!MARK && cnt >= two_k) return 0;                    // "this path is not dead"
+        if (MARK && n == len) return n;
+        const u64 fo = first_out[cur];
+        if (fo == 0) return n;                                  // no out-edge: the whole path is dead
+        const u32 e = (u32)fo;
+        if (MARK) atomicAdd(&mult[e], 1u);
+        ++n;
+        cur = (u32)dst[e];
+        if ((u32)node_deg[cur] >= 3) return n;                  // neighbors_directed(current, Incoming).nth(2).is_some()
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void walk_kernel(u64 N, u32 two_k, const u64* __restrict__ first_out, const u64* __restrict__ dst,
+                                                     const u64* __restrict__ node_deg, u32* __restrict__ mult,
+                                                     u64* __restrict__ totals /* [0] marks, [1] dead walks, [2] walks */) {
+    __shared__ u32 inputs[WALK_TILE];
+    __shared__ u32 n_inputs;
+    __shared__ u32 blk_marks, blk_dead;
+    for (u64 tile = blockIdx.x; tile * WALK_TILE < N; tile += gridDim.x) {
+        if (threadIdx.x == 0) { n_inputs = 0; blk_marks = 0; blk_dead = 0; }
+        __syncthreads();
+        const u64 base = tile * WALK_TILE;
+        for (u32 j = threadIdx.x; j < WALK_TILE; j += BLOCK) {
+            const u64 v = base + j;
+            // Externals (pruner.rs:165-195): Input = no incoming edge.  (A vertex with no edge at all cannot exist here.)
+            if (v < N && (u32)node_deg[v] == 0) inputs[atomicAdd(&n_inputs, 1u)] = (u32)v;
+        }
+        __syncthreads();
+        const u32 cnt = n_inputs;
+        u32 marks = 0, dead = 0;
+        for (u32 j = threadIdx.x; j < cnt; j += BLOCK) {
+            const u32 v = inputs[j];
+            const u32 len = walk<false>(v, two_k, first_out, dst, node_deg, nullptr, 0);
+            if (len) { walk<true>(v, two_k, first_out, dst, node_deg, mult, len); marks += len; dead += 1; }
+        }
+        if (marks) atomicAdd(&blk_marks, marks);
+        if (dead) atomicAdd(&blk_dead, dead);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (blk_marks) atomicAdd((unsigned long long*)&totals[0], (unsigned long long)blk_marks);
+            if (blk_dead) atomicAdd((unsigned long long*)&totals[1], (unsigned long long)blk_dead);
+            if (cnt) atomicAdd((unsigned long long*)&totals[2], (unsigned long long)cnt);
+        }
+        __syncthreads();
+    }
+}
+
+// marked edge indices, ascending, with their multiplicity: count / scan / write
+__global__ __launch_bounds__(BLOCK) void mark_count_kernel(const u32* __restrict__ mult, u64 E, u32* __restrict__ counts) {
+    __shared__ u32 total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const u64 base = ((u64)blockIdx.x * BLOCK + threadIdx.x) * MARK_ITEMS;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j) c += (base + j < E && mult[base + j] != 0);
+    if (c) atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(BLOCK) void mark_write_kernel(const u32* __restrict__ mult, u64 E, const u64* __restrict__ block_offs,
+                                                           u32* __restrict__ out_pos, u32* __restrict__ out_mult) {
+    __shared__ u32 wsum[BLOCK / 64];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = ((u64)blockIdx.x * BLOCK + tid) * MARK_ITEMS;
+    u32 m[MARK_ITEMS], c = 0;
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j) { m[j] = base + j < E ? mult[base + j] : 0; c += m[j] != 0; }
+    u32 incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < wave; ++w) woff += wsum[w];
+    u64 pos = block_offs[blockIdx.x] + woff + incl - c;
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j) if (m[j]) { out_pos[pos] = (u32)(base + j); out_mult[pos] = m[j]; ++pos; }
+}
+
+// which endpoints lose their last edge with removal t: take the removed edges out of the degree words, remember the
+// last removal that touched each node, then ask per removal
+__global__ __launch_bounds__(BLOCK) void death_count_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
+                                                            const u64* __restrict__ dst, u64* __restrict__ node_deg,
+                                                            u32* __restrict__ last_touch) {
+    for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
+        const u32 e = victims[t];
+        const u64 a = src[e], b = dst[e];
+        atomicAdd((unsigned long long*)&node_deg[a], 0ull - (1ull << 32));
+        atomicAdd((unsigned long long*)&node_deg[b], 0ull - 1ull);
+        atomicMax(&last_touch[a], (u32)t + 1u);
+        atomicMax(&last_touch[b], (u32)t + 1u);
+    }
+}
+__global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
+                                                           const u64* __restrict__ dst, const u64* __restrict__ node_deg,
+                                                           const u32* __restrict__ last_touch, u32* __restrict__ die) {
+    for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
+        const u32 e = victims[t];
+        const u64 a = src[e], b = dst[e];
+        const bool da = node_deg[a] == 0 && last_touch[a] == (u32)t + 1u;
+        const bool db = b != a && node_deg[b] == 0 && last_touch[b] == (u32)t + 1u;
+        die[2 * t] = da ? (u32)a : NONE32;
+        die[2 * t + 1] = db ? (u32)b : NONE32;
+    }
+}
+
+// moves: every array entry of the edge (node) at `from` goes to `to`; sources lie at or above the new count and
+// targets below it, so the copies never overlap
+__global__ __launch_bounds__(BLOCK) void move_edges_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
+                                                           u64* __restrict__ src, u64* __restrict__ dst, u32* __restrict__ weight,
+                                                           u32* __restrict__ orig, u64* __restrict__ key) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u64 d = to[i], s = from[i];
+        src[d] = src[s]; dst[d] = dst[s]; weight[d] = weight[s]; orig[d] = orig[s];
+        for (u32 w = 0; w < nw; ++w) key[d * nw + w] = key[s * nw + w];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void move_nodes_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
+                                                           u64 n_new, u64* __restrict__ node_key, u32* __restrict__ tail_map) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u64 d = to[i], s = from[i];
+        for (u32 w = 0; w < nw; ++w) node_key[d * nw + w] = node_key[s * nw + w];
+        tail_map[s - n_new] = (u32)d;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void remap_kernel(u64* __restrict__ src, u64* __restrict__ dst, u64 E, u64 n_new,
+                                                      const u32* __restrict__ tail_map) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
+        const u64 a = src[e], b = dst[e];
+        if (a >= n_new) src[e] = tail_map[a - n_new];
+        if (b >= n_new) dst[e] = tail_map[b - n_new];
+    }
+}
+
+// ---- host: the sequential swap_remove replays -------------------------------------------------------------------
+// Edges (remove_paths, pruner.rs:199-217 over Graph::remove_edge): indices arrive ascending with multiplicities and
+// are consumed from the top.  The entry being removed and the last position both only move down, so the occupants
+// that differ from the identity live in an array aligned with the entries.
+struct EdgeReplay {
+    std::vector<u32> victims;          // identity (position at the start of the pass) of each removed edge, in order
+    std::vector<u32> move_to, move_from;
+    u64 n_new = 0, from_duplicates = 0;
+};
+void replay_edges(const u32* pos, const u32* mult, u64 u, u64 E, EdgeReplay& out) {
+    std::vector<u32> occ(pos, pos + u);                    // occupant of position pos[j]
+    u64 size = E;
+    long long q = (long long)u - 1;
+    out.victims.clear();
+    for (long long j = (long long)u - 1; j >= 0; --j) {
+        const u32 d = pos[j];
+        for (u32 r = 0; r < mult[j]; ++r) {
+            if (d >= size) break;                          // edge_endpoints(e) == None, remove_edge(e) == None
+            const u32 last = (u32)(size - 1);
+            while (q >= 0 && pos[q] > last) --q;
+            const u32 mover = (q >= 0 && pos[q] == last) ? occ[q] : last;
+            out.victims.push_back(occ[j]);
+            if (r) ++out.from_duplicates;
+            if (d != last) occ[j] = mover;
+            --size;
+        }
+    }
+    out.n_new = size;
+    out.move_to.clear(); out.move_from.clear();
+    for (u64 j = 0; j < u && pos[j] < size; ++j)
+        if (occ[j] != pos[j]) { out.move_to.push_back(pos[j]); out.move_from.push_back(occ[j]); }
+}
+
+// Nodes (remove_single_node after every removed edge, the endpoint with the larger CURRENT index first,
+// pruner.rs:206-215, over Graph::remove_node): only nodes in the tail that disappears are ever re-labelled.
+struct NodeReplay {
+    std::vector<u32> move_to, move_from;
+    u64 n_new = 0;
+};
+void replay_nodes(const u32* die, u64 m, u64 N, NodeReplay& out) {
+    u64 n_die = 0;
+    for (u64 i = 0; i < 2 * m; ++i) n_die += die[i] != NONE32;
+    const u64 base = N - n_die;
+    std::vector<u32> tail_pos(n_die), tail_occ(n_die);
+    std::vector<uint8_t> dead(n_die, 0);
+    for (u64 i = 0; i < n_die; ++i) tail_pos[i] = tail_occ[i] = (u32)(base + i);
+    u64 size = N;
+    auto pos_of = [&](u32 v) -> u32 { return v < base ? v : tail_pos[v - base]; };
+    auto remove = [&](u32 v) {
+        const u32 p = pos_of(v), top = (u32)(size - 1), y = tail_occ[top - base];
+        if (v >= base) dead[v - base] = 1;
+        if (p != top) {
+            if (p >= base) tail_occ[p - base] = y;
+            tail_pos[y - base] = p;
+        }
+        --size;
+    };
+    for (u64 t = 0; t < m; ++t) {
+        const u32 a = die[2 * t], b = die[2 * t + 1];
+        if (a != NONE32 && b != NONE32) {
+            if (pos_of(a) < pos_of(b)) { remove(b); remove(a); } else { remove(a); remove(b); }
+        } else if (a != NONE32) {
+            remove(a);
+        } else if (b != NONE32) {
+            remove(b);
+        }
+    }
+    out.n_new = size;
+    out.move_to.clear(); out.move_from.clear();
+    for (u64 i = 0; i < n_die; ++i)
+        if (!dead[i]) { out.move_to.push_back(tail_pos[i]); out.move_from.push_back((u32)(base + i)); }
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int upload(DevBuf& d, const std::vector<u32>& h, hipStream_t stream) {
+    KCHECK(d.alloc(h.size() * 4 + 16, stream));
+    if (!h.empty()) KCHECK_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream));
+    return KATOME_OK;
+}
+
+}  // namespace
+
+int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream) {
+    katome_prune_stats local;
+    memset(&local, 0, sizeof local);
+    if (g.n_edges >= 0xFFFFFFFFull || g.n_nodes >= 0xFFFFFFFFull) {
+        set_error("remove_dead_paths: more than 2^32 edges or nodes on one GPU");
+        return KATOME_E_UNSUPPORTED;
+    }
+    const u32 nw = g.nw, two_k = 2 * k;
+    u64 E = g.n_edges, N = g.n_nodes;
+    u64* src = g.edge_src->as<u64>(); u64* dst = g.edge_dst->as<u64>();
+    u32* weight = g.edge_weight->as<u32>(); u64* key = g.edge_key->as<u64>(); u64* node_key = g.node_key->as<u64>();
+    DevBuf orig(stream), node_deg(stream), first_out(stream), mult(stream), totals(stream);
+    KCHECK(orig.alloc((E + 1) * 4));
+    KCHECK(dev_iota(orig.as<u32>(), E, stream));
+    KCHECK(node_deg.alloc((N + 1) * 8)); KCHECK(first_out.alloc((N + 1) * 8)); KCHECK(mult.alloc((E + 1) * 4));
+    KCHECK(totals.alloc(32));
+    std::vector<u32> h_pos, h_mult, h_die;
+    EdgeReplay er; NodeReplay nr;
+    while (E) {
+        // (1) adjacency summary + walks
+        KCHECK_HIP(hipMemsetAsync(node_deg.p, 0, N * 8, stream));
+        KCHECK_HIP(hipMemsetAsync(first_out.p, 0, N * 8, stream));
+        KCHECK_HIP(hipMemsetAsync(mult.p, 0, E * 4, stream));
+        KCHECK_HIP(hipMemsetAsync(totals.p, 0, 32, stream));
+        hipLaunchKernelGGL(degree_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, orig.as<u32>(), E,
+                           node_deg.as<u64>(), first_out.as<u64>());
+        hipLaunchKernelGGL(walk_kernel, dim3(grid_for(N, WALK_TILE, 256u * 32u)), dim3(BLOCK), 0, stream, N, two_k, first_out.as<u64>(),
+                           dst, node_deg.as<u64>(), mult.as<u32>(), totals.as<u64>());
+        KCHECK_HIP(hipGetLastError());
+        u64 h_tot[3] = {0, 0, 0};
+        KCHECK_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        local.passes += 1;
+        local.walks += h_tot[2];
+        if (h_tot[0] == 0) break;                         // to_remove.is_empty() (pruner.rs:76)
+        local.dead_walks += h_tot[1];
+        local.marked += h_tot[0];
+        // (2) the marked indices, ascending (the reference sorts them descending; they are consumed from the top)
+        const u64 nblocks = (E + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
+        DevBuf counts(stream), offs(stream), d_pos(stream), d_mult(stream);
+        KCHECK(counts.alloc(nblocks * 4 + 16)); KCHECK(offs.alloc((nblocks + 1) * 8 + 16));
+        hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, counts.as<u32>());
+        KCHECK(dev_scan_counts(counts.as<u32>(), nblocks, offs.as<u64>(), stream));
+        u64 u = 0;
+        KCHECK_HIP(hipMemcpyAsync(&u, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        KCHECK(d_pos.alloc(u * 4 + 16)); KCHECK(d_mult.alloc(u * 4 + 16));
+        hipLaunchKernelGGL(mark_write_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, offs.as<u64>(),
+                           d_pos.as<u32>(), d_mult.as<u32>());
+        KCHECK_HIP(hipGetLastError());
+        h_pos.resize(u); h_mult.resize(u);
+        KCHECK_HIP(hipMemcpyAsync(h_pos.data(), d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipMemcpyAsync(h_mult.data(), d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        d_pos.release(); d_mult.release(); counts.release(); offs.release();
+        // (3) replay of remove_edge
+        double t0 = now_ms();
+        replay_edges(h_pos.data(), h_mult.data(), u, E, er);
+        local.host_ms += now_ms() - t0;
+        const u64 m = er.victims.size();
+        local.removed_edges += m;
+        local.removed_by_duplicates += er.from_duplicates;
+        // (4) the nodes each removal isolates
+        DevBuf d_victims(stream), last_touch(stream), d_die(stream);
+        KCHECK(upload(d_victims, er.victims, stream));
+        KCHECK(last_touch.alloc((N + 1) * 4)); KCHECK(d_die.alloc(2 * m * 4 + 16));
+        KCHECK_HIP(hipMemsetAsync(last_touch.p, 0, N * 4, stream));
+        hipLaunchKernelGGL(death_count_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
+                           node_deg.as<u64>(), last_touch.as<u32>());
+        hipLaunchKernelGGL(death_emit_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
+                           node_deg.as<u64>(), last_touch.as<u32>(), d_die.as<u32>());
+        KCHECK_HIP(hipGetLastError());
+        h_die.resize(2 * m);
+        KCHECK_HIP(hipMemcpyAsync(h_die.data(), d_die.p, 2 * m * 4, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        d_victims.release(); last_touch.release(); d_die.release();
+        // (5) replay of remove_node
+        t0 = now_ms();
+        replay_nodes(h_die.data(), m, N, nr);
+        local.host_ms += now_ms() - t0;
+        local.removed_nodes += N - nr.n_new;
+        // (6) apply the moves, re-label the endpoints of the surviving edges
+        {
+            DevBuf to(stream), from(stream), tail_map(stream);
+            KCHECK(upload(to, er.move_to, stream)); KCHECK(upload(from, er.move_from, stream));
+            const u64 ne = er.move_to.size();
+            if (ne) hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(ne, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
+                                       from.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key);
+            E = er.n_new;
+            KCHECK(upload(to, nr.move_to, stream)); KCHECK(upload(from, nr.move_from, stream));
+            const u64 nn = nr.move_to.size();
+            KCHECK(tail_map.alloc((N - nr.n_new + 1) * 4));
+            if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
+                                       from.as<u32>(), nn, nw, nr.n_new, node_key, tail_map.as<u32>());
+            if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, nr.n_new,
+                                            tail_map.as<u32>());
+            KCHECK_HIP(hipGetLastError());
+            N = nr.n_new;
+            KCHECK_HIP(hipStreamSynchronize(stream));      // the host vectors are reused by the next pass
+        }
+    }
+    g.n_edges = E; g.n_nodes = N;
+    if (st) *st = local;
+    return KATOME_OK;
+}
+
+}  // namespace katome

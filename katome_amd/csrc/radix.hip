@@ -400,6 +400,12 @@ __global__ __launch_bounds__(BLOCK) void uniq_write_kernel(const u64* __restrict
     for (int j = 0; j < UNIQ_ITEMS; ++j) if (head[j]) { store_key<NW>(out, pos, load_key<NW>(keys, base + j)); ++pos; }
 }
 
+int dev_scan_counts(const uint32_t* d_counts, uint64_t m, uint64_t* d_offs, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, d_counts, m, d_offs);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
 int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipStream_t stream) {
     *n_out = n;
     if (n < 2) return KATOME_OK;

@@ -199,6 +199,13 @@ class Builder:
         _check(_lib.lib().katome_dev_finalize(self._h, C.byref(dg), _stream()))
         return DeviceGraph(dg, self, self.tdev)
 
+    def remove_dead_paths(self):
+        """Prunable::remove_dead_paths (pruner.rs:36-82) on the finalized first-seen-ordered graph, in place
+        -> (DeviceGraph, stats dict)"""
+        dg, st = _lib.DevGraph(), _lib.PruneStats()
+        _check(_lib.lib().katome_dev_remove_dead_paths(self._h, C.byref(dg), C.byref(st), _stream()))
+        return DeviceGraph(dg, self, self.tdev), {f: getattr(st, f) for f, _ in _lib.PruneStats._fields_}
+
 
 # ---- primitives ------------------------------------------------------------------------------------
 def sort_keys(keys, key_bits, key_words, values=None, device=0):

@@ -461,6 +461,125 @@ static uint64_t pg_degree(const pgraph_t *g, uint64_t n, int dir)
     return c;
 }
 
+/* ---- petgraph 0.4.13 removal, restated from its published source (crate absent): edges and nodes live in Vecs,
+ * removal is swap_remove (the last element takes the freed index), adjacency is two singly linked lists per node. */
+static void pg_change_edge_links(pgraph_t *g, const uint64_t edge_node[2], uint64_t e, const uint64_t edge_next[2])
+{
+    for (int k = 0; k < 2; ++k) {
+        if (edge_node[k] >= g->n_nodes) return;
+        uint64_t fst = g->node_next[k][edge_node[k]];
+        if (fst == e) {
+            g->node_next[k][edge_node[k]] = edge_next[k];
+        } else {
+            for (uint64_t cur = fst; cur != END && cur < g->n_edges; cur = g->edge_next[k][cur])
+                if (g->edge_next[k][cur] == e) { g->edge_next[k][cur] = edge_next[k]; break; }
+        }
+    }
+}
+/* Graph::remove_edge + remove_edge_adjust_indices; returns 0 if e is out of range */
+static int pg_remove_edge(pgraph_t *g, uint64_t e)
+{
+    if (e >= g->n_edges) return 0;
+    uint64_t en[2] = {g->edge_node[0][e], g->edge_node[1][e]}, nx[2] = {g->edge_next[0][e], g->edge_next[1][e]};
+    pg_change_edge_links(g, en, e, nx);
+    uint64_t last = g->n_edges - 1;                          /* swap_remove */
+    if (e != last) {
+        for (int k = 0; k < 2; ++k) { g->edge_node[k][e] = g->edge_node[k][last]; g->edge_next[k][e] = g->edge_next[k][last]; }
+        g->edge_w[e] = g->edge_w[last]; g->edge_slot[e] = g->edge_slot[last];
+    }
+    g->n_edges = last;
+    if (e < g->n_edges) {                                    /* an edge was swapped in: relink `last` -> `e` */
+        uint64_t swap[2] = {g->edge_node[0][e], g->edge_node[1][e]}, ee[2] = {e, e};
+        pg_change_edge_links(g, swap, last, ee);
+    }
+    return 1;
+}
+static void pg_remove_node(pgraph_t *g, uint64_t a)
+{
+    if (a >= g->n_nodes) return;
+    for (int k = 0; k < 2; ++k)
+        while (g->node_next[k][a] != END) pg_remove_edge(g, g->node_next[k][a]);
+    uint64_t last = g->n_nodes - 1;                          /* swap_remove */
+    if (a != last) { g->node_next[0][a] = g->node_next[0][last]; g->node_next[1][a] = g->node_next[1][last]; }
+    g->n_nodes = last;
+    if (a < g->n_nodes)                                      /* the relocated node's edges point at its new index */
+        for (int k = 0; k < 2; ++k)
+            for (uint64_t cur = g->node_next[k][a]; cur != END; cur = g->edge_next[k][cur]) g->edge_node[k][cur] = a;
+}
+static int pg_degree_at_least(const pgraph_t *g, uint64_t n, int dir, uint64_t want)
+{
+    if (n >= g->n_nodes) return want == 0;
+    uint64_t c = 0;
+    for (uint64_t e = g->node_next[dir][n]; e != END; e = g->edge_next[dir][e]) if (++c >= want) return 1;
+    return c >= want;
+}
+
+/* ============================ pruner.rs:36-82,199-257 (PtGraph) ===================== */
+typedef struct { uint64_t *v; size_t n, cap; } evec_t;
+static void evec_push(evec_t *v, uint64_t x)
+{
+    if (v->n == v->cap) { v->cap = v->cap ? v->cap * 2 : 256; v->v = (uint64_t *)xrealloc(v->v, v->cap * 8); }
+    v->v[v->n++] = x;
+}
+/* pruner.rs:229-257; dir0 = first_direction, dir1 = second_direction (0 Outgoing, 1 Incoming) */
+static void check_dead_path(const pgraph_t *g, uint64_t vertex, int first_direction, int second_direction, evec_t *out)
+{
+    uint64_t current = vertex, cnt = 0;
+    for (;;) {
+        cnt += 1;
+        if (cnt >= 2 * K_SIZE) { out->n = 0; return; }           /* this path is not dead */
+        uint64_t e = g->node_next[second_direction][current];     /* first_edge(current, second_direction) */
+        if (e != END) {
+            evec_push(out, e);
+            current = g->edge_node[1][e];                         /* edge_endpoints(e).1 */
+        } else {
+            return;
+        }
+        if (pg_degree_at_least(g, current, first_direction, 3)) return;   /* neighbors_directed(..).nth(2).is_some() */
+    }
+}
+static int cmp_desc(const void *a, const void *b)
+{
+    uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+    return x < y ? 1 : x > y ? -1 : 0;
+}
+static void remove_single_node(pgraph_t *g, uint64_t node)      /* pruner.rs:219-225 */
+{
+    if (!pg_degree_at_least(g, node, 1, 1) && !pg_degree_at_least(g, node, 0, 1)) pg_remove_node(g, node);
+}
+/* Prunable::remove_dead_paths for PtGraph (pruner.rs:36-82) with remove_paths (199-217) */
+static uint64_t g_prune_passes = 0;      /* iterations of the outer loop in the last remove_dead_paths (the empty one included) */
+uint64_t ko_last_prune_passes(void) { return g_prune_passes; }
+static void remove_dead_paths(pgraph_t *g)
+{
+    evec_t to_remove = {0, 0, 0}, path = {0, 0, 0};
+    g_prune_passes = 0;
+    for (;;) {
+        g_prune_passes += 1;
+        for (uint64_t v = 0; v < g->n_nodes; ++v) {               /* Externals (pruner.rs:165-195) */
+            path.n = 0;
+            if (g->node_next[1][v] == END) check_dead_path(g, v, 1, 0, &path);          /* Input: no incoming edge */
+            else if (g->node_next[0][v] == END) check_dead_path(g, v, 0, 1, &path);     /* Output: no outgoing edge */
+            else continue;
+            for (size_t i = 0; i < path.n; ++i) evec_push(&to_remove, path.v[i]);
+        }
+        if (to_remove.n == 0) break;
+        qsort(to_remove.v, to_remove.n, 8, cmp_desc);
+        for (size_t i = 0; i < to_remove.n; ++i) {                /* remove_paths */
+            uint64_t e = to_remove.v[i];
+            int have = e < g->n_edges;
+            uint64_t a = have ? g->edge_node[0][e] : 0, b = have ? g->edge_node[1][e] : 0;
+            pg_remove_edge(g, e);
+            if (have) {
+                if (a < b) { remove_single_node(g, b); remove_single_node(g, a); }
+                else { remove_single_node(g, a); remove_single_node(g, b); }
+            }
+        }
+        to_remove.n = 0;
+    }
+    free(to_remove.v); free(path.v);
+}
+
 /* ==================== PtGraphBuilder (pt_graph.rs:104-110) ========================= */
 typedef struct {
     pgraph_t graph;
@@ -844,8 +963,12 @@ static void pt_stats(const pgraph_t *g, ko_stats *st)
 }
 
 /* PtGraph::create tail (pt_graph.rs:339-344): recode every slot kmer->edge format */
+static int g_prune_dead_paths = 0;      /* set by ko_set_prune_dead_paths: run remove_dead_paths before the result is read out */
+void ko_set_prune_dead_paths(int on) { g_prune_dead_paths = on; }
+
 static ko_graph *finish(build_ctx *c)
 {
+    if (g_prune_dead_paths) remove_dead_paths(&c->b.graph);
     ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
     pgraph_t *p = &c->b.graph;
     g->n_nodes = p->n_nodes; g->n_edges = p->n_edges; g->read_bytes = c->total;

@@ -97,6 +97,10 @@ int  ko_build_bfc(const char *const *paths, size_t n_paths, int reverse_compleme
  * of builder.rs:155-157 is applied exactly as for file input                        */
 int  ko_build_ascii(const uint8_t *reads, size_t n_reads, size_t read_len,
                     int reverse_complement, size_t k, int with_gir, ko_graph **out);
+/* when on, every ko_build_* runs Prunable::remove_dead_paths (pruner.rs:36-82; restated with petgraph 0.4.13's
+ * swap-remove index semantics) on the finished PtGraph before the result arrays are read out */
+void ko_set_prune_dead_paths(int on);
+uint64_t ko_last_prune_passes(void);
 /* Clean::remove_weak_edges for PtGraph (pruner.rs:84-93), in place on a built graph */
 void ko_remove_weak_edges(ko_graph *g, uint32_t threshold);
 void ko_graph_free(ko_graph *g);

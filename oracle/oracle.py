@@ -85,6 +85,9 @@ def lib():
                                      C.POINTER(C.POINTER(KoGraph))]
         L.ko_graph_free.argtypes = [C.POINTER(KoGraph)]
         L.ko_remove_weak_edges.argtypes = [C.POINTER(KoGraph), C.c_uint32]
+        L.ko_set_prune_dead_paths.argtypes = [C.c_int]
+        L.ko_set_prune_dead_paths.restype = None
+        L.ko_last_prune_passes.restype = C.c_uint64
         L.ko_last_error.restype = C.c_char_p
         L.ko_scan_files.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.POINTER(C.POINTER(KoReads))]
         L.ko_reads_free.argtypes = [C.POINTER(KoReads)]
@@ -237,10 +240,13 @@ def _paths(paths):
     return arr
 
 
-def build_files(paths, k, reverse_complement=False, file_type=1, with_gir=False, remove_weak_edges=None):
+def build_files(paths, k, reverse_complement=False, file_type=1, with_gir=False, remove_weak_edges=None,
+                remove_dead_paths=False):
     gp = C.POINTER(KoGraph)()
+    lib().ko_set_prune_dead_paths(1 if remove_dead_paths else 0)
     rc = lib().ko_build_files(_paths(paths), len(paths), file_type, int(reverse_complement), k, int(with_gir),
                               C.byref(gp))
+    lib().ko_set_prune_dead_paths(0)
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:
@@ -262,12 +268,14 @@ def build_bfc(paths, k, reverse_complement=False, threshold=0):
         lib().ko_graph_free(gp)
 
 
-def build_ascii(reads, k, reverse_complement=False, with_gir=False):
+def build_ascii(reads, k, reverse_complement=False, with_gir=False, remove_dead_paths=False):
     """reads: uint8 array [n_reads, read_len] of ASCII codes."""
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
     gp = C.POINTER(KoGraph)()
+    lib().ko_set_prune_dead_paths(1 if remove_dead_paths else 0)
     rc = lib().ko_build_ascii(reads.ctypes.data, reads.shape[0], reads.shape[1], int(reverse_complement), k,
                               int(with_gir), C.byref(gp))
+    lib().ko_set_prune_dead_paths(0)
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:
@@ -297,3 +305,8 @@ def synth_reads(first_read, n_reads, read_len, genome_len, err_rate, n_inject_pe
     out = np.empty((n_reads, read_len), dtype=np.uint8)
     lib().ko_synth_reads(first_read, n_reads, read_len, genome_len, err_rate, n_inject_percent, out.ctypes.data)
     return out
+
+
+def last_prune_passes():
+    """iterations of remove_dead_paths' outer loop in the last pruned build (the final empty one included)"""
+    return int(lib().ko_last_prune_passes())
