@@ -14,21 +14,26 @@
 //     largest first-seen index; swap_remove re-labels edges but never reorders the lists), the walks, the marks per
 //     edge index, which endpoints die with which removal, and applying the resulting moves to the arrays;
 //   * host: the two sequential swap_remove replays (edges: two descending streams; nodes: arrays over the dying tail).
+#include <stdlib.h>
+
 #include <chrono>
 #include <vector>
 
 #include "common.h"
+#include "prune_replay.h"
 
 namespace katome {
 namespace {
 
 typedef uint32_t u32;
-constexpr u32 NONE32 = 0xFFFFFFFFu;
+constexpr u32 NONE32 = REPLAY_NONE;
 constexpr int WALK_TILE = 2048;        // nodes per workgroup in the walk kernel
 constexpr int MARK_ITEMS = 8;          // edges per thread in the mark compaction
+constexpr u64 REDO_FIRST_OUT = 1ull << 63;   // in node_deg: the node lost its first out-edge, first_out is being rebuilt
 
 // node_deg[v]: in-degree in the low half, out-degree in the high half.  first_out[v]: (first-seen index + 1) << 32 | position
-// of the out-edge with the largest first-seen index (0 = none).
+// of the out-edge with the largest first-seen index (0 = none).  Both are built once and then kept up to date by the
+// kernels below as edges go and as edges and nodes are moved.
 __global__ __launch_bounds__(BLOCK) void degree_kernel(const u64* __restrict__ src, const u64* __restrict__ dst,
                                                        const u32* __restrict__ orig, u64 E, u64* __restrict__ node_deg,
                                                        u64* __restrict__ first_out) {
@@ -61,7 +66,7 @@ __device__ __forceinline__ u32 walk(u32 v, u32 two_k, const u64* __restrict__ fi
 }
 
 __global__ __launch_bounds__(BLOCK) void walk_kernel(u64 N, u32 two_k, const u64* __restrict__ first_out, const u64* __restrict__ dst,
-                                                     const u64* __restrict__ node_deg, u32* __restrict__ mult,
+                                                     u64* __restrict__ node_deg, u32* __restrict__ mult,
                                                      u64* __restrict__ totals /* [0] marks, [1] dead walks, [2] walks */) {
     __shared__ u32 inputs[WALK_TILE];
     __shared__ u32 n_inputs;
@@ -73,7 +78,11 @@ __global__ __launch_bounds__(BLOCK) void walk_kernel(u64 N, u32 two_k, const u64
         for (u32 j = threadIdx.x; j < WALK_TILE; j += BLOCK) {
             const u64 v = base + j;
             // Externals (pruner.rs:165-195): Input = no incoming edge.  (A vertex with no edge at all cannot exist here.)
-            if (v < N && (u32)node_deg[v] == 0) inputs[atomicAdd(&n_inputs, 1u)] = (u32)v;
+            if (v < N) {
+                const u64 deg = node_deg[v];
+                if (deg & REDO_FIRST_OUT) node_deg[v] = deg & ~REDO_FIRST_OUT;      // (walks only read the low half)
+                if ((u32)deg == 0) inputs[atomicAdd(&n_inputs, 1u)] = (u32)v;
+            }
         }
         __syncthreads();
         const u32 cnt = n_inputs;
@@ -128,14 +137,23 @@ __global__ __launch_bounds__(BLOCK) void mark_write_kernel(const u32* __restrict
     for (int j = 0; j < MARK_ITEMS; ++j) if (m[j]) { out_pos[pos] = (u32)(base + j); out_mult[pos] = m[j]; ++pos; }
 }
 
+__global__ __launch_bounds__(BLOCK) void mark_clear_kernel(const u32* __restrict__ pos, u64 n, u32* __restrict__ mult) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) mult[pos[i]] = 0;
+}
+
 // which endpoints lose their last edge with removal t: take the removed edges out of the degree words, remember the
 // last removal that touched each node, then ask per removal
 __global__ __launch_bounds__(BLOCK) void death_count_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
                                                             const u64* __restrict__ dst, u64* __restrict__ node_deg,
-                                                            u32* __restrict__ last_touch) {
+                                                            u64* __restrict__ first_out, u32* __restrict__ last_touch) {
     for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
         const u32 e = victims[t];
         const u64 a = src[e], b = dst[e];
+        const u64 fo = first_out[a];
+        if (fo != 0 && (u32)fo == e) {              // the list head goes: the next live out-edge is found by first_out_redo_kernel
+            first_out[a] = 0;
+            atomicOr((unsigned long long*)&node_deg[a], REDO_FIRST_OUT);
+        }
         atomicAdd((unsigned long long*)&node_deg[a], 0ull - (1ull << 32));
         atomicAdd((unsigned long long*)&node_deg[b], 0ull - 1ull);
         atomicMax(&last_touch[a], (u32)t + 1u);
@@ -148,8 +166,8 @@ __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict
     for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
         const u32 e = victims[t];
         const u64 a = src[e], b = dst[e];
-        const bool da = node_deg[a] == 0 && last_touch[a] == (u32)t + 1u;
-        const bool db = b != a && node_deg[b] == 0 && last_touch[b] == (u32)t + 1u;
+        const bool da = (node_deg[a] & ~REDO_FIRST_OUT) == 0 && last_touch[a] == (u32)t + 1u;
+        const bool db = b != a && (node_deg[b] & ~REDO_FIRST_OUT) == 0 && last_touch[b] == (u32)t + 1u;
         die[2 * t] = da ? (u32)a : NONE32;
         die[2 * t + 1] = db ? (u32)b : NONE32;
     }
@@ -159,18 +177,22 @@ __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict
 // targets below it, so the copies never overlap
 __global__ __launch_bounds__(BLOCK) void move_edges_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
                                                            u64* __restrict__ src, u64* __restrict__ dst, u32* __restrict__ weight,
-                                                           u32* __restrict__ orig, u64* __restrict__ key) {
+                                                           u32* __restrict__ orig, u64* __restrict__ key, u64* __restrict__ first_out) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         const u64 d = to[i], s = from[i];
-        src[d] = src[s]; dst[d] = dst[s]; weight[d] = weight[s]; orig[d] = orig[s];
+        const u64 a = src[s], fo = first_out[a];
+        if (fo != 0 && (u32)fo == (u32)s) first_out[a] = (fo & 0xFFFFFFFF00000000ull) | d;      // the head follows its edge
+        src[d] = a; dst[d] = dst[s]; weight[d] = weight[s]; orig[d] = orig[s];
         for (u32 w = 0; w < nw; ++w) key[d * nw + w] = key[s * nw + w];
     }
 }
 __global__ __launch_bounds__(BLOCK) void move_nodes_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
-                                                           u64 n_new, u64* __restrict__ node_key, u32* __restrict__ tail_map) {
+                                                           u64 n_new, u64* __restrict__ node_key, u64* __restrict__ node_deg,
+                                                           u64* __restrict__ first_out, u32* __restrict__ tail_map) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         const u64 d = to[i], s = from[i];
         for (u32 w = 0; w < nw; ++w) node_key[d * nw + w] = node_key[s * nw + w];
+        node_deg[d] = node_deg[s]; first_out[d] = first_out[s];
         tail_map[s - n_new] = (u32)d;
     }
 }
@@ -183,78 +205,30 @@ __global__ __launch_bounds__(BLOCK) void remap_kernel(u64* __restrict__ src, u64
     }
 }
 
-// ---- host: the sequential swap_remove replays -------------------------------------------------------------------
-// Edges (remove_paths, pruner.rs:199-217 over Graph::remove_edge): indices arrive ascending with multiplicities and
-// are consumed from the top.  The entry being removed and the last position both only move down, so the occupants
-// that differ from the identity live in an array aligned with the entries.
-struct EdgeReplay {
-    std::vector<u32> victims;          // identity (position at the start of the pass) of each removed edge, in order
-    std::vector<u32> move_to, move_from;
-    u64 n_new = 0, from_duplicates = 0;
-};
-void replay_edges(const u32* pos, const u32* mult, u64 u, u64 E, EdgeReplay& out) {
-    std::vector<u32> occ(pos, pos + u);                    // occupant of position pos[j]
-    u64 size = E;
-    long long q = (long long)u - 1;
-    out.victims.clear();
-    for (long long j = (long long)u - 1; j >= 0; --j) {
-        const u32 d = pos[j];
-        for (u32 r = 0; r < mult[j]; ++r) {
-            if (d >= size) break;                          // edge_endpoints(e) == None, remove_edge(e) == None
-            const u32 last = (u32)(size - 1);
-            while (q >= 0 && pos[q] > last) --q;
-            const u32 mover = (q >= 0 && pos[q] == last) ? occ[q] : last;
-            out.victims.push_back(occ[j]);
-            if (r) ++out.from_duplicates;
-            if (d != last) occ[j] = mover;
-            --size;
-        }
+// nodes that lost their first out-edge: the largest first-seen index among the out-edges that are left
+__global__ __launch_bounds__(BLOCK) void first_out_redo_kernel(const u64* __restrict__ src, const u32* __restrict__ orig, u64 E,
+                                                               const u64* __restrict__ node_deg, u64* __restrict__ first_out) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
+        const u64 a = src[e];
+        if (node_deg[a] & REDO_FIRST_OUT)
+            atomicMax((unsigned long long*)&first_out[a], ((unsigned long long)(orig[e] + 1u) << 32) | (unsigned long long)e);
     }
-    out.n_new = size;
-    out.move_to.clear(); out.move_from.clear();
-    for (u64 j = 0; j < u && pos[j] < size; ++j)
-        if (occ[j] != pos[j]) { out.move_to.push_back(pos[j]); out.move_from.push_back(occ[j]); }
 }
 
-// Nodes (remove_single_node after every removed edge, the endpoint with the larger CURRENT index first,
-// pruner.rs:206-215, over Graph::remove_node): only nodes in the tail that disappears are ever re-labelled.
-struct NodeReplay {
-    std::vector<u32> move_to, move_from;
-    u64 n_new = 0;
-};
-void replay_nodes(const u32* die, u64 m, u64 N, NodeReplay& out) {
-    u64 n_die = 0;
-    for (u64 i = 0; i < 2 * m; ++i) n_die += die[i] != NONE32;
-    const u64 base = N - n_die;
-    std::vector<u32> tail_pos(n_die), tail_occ(n_die);
-    std::vector<uint8_t> dead(n_die, 0);
-    for (u64 i = 0; i < n_die; ++i) tail_pos[i] = tail_occ[i] = (u32)(base + i);
-    u64 size = N;
-    auto pos_of = [&](u32 v) -> u32 { return v < base ? v : tail_pos[v - base]; };
-    auto remove = [&](u32 v) {
-        const u32 p = pos_of(v), top = (u32)(size - 1), y = tail_occ[top - base];
-        if (v >= base) dead[v - base] = 1;
-        if (p != top) {
-            if (p >= base) tail_occ[p - base] = y;
-            tail_pos[y - base] = p;
-        }
-        --size;
-    };
-    for (u64 t = 0; t < m; ++t) {
-        const u32 a = die[2 * t], b = die[2 * t + 1];
-        if (a != NONE32 && b != NONE32) {
-            if (pos_of(a) < pos_of(b)) { remove(b); remove(a); } else { remove(a); remove(b); }
-        } else if (a != NONE32) {
-            remove(a);
-        } else if (b != NONE32) {
-            remove(b);
-        }
+// grow-only pinned host buffer: the per-pass device -> host copies run at link speed and stay asynchronous
+struct PinnedU32 {
+    u32* p = nullptr; size_t cap = 0;
+    ~PinnedU32() { if (p) (void)hipHostFree(p); }
+    int need(size_t n) {
+        if (n <= cap) return KATOME_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = n + n / 4 + 1024;
+        if (hipHostMalloc((void**)&p, want * 4, hipHostMallocDefault) != hipSuccess) { p = nullptr; set_error("out of pinned host memory (%zu bytes)", want * 4); return KATOME_E_OOM; }
+        cap = want;
+        return KATOME_OK;
     }
-    out.n_new = size;
-    out.move_to.clear(); out.move_from.clear();
-    for (u64 i = 0; i < n_die; ++i)
-        if (!dead[i]) { out.move_to.push_back(tail_pos[i]); out.move_from.push_back((u32)(base + i)); }
-}
+};
 
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -284,16 +258,21 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     KCHECK(dev_iota(orig.as<u32>(), E, stream));
     KCHECK(node_deg.alloc((N + 1) * 8)); KCHECK(first_out.alloc((N + 1) * 8)); KCHECK(mult.alloc((E + 1) * 4));
     KCHECK(totals.alloc(32));
-    std::vector<u32> h_pos, h_mult, h_die;
+    PinnedU32 h_pos, h_mult, h_die;
     EdgeReplay er; NodeReplay nr;
+    const bool trace = getenv("KATOME_TRACE_PRUNE") != nullptr;
+    // adjacency summary, once
+    KCHECK_HIP(hipMemsetAsync(node_deg.p, 0, N * 8, stream));
+    KCHECK_HIP(hipMemsetAsync(first_out.p, 0, N * 8, stream));
+    KCHECK_HIP(hipMemsetAsync(mult.p, 0, E * 4, stream));
+    if (E) hipLaunchKernelGGL(degree_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, orig.as<u32>(), E,
+                              node_deg.as<u64>(), first_out.as<u64>());
+    KCHECK_HIP(hipGetLastError());
     while (E) {
-        // (1) adjacency summary + walks
-        KCHECK_HIP(hipMemsetAsync(node_deg.p, 0, N * 8, stream));
-        KCHECK_HIP(hipMemsetAsync(first_out.p, 0, N * 8, stream));
-        KCHECK_HIP(hipMemsetAsync(mult.p, 0, E * 4, stream));
+        const double pass_t0 = now_ms();
+        double pass_host = 0;
+        // (1) walks
         KCHECK_HIP(hipMemsetAsync(totals.p, 0, 32, stream));
-        hipLaunchKernelGGL(degree_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, orig.as<u32>(), E,
-                           node_deg.as<u64>(), first_out.as<u64>());
         hipLaunchKernelGGL(walk_kernel, dim3(grid_for(N, WALK_TILE, 256u * 32u)), dim3(BLOCK), 0, stream, N, two_k, first_out.as<u64>(),
                            dst, node_deg.as<u64>(), mult.as<u32>(), totals.as<u64>());
         KCHECK_HIP(hipGetLastError());
@@ -317,16 +296,18 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK(d_pos.alloc(u * 4 + 16)); KCHECK(d_mult.alloc(u * 4 + 16));
         hipLaunchKernelGGL(mark_write_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, offs.as<u64>(),
                            d_pos.as<u32>(), d_mult.as<u32>());
+        if (u) hipLaunchKernelGGL(mark_clear_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos.as<u32>(), u, mult.as<u32>());
         KCHECK_HIP(hipGetLastError());
-        h_pos.resize(u); h_mult.resize(u);
-        KCHECK_HIP(hipMemcpyAsync(h_pos.data(), d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
-        KCHECK_HIP(hipMemcpyAsync(h_mult.data(), d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
+        KCHECK(h_pos.need(u)); KCHECK(h_mult.need(u));
+        KCHECK_HIP(hipMemcpyAsync(h_pos.p, d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipMemcpyAsync(h_mult.p, d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
         d_pos.release(); d_mult.release(); counts.release(); offs.release();
         // (3) replay of remove_edge
         double t0 = now_ms();
-        replay_edges(h_pos.data(), h_mult.data(), u, E, er);
-        local.host_ms += now_ms() - t0;
+        replay_edges(h_pos.p, h_mult.p, u, E, h_tot[0], er);
+        const double t_edges = now_ms() - t0;
+        local.host_ms += t_edges; pass_host += t_edges;
         const u64 m = er.victims.size();
         local.removed_edges += m;
         local.removed_by_duplicates += er.from_duplicates;
@@ -336,18 +317,19 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK(last_touch.alloc((N + 1) * 4)); KCHECK(d_die.alloc(2 * m * 4 + 16));
         KCHECK_HIP(hipMemsetAsync(last_touch.p, 0, N * 4, stream));
         hipLaunchKernelGGL(death_count_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
-                           node_deg.as<u64>(), last_touch.as<u32>());
+                           node_deg.as<u64>(), first_out.as<u64>(), last_touch.as<u32>());
         hipLaunchKernelGGL(death_emit_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
                            node_deg.as<u64>(), last_touch.as<u32>(), d_die.as<u32>());
         KCHECK_HIP(hipGetLastError());
-        h_die.resize(2 * m);
-        KCHECK_HIP(hipMemcpyAsync(h_die.data(), d_die.p, 2 * m * 4, hipMemcpyDeviceToHost, stream));
+        KCHECK(h_die.need(2 * m));
+        KCHECK_HIP(hipMemcpyAsync(h_die.p, d_die.p, 2 * m * 4, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
         d_victims.release(); last_touch.release(); d_die.release();
         // (5) replay of remove_node
         t0 = now_ms();
-        replay_nodes(h_die.data(), m, N, nr);
-        local.host_ms += now_ms() - t0;
+        replay_nodes(h_die.p, m, N, nr);
+        const double t_nodes = now_ms() - t0;
+        local.host_ms += t_nodes; pass_host += t_nodes;
         local.removed_nodes += N - nr.n_new;
         // (6) apply the moves, re-label the endpoints of the surviving edges
         {
@@ -355,19 +337,26 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             KCHECK(upload(to, er.move_to, stream)); KCHECK(upload(from, er.move_from, stream));
             const u64 ne = er.move_to.size();
             if (ne) hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(ne, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
-                                       from.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key);
+                                       from.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>());
             E = er.n_new;
             KCHECK(upload(to, nr.move_to, stream)); KCHECK(upload(from, nr.move_from, stream));
             const u64 nn = nr.move_to.size();
             KCHECK(tail_map.alloc((N - nr.n_new + 1) * 4));
             if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
-                                       from.as<u32>(), nn, nw, nr.n_new, node_key, tail_map.as<u32>());
+                                       from.as<u32>(), nn, nw, nr.n_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
             if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, nr.n_new,
                                             tail_map.as<u32>());
+            if (E) hipLaunchKernelGGL(first_out_redo_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, orig.as<u32>(), E,
+                                      node_deg.as<u64>(), first_out.as<u64>());
             KCHECK_HIP(hipGetLastError());
             N = nr.n_new;
             KCHECK_HIP(hipStreamSynchronize(stream));      // the host vectors are reused by the next pass
         }
+        if (trace)
+            fprintf(stderr, "[prune] pass %llu: E %llu N %llu walks %llu dead %llu marked %llu removed %llu (dup %llu) nodes %llu | %.2f ms, host %.2f (edges %.2f nodes %.2f)\n",
+                    (unsigned long long)local.passes, (unsigned long long)E, (unsigned long long)N, (unsigned long long)h_tot[2],
+                    (unsigned long long)h_tot[1], (unsigned long long)h_tot[0], (unsigned long long)m,
+                    (unsigned long long)er.from_duplicates, (unsigned long long)nr.move_to.size(), now_ms() - pass_t0, pass_host, t_edges, t_nodes);
     }
     g.n_edges = E; g.n_nodes = N;
     if (st) *st = local;

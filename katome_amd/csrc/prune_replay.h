@@ -1,0 +1,103 @@
+// prune_replay.h -- the two sequential replays of petgraph 0.4.13's swap_remove bookkeeping that
+// Prunable::remove_dead_paths implies (reference pruner.rs:199-225 over Graph::remove_edge / remove_node).
+// Host-only, no HIP: included by prune.hip and by tests/hostshim.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+namespace katome {
+
+constexpr uint32_t REPLAY_NONE = 0xFFFFFFFFu;
+
+// Edges (remove_paths, pruner.rs:199-217): the collected indices arrive ascending with multiplicities and are
+// consumed from the top, as the reference's descending sort does.  remove_edge(d) moves the edge at the last
+// position into d, so an index listed twice removes whatever was moved in.  The entry being removed and the last
+// position both only move down, so the occupants that differ from the identity live in an array aligned with the
+// entries and everything streams.
+struct EdgeReplay {
+    std::vector<uint32_t> victims;     // identity (position at the start of the pass) of each removed edge, in order
+    std::vector<uint32_t> move_to, move_from;
+    std::vector<uint32_t> occ;
+    uint64_t n_new = 0, from_duplicates = 0;
+};
+inline void replay_edges(const uint32_t* pos, const uint32_t* mult, uint64_t u, uint64_t n_edges, uint64_t marks, EdgeReplay& out) {
+    out.occ.assign(pos, pos + u);                      // occupant of position pos[j]
+    out.victims.resize(marks);
+    uint32_t* occ = out.occ.data();
+    uint32_t* victims = out.victims.data();
+    uint64_t size = n_edges, nv = 0, dups = 0;
+    long long q = (long long)u - 1;
+    for (long long j = (long long)u - 1; j >= 0; --j) {
+        const uint32_t d = pos[j], c = mult[j];
+        for (uint32_t r = 0; r < c; ++r) {
+            if (d >= size) break;                      // edge_endpoints(e) == None and remove_edge(e) == None
+            const uint32_t last = (uint32_t)(size - 1);
+            while (q >= 0 && pos[q] > last) --q;
+            const uint32_t mover = (q >= 0 && pos[q] == last) ? occ[q] : last;
+            victims[nv++] = occ[j];
+            dups += r != 0;
+            if (d != last) occ[j] = mover;
+            --size;
+        }
+    }
+    out.victims.resize(nv);
+    out.n_new = size;
+    out.from_duplicates = dups;
+    out.move_to.clear(); out.move_from.clear();
+    for (uint64_t j = 0; j < u && pos[j] < size; ++j)
+        if (occ[j] != pos[j]) { out.move_to.push_back(pos[j]); out.move_from.push_back(occ[j]); }
+}
+
+// Nodes (remove_single_node after every removed edge, pruner.rs:206-225): die[2t], die[2t+1] name the endpoints
+// (source, target) that removal t leaves without edges (REPLAY_NONE = stays); when both go, the one with the larger
+// CURRENT index goes first.  remove_node moves the last node into the freed index, so only nodes of the tail that
+// disappears are ever re-labelled: two arrays over that tail hold the whole state.
+struct NodeReplay {
+    std::vector<uint32_t> move_to, move_from;
+    std::vector<uint32_t> tail_pos, tail_occ;
+    uint64_t n_new = 0;
+};
+inline void replay_nodes(const uint32_t* die, uint64_t m, uint64_t n_nodes, NodeReplay& out) {
+    uint64_t n_die = 0;
+    for (uint64_t i = 0; i < 2 * m; ++i) n_die += die[i] != REPLAY_NONE;
+    const uint64_t base = n_nodes - n_die;
+    out.tail_pos.resize(n_die); out.tail_occ.resize(n_die);
+    uint32_t* tail_pos = out.tail_pos.data();          // current index of tail node base+i (REPLAY_NONE once removed)
+    uint32_t* tail_occ = out.tail_occ.data();          // node at tail index base+i
+    for (uint64_t i = 0; i < n_die; ++i) tail_pos[i] = tail_occ[i] = (uint32_t)(base + i);
+    uint64_t size = n_nodes;
+    auto pos_of = [&](uint32_t v) -> uint32_t { return v < base ? v : tail_pos[v - base]; };
+    auto remove = [&](uint32_t v, uint32_t p) {
+        const uint32_t top = (uint32_t)(size - 1), y = tail_occ[top - base];
+        if (p != top) {
+            if (p >= base) tail_occ[p - base] = y;
+            tail_pos[y - base] = p;
+        }
+        if (v >= base) tail_pos[v - base] = REPLAY_NONE;
+        --size;
+    };
+    constexpr uint64_t AHEAD = 24;                     // the tail arrays do not fit the caches: fetch ahead of use
+    for (uint64_t t = 0; t < m; ++t) {
+        if (t + AHEAD < m) {
+            const uint32_t pa = die[2 * (t + AHEAD)], pb = die[2 * (t + AHEAD) + 1];
+            if (pa != REPLAY_NONE && pa >= base) __builtin_prefetch(&tail_pos[pa - base], 1);
+            if (pb != REPLAY_NONE && pb >= base) __builtin_prefetch(&tail_pos[pb - base], 1);
+        }
+        const uint32_t a = die[2 * t], b = die[2 * t + 1];
+        if (a != REPLAY_NONE && b != REPLAY_NONE) {
+            const uint32_t pa = pos_of(a), pb = pos_of(b);
+            if (pa < pb) { remove(b, pb); remove(a, pos_of(a)); } else { remove(a, pa); remove(b, pos_of(b)); }
+        } else if (a != REPLAY_NONE) {
+            remove(a, pos_of(a));
+        } else if (b != REPLAY_NONE) {
+            remove(b, pos_of(b));
+        }
+    }
+    out.n_new = size;
+    out.move_to.clear(); out.move_from.clear();
+    for (uint64_t i = 0; i < n_die; ++i)
+        if (tail_pos[i] != REPLAY_NONE) { out.move_to.push_back(tail_pos[i]); out.move_from.push_back((uint32_t)(base + i)); }
+}
+
+}  // namespace katome

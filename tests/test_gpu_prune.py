@@ -131,7 +131,6 @@ def test_synthetic_workload_against_oracle(oracle, k, rc, n, L, glen):
     ref = oracle.build_ascii(ascii_reads, k, rc, remove_dead_paths=True)
     full = oracle.build_ascii(ascii_reads, k, rc)
     assert 0 < ref.n_edges < full.n_edges                  # the case prunes something and keeps something
-    assert oracle.last_prune_passes() is not None
     _same(g, ref, k)
 
 
