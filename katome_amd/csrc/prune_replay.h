@@ -77,13 +77,7 @@ inline void replay_nodes(const uint32_t* die, uint64_t m, uint64_t n_nodes, Node
         if (v >= base) tail_pos[v - base] = REPLAY_NONE;
         --size;
     };
-    constexpr uint64_t AHEAD = 24;                     // the tail arrays do not fit the caches: fetch ahead of use
     for (uint64_t t = 0; t < m; ++t) {
-        if (t + AHEAD < m) {
-            const uint32_t pa = die[2 * (t + AHEAD)], pb = die[2 * (t + AHEAD) + 1];
-            if (pa != REPLAY_NONE && pa >= base) __builtin_prefetch(&tail_pos[pa - base], 1);
-            if (pb != REPLAY_NONE && pb >= base) __builtin_prefetch(&tail_pos[pb - base], 1);
-        }
         const uint32_t a = die[2 * t], b = die[2 * t + 1];
         if (a != REPLAY_NONE && b != REPLAY_NONE) {
             const uint32_t pa = pos_of(a), pb = pos_of(b);
