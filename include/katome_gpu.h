@@ -191,6 +191,18 @@ int katome_dev_extract_var(katome_builder *b, const uint8_t *d_packed, uint64_t 
 int katome_dev_partition(int device, const uint64_t *d_records, const uint32_t *d_values, uint64_t n_records,
                          uint32_t key_words, uint32_t n_parts, uint64_t *d_out, uint32_t *d_values_out,
                          uint64_t *h_counts, void *stream);
+/* same, with the owner taken from the key's CORE instead of the whole key: the `core_bases` bases that end
+ * `core_shift` bits above the key's low end, canonically (smaller of the core and its reverse complement):
+ * owner = mulhi(mix(canonical core), n_parts).  The multi-GPU build routes k-mers with (core_shift 2, core k-2) --
+ * the middle (k-2)-mer, which a k-mer shares with its reverse complement and with its source node's tail -- and
+ * (k-1)-mer nodes with (0, k-2), so that every out-edge of a node, in either orientation's bookkeeping, lives on
+ * the rank that owns the node (the HmGIR shape, hm_gir.rs:91-153: a node and its <= 4 out-edges in one place). */
+int katome_dev_partition_core(int device, const uint64_t *d_records, const uint32_t *d_values, uint64_t n_records,
+                              uint32_t key_words, uint32_t core_shift, uint32_t core_bases, uint32_t n_parts,
+                              uint64_t *d_out, uint32_t *d_values_out, uint64_t *h_counts, void *stream);
+/* host helper: the owner the two calls above compute for one key (core_bases 0 = whole key) */
+uint32_t katome_key_owner(const uint64_t *key, uint32_t key_words, uint32_t core_shift, uint32_t core_bases,
+                          uint32_t n_parts);
 
 /* add_single_edge_fastaq (pt_graph.rs:172-198) for a batch: find-or-insert each record's
  * k-mer in the open-address table and add 1 to its weight (u32, wrapping).  Grows the table
@@ -290,6 +302,10 @@ int katome_dev_rank(int device, const uint64_t *d_sorted, uint64_t n_sorted, uin
 int katome_dev_node_ids(int device, const uint64_t *d_edge_key, uint64_t n_edges, uint32_t k, uint64_t *d_node_key,
                         uint64_t *d_edge_src, uint64_t *d_edge_dst, uint64_t *n_nodes, void *stream);
 /* derive (k-1)-mer endpoint keys of each edge: d_src/d_dst [n][key_words]                  */
+/* first half of katome_dev_node_ids: the distinct source (k-1)-mers of sorted edges, ascending (d_node_key:
+ * room for n_edges keys), and each edge's position among them                                          */
+int katome_dev_source_ids(int device, const uint64_t *d_edge_key, uint64_t n_edges, uint32_t k,
+                          uint64_t *d_node_key, uint64_t *d_edge_src, uint64_t *n_sources, void *stream);
 int katome_dev_endpoints(int device, const uint64_t *d_edge_key, uint64_t n, uint32_t k,
                          uint64_t *d_src_key, uint64_t *d_dst_key, void *stream);
 /* compress_edge-format labels (compress.rs:250-271) of packed k-mers                       */

@@ -74,6 +74,9 @@ SYMBOLS = {
     "katome_dev_extract_fixed": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
     "katome_dev_extract_var": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
     "katome_dev_partition": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp, _vp, u64p, _vp]),
+    "katome_dev_partition_core": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _vp, u64p, _vp]),
+    "katome_key_owner": (_u32, [u64p, _u32, _u32, _u32, _u32]),
+    "katome_dev_source_ids": (_i, [_i, _vp, _u64, _u32, _vp, _vp, u64p, _vp]),
     "katome_dev_insert": (_i, [_vp, _vp, _u64, _vp]),
     "katome_dev_insert_weighted": (_i, [_vp, _vp, _vp, _u64, _vp]),
     "katome_dev_remove_weak_edges": (_i, [_vp, _u32]),

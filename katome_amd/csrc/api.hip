@@ -150,6 +150,22 @@ int katome_dev_partition(int device, const uint64_t* d_records, const uint32_t* 
     KCHECK(use_device(device));
     return dev_partition(d_records, d_values, n_records, key_words, n_parts, d_out, d_values_out, h_counts, (hipStream_t)stream);
 }
+int katome_dev_partition_core(int device, const uint64_t* d_records, const uint32_t* d_values, uint64_t n_records, uint32_t key_words,
+                              uint32_t core_shift, uint32_t core_bases, uint32_t n_parts, uint64_t* d_out, uint32_t* d_values_out,
+                              uint64_t* h_counts, void* stream) {
+    KCHECK(use_device(device));
+    if (core_bases == 0) { set_error("partition_core: core_bases must be > 0"); return KATOME_E_ARG; }
+    return dev_partition(d_records, d_values, n_records, key_words, n_parts, d_out, d_values_out, h_counts, (hipStream_t)stream,
+                         core_shift, core_bases);
+}
+uint32_t katome_key_owner(const uint64_t* key, uint32_t key_words, uint32_t core_shift, uint32_t core_bases, uint32_t n_parts) {
+    if (key_words == 1) {
+        Key<1> a; a.w[0] = key[0];
+        return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
+    }
+    Key<2> a; a.w[0] = key[0]; a.w[1] = key[1];
+    return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
+}
 
 }  // extern "C"
 
@@ -591,6 +607,16 @@ int katome_dev_node_ids(int device, const uint64_t* d_edge_key, uint64_t n_edges
     return KATOME_OK;
 }
 
+int katome_dev_source_ids(int device, const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, uint64_t* d_node_key,
+                          uint64_t* d_edge_src, uint64_t* n_sources, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK(use_device(device));
+    KCHECK(check_k(k));
+    DevBuf nodes(stream);
+    KCHECK(dev_source_ids(d_edge_key, n_edges, k, nodes, d_edge_src, n_sources, stream));
+    if (*n_sources) KCHECK_HIP(hipMemcpyAsync(d_node_key, nodes.p, *n_sources * 8 * key_words_for_k(k), hipMemcpyDeviceToDevice, stream));
+    return KATOME_OK;
+}
 int katome_dev_endpoints(int device, const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src_key, uint64_t* d_dst_key, void* stream) {
     KCHECK(use_device(device));
     KCHECK(check_k(k));

@@ -102,7 +102,9 @@ int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t pa
 // radix.hip
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
-                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream);
+                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift = 0, uint32_t core_bases = 0);
+int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src, uint64_t* n_src,
+                   hipStream_t stream);
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream);
 int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipStream_t stream);

@@ -140,6 +140,16 @@ template <int NW> KD Key<NW> canonical_flip(const Key<NW>& a, u32 k, bool& flipp
 }
 
 // ---- edge endpoints (the two halves of compress_kmer, compress.rs:23-26) --------------------
+// Owner of a key among n ranks by its CORE: the `core` bases that end `shift/2` bases before the key's right end, taken
+// canonically (the smaller of the core and its reverse complement).  For a k-mer, shift = 2 and core = k-2 name its
+// middle (k-2)-mer: shared by the k-mer and its reverse complement (so a stored canonical k-mer and both oriented edges
+// it stands for agree) and equal to the last k-2 bases of its source node.  For a (k-1)-mer node, shift = 0 and
+// core = k-2 name that same tail: every out-edge of a node lives on the rank that owns the node.
+template <int NW> KD u64 core_owner(const Key<NW>& a, u32 shift, u32 core, u64 n) {
+    const Key<NW> m = key_low_bits(key_shr(a, shift), 2 * core);
+    return hash_to_range(hash_key(canonical(m, core)), n);
+}
+
 template <int NW> KD Key<NW> source_node(const Key<NW>& kmer) { return key_shr(kmer, 2); }
 template <int NW> KD Key<NW> target_node(const Key<NW>& kmer, u32 k) { return key_low_bits(kmer, 2 * (k - 1)); }
 

@@ -29,8 +29,10 @@ template <int NW> struct RadixDigit {
 };
 template <int NW> struct OwnerDigit {
     u64 n_parts;
+    u32 core_shift, core_bases;          // core_bases == 0: owner by the whole key; else kmer_bits.h core_owner
     __device__ __forceinline__ u32 operator()(const Key<NW>& k) const {
-        return key_valid(k) ? (u32)hash_to_range(hash_key(k), n_parts) : (u32)n_parts;
+        if (!key_valid(k)) return (u32)n_parts;
+        return core_bases ? (u32)core_owner(k, core_shift, core_bases, n_parts) : (u32)hash_to_range(hash_key(k), n_parts);
     }
 };
 
@@ -277,7 +279,8 @@ int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32
 // group records by owner rank; invalid records go last (part n_parts) and are not counted.
 // Optional u32 values travel with their records.
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
-                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream) {
+                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift, uint32_t core_bases) {
+    if (core_bases && (core_shift + 2 * core_bases > 64u * nw || 2 * core_bases > 126)) { set_error("partition: core outside the key"); return KATOME_E_ARG; }
     if (n_parts == 0 || n_parts >= (u32)RADIX) { set_error("n_parts must be 1..255"); return KATOME_E_ARG; }
     if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
     if ((v_in == nullptr) != (v_out == nullptr)) { set_error("partition: values in and out must both be given"); return KATOME_E_ARG; }
@@ -286,11 +289,11 @@ int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32
     PassBuffers pb;
     KCHECK(pb.init(n, stream));
     if (nw == 1) {
-        OwnerDigit<1> dg{n_parts};
+        OwnerDigit<1> dg{n_parts, core_shift, core_bases};
         if (v_in) KCHECK((radix_pass<1, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
         else      KCHECK((radix_pass<1, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
     } else {
-        OwnerDigit<2> dg{n_parts};
+        OwnerDigit<2> dg{n_parts, core_shift, core_bases};
         if (v_in) KCHECK((radix_pass<2, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
         else      KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
     }
@@ -603,27 +606,45 @@ __global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restri
     }
 }
 
+// the distinct source (k-1)-mers of sorted edges (the run heads of key >> 2), ascending, and every edge's position among them
 template <int NW>
-static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64* edge_src, u64* edge_dst, u64* n_nodes,
-                      hipStream_t stream) {
-    *n_nodes = 0;
+static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edge_src, u64* n_src_out, hipStream_t stream) {
+    *n_src_out = 0;
     if (E == 0) { KCHECK(node_key.alloc(16, stream)); return KATOME_OK; }
-    const u32 node_bits = 2 * (k - 1);
     const u64 nblocks = (E + UNIQ_TILE - 1) / UNIQ_TILE;
     if (nblocks > 0x7fffffffull) { set_error("node numbering: too many edges"); return KATOME_E_ARG; }
-    DevBuf counts(stream), offs(stream), aux(stream);
+    DevBuf counts(stream), offs(stream);
     KCHECK(counts.alloc(nblocks * 4));
     KCHECK(offs.alloc((nblocks + 1) * 8));
-    KCHECK(aux.alloc(16));
-    KCHECK_HIP(hipMemsetAsync(aux.p, 0, 16, stream));
     hipLaunchKernelGGL(src_count_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, counts.as<u32>());
     hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<u32>(), nblocks, offs.as<u64>());
     u64 n_src = 0;
     KCHECK_HIP(hipMemcpyAsync(&n_src, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     KCHECK(node_key.alloc((n_src + 1) * 8 * NW, stream));
+    hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), node_key.as<u64>(), edge_src);
+    KCHECK_HIP(hipGetLastError());
+    *n_src_out = n_src;
+    return KATOME_OK;
+}
+int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src, uint64_t* n_src,
+                   hipStream_t stream) {
+    if (key_words_for_k(k) == 1) return source_ids_t<1>(d_edge_key, n_edges, node_key, d_edge_src, n_src, stream);
+    return source_ids_t<2>(d_edge_key, n_edges, node_key, d_edge_src, n_src, stream);
+}
+
+template <int NW>
+static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64* edge_src, u64* edge_dst, u64* n_nodes,
+                      hipStream_t stream) {
+    *n_nodes = 0;
+    if (E == 0) { KCHECK(node_key.alloc(16, stream)); return KATOME_OK; }
+    const u32 node_bits = 2 * (k - 1);
+    DevBuf aux(stream);
+    KCHECK(aux.alloc(16));
+    KCHECK_HIP(hipMemsetAsync(aux.p, 0, 16, stream));
+    u64 n_src = 0;
+    KCHECK((source_ids_t<NW>(d_edge_key, E, node_key, edge_src, &n_src, stream)));
     u64* nodes = node_key.as<u64>();
-    hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), nodes, edge_src);
     // targets -> positions among the sources
     u32 B = 1;
     while ((2ull << B) <= n_src / 8 && B < 27) ++B;

@@ -157,15 +157,20 @@ class Builder:
         return out[:total_windows * self.nw]
 
     # ---- routing for the multi-GPU exchange -----------------------------------------------------
-    def partition(self, records, n_parts, key_words=None, values=None):
-        """records grouped by owner rank (stable, invalid dropped); -> (records_out, counts[, values_out])"""
+    def partition(self, records, n_parts, key_words=None, values=None, core=None):
+        """records grouped by owner rank (stable, invalid dropped); -> (records_out, counts[, values_out]).
+        core=(shift_bits, bases): owner by the key's canonical core instead of the whole key (katome_dev_partition_core)"""
         nw = key_words or self.nw
         n = records.numel() // nw
         out = torch.empty_like(records)
         vout = torch.empty_like(values) if values is not None else None
         counts = (C.c_uint64 * n_parts)()
-        _check(_lib.lib().katome_dev_partition(self.device, _ptr(records), _ptr(values), n, nw, n_parts, _ptr(out), _ptr(vout),
-                                               counts, _stream()))
+        if core is None:
+            _check(_lib.lib().katome_dev_partition(self.device, _ptr(records), _ptr(values), n, nw, n_parts, _ptr(out), _ptr(vout),
+                                                   counts, _stream()))
+        else:
+            _check(_lib.lib().katome_dev_partition_core(self.device, _ptr(records), _ptr(values), n, nw, core[0], core[1], n_parts,
+                                                        _ptr(out), _ptr(vout), counts, _stream()))
         counts = [int(c) for c in counts]
         return (out, counts) if values is None else (out, counts, vout)
 
@@ -232,6 +237,25 @@ def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
 def release_cache(device=0):
     """hand the library's cached device blocks back to the driver"""
     _check(_lib.lib().katome_dev_release_cache(device))
+
+
+def source_ids(edge_keys, k, device=0):
+    """distinct source (k-1)-mers of sorted distinct edges, ascending, and each edge's position among them
+    -> (node_keys [n_src*nw], edge_src [E])"""
+    nw = record_words(k)
+    n = edge_keys.numel() // nw
+    nodes = torch.empty(max(n, 1) * nw, dtype=torch.int64, device=edge_keys.device)
+    src = torch.empty(max(n, 1), dtype=torch.int64, device=edge_keys.device)
+    ns = C.c_uint64()
+    _check(_lib.lib().katome_dev_source_ids(device, _ptr(edge_keys), n, k, _ptr(nodes), _ptr(src), C.byref(ns), _stream()))
+    return nodes[:ns.value * nw], src[:n]
+
+
+def key_owner(key_words_list, n_parts, core=None):
+    """host: owner of one key given as its u64 words (most significant first)"""
+    nw = len(key_words_list)
+    arr = (C.c_uint64 * nw)(*key_words_list)
+    return _lib.lib().katome_key_owner(arr, nw, core[0] if core else 0, core[1] if core else 0, n_parts)
 
 
 def node_ids(edge_keys, k, device=0):

@@ -5,14 +5,18 @@ read set (reads are independent until their k-mers meet in the graph), with ONE 
 step per batch:
 
   1. each rank extracts the k-mer records of its own reads (contiguous shard by read index);
-  2. records are routed to `owner = mulhi(mix(kmer), world)` -- a single all-to-all of fixed-size
-     records (RCCL has no alltoallv, so split sizes travel first in a tiny all-to-all);
+  2. records are routed to `owner = mulhi(mix(canonical middle (k-2)-mer of the k-mer), world)` -- a single
+     all-to-all of fixed-size records (RCCL has no alltoallv, so split sizes travel first in a tiny all-to-all);
   3. each rank inserts what it received into its own table: every distinct k-mer lives on exactly
      one rank, so the union of the ranks' edge lists IS the edge multiset of the whole input and
      does not depend on the number of ranks;
-  4. node numbering needs a second, small exchange on distinct keys only: each (k-1)-mer is owned
-     by `mulhi(mix(node), world)`; owners number their nodes (rank offset + position in ascending
-     key order) and answer the id queries of the ranks that hold the incident edges.
+  4. node numbering: a k-mer shares its middle with its reverse complement and with the tail of its source
+     node, so with nodes owned by `mulhi(mix(canonical last k-2 bases), world)` every out-edge of a node --
+     whichever strand produced it -- already sits on the node's owner (the HmGIR shape, hm_gir.rs:91-153).
+     Source ids are therefore read off the rank's own sorted edges; only the TARGET of each edge is asked
+     from its owner (one key out, one id back), which is also how nodes without out-edges get registered
+     (they count in node_count, stats/collections.rs:196).  Global id = rank offset + position in the
+     owner's list (its nodes with out-edges ascending, then its other nodes ascending).
 
 The 8 GPUs of an MI355X node are a full xGMI mesh, so the all-to-all runs on all 7 links of every
 GPU at once and is bound by the most loaded link; balanced hashing keeps the links even.
@@ -38,8 +42,8 @@ class HipOps:
     def extract_fixed(self, packed, n_reads, read_len, skip, out, first_read):
         return self.b.extract_fixed(packed, n_reads, read_len, skip, out=out, first_read=first_read)
 
-    def partition(self, records, n_parts, key_words=None, values=None):
-        return self.b.partition(records, n_parts, key_words=key_words, values=values)
+    def partition(self, records, n_parts, key_words=None, values=None, core=None):
+        return self.b.partition(records, n_parts, key_words=key_words, values=values, core=core)
 
     def insert(self, records, weights=None):
         self.b.insert(records, weights)
@@ -63,8 +67,11 @@ class HipOps:
     def edges(self):
         return self.b.edges()
 
-    def node_ids(self, keys):
-        return self.kd.node_ids(keys.reshape(-1), self.k, self.dev)
+    def source_ids(self, keys):
+        return self.kd.source_ids(keys.reshape(-1), self.k, self.dev)
+
+    def target_keys(self, keys):
+        return self.kd.endpoints(keys.reshape(-1), self.k, self.dev)[1]
 
     def sort_unique(self, keys, bits):
         self.kd.sort_keys(keys, bits, self.nw, device=self.dev)
@@ -217,6 +224,7 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
     span = ops.tile_span(read_len)
     # the span must be the same on every rank (it is a function of k and the read length)
     nwr = ops.tile_words(span) if span > 1 else ops.nw
+    kmer_core = (2, ops.k - 2)                # owner of a k-mer: its canonical middle (see the module docstring)
     per_read = W // span
     recbuf = ops.empty(max(1, min(batch_reads, max(n_reads, 1)) * per_read * nwr))
     n_batches = (n_reads + batch_reads - 1) // batch_reads
@@ -232,7 +240,7 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
             else:
                 rec = ops.extract_fixed(packed, nr, read_len, skip, recbuf, r0)
             with phases("route_records"):
-                part, counts = ops.partition(rec, world, key_words=nwr)
+                part, counts = ops.partition(rec, world, key_words=nwr, core=None if span > 1 else kmer_core)
         else:
             part, counts = recbuf[:0], [0] * world
         with phases("exchange_records"):
@@ -246,7 +254,7 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
         keys, weights = ops.expand_tiles()               # this rank's distinct tiles as (k-mer, weight) records
         with phases("route_kmers"):
             if weights.numel():
-                pk, counts, pw = ops.partition(keys, world, key_words=ops.nw, values=weights)
+                pk, counts, pw = ops.partition(keys, world, key_words=ops.nw, values=weights, core=kmer_core)
             else:
                 pk, counts, pw = keys, [0] * world, weights
         with phases("exchange_kmers"):
@@ -261,29 +269,41 @@ def finalize_distributed(ops, group=None, phases=_NO_PHASES):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nw, k = ops.nw, ops.k
     node_bits = 2 * (k - 1)
+    node_core = (0, k - 2)                            # owner of a node: its canonical tail = the middle of its out-edges
     keys, weights = ops.edges()                       # [E, nw] ascending, [E]
     E = weights.numel()
     dev = weights.device
-    # the distinct endpoint keys seen on this rank and the edges' positions in that list (read off the
-    # sorted edge list, no sort)
+    # this rank's nodes that have out-edges are the sources of its own edges: read off the sorted list, no sort
     if E:
-        with phases("local_node_ids"):
-            U, lsrc, ldst = ops.node_ids(keys)
+        with phases("local_source_ids"):
+            S, lsrc = ops.source_ids(keys)
+            T = ops.target_keys(keys)
     else:
-        U, lsrc, ldst = ops.empty(0), ops.empty(0), ops.empty(0)
-    nU = U.numel() // nw
-    # route them to their owners, remembering where each came from
-    with phases("route_nodes"):
-        if nU:
-            P, counts, origin = ops.partition(U, world, key_words=nw, values=torch.arange(nU, dtype=torch.int32, device=dev))
+        S, lsrc, T = ops.empty(0), ops.empty(0), ops.empty(0)
+    n_src = S.numel() // nw
+    # every edge asks the owner of its target for the id, remembering which edge asked
+    with phases("route_targets"):
+        if E:
+            P, counts, origin = ops.partition(T, world, key_words=nw, values=torch.arange(E, dtype=torch.int32, device=dev),
+                                              core=node_core)
         else:
-            P, counts, origin = U, [0] * world, torch.empty(0, dtype=torch.int32, device=dev)
-    with phases("exchange_nodes"):
+            P, counts, origin = T, [0] * world, torch.empty(0, dtype=torch.int32, device=dev)
+        del T
+    with phases("exchange_targets"):
         R, recv_counts = _exchange(P, counts, nw, group)
-    # nodes this rank owns, in ascending key order
-    with phases("own_nodes_sort"):
-        N = ops.sort_unique(R.clone(), node_bits) if R.numel() else R
-    n_owned = N.numel() // nw
+    del P
+    # answer: position among the sources, or -- for a node without out-edges -- among the (few) other nodes owned here
+    with phases("answer_ids"):
+        nR = R.numel() // nw
+        local = ops.rank(S, R, node_bits) if (nR and n_src) else torch.full((nR,), -1, dtype=torch.int64, device=dev)
+        missing = local < 0
+        if nR and bool(missing.any()):
+            mk = R.reshape(-1, nw)[missing].reshape(-1).contiguous()
+            sinks = ops.sort_unique(mk.clone(), node_bits)
+            local[missing] = ops.rank(sinks, mk, node_bits) + n_src
+        else:
+            sinks = ops.empty(0)
+    n_owned = n_src + sinks.numel() // nw
     cdev = torch.device("cpu") if dist.get_backend(group) == "gloo" else dev      # gloo gathers on the host
     pieces = [torch.empty(1, dtype=torch.int64, device=cdev) for _ in range(world)]
     dist.all_gather(pieces, torch.tensor([n_owned], dtype=torch.int64, device=cdev), group=group)
@@ -291,24 +311,22 @@ def finalize_distributed(ops, group=None, phases=_NO_PHASES):
     bases = torch.cumsum(all_n, 0) - all_n
     base = int(bases[rank].item())
     total_nodes = int(all_n.sum().item())
-    # answer the queries: global id of every key received, in the order received
-    with phases("answer_ids"):
-        ids_R = (ops.rank(N, R, node_bits) + base) if R.numel() else ops.empty(0)
     with phases("exchange_ids"):
-        ids_P, _ = _exchange(ids_R, recv_counts, 1, group)     # reverse route: same split sizes, mirrored
-    if nU:
-        del P, R, ids_R
+        ids_P, _ = _exchange(local + base, recv_counts, 1, group)     # reverse route: same split sizes, mirrored
+    del R, local
+    if E:
         with phases("apply_ids"):
-            id_of_U = _empty(nU, torch.int64, dev)
-            id_of_U[origin[:nU].to(torch.int64)] = ids_P       # ids_P is aligned with P; origin says which U entry that was
-            edge_src, edge_dst = id_of_U[lsrc], id_of_U[ldst]
+            edge_dst = _empty(E, torch.int64, dev)
+            edge_dst[origin[:E].to(torch.int64)] = ids_P             # ids_P is aligned with the routed targets
+            edge_src = lsrc + base
         label = ops.labels(keys)
     else:
         edge_src = edge_dst = ops.empty(0)
         label = torch.empty((0, 1 + (k + 3) // 4), dtype=torch.uint8, device=dev)
+    node_key = torch.cat([S.reshape(-1), sinks.reshape(-1)]).reshape(-1, nw)
     tot = torch.tensor([E], dtype=torch.int64, device=dev)
     _all_reduce(tot, dist.ReduceOp.SUM, group)
-    return RankGraph(keys, weights, edge_src, edge_dst, label, N.reshape(-1, nw), base, total_nodes, int(tot.item()))
+    return RankGraph(keys, weights, edge_src, edge_dst, label, node_key, base, total_nodes, int(tot.item()))
 
 
 def shard_range(total_reads, world, rank):

@@ -89,6 +89,8 @@ def hostshim():
         L.hs_hash.restype = C.c_uint64
         L.hs_owner.argtypes = [u64p, C.c_int, C.c_uint64]
         L.hs_owner.restype = C.c_uint64
+        L.hs_core_owner.argtypes = [u64p, C.c_int, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.hs_core_owner.restype = C.c_uint64
         L.hs_digit.argtypes = [u64p, C.c_int, C.c_uint32, C.c_uint32]
         L.hs_digit.restype = C.c_uint32
         L.hs_splitmix64.argtypes = [C.c_uint64]

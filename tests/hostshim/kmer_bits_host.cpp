@@ -61,6 +61,9 @@ void hs_label(const uint64_t* in, uint32_t k, uint8_t* out) {
 }
 uint64_t hs_hash(const uint64_t* in, int nw) { return nw == 1 ? hash_key(ld<1>(in)) : hash_key(ld<2>(in)); }
 uint64_t hs_owner(const uint64_t* in, int nw, uint64_t n) { return hash_to_range(hs_hash(in, nw), n); }
+uint64_t hs_core_owner(const uint64_t* in, int nw, uint32_t shift, uint32_t core, uint64_t n) {
+    return nw == 1 ? core_owner(ld<1>(in), shift, core, n) : core_owner(ld<2>(in), shift, core, n);
+}
 uint32_t hs_digit(const uint64_t* in, int nw, uint32_t shift, uint32_t bits) { return nw == 1 ? key_digit(ld<1>(in), shift, bits) : key_digit(ld<2>(in), shift, bits); }
 uint64_t hs_splitmix64(uint64_t x) { return splitmix64(x); }
 }

@@ -59,17 +59,21 @@ class NumpyOps:
                 recs.append(min(v, _rc(v, self.k)) if self.rc else v)
         return self._to_tensor(recs)
 
-    def _owner(self, v, n_parts, nw):
+    def _owner(self, v, n_parts, nw, core=None):
+        if core is not None:                  # kmer_bits.h core_owner: canonical core of `bases` bases, `shift` bits up
+            shift, bases = core
+            m = (v >> shift) & ((1 << (2 * bases)) - 1)
+            v, nw = min(m, _rc(m, bases)), nw
         return self.L.hs_owner((C.c_uint64 * nw)(*int_to_words(v, nw)), nw, n_parts)
 
-    def partition(self, records, n_parts, key_words=None, values=None):
+    def partition(self, records, n_parts, key_words=None, values=None, core=None):
         nw = key_words or self.nw
         ints = self._to_ints(records, nw)
         vals = values.tolist() if values is not None else [0] * len(ints)
         parts = [[] for _ in range(n_parts)]
         for v, x in zip(ints, vals):
             if v != INVALID:
-                parts[self._owner(v, n_parts, nw)].append((v, x))
+                parts[self._owner(v, n_parts, nw, core)].append((v, x))
         flat = [v for p in parts for v, _ in p]
         counts = [len(p) for p in parts]
         out = self._to_tensor(flat, nw)
@@ -142,6 +146,16 @@ class NumpyOps:
         keys = sorted(out)
         return (self._to_tensor(keys).reshape(-1, self.nw),
                 torch.tensor([out[v] for v in keys], dtype=torch.int64).to(torch.int32))
+
+    def source_ids(self, keys):
+        ints = self._to_ints(keys.reshape(-1))
+        srcs = sorted({v >> 2 for v in ints})
+        pos = {v: i for i, v in enumerate(srcs)}
+        return self._to_tensor(srcs), torch.tensor([pos[v >> 2] for v in ints], dtype=torch.int64)
+
+    def target_keys(self, keys):
+        mask = (1 << (2 * (self.k - 1))) - 1
+        return self._to_tensor([v & mask for v in self._to_ints(keys.reshape(-1))])
 
     def node_ids(self, keys):
         ints = self._to_ints(keys.reshape(-1))

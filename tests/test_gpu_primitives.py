@@ -142,6 +142,53 @@ def test_partition_by_owner(k, n_parts):
     b.close()
 
 
+@pytest.mark.parametrize("k,n_parts,node", [(31, 8, False), (31, 3, True), (40, 8, False), (63, 5, True), (5, 2, False), (3, 4, True)])
+def test_partition_by_core_owner(k, n_parts, node):
+    """katome_dev_partition_core against the host statement of the same owner function (kmer_bits.h core_owner):
+    k-mers by their canonical middle, (k-1)-mer nodes by their canonical tail"""
+    import ctypes as C
+    from katome_amd import device as kd
+    from helpers import hostshim
+    nw = kd.record_words(k)
+    rng = np.random.default_rng(7 * k + n_parts)
+    n = 50021
+    a = _keys(rng, n, nw, 2 * (k - 1) if node else 2 * k)
+    core = (0, k - 2) if node else (2, k - 2)
+    b = kd.Builder(k, True)
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    out, counts, vout = b.partition(_to_dev(a).view(-1), n_parts, values=vals, core=core)
+    torch.cuda.synchronize()
+    L = hostshim()
+    owners = np.array([L.hs_core_owner((C.c_uint64 * nw)(*[int(x) for x in row]), nw, core[0], core[1], n_parts) for row in a])
+    assert [kd.key_owner([int(x) for x in row], n_parts, core) for row in a[:200]] == owners[:200].tolist()
+    assert counts == [int((owners == p).sum()) for p in range(n_parts)] and sum(counts) == n
+    got, pos = _from_dev(out, nw), 0
+    for p in range(n_parts):
+        assert np.array_equal(got[pos:pos + counts[p]], a[owners == p])          # stable
+        pos += counts[p]
+    assert np.array_equal(a[vout.cpu().numpy()], got[:n])
+    b.close()
+
+
+@pytest.mark.parametrize("k", [5, 31, 40])
+def test_source_ids(k):
+    """first half of node numbering: distinct sources of sorted edges and every edge's position among them"""
+    from katome_amd import device as kd
+    from helpers import words_to_int
+    nw = kd.record_words(k)
+    rng = np.random.default_rng(k)
+    a = _keys(rng, 30000 if k > 5 else 700, nw, 2 * k)
+    ints = sorted({words_to_int(r) for r in a})
+    edges = np.array([[(v >> 64) & (2**64 - 1), v & (2**64 - 1)][2 - nw:] for v in ints], dtype=np.uint64).reshape(-1, nw)
+    nodes, src = kd.source_ids(_to_dev(edges).view(-1), k)
+    torch.cuda.synchronize()
+    want_nodes = sorted({v >> 2 for v in ints})
+    got_nodes = [words_to_int(r) for r in _from_dev(nodes, nw)]
+    assert got_nodes == want_nodes
+    pos = {v: i for i, v in enumerate(want_nodes)}
+    assert src.cpu().tolist() == [pos[v >> 2] for v in ints]
+
+
 @pytest.mark.parametrize("k", [3, 31, 32, 40, 63])
 def test_endpoints_and_labels(oracle, k):
     from katome_amd import device as kd

@@ -108,3 +108,31 @@ def test_splitmix_matches_oracle(oracle):
     L = hostshim()
     for x in (0, 1, 2 ** 63, 0x6B61746F6D650001, 2 ** 64 - 1):
         assert L.hs_splitmix64(x) == oracle.splitmix64(x)
+
+
+@pytest.mark.parametrize("k", [3, 4, 5, 16, 31, 32, 33, 40, 63])
+def test_core_owner_keeps_a_node_with_its_out_edges(k):
+    """kmer_bits.h core_owner: a k-mer, its reverse complement and the source nodes of both land on the same rank
+    (what lets the multi-GPU build read source ids off each rank's own edges); owners spread over the ranks"""
+    import random
+    from helpers import revcomp_str
+    L = hostshim()
+    rng = random.Random(k)
+    nw = 1 if 2 * k <= 62 else 2
+    seen = set()
+    for _ in range(300):
+        s = "".join(rng.choice("ACGT") for _ in range(k))
+        x, r = kmer_to_int(s), kmer_to_int(revcomp_str(s))
+        for n in (2, 3, 8):
+            o = L.hs_core_owner(shim_words(x, nw), nw, 2, k - 2, n)
+            assert 0 <= o < n
+            assert o == L.hs_core_owner(shim_words(r, nw), nw, 2, k - 2, n)            # the stored canonical k-mer decides for both
+            assert o == L.hs_core_owner(shim_words(x >> 2, nw), nw, 0, k - 2, n)       # source node of x
+            assert o == L.hs_core_owner(shim_words(r >> 2, nw), nw, 0, k - 2, n)       # source node of rc(x)
+            if n == 8:
+                seen.add(o)
+        # all four out-edges of a node share the owner
+        node = x >> 2
+        owners = {L.hs_core_owner(shim_words((node << 2) | b, nw), nw, 2, k - 2, 8) for b in range(4)}
+        assert len(owners) == 1
+    assert len(seen) >= (2 if k <= 4 else 6)
