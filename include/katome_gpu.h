@@ -30,7 +30,8 @@ extern "C" {
  * petgraph edge indices in the order `add_edge` is first called for them, node indices in the order `add_node`
  * is (pt_graph.rs:149,194) -- instead of by packed key.  Downstream stages that walk petgraph's adjacency
  * (pruner.rs:241, collapser.rs:120) then see the same graph, index for index.  Costs two extra atomics per
- * counted record and two more sorts at the end; fixed-length reads, one GPU.                            */
+ * counted record and two more sorts at the end; one GPU (reads of unequal length go through the general
+ * one-record-per-window route).                                                                     */
 #define KATOME_FLAG_FIRST_SEEN_ORDER 1u
 /* REMOVE_DEAD_PATHS (host entries katome_build_*): run Prunable::remove_dead_paths (pruner.rs:36-82) on the built
  * graph before it is handed back, as assemble() does right after the build (asm/basic_assembler.rs:58-62).  The reference's

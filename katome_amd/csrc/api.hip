@@ -55,6 +55,9 @@ struct katome_builder {
     bool first_seen = false;
     uint64_t reads_inserted = 0;       // reads whose records have been handed to an insert so far
     uint32_t seen_read_len = 0;        // read length of the last extraction (records per read follow from it)
+    const uint64_t* var_prefix = nullptr;   // variable-length reads: window prefix of the last extraction (device), its reads
+    uint64_t var_reads = 0, var_windows = 0;   // and windows; var_seq_base: sequence numbers handed out by earlier batches
+    uint64_t var_seq_base = 0;
     DevBuf edge_seq;                   // sequence number of each edge's first insertion, aligned with edge_key
     uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
     uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
@@ -139,10 +142,13 @@ int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t 
                            const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                            uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
-    if (b->first_seen) { set_error("first-seen order is implemented for fixed-length reads only"); return KATOME_E_UNSUPPORTED; }
+    if (b->first_seen) {
+        if (b->reads_inserted) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
+        b->var_prefix = d_win_prefix; b->var_reads = n_reads; b->var_windows = total_windows;   // the insert that follows reads them
+    }
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     return launch_extract_var(b->s.k, b->rc, d_packed, packed_bytes, d_byte_off, d_len, d_win_prefix, n_reads, total_windows,
-                              d_records, (hipStream_t)stream);
+                              d_records, (hipStream_t)stream, b->first_seen && b->rc);
 }
 
 int katome_dev_partition(int device, const uint64_t* d_records, const uint32_t* d_values, uint64_t n_records, uint32_t key_words,
@@ -294,7 +300,11 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
     // measured on MI355X the insert kernel is bound by atomic throughput, not by where the slots live.
     const uint64_t* k_in = d_records; const uint32_t* w_in = d_weights;
     SeenOrigin origin;
-    if (b->first_seen) {
+    if (b->first_seen && b->var_prefix) {
+        if (n_records != b->var_windows) { set_error("first-seen order: insert the whole batch katome_dev_extract_var produced"); return KATOME_E_ARG; }
+        origin.win_prefix = b->var_prefix; origin.n_reads = b->var_reads; origin.seq_base = b->var_seq_base; origin.rc = b->rc;
+    } else if (b->first_seen) {
+        if (b->var_seq_base) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
         if (b->seen_read_len < b->s.k) { set_error("first-seen order: extract the records with this builder first"); return KATOME_E_ARG; }
         origin.windows = b->seen_read_len - b->s.k + 1; origin.per_read = origin.windows; origin.span = 1; origin.rc = b->rc;
         origin.read0 = b->reads_inserted;
@@ -318,7 +328,12 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
         KCHECK(table_insert(b->table, k_in + done * b->nw, w_in ? w_in + done : nullptr, n, stream, b->first_seen ? &origin : nullptr));
         done += n;
     }
-    if (b->first_seen) b->reads_inserted += n_records / origin.per_read;
+    if (b->first_seen && origin.win_prefix) {
+        b->var_seq_base += 2 * n_records;
+        b->var_prefix = nullptr; b->var_reads = b->var_windows = 0;
+    } else if (b->first_seen) {
+        b->reads_inserted += n_records / origin.per_read;
+    }
     return KATOME_OK;
 }
 int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_records, void* stream) {
@@ -452,7 +467,8 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         PhaseScope ps(b->prof, PH_FIRST_SEEN, stream);
         const uint64_t N = b->n_nodes;
         if (N >= (1ull << 32)) { set_error("first-seen order: more than 2^32 nodes on one GPU"); return KATOME_E_UNSUPPORTED; }
-        const uint64_t max_seq = 2 * (b->reads_inserted + 1) * 2 * (uint64_t)(b->seen_read_len - k + 1) + 2;
+        const uint64_t max_seq = b->var_seq_base ? 2 * b->var_seq_base + 2
+                                                 : 2 * (b->reads_inserted + 1) * 2 * (uint64_t)(b->seen_read_len - k + 1) + 2;
         uint32_t bits = 1;
         while (bits < 64 && (max_seq >> bits)) ++bits;
         // (buffers are taken and given back one at a time: at C3 every one of them is 6-13 GB)
@@ -813,7 +829,8 @@ int katome_build_files(const katome_settings* s, const char* const* paths, size_
         if (hipMemcpy(d_packed.p, hr.packed, hr.packed_bytes, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_off.p, hr.byte_off, (hr.n_reads + 1) * 8, hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(d_len.p, hr.len, hr.n_reads * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
-        const uint64_t cap = batch_records(b->nw);
+        uint64_t cap = batch_records(b->nw);
+        if (const char* e = getenv("KATOME_VAR_BATCH_RECORDS")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests: many small batches
         std::vector<uint64_t> pref;
         for (uint64_t r0 = 0; r0 < hr.n_reads && !rc;) {
             pref.assign(1, 0);

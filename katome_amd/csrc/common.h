@@ -97,7 +97,7 @@ int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t 
                          const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span = 1, bool mark = false);
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                        const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
-                       uint64_t* d_records, hipStream_t stream);
+                       uint64_t* d_records, hipStream_t stream, bool mark = false);
 
 // radix.hip
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
@@ -144,7 +144,12 @@ struct Table {
     void release() { slots.release(); counter.release(); seen.release(); }
 };
 // where a batch of records sits in the read-ordered stream (first-seen-order mode)
-struct SeenOrigin { uint64_t read0 = 0, rec0 = 0; uint32_t per_read = 1, span = 1, windows = 1; bool rc = false; };
+struct SeenOrigin {
+    uint64_t read0 = 0, rec0 = 0; uint32_t per_read = 1, span = 1, windows = 1; bool rc = false;
+    // variable-length reads: record g of the batch is window g - win_prefix[r] of the read r with win_prefix[r] <= g;
+    // seq_base = sequence numbers used by the batches before this one
+    const uint64_t* win_prefix = nullptr; uint64_t n_reads = 0, seq_base = 0;
+};
 int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream);
 int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream,
                  const SeenOrigin* origin = nullptr);

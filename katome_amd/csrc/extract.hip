@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
 // thread, read located by binary search over the window prefix sums, bytes fetched through L1/L2.
 // ---------------------------------------------------------------------------------------------
 struct ArrayAddr {
-    const u64* byte_off; const u32* len; const u64* win_prefix; u64 n_reads;
+    const u64* byte_off; const u32* len; const u64* win_prefix; u64 n_reads; bool mark_;
     __device__ __forceinline__ void locate(u64 i, u64& boff, u32& w) const {
         u64 lo = 0, hi = n_reads;            // largest r with win_prefix[r] <= i
         while (hi - lo > 1) {
@@ -118,7 +118,7 @@ struct ArrayAddr {
         w = (u32)(i - win_prefix[lo]);
     }
     __device__ __forceinline__ bool skipped(u64) const { return false; }
-    __device__ __forceinline__ bool mark() const { return false; }
+    __device__ __forceinline__ bool mark() const { return mark_; }
 };
 struct FixedAddr {
     u64 stride_bytes; u64 W; const uint8_t* skip; u64 r; u32 step;
@@ -211,9 +211,9 @@ int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t 
 
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                        const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
-                       uint64_t* d_records, hipStream_t stream) {
+                       uint64_t* d_records, hipStream_t stream, bool mark) {
     if (total_windows == 0 || n_reads == 0) return KATOME_OK;
-    ArrayAddr a{d_byte_off, d_len, d_win_prefix, n_reads};
+    ArrayAddr a{d_byte_off, d_len, d_win_prefix, n_reads, mark};
     const int nw = key_words_for_k(k);
     dim3 grid(grid_for(total_windows, BLOCK)), block(BLOCK);
     if (nw == 1) {

@@ -122,6 +122,8 @@ struct SeenParams {
     u32 span;             // windows per record
     u32 windows;          // W
     u32 rc;
+    const u64* win_prefix; // variable-length reads (SeenOrigin): windows before each read of the batch, [n_reads + 1]
+    u64 n_reads, seq_base;
 };
 
 template <int NW, bool SEEN>
@@ -139,8 +141,17 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
             key.w[0] &= ~RC_MARK;
             u64 slot;
             fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err, &slot);
-            const u64 g = sp.rec0 + i, r = sp.read0 + g / sp.per_read, i0 = (g % sp.per_read) * sp.span;
-            const u64 P = r * 2 * sp.windows + i0, Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
+            const u64 g = sp.rec0 + i;
+            u64 P, Q;
+            if (sp.win_prefix) {        // a read's forward windows take 2*prefix + [0, W), its reverse complement's the next W
+                u64 lo = 0, hi = sp.n_reads;
+                while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (sp.win_prefix[mid] <= g) lo = mid; else hi = mid; }
+                const u64 w0 = sp.win_prefix[lo], W = sp.win_prefix[lo + 1] - w0, i0 = g - w0;
+                P = sp.seq_base + 2 * w0 + i0; Q = sp.seq_base + 2 * w0 + 2 * W - i0 - 1;
+            } else {
+                const u64 r = sp.read0 + g / sp.per_read, i0 = (g % sp.per_read) * sp.span;
+                P = r * 2 * sp.windows + i0; Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
+            }
             if (sp.rc) {
                 atomicMin((unsigned long long*)&sp.seen[2 * slot + 0], (unsigned long long)(flipped ? Q : P));
                 atomicMin((unsigned long long*)&sp.seen[2 * slot + 1], (unsigned long long)(flipped ? P : Q));
@@ -366,6 +377,7 @@ int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights,
         if (!origin) { set_error("first-seen order: records must come with their position in the read stream"); return KATOME_E_ARG; }
         sp.seen = t.seen.as<u64>(); sp.read0 = origin->read0; sp.rec0 = origin->rec0; sp.per_read = origin->per_read;
         sp.span = origin->span; sp.windows = origin->windows; sp.rc = origin->rc;
+        sp.win_prefix = origin->win_prefix; sp.n_reads = origin->n_reads; sp.seq_base = origin->seq_base;
         if (t.nw == 1)
             hipLaunchKernelGGL((insert_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
         else

@@ -149,3 +149,40 @@ def test_before_finalize_is_an_error():
     with pytest.raises(KatomePanic):
         b.remove_dead_paths()
     b.close()
+
+
+def _variable_length_fastq(path, seed, n_reads, k, genome_len=3000, err=0.01):
+    """reads of every length from k to ~5k off one genome (so they overlap), a few with an N, both header styles"""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, genome_len)
+    lines = []
+    for i in range(n_reads):
+        n = int(rng.integers(k, 5 * k + 7))
+        s0 = int(rng.integers(0, genome_len - n + 1))
+        r = genome[s0:s0 + n].copy()
+        m = rng.random(n) < err
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        s = "".join("ACGT"[c] for c in r)
+        if i % 23 == 5:
+            s = s[:3] + "N" + s[4:]
+        lines += ["@r%d" % i, s, "+", "I" * n]
+    with open(path, "w") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+@pytest.mark.parametrize("k,rc,n_reads", [(11, True, 900), (12, False, 700), (31, True, 1500), (40, True, 800), (5, True, 200)])
+def test_variable_length_reads_in_reference_order(oracle, tmp_path, monkeypatch, k, rc, n_reads):
+    """first-seen numbering and remove_dead_paths for reads of unequal length (the general file route: one record
+    per window, sequence numbers from the per-read window prefix), in one batch and in many"""
+    from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
+    fq = str(tmp_path / "var.fq")
+    _variable_length_fastq(fq, 3 * k + n_reads, n_reads, k)
+    set_global_k_sizes(k)
+    if n_reads % 200:
+        monkeypatch.setenv("KATOME_VAR_BATCH_RECORDS", "1500")
+    g, rb = GpuGraph.create([fq], InputFileType.Fastq, rc, 0, first_seen_order=True)
+    ref = oracle.build_files([fq], k, rc)
+    assert rb == ref.read_bytes
+    _same(g, ref, k)
+    g, _ = GpuGraph.create([fq], InputFileType.Fastq, rc, 0, first_seen_order=True, remove_dead_paths=True)
+    _same(g, oracle.build_files([fq], k, rc, remove_dead_paths=True), k)
