@@ -236,7 +236,11 @@ int katome_dev_expand_tiles(katome_builder *b, uint64_t **d_keys, uint32_t **d_w
 /* Clean::remove_weak_edges(threshold) for PtGraph (pruner.rs:84-93): keep the edges with weight >= threshold,
  * then drop the vertices left without neighbours.  Call before katome_dev_edges / katome_dev_finalize: the
  * filter is applied when the edges are read out of the table, so the sort and the node numbering only see
- * the surviving edges (and the nodes are exactly their endpoints).                                   */
+ * the surviving edges (and the nodes are exactly their endpoints).
+ * FIRST_SEEN_ORDER builders instead number the whole graph first and then remove as petgraph's retain_edges /
+ * retain_nodes do (indices visited in descending order, rejected ones swap_removed), so the result keeps the
+ * reference's numbering; on such a builder the call is also accepted AFTER katome_dev_finalize (e.g. after
+ * katome_dev_remove_dead_paths, the order of asm/basic_assembler.rs:58-66) and then acts at once.       */
 int katome_dev_remove_weak_edges(katome_builder *b, uint32_t threshold);
 
 /* number of distinct keys in the table so far (synchronises) */
@@ -272,6 +276,9 @@ typedef struct {
     double   total_ms;
 } katome_prune_stats;
 int katome_dev_remove_dead_paths(katome_builder *b, katome_dev_graph *graph, katome_prune_stats *stats, void *stream);
+
+/* the finalized graph as it stands now (after katome_dev_remove_dead_paths / katome_dev_remove_weak_edges) */
+int katome_dev_current_graph(katome_builder *b, katome_dev_graph *out);
 
 /* first half of finalize only: sorted distinct edges (key, weight); used by the multi-GPU
  * driver, which resolves node ids across ranks itself                                      */

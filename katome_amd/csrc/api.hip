@@ -69,6 +69,7 @@ struct katome_builder {
     DevBuf scratch_k[2], scratch_w[2];
     // finalized graph
     DevBuf edge_src, edge_dst, edge_label, node_key;
+    DevBuf edge_age;                   // first-seen-order graphs once remove_* has moved edges (PruneGraph::edge_age)
     uint64_t n_nodes = 0;
     bool finalized = false;
 };
@@ -388,8 +389,23 @@ int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_w
     return KATOME_OK;
 }
 
+static int weak_edges_ordered(katome_builder* b, uint32_t threshold, hipStream_t stream) {
+    PruneGraph g{&b->edge_src, &b->edge_dst, &b->edge_weight, &b->edge_key, &b->node_key, &b->edge_age, b->n_edges, b->n_nodes, b->nw};
+    KCHECK(dev_remove_weak_edges_ordered(g, threshold, stream));
+    b->n_edges = g.n_edges; b->n_nodes = g.n_nodes;
+    return KATOME_OK;
+}
+
 int katome_dev_remove_weak_edges(katome_builder* b, uint32_t threshold) {
     if (!b) { set_error("null argument"); return KATOME_E_ARG; }
+    if (b->finalized && b->first_seen) {
+        // on the finished graph, with petgraph's numbering (retain_edges / retain_nodes: descending swap_removes)
+        KCHECK_HIP(hipSetDevice(b->s.device));
+        KCHECK(weak_edges_ordered(b, threshold, nullptr));
+        KCHECK(dev_labels(b->edge_key.as<u64>(), b->n_edges, b->s.k, b->edge_label.as<uint8_t>(), nullptr));
+        KCHECK_HIP(hipStreamSynchronize(nullptr));
+        return KATOME_OK;
+    }
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
     b->prune_weight = threshold;
     return KATOME_OK;
@@ -414,7 +430,8 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             DevBuf raw_w(stream), raw_seq(stream);
             {
                 PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
-                if (b->first_seen) KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->prune_weight, b->edge_key, raw_w, &b->n_edges, stream, &raw_seq));
+                // (first-seen order: the threshold is applied after the numbering, as the reference's retain passes do)
+                if (b->first_seen) KCHECK(table_emit_edges(b->table, b->s.k, b->rc, 0, b->edge_key, raw_w, &b->n_edges, stream, &raw_seq));
                 else KCHECK(table_emit_edges(b->table, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, stream));
             }
             for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
@@ -514,18 +531,19 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
             KCHECK(dev_gather_mapped(b->edge_dst.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, o.as<u64>(), stream));
             const size_t n = o.bytes; b->edge_dst.adopt(o.take(), n);
         }
+        if (b->prune_weight) KCHECK(weak_edges_ordered(b, b->prune_weight, stream));
         cand = b->node_key.as<u64>();
     }
     const uint32_t stride = label_stride_for_k(k);
     KCHECK(b->edge_label.alloc((E + 1) * (size_t)stride + 16, stream));
     {
         PhaseScope ps(b->prof, PH_LABELS, stream);
-        KCHECK(dev_labels(b->edge_key.as<u64>(), E, k, b->edge_label.as<uint8_t>(), stream));
+        KCHECK(dev_labels(b->edge_key.as<u64>(), b->n_edges, k, b->edge_label.as<uint8_t>(), stream));
     }
     KCHECK_HIP(hipStreamSynchronize(stream));
     b->finalized = true;
     if (out) {
-        out->n_nodes = b->n_nodes; out->n_edges = E;
+        out->n_nodes = b->n_nodes; out->n_edges = b->n_edges;
         out->key_words = nw; out->label_stride = stride;
         out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
@@ -541,7 +559,7 @@ int katome_dev_remove_dead_paths(katome_builder* b, katome_dev_graph* out, katom
     if (!b->first_seen) { set_error("remove_dead_paths needs a KATOME_FLAG_FIRST_SEEN_ORDER builder"); return KATOME_E_ARG; }
     if (!b->finalized) { set_error("remove_dead_paths: call katome_dev_finalize first"); return KATOME_E_ARG; }
     const auto t0 = std::chrono::steady_clock::now();
-    PruneGraph g{&b->edge_src, &b->edge_dst, &b->edge_weight, &b->edge_key, &b->node_key, b->n_edges, b->n_nodes, b->nw};
+    PruneGraph g{&b->edge_src, &b->edge_dst, &b->edge_weight, &b->edge_key, &b->node_key, &b->edge_age, b->n_edges, b->n_nodes, b->nw};
     katome_prune_stats st;
     {
         PhaseScope ps(b->prof, PH_DEAD_PATHS, stream);
@@ -560,6 +578,17 @@ int katome_dev_remove_dead_paths(katome_builder* b, katome_dev_graph* out, katom
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
         out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = b->node_key.as<u64>();
     }
+    return KATOME_OK;
+}
+
+int katome_dev_current_graph(katome_builder* b, katome_dev_graph* out) {
+    if (!b || !out) { set_error("null argument"); return KATOME_E_ARG; }
+    if (!b->finalized) { set_error("katome_dev_current_graph: call katome_dev_finalize first"); return KATOME_E_ARG; }
+    out->n_nodes = b->n_nodes; out->n_edges = b->n_edges;
+    out->key_words = b->nw; out->label_stride = label_stride_for_k(b->s.k);
+    out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
+    out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
+    out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = b->node_key.as<u64>();
     return KATOME_OK;
 }
 

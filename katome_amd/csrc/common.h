@@ -127,10 +127,14 @@ int dev_scan_counts(const uint32_t* d_counts, uint64_t m, uint64_t* d_offs, hipS
 // prune.hip: Prunable::remove_dead_paths on a first-seen-ordered graph, in place (counts shrink, buffers stay)
 struct PruneGraph {
     DevBuf *edge_src, *edge_dst, *edge_weight, *edge_key, *node_key;
+    DevBuf *edge_age;      // u32 per edge: its first-seen index = its place in petgraph's adjacency lists (swap_remove re-labels
+                           // edges but never reorders the lists); empty = the edges still sit at their first-seen positions
     uint64_t n_edges, n_nodes;
     uint32_t nw;
 };
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream);
+// Clean::remove_weak_edges with petgraph's retain_edges / retain_nodes numbering, same graph, in place
+int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t stream);
 
 // table.hip
 struct Table {

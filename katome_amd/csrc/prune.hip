@@ -16,6 +16,7 @@
 //   * host: the two sequential swap_remove replays (edges: two descending streams; nodes: arrays over the dying tail).
 #include <stdlib.h>
 
+#include <algorithm>
 #include <chrono>
 #include <vector>
 
@@ -180,8 +181,11 @@ __global__ __launch_bounds__(BLOCK) void move_edges_kernel(const u32* __restrict
                                                            u32* __restrict__ orig, u64* __restrict__ key, u64* __restrict__ first_out) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         const u64 d = to[i], s = from[i];
-        const u64 a = src[s], fo = first_out[a];
-        if (fo != 0 && (u32)fo == (u32)s) first_out[a] = (fo & 0xFFFFFFFF00000000ull) | d;      // the head follows its edge
+        const u64 a = src[s];
+        if (first_out) {
+            const u64 fo = first_out[a];
+            if (fo != 0 && (u32)fo == (u32)s) first_out[a] = (fo & 0xFFFFFFFF00000000ull) | d;  // the head follows its edge
+        }
         src[d] = a; dst[d] = dst[s]; weight[d] = weight[s]; orig[d] = orig[s];
         for (u32 w = 0; w < nw; ++w) key[d * nw + w] = key[s * nw + w];
     }
@@ -192,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void move_nodes_kernel(const u32* __restrict
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         const u64 d = to[i], s = from[i];
         for (u32 w = 0; w < nw; ++w) node_key[d * nw + w] = node_key[s * nw + w];
-        node_deg[d] = node_deg[s]; first_out[d] = first_out[s];
+        if (node_deg) { node_deg[d] = node_deg[s]; first_out[d] = first_out[s]; }
         tail_map[s - n_new] = (u32)d;
     }
 }
@@ -203,6 +207,18 @@ __global__ __launch_bounds__(BLOCK) void remap_kernel(u64* __restrict__ src, u64
         if (a >= n_new) src[e] = tail_map[a - n_new];
         if (b >= n_new) dst[e] = tail_map[b - n_new];
     }
+}
+
+// Clean::remove_weak_edges (pruner.rs:84-93): flags for the two retain passes
+__global__ __launch_bounds__(BLOCK) void weak_flag_kernel(const u32* __restrict__ weight, u64 E, u32 threshold, u32* __restrict__ flag) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) flag[e] = weight[e] < threshold ? 1u : 0u;
+}
+__global__ __launch_bounds__(BLOCK) void touch_nodes_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, u64 E,
+                                                            u32* __restrict__ lonely) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) { lonely[src[e]] = 0; lonely[dst[e]] = 0; }
+}
+__global__ __launch_bounds__(BLOCK) void fill_u32_kernel(u32* __restrict__ p, u64 n, u32 v) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) p[i] = v;
 }
 
 // nodes that lost their first out-edge: the largest first-seen index among the out-edges that are left
@@ -253,9 +269,12 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     u64 E = g.n_edges, N = g.n_nodes;
     u64* src = g.edge_src->as<u64>(); u64* dst = g.edge_dst->as<u64>();
     u32* weight = g.edge_weight->as<u32>(); u64* key = g.edge_key->as<u64>(); u64* node_key = g.node_key->as<u64>();
-    DevBuf orig(stream), node_deg(stream), first_out(stream), mult(stream), totals(stream);
-    KCHECK(orig.alloc((E + 1) * 4));
-    KCHECK(dev_iota(orig.as<u32>(), E, stream));
+    DevBuf node_deg(stream), first_out(stream), mult(stream), totals(stream);
+    DevBuf& orig = *g.edge_age;
+    if (orig.bytes < (E + 1) * 4) {
+        KCHECK(orig.alloc((E + 1) * 4, stream));
+        KCHECK(dev_iota(orig.as<u32>(), E, stream));
+    }
     KCHECK(node_deg.alloc((N + 1) * 8)); KCHECK(first_out.alloc((N + 1) * 8)); KCHECK(mult.alloc((E + 1) * 4));
     KCHECK(totals.alloc(32));
     PinnedU32 h_pos, h_mult, h_die;
@@ -360,6 +379,74 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     }
     g.n_edges = E; g.n_nodes = N;
     if (st) *st = local;
+    return KATOME_OK;
+}
+
+// flagged indices ascending (flag[i] != 0) -> host; then the swap_remove replay over them from the top
+static int flagged_replay(const u32* d_flag, u64 n, PinnedU32& h_pos, PinnedU32& h_mult, EdgeReplay& er, hipStream_t stream) {
+    const u64 nblocks = (n + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
+    DevBuf counts(stream), offs(stream), d_pos(stream), d_mult(stream);
+    KCHECK(counts.alloc(nblocks * 4 + 16)); KCHECK(offs.alloc((nblocks + 1) * 8 + 16));
+    hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_flag, n, counts.as<u32>());
+    KCHECK(dev_scan_counts(counts.as<u32>(), nblocks, offs.as<u64>(), stream));
+    u64 u = 0;
+    KCHECK_HIP(hipMemcpyAsync(&u, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    KCHECK(d_pos.alloc(u * 4 + 16)); KCHECK(d_mult.alloc(u * 4 + 16));
+    hipLaunchKernelGGL(mark_write_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_flag, n, offs.as<u64>(), d_pos.as<u32>(), d_mult.as<u32>());
+    KCHECK_HIP(hipGetLastError());
+    KCHECK(h_pos.need(u)); KCHECK(h_mult.need(u));
+    KCHECK_HIP(hipMemcpyAsync(h_pos.p, d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipMemcpyAsync(h_mult.p, d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    replay_edges(h_pos.p, h_mult.p, u, n, u, er);
+    return KATOME_OK;
+}
+
+// Clean::remove_weak_edges for PtGraph (pruner.rs:84-93) with petgraph's numbering: retain_edges visits the edge
+// indices in descending order and swap_removes those below the threshold, then retain_nodes does the same with the
+// nodes left without neighbours -- the replay of prune_replay.h with every index listed once, for edges and for nodes.
+int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t stream) {
+    if (g.n_edges >= 0xFFFFFFFFull || g.n_nodes >= 0xFFFFFFFFull) {
+        set_error("remove_weak_edges: more than 2^32 edges or nodes on one GPU");
+        return KATOME_E_UNSUPPORTED;
+    }
+    const u32 nw = g.nw;
+    u64 E = g.n_edges, N = g.n_nodes;
+    if (E == 0) return KATOME_OK;
+    u64* src = g.edge_src->as<u64>(); u64* dst = g.edge_dst->as<u64>();
+    u32* weight = g.edge_weight->as<u32>(); u64* key = g.edge_key->as<u64>(); u64* node_key = g.node_key->as<u64>();
+    PinnedU32 h_pos, h_mult;
+    EdgeReplay er;
+    DevBuf flag(stream), to(stream), from(stream);
+    KCHECK(flag.alloc((std::max(E, N) + 1) * 4));
+    DevBuf& orig = *g.edge_age;                            // the edges' ages move with them: remove_dead_paths may follow
+    if (orig.bytes < (E + 1) * 4) {
+        KCHECK(orig.alloc((E + 1) * 4, stream));
+        KCHECK(dev_iota(orig.as<u32>(), E, stream));
+    }
+    hipLaunchKernelGGL(weak_flag_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, weight, E, threshold, flag.as<u32>());
+    KCHECK(flagged_replay(flag.as<u32>(), E, h_pos, h_mult, er, stream));
+    KCHECK(upload(to, er.move_to, stream)); KCHECK(upload(from, er.move_from, stream));
+    if (!er.move_to.empty())
+        hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(er.move_to.size(), BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
+                           from.as<u32>(), (u64)er.move_to.size(), nw, src, dst, weight, orig.as<u32>(), key, (u64*)nullptr);
+    E = er.n_new;
+    // retain_nodes(|n| has a neighbour)
+    hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, flag.as<u32>(), N, 1u);
+    if (E) hipLaunchKernelGGL(touch_nodes_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, flag.as<u32>());
+    KCHECK_HIP(hipGetLastError());
+    KCHECK(flagged_replay(flag.as<u32>(), N, h_pos, h_mult, er, stream));
+    KCHECK(upload(to, er.move_to, stream)); KCHECK(upload(from, er.move_from, stream));
+    const u64 nn = er.move_to.size(), N_new = er.n_new;
+    DevBuf tail_map(stream);
+    KCHECK(tail_map.alloc((N - N_new + 1) * 4));
+    if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(), from.as<u32>(),
+                               nn, nw, N_new, node_key, (u64*)nullptr, (u64*)nullptr, tail_map.as<u32>());
+    if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, N_new, tail_map.as<u32>());
+    KCHECK_HIP(hipGetLastError());
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    g.n_edges = E; g.n_nodes = N_new;
     return KATOME_OK;
 }
 

@@ -183,8 +183,16 @@ class Builder:
             _check(_lib.lib().katome_dev_insert_weighted(self._h, _ptr(records), _ptr(weights), n, _stream()))
 
     def remove_weak_edges(self, threshold):
-        """Clean::remove_weak_edges (pruner.rs:84-93), applied when the edges are read out of the table"""
+        """Clean::remove_weak_edges (pruner.rs:84-93).  Before finalize(): applied when the edges are read out (first-seen
+        order: after the numbering, with petgraph's retain_edges / retain_nodes re-numbering).  On a finalized
+        first-seen-order builder: applied now, same re-numbering; fetch the arrays again with graph()."""
         _check(_lib.lib().katome_dev_remove_weak_edges(self._h, threshold))
+
+    def graph(self):
+        """the finalized graph as it stands (after remove_dead_paths / remove_weak_edges)"""
+        dg = _lib.DevGraph()
+        _check(_lib.lib().katome_dev_current_graph(self._h, C.byref(dg)))
+        return DeviceGraph(dg, self, self.tdev)
 
     def table_count(self):
         out = C.c_uint64()

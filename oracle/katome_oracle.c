@@ -963,12 +963,39 @@ static void pt_stats(const pgraph_t *g, ko_stats *st)
 }
 
 /* PtGraph::create tail (pt_graph.rs:339-344): recode every slot kmer->edge format */
-static int g_prune_dead_paths = 0;      /* set by ko_set_prune_dead_paths: run remove_dead_paths before the result is read out */
-void ko_set_prune_dead_paths(int on) { g_prune_dead_paths = on; }
+/* Clean for PtGraph (pruner.rs:84-93) over petgraph 0.4.13's retain_edges / retain_nodes, which visit the indices in
+ * DESCENDING order and remove_edge / remove_node (swap_remove) the ones the predicate rejects */
+static void remove_single_vertices(pgraph_t *g)                     /* pruner.rs:85-87 */
+{
+    for (uint64_t n = g->n_nodes; n-- > 0;)
+        if (g->node_next[0][n] == END && g->node_next[1][n] == END) pg_remove_node(g, n);   /* neighbors_undirected(n).next().is_none() */
+}
+static void remove_weak_edges(pgraph_t *g, uint32_t threshold)      /* pruner.rs:89-92 */
+{
+    for (uint64_t e = g->n_edges; e-- > 0;)
+        if (!(g->edge_w[e] >= threshold)) pg_remove_edge(g, e);
+    remove_single_vertices(g);
+}
+
+/* stages run on the finished PtGraph before the result is read out, in the order given: 'd' = remove_dead_paths,
+ * 'w' = remove_weak_edges(threshold) */
+static char g_stages[8] = "";
+static uint32_t g_weak_threshold = 0;
+void ko_set_post_build(const char *stages, uint32_t weak_threshold)
+{
+    size_t n = stages ? strlen(stages) : 0;
+    if (n >= sizeof g_stages) n = sizeof g_stages - 1;
+    memcpy(g_stages, stages ? stages : "", n); g_stages[n] = 0;
+    g_weak_threshold = weak_threshold;
+}
+void ko_set_prune_dead_paths(int on) { ko_set_post_build(on ? "d" : "", 0); }
 
 static ko_graph *finish(build_ctx *c)
 {
-    if (g_prune_dead_paths) remove_dead_paths(&c->b.graph);
+    for (const char *st = g_stages; *st; ++st) {
+        if (*st == 'd') remove_dead_paths(&c->b.graph);
+        else if (*st == 'w') remove_weak_edges(&c->b.graph, g_weak_threshold);
+    }
     ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
     pgraph_t *p = &c->b.graph;
     g->n_nodes = p->n_nodes; g->n_edges = p->n_edges; g->read_bytes = c->total;
@@ -1125,45 +1152,3 @@ void ko_synth_reads(uint64_t first_read, uint64_t n_reads, uint32_t read_len, ui
 }
 
 /* ============================ pruner.rs:84-93 (PtGraph) ============================= */
-/* Clean::remove_weak_edges = retain_edges(weight >= threshold) then remove_single_vertices = retain_nodes(has a
- * neighbour).  Only the surviving COUNTS and the edge multiset are observable in the reference's tests
- * (tests/pruner.rs:37-169), so the restatement filters the result arrays instead of replaying petgraph's
- * swap-remove index shuffling.  Node ids are renumbered densely in their old order.                    */
-void ko_remove_weak_edges(ko_graph *g, uint32_t threshold)
-{
-    uint64_t ne = 0;
-    for (uint64_t e = 0; e < g->n_edges; ++e) {
-        if (g->edge_weight[e] < threshold) continue;
-        g->edge_src[ne] = g->edge_src[e]; g->edge_dst[ne] = g->edge_dst[e];
-        g->edge_weight[ne] = g->edge_weight[e]; g->edge_slot[ne] = g->edge_slot[e];
-        memmove(g->edge_label + ne * (size_t)g->label_stride, g->edge_label + e * (size_t)g->label_stride, g->label_stride);
-        ++ne;
-    }
-    g->n_edges = ne;
-    uint64_t *remap = (uint64_t *)xrealloc(NULL, (g->n_nodes ? g->n_nodes : 1) * 8);
-    memset(remap, 0xFF, (g->n_nodes ? g->n_nodes : 1) * 8);
-    for (uint64_t e = 0; e < ne; ++e) { remap[g->edge_src[e]] = 0; remap[g->edge_dst[e]] = 0; }
-    uint64_t nn = 0;
-    for (uint64_t n = 0; n < g->n_nodes; ++n) if (remap[n] == 0) remap[n] = nn++;
-    for (uint64_t e = 0; e < ne; ++e) { g->edge_src[e] = remap[g->edge_src[e]]; g->edge_dst[e] = remap[g->edge_dst[e]]; }
-    g->n_nodes = nn;
-    free(remap);
-    /* stats of the pruned graph (stats/collections.rs:137-168) */
-    memset(&g->stats, 0, sizeof g->stats);
-    g->stats.node_count = nn; g->stats.edge_count = ne;
-    uint64_t *od = (uint64_t *)calloc(nn ? nn : 1, 8), *id = (uint64_t *)calloc(nn ? nn : 1, 8), sw = 0, so = 0;
-    for (uint64_t e = 0; e < ne; ++e) {
-        if (g->edge_weight[e] > g->stats.max_edge_weight) g->stats.max_edge_weight = g->edge_weight[e];
-        sw += g->edge_weight[e]; od[g->edge_src[e]]++; id[g->edge_dst[e]]++;
-    }
-    for (uint64_t n = 0; n < nn; ++n) {
-        if (od[n] > g->stats.max_out_degree) g->stats.max_out_degree = od[n];
-        if (id[n] > g->stats.max_in_degree) g->stats.max_in_degree = id[n];
-        so += od[n];
-        if (!id[n]) g->stats.incoming_vert_count++;
-        if (!od[n]) g->stats.outgoing_vert_count++;
-    }
-    g->stats.avg_edge_weight = (double)sw / (double)ne;
-    g->stats.avg_out_degree = (double)so / (double)nn;
-    free(od); free(id);
-}

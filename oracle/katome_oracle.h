@@ -101,8 +101,10 @@ int  ko_build_ascii(const uint8_t *reads, size_t n_reads, size_t read_len,
  * swap-remove index semantics) on the finished PtGraph before the result arrays are read out */
 void ko_set_prune_dead_paths(int on);
 uint64_t ko_last_prune_passes(void);
-/* Clean::remove_weak_edges for PtGraph (pruner.rs:84-93), in place on a built graph */
-void ko_remove_weak_edges(ko_graph *g, uint32_t threshold);
+/* general form: `stages` is applied in order to the finished PtGraph of every ko_build_*: 'd' = remove_dead_paths,
+ * 'w' = Clean::remove_weak_edges(weak_threshold) (pruner.rs:84-93, over petgraph's retain_edges / retain_nodes:
+ * indices visited in descending order, rejected ones swap_removed); "" = none */
+void ko_set_post_build(const char *stages, uint32_t weak_threshold);
 void ko_graph_free(ko_graph *g);
 const char *ko_last_error(void);
 

@@ -84,9 +84,8 @@ def lib():
         L.ko_build_ascii.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_size_t, C.c_int,
                                      C.POINTER(C.POINTER(KoGraph))]
         L.ko_graph_free.argtypes = [C.POINTER(KoGraph)]
-        L.ko_remove_weak_edges.argtypes = [C.POINTER(KoGraph), C.c_uint32]
-        L.ko_set_prune_dead_paths.argtypes = [C.c_int]
-        L.ko_set_prune_dead_paths.restype = None
+        L.ko_set_post_build.argtypes = [C.c_char_p, C.c_uint32]
+        L.ko_set_post_build.restype = None
         L.ko_last_prune_passes.restype = C.c_uint64
         L.ko_last_error.restype = C.c_char_p
         L.ko_scan_files.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.POINTER(C.POINTER(KoReads))]
@@ -240,18 +239,24 @@ def _paths(paths):
     return arr
 
 
+def _stages(remove_weak_edges, remove_dead_paths, stages):
+    """post-build stages on the PtGraph, in order: 'w' = Clean::remove_weak_edges(threshold) (pruner.rs:84-93),
+    'd' = Prunable::remove_dead_paths (pruner.rs:36-82); default: weak edges first if both are asked for"""
+    if stages is None:
+        stages = ("w" if remove_weak_edges is not None else "") + ("d" if remove_dead_paths else "")
+    lib().ko_set_post_build(stages.encode(), int(remove_weak_edges or 0))
+
+
 def build_files(paths, k, reverse_complement=False, file_type=1, with_gir=False, remove_weak_edges=None,
-                remove_dead_paths=False):
+                remove_dead_paths=False, stages=None):
     gp = C.POINTER(KoGraph)()
-    lib().ko_set_prune_dead_paths(1 if remove_dead_paths else 0)
+    _stages(remove_weak_edges, remove_dead_paths, stages)
     rc = lib().ko_build_files(_paths(paths), len(paths), file_type, int(reverse_complement), k, int(with_gir),
                               C.byref(gp))
-    lib().ko_set_prune_dead_paths(0)
+    lib().ko_set_post_build(b"", 0)
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:
-        if remove_weak_edges is not None:
-            lib().ko_remove_weak_edges(gp, remove_weak_edges)      # Clean::remove_weak_edges (pruner.rs:84-93)
         return OracleGraph(gp, k)
     finally:
         lib().ko_graph_free(gp)
@@ -268,14 +273,15 @@ def build_bfc(paths, k, reverse_complement=False, threshold=0):
         lib().ko_graph_free(gp)
 
 
-def build_ascii(reads, k, reverse_complement=False, with_gir=False, remove_dead_paths=False):
+def build_ascii(reads, k, reverse_complement=False, with_gir=False, remove_dead_paths=False, remove_weak_edges=None,
+                stages=None):
     """reads: uint8 array [n_reads, read_len] of ASCII codes."""
     reads = np.ascontiguousarray(reads, dtype=np.uint8)
     gp = C.POINTER(KoGraph)()
-    lib().ko_set_prune_dead_paths(1 if remove_dead_paths else 0)
+    _stages(remove_weak_edges, remove_dead_paths, stages)
     rc = lib().ko_build_ascii(reads.ctypes.data, reads.shape[0], reads.shape[1], int(reverse_complement), k,
                               int(with_gir), C.byref(gp))
-    lib().ko_set_prune_dead_paths(0)
+    lib().ko_set_post_build(b"", 0)
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:

@@ -186,3 +186,55 @@ def test_variable_length_reads_in_reference_order(oracle, tmp_path, monkeypatch,
     _same(g, ref, k)
     g, _ = GpuGraph.create([fq], InputFileType.Fastq, rc, 0, first_seen_order=True, remove_dead_paths=True)
     _same(g, oracle.build_files([fq], k, rc, remove_dead_paths=True), k)
+
+
+def _dev_arrays(dg):
+    return (dg.edge_label.cpu().numpy(), dg.edge_weight.cpu().numpy().view(np.uint32),
+            dg.edge_src.cpu().numpy().view(np.uint64), dg.edge_dst.cpu().numpy().view(np.uint64))
+
+
+def _assert_dev_same(dg, ref):
+    assert (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
+    lab, w, s, d = _dev_arrays(dg)
+    assert np.array_equal(lab, ref.edge_label) and np.array_equal(w, ref.edge_weight)
+    assert np.array_equal(s, ref.edge_src) and np.array_equal(d, ref.edge_dst)
+
+
+@pytest.mark.parametrize("k,rc,thr", [(31, True, 2), (12, False, 3), (40, True, 2), (6, True, 30), (21, True, 4)])
+def test_remove_weak_edges_in_reference_order(oracle, k, rc, thr):
+    """Clean::remove_weak_edges on a first-seen-order builder: petgraph's retain_edges / retain_nodes numbering
+    (descending swap_removes), asked for before finalize, after it, and around remove_dead_paths in both orders"""
+    from katome_amd import device as kd
+    n, L = 2500, 110
+    ascii_reads = oracle.synth_reads(0, n, L, 15000, 1e-2, 0)
+    packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1).copy()).cuda()
+
+    def build():
+        b = kd.Builder(k, rc, first_seen_order=True)
+        span = b.tile_span(L)
+        if span > 1:
+            b.insert_tiles(b.extract_tiles(packed, n, L, span), span)
+        else:
+            b.insert(b.extract_fixed(packed, n, L))
+        return b
+
+    full = oracle.build_ascii(ascii_reads, k, rc)
+    want_w = oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=thr)
+    assert 0 < want_w.n_edges < full.n_edges
+    b = build()
+    b.remove_weak_edges(thr)                       # before finalize
+    _assert_dev_same(b.finalize(), want_w)
+    dg, _ = b.remove_dead_paths()                  # ... then dead paths
+    _assert_dev_same(dg, oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=thr, remove_dead_paths=True, stages="wd"))
+    b.close()
+    b = build()
+    b.finalize()
+    b.remove_weak_edges(thr)                       # after finalize
+    _assert_dev_same(b.graph(), want_w)
+    b.close()
+    b = build()
+    b.finalize()
+    b.remove_dead_paths()
+    b.remove_weak_edges(thr)                       # the assembler's order (asm/basic_assembler.rs:58-66, without the shrink between)
+    _assert_dev_same(b.graph(), oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=thr, remove_dead_paths=True, stages="dw"))
+    b.close()
