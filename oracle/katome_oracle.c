@@ -977,8 +977,129 @@ static void remove_weak_edges(pgraph_t *g, uint32_t threshold)      /* pruner.rs
     remove_single_vertices(g);
 }
 
+/* ============================ shrinker.rs:38-209 (PtGraph) ========================== */
+/* After PtGraph::create every SEQUENCES slot holds one edge in compress_edge format (pt_graph.rs:339-343); shrink
+ * merges them (EdgeSlice::merge, slices.rs:23-34), so slots get their own growable byte strings here. */
+typedef struct { uint8_t **bytes; size_t *len; size_t n; } labels_t;
+static void labels_free(labels_t *l)
+{
+    if (!l->bytes) return;
+    for (size_t i = 0; i < l->n; ++i) free(l->bytes[i]);
+    free(l->bytes); free(l->len); l->bytes = NULL; l->len = NULL; l->n = 0;
+}
+/* EdgeSlice::merge (slices.rs:23-34): self <- extend_edge(self, decompress_edge(other)[K1_SIZE..]); other <- empty */
+static void label_merge(labels_t *l, uint64_t self_idx, uint64_t other_idx)
+{
+    size_t on = l->len[other_idx];
+    uint8_t *ascii = (uint8_t *)xrealloc(NULL, on * 4 + 8);
+    size_t an = ko_decompress_edge(l->bytes[other_idx], on, ascii);
+    if (!(an > K1_SIZE)) { fprintf(stderr, "oracle: assertion failed: other_uncompressed.len() > K1_SIZE\n"); abort(); }
+    uint8_t *out = (uint8_t *)xrealloc(NULL, l->len[self_idx] + (an - K1_SIZE) / 4 + 8);
+    size_t n = ko_extend_edge(l->bytes[self_idx], l->len[self_idx], ascii + K1_SIZE, an - K1_SIZE, out);
+    free(ascii);
+    free(l->bytes[other_idx]); l->bytes[other_idx] = NULL; l->len[other_idx] = 0;
+    free(l->bytes[self_idx]); l->bytes[self_idx] = out; l->len[self_idx] = n;
+}
+static uint64_t pg_degree_exact(const pgraph_t *g, uint64_t n, int dir)
+{
+    uint64_t c = 0;
+    for (uint64_t e = g->node_next[dir][n]; e != END; e = g->edge_next[dir][e]) ++c;
+    return c;
+}
+/* ShrinkTraverse (shrinker.rs:38-147) */
+typedef struct { uint8_t *fb; size_t n; uint64_t *stack; size_t sp, cap; size_t node_offset; } shrink_traverse;
+static void st_push(shrink_traverse *t, uint64_t v)
+{
+    if (t->sp == t->cap) { t->cap = t->cap ? t->cap * 2 : 256; t->stack = (uint64_t *)xrealloc(t->stack, t->cap * 8); }
+    t->stack[t->sp++] = v;
+}
+static void st_new(shrink_traverse *t, const pgraph_t *g)      /* shrinker.rs:48-60 */
+{
+    memset(t, 0, sizeof *t);
+    for (uint64_t n = 0; n < g->n_nodes; ++n) if (g->node_next[1][n] == END) st_push(t, n);   /* graph.externals(Incoming) */
+    t->n = g->n_nodes;
+    t->fb = (uint8_t *)calloc(t->n ? t->n : 1, 1);
+}
+static uint64_t st_next(shrink_traverse *t, const pgraph_t *g) /* shrinker.rs:62-135 */
+{
+    int iter = 0;
+    evec_t single_nodes = {0, 0, 0};
+    for (;;) {
+        while (t->sp) {
+            uint64_t current_node = t->stack[t->sp - 1];
+            for (;;) {
+                int new_ancestor = 0;
+                for (uint64_t e = g->node_next[0][current_node]; e != END; e = g->edge_next[0][e]) {
+                    uint64_t n = g->edge_node[1][e];
+                    if (t->fb[n]) continue;
+                    t->fb[n] = 1;
+                    if (current_node == n) continue;
+                    else if (pg_degree_exact(g, n, 0) == 1 && pg_degree_exact(g, n, 1) == 1) { free(single_nodes.v); return e; }
+                    else { st_push(t, n); current_node = n; new_ancestor = 1; break; }
+                }
+                if (!new_ancestor) { t->sp--; t->fb[current_node] = 1; break; }
+            }
+        }
+        /* components with a cycle at their root: the next unvisited node -- self.fb.zeros().skip(self.node_offset).enumerate() */
+        size_t zeros_seen = 0, i = 0;
+        for (size_t n = 0; n < t->n; ++n) {
+            if (t->fb[n]) continue;
+            if (zeros_seen++ < t->node_offset) continue;
+            if (g->node_next[1][n] == END && g->node_next[0][n] == END) {
+                evec_push(&single_nodes, n);
+            } else {
+                st_push(t, n);
+                t->node_offset += i;
+                iter = 1;
+                break;
+            }
+            ++i;
+        }
+        if (!iter) break;
+        iter = 0;
+        for (size_t j = 0; j < single_nodes.n; ++j) t->fb[single_nodes.v[j]] = 1;
+        single_nodes.n = 0;
+    }
+    free(single_nodes.v);
+    return END;
+}
+/* Shrinkable::shrink_single_path (shrinker.rs:178-209) */
+static uint64_t shrink_single_path(pgraph_t *g, labels_t *l, uint64_t base_edge)
+{
+    uint64_t start_node = g->edge_node[0][base_edge], mid_node = g->edge_node[1][base_edge];
+    for (;;) {
+        uint64_t next_edge = g->node_next[0][mid_node];                  /* first_edge(mid_node, Outgoing) */
+        uint64_t base_slot = g->edge_slot[base_edge]; uint32_t base_w = g->edge_w[base_edge];
+        uint64_t target = g->edge_node[1][next_edge];
+        uint64_t next_slot;
+        if (base_edge < next_edge) {                                     /* higher index first */
+            next_slot = g->edge_slot[next_edge];
+            pg_remove_edge(g, next_edge);
+            pg_remove_edge(g, base_edge);
+        } else if (base_edge == next_edge) {
+            return base_edge;
+        } else {
+            pg_remove_edge(g, base_edge);
+            next_slot = g->edge_slot[next_edge];                         /* remove_edge(next_edge) returns the weight found AT that index now */
+            pg_remove_edge(g, next_edge);
+        }
+        label_merge(l, base_slot, next_slot);
+        base_edge = pg_add_edge(g, start_node, target, base_slot, base_w);
+        mid_node = target;
+        if (pg_degree_exact(g, mid_node, 1) != 1 || pg_degree_exact(g, mid_node, 0) != 1 || mid_node == start_node) return base_edge;
+    }
+}
+/* Shrinkable::shrink (shrinker.rs:165-176) */
+static void shrink(pgraph_t *g, labels_t *l)
+{
+    shrink_traverse t; st_new(&t, g);
+    for (uint64_t base_edge; (base_edge = st_next(&t, g)) != END;) shrink_single_path(g, l, base_edge);
+    remove_single_vertices(g);
+    free(t.fb); free(t.stack);
+}
+
 /* stages run on the finished PtGraph before the result is read out, in the order given: 'd' = remove_dead_paths,
- * 'w' = remove_weak_edges(threshold) */
+ * 'w' = remove_weak_edges(threshold), 's' = shrink */
 static char g_stages[8] = "";
 static uint32_t g_weak_threshold = 0;
 void ko_set_post_build(const char *stages, uint32_t weak_threshold)
@@ -992,9 +1113,23 @@ void ko_set_prune_dead_paths(int on) { ko_set_post_build(on ? "d" : "", 0); }
 
 static ko_graph *finish(build_ctx *c)
 {
+    labels_t labels = {0, 0, 0};
     for (const char *st = g_stages; *st; ++st) {
         if (*st == 'd') remove_dead_paths(&c->b.graph);
         else if (*st == 'w') remove_weak_edges(&c->b.graph, g_weak_threshold);
+        else if (*st == 's') {
+            if (!labels.bytes) {                       /* the post-pass of PtGraph::create (pt_graph.rs:339-343): slots -> edge format */
+                labels.n = c->b.seqs.len;
+                labels.bytes = (uint8_t **)calloc(labels.n, sizeof(uint8_t *));
+                labels.len = (size_t *)calloc(labels.n, sizeof(size_t));
+                const size_t stride = 1 + ceil_div(K_SIZE, CHARS_PER_CARRIER);
+                for (size_t i = 1; i < labels.n; ++i) {
+                    labels.bytes[i] = (uint8_t *)xrealloc(NULL, stride + 8);
+                    labels.len[i] = ko_kmer_to_edge(c->b.seqs.data + i * c->b.seqs.slot, c->b.seqs.slot, labels.bytes[i]);
+                }
+            }
+            shrink(&c->b.graph, &labels);
+        }
     }
     ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
     pgraph_t *p = &c->b.graph;
@@ -1014,12 +1149,65 @@ static ko_graph *finish(build_ctx *c)
         ko_kmer_to_edge(c->b.seqs.data + p->edge_slot[e] * c->b.seqs.slot, c->b.seqs.slot,
                         g->edge_label + e * (size_t)g->label_stride);
     }
+    if (labels.bytes) {      /* shrunk: labels of any length, handed out as ASCII (decompress_edge) with offsets */
+        g->edge_seq_off = (uint64_t *)xrealloc(NULL, (p->n_edges + 1) * 8);
+        size_t total = 0;
+        for (uint64_t e = 0; e < p->n_edges; ++e) total += labels.len[p->edge_slot[e]] * 4;
+        g->edge_seq = (uint8_t *)xrealloc(NULL, total + 8);
+        size_t at = 0;
+        for (uint64_t e = 0; e < p->n_edges; ++e) {
+            g->edge_seq_off[e] = at;
+            at += ko_decompress_edge(labels.bytes[p->edge_slot[e]], labels.len[p->edge_slot[e]], g->edge_seq + at);
+        }
+        g->edge_seq_off[p->n_edges] = at;
+        labels_free(&labels);
+    }
     pt_stats(p, &g->stats);
     if (c->with_gir) {       /* stats/collections.rs:190-208 */
         g->gir_node_count = c->gir.map.len;
         for (size_t i = 0; i < c->gir.n_out; ++i) g->gir_edge_count += c->gir.out[i].n;
     }
     return g;
+}
+
+/* PtGraph::from_edges + Shrinkable::shrink on hand-made graphs, the shape of shrinker.rs's in-file tests (237-488): SEQUENCES
+ * slot i holds compress_edge(slot_ascii[i]) (slot 0 = scratch), edge j = (src, dst, (EdgeSlice(slot), weight)) */
+int ko_shrink_from_edges(const uint64_t *src, const uint64_t *dst, const uint64_t *slot, const uint32_t *w, size_t n_edges,
+                         const char *const *slot_ascii, size_t n_slots, size_t k, ko_graph **out)
+{
+    *out = NULL; g_err[0] = 0;
+    ko_set_global_k_sizes(k);
+    pgraph_t p; pg_init(&p);
+    uint64_t max_node = 0;
+    for (size_t e = 0; e < n_edges; ++e) { if (src[e] > max_node) max_node = src[e]; if (dst[e] > max_node) max_node = dst[e]; }
+    if (n_edges) for (uint64_t n = 0; n <= max_node; ++n) pg_add_node(&p);        /* from_edges adds the missing nodes */
+    for (size_t e = 0; e < n_edges; ++e) pg_add_edge(&p, src[e], dst[e], slot[e], w[e]);
+    labels_t l; l.n = n_slots; l.bytes = (uint8_t **)calloc(n_slots ? n_slots : 1, sizeof(uint8_t *)); l.len = (size_t *)calloc(n_slots ? n_slots : 1, sizeof(size_t));
+    for (size_t i = 1; i < n_slots; ++i) {
+        size_t n = strlen(slot_ascii[i]);
+        l.bytes[i] = (uint8_t *)xrealloc(NULL, n / 4 + 8);
+        l.len[i] = ko_compress_edge((const uint8_t *)slot_ascii[i], n, l.bytes[i]);
+    }
+    shrink(&p, &l);
+    ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
+    g->n_nodes = p.n_nodes; g->n_edges = p.n_edges;
+    g->edge_src = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8); g->edge_dst = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8);
+    g->edge_slot = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8); g->edge_weight = (uint32_t *)xrealloc(NULL, (p.n_edges + 1) * 4);
+    g->edge_seq_off = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8);
+    size_t total = 0;
+    for (uint64_t e = 0; e < p.n_edges; ++e) total += l.len[p.edge_slot[e]] * 4;
+    g->edge_seq = (uint8_t *)xrealloc(NULL, total + 8);
+    size_t at = 0;
+    for (uint64_t e = 0; e < p.n_edges; ++e) {
+        g->edge_src[e] = p.edge_node[0][e]; g->edge_dst[e] = p.edge_node[1][e]; g->edge_slot[e] = p.edge_slot[e]; g->edge_weight[e] = p.edge_w[e];
+        g->edge_seq_off[e] = at;
+        at += ko_decompress_edge(l.bytes[p.edge_slot[e]], l.len[p.edge_slot[e]], g->edge_seq + at);
+    }
+    g->edge_seq_off[p.n_edges] = at;
+    pt_stats(&p, &g->stats);
+    labels_free(&l); pg_free(&p);
+    *out = g;
+    return KO_OK;
 }
 
 int ko_build_files(const char *const *paths, size_t n_paths, int file_type, int reverse_complement,
@@ -1085,6 +1273,7 @@ void ko_graph_free(ko_graph *g)
 {
     if (!g) return;
     free(g->edge_src); free(g->edge_dst); free(g->edge_slot); free(g->edge_weight); free(g->edge_label);
+    free(g->edge_seq_off); free(g->edge_seq);
     free(g);
 }
 

@@ -72,6 +72,10 @@ typedef struct {
     /* HmGIR/HsGIR observable (stats/collections.rs:170-208): same sets, counted by the
      * GIR restatement (hm_gir.rs:91-153) run beside the graph build.                 */
     uint64_t  gir_node_count, gir_edge_count;
+    /* after a 's' (shrink) stage: every edge's whole sequence as ASCII, edge e = edge_seq[edge_seq_off[e] ..
+     * edge_seq_off[e+1]); edge_label then only holds meaningful bytes for edges that were never merged        */
+    uint64_t *edge_seq_off;
+    uint8_t  *edge_seq;
 } ko_graph;
 
 /* error codes mirror the reference's panics */
@@ -103,8 +107,14 @@ void ko_set_prune_dead_paths(int on);
 uint64_t ko_last_prune_passes(void);
 /* general form: `stages` is applied in order to the finished PtGraph of every ko_build_*: 'd' = remove_dead_paths,
  * 'w' = Clean::remove_weak_edges(weak_threshold) (pruner.rs:84-93, over petgraph's retain_edges / retain_nodes:
- * indices visited in descending order, rejected ones swap_removed); "" = none */
+ * indices visited in descending order, rejected ones swap_removed), 's' = Shrinkable::shrink (shrinker.rs:38-209,
+ * with EdgeSlice::merge slices.rs:23-34); "" = none */
 void ko_set_post_build(const char *stages, uint32_t weak_threshold);
+/* PtGraph::from_edges + shrink on a hand-made graph (the in-file tests of shrinker.rs:237-488): slot i of SEQUENCES =
+ * compress_edge(slot_ascii[i]) (slot 0 unused); edge j = (src[j], dst[j], (EdgeSlice(slot[j]), w[j])).  Result: endpoints,
+ * weights and edge_seq of the shrunk graph (no fixed-stride labels) */
+int  ko_shrink_from_edges(const uint64_t *src, const uint64_t *dst, const uint64_t *slot, const uint32_t *w, size_t n_edges,
+                          const char *const *slot_ascii, size_t n_slots, size_t k, ko_graph **out);
 void ko_graph_free(ko_graph *g);
 const char *ko_last_error(void);
 

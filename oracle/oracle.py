@@ -37,7 +37,8 @@ class KoGraph(C.Structure):
                 ("edge_weight", C.POINTER(C.c_uint32)), ("edge_slot", C.POINTER(C.c_uint64)),
                 ("edge_label", C.POINTER(C.c_uint8)), ("label_stride", C.c_uint32),
                 ("n_sequences", C.c_uint64), ("stats", KoStats),
-                ("gir_node_count", C.c_uint64), ("gir_edge_count", C.c_uint64)]
+                ("gir_node_count", C.c_uint64), ("gir_edge_count", C.c_uint64),
+                ("edge_seq_off", C.POINTER(C.c_uint64)), ("edge_seq", C.POINTER(C.c_uint8))]
 
 
 class KoReads(C.Structure):
@@ -217,13 +218,22 @@ class OracleGraph:
         self.edge_weight = np.ctypeslib.as_array(g.edge_weight, (ne,)).copy() if ne else np.zeros(0, np.uint32)
         self.edge_slot = np.ctypeslib.as_array(g.edge_slot, (ne,)).copy() if ne else np.zeros(0, np.uint64)
         self.edge_label = (np.ctypeslib.as_array(g.edge_label, (ne, g.label_stride)).copy()
-                           if ne else np.zeros((0, g.label_stride), np.uint8))
+                           if ne and bool(g.edge_label) else np.zeros((0, g.label_stride), np.uint8))
         s = g.stats
         self.stats = dict(node_count=s.node_count, edge_count=s.edge_count, max_edge_weight=s.max_edge_weight,
                           avg_edge_weight=s.avg_edge_weight, max_in_degree=s.max_in_degree,
                           max_out_degree=s.max_out_degree, avg_out_degree=s.avg_out_degree,
                           incoming_vert_count=s.incoming_vert_count, outgoing_vert_count=s.outgoing_vert_count)
         self.gir_counts = (g.gir_node_count, g.gir_edge_count)
+        self.edge_seq = None                 # after a shrink stage: every edge's whole sequence
+        if bool(g.edge_seq_off):
+            off = np.ctypeslib.as_array(g.edge_seq_off, (ne + 1,)).copy()
+            raw = bytes(np.ctypeslib.as_array(g.edge_seq, (max(int(off[-1]), 1),))[:int(off[-1])])
+            self.edge_seq = [raw[int(off[i]):int(off[i + 1])].decode() for i in range(ne)]
+
+    def contigs(self):
+        """after shrink: sorted (sequence, weight) of every edge; the endpoints are its first and last k-1 bases"""
+        return sorted(zip(self.edge_seq, (int(w) for w in self.edge_weight)))
 
     def kmer_strings(self):
         """decompress_edge of every label -> list of ASCII k-mers (small graphs only)."""
@@ -241,7 +251,8 @@ def _paths(paths):
 
 def _stages(remove_weak_edges, remove_dead_paths, stages):
     """post-build stages on the PtGraph, in order: 'w' = Clean::remove_weak_edges(threshold) (pruner.rs:84-93),
-    'd' = Prunable::remove_dead_paths (pruner.rs:36-82); default: weak edges first if both are asked for"""
+    'd' = Prunable::remove_dead_paths (pruner.rs:36-82), 's' = Shrinkable::shrink (shrinker.rs:165-176);
+    default: weak edges first if both are asked for"""
     if stages is None:
         stages = ("w" if remove_weak_edges is not None else "") + ("d" if remove_dead_paths else "")
     lib().ko_set_post_build(stages.encode(), int(remove_weak_edges or 0))
@@ -282,6 +293,27 @@ def build_ascii(reads, k, reverse_complement=False, with_gir=False, remove_dead_
     rc = lib().ko_build_ascii(reads.ctypes.data, reads.shape[0], reads.shape[1], int(reverse_complement), k,
                               int(with_gir), C.byref(gp))
     lib().ko_set_post_build(b"", 0)
+    if rc:
+        raise OracleError(rc, lib().ko_last_error().decode())
+    try:
+        return OracleGraph(gp, k)
+    finally:
+        lib().ko_graph_free(gp)
+
+
+def shrink_from_edges(edges, slot_ascii, k):
+    """PtGraph::from_edges(edges) then shrink(): edges = [(src, dst, slot, weight)], slot_ascii[i] = the ASCII edge in
+    SEQUENCES slot i (slot 0 unused) -> OracleGraph with edge_seq"""
+    n = len(edges)
+    arr = lambda vals, t: (t * max(n, 1))(*vals)
+    slots = (C.c_char_p * len(slot_ascii))(*[x.encode() if x else b"" for x in slot_ascii])
+    gp = C.POINTER(KoGraph)()
+    L = lib()
+    L.ko_shrink_from_edges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                       C.c_size_t, C.POINTER(C.POINTER(KoGraph))]
+    rc = L.ko_shrink_from_edges(arr([e[0] for e in edges], C.c_uint64), arr([e[1] for e in edges], C.c_uint64),
+                                arr([e[2] for e in edges], C.c_uint64), arr([e[3] for e in edges], C.c_uint32), n,
+                                slots, len(slot_ascii), k, C.byref(gp))
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:
