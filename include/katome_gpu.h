@@ -280,6 +280,27 @@ int katome_dev_remove_dead_paths(katome_builder *b, katome_dev_graph *graph, kat
 /* the finalized graph as it stands now (after katome_dev_remove_dead_paths / katome_dev_remove_weak_edges) */
 int katome_dev_current_graph(katome_builder *b, katome_dev_graph *out);
 
+/* Shrinkable::shrink for PtGraph (shrinker.rs:165-209; labels merged as EdgeSlice::merge does, slices.rs:23-34) on
+ * the finalized graph as it stands: every maximal straight path (inner vertices with exactly one edge in and one out)
+ * becomes ONE edge spelling the whole path, with the weight of the path's first edge (shrinker.rs:181,200); the inner
+ * vertices disappear (remove_single_vertices, shrinker.rs:172).  The graph of the builder is left untouched; the
+ * result is a separate set of device arrays owned by the builder (valid until the next call or destroy):
+ *   d_edge_label: the paths in compress_edge format (compress.rs:250-271: [pad][packed bases, left-aligned]), edge i
+ *   at bytes [d_edge_label_off[i], d_edge_label_off[i+1]); d_edge_kmers[i] = k-mers merged into edge i.
+ * The SET of merged edges (sequence, weight, end vertices) is the reference's wherever its traversal starts from a
+ * vertex without incoming edges; the numbering is this library's (edges in the order of their first k-mer in the
+ * input graph, vertices in their input order) -- see DESIGN.md "shrink" for what the reference's order depends on. */
+typedef struct {
+    uint64_t  n_nodes, n_edges, label_bytes;
+    uint32_t  key_words, _pad;
+    uint64_t *d_edge_src, *d_edge_dst;
+    uint32_t *d_edge_weight, *d_edge_kmers;
+    uint64_t *d_edge_label_off;
+    uint8_t  *d_edge_label;
+    uint64_t *d_node_key;
+} katome_dev_contigs;
+int katome_dev_shrink(katome_builder *b, katome_dev_contigs *out, void *stream);
+
 /* first half of finalize only: sorted distinct edges (key, weight); used by the multi-GPU
  * driver, which resolves node ids across ranks itself                                      */
 int katome_dev_edges(katome_builder *b, uint64_t **d_edge_key, uint32_t **d_edge_weight,

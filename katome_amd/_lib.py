@@ -44,6 +44,13 @@ class PruneStats(C.Structure):
                 ("host_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class DevContigs(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("label_bytes", C.c_uint64), ("key_words", C.c_uint32),
+                ("_pad", C.c_uint32), ("d_edge_src", C.c_void_p), ("d_edge_dst", C.c_void_p), ("d_edge_weight", C.c_void_p),
+                ("d_edge_kmers", C.c_void_p), ("d_edge_label_off", C.c_void_p), ("d_edge_label", C.c_void_p),
+                ("d_node_key", C.c_void_p)]
+
+
 class DevGraph(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("key_words", C.c_uint32),
                 ("label_stride", C.c_uint32), ("d_edge_key", C.c_void_p), ("d_edge_weight", C.c_void_p),
@@ -87,6 +94,7 @@ SYMBOLS = {
     "katome_dev_insert_tiles": (_i, [_vp, _vp, _u64, _u32, _vp]),
     "katome_dev_expand_tiles": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
     "katome_dev_finalize": (_i, [_vp, C.POINTER(DevGraph), _vp]),
+    "katome_dev_shrink": (_i, [_vp, C.POINTER(DevContigs), _vp]),
     "katome_dev_current_graph": (_i, [_vp, C.POINTER(DevGraph)]),
     "katome_dev_remove_dead_paths": (_i, [_vp, C.POINTER(DevGraph), C.POINTER(PruneStats), _vp]),
     "katome_dev_edges": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),

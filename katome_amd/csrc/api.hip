@@ -16,9 +16,9 @@ using namespace katome;
 
 // optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
 enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
-             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_COUNT };
+             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_SHRINK, PH_COUNT };
 static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
-                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles", "first_seen_order", "remove_dead_paths"};
+                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles", "first_seen_order", "remove_dead_paths", "shrink"};
 struct Profiler {
     bool on = false;
     struct Ev { int phase; hipEvent_t a, b; };
@@ -69,6 +69,7 @@ struct katome_builder {
     DevBuf scratch_k[2], scratch_w[2];
     // finalized graph
     DevBuf edge_src, edge_dst, edge_label, node_key;
+    ShrinkOutput shrunk;               // result of katome_dev_shrink
     DevBuf edge_age;                   // first-seen-order graphs once remove_* has moved edges (PruneGraph::edge_age)
     uint64_t n_nodes = 0;
     bool finalized = false;
@@ -578,6 +579,27 @@ int katome_dev_remove_dead_paths(katome_builder* b, katome_dev_graph* out, katom
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
         out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = b->node_key.as<u64>();
     }
+    return KATOME_OK;
+}
+
+int katome_dev_shrink(katome_builder* b, katome_dev_contigs* out, void* stream_) {
+    if (!b || !out) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (!b->finalized) { set_error("shrink: call katome_dev_finalize first"); return KATOME_E_ARG; }
+    ShrinkInput in{b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_weight.as<u32>(), b->edge_key.as<u64>(), b->node_key.as<u64>(),
+                   b->n_edges, b->n_nodes, b->nw, b->s.k};
+    {
+        PhaseScope ps(b->prof, PH_SHRINK, stream);
+        KCHECK(dev_shrink(in, b->shrunk, stream));
+    }
+    memset(out, 0, sizeof *out);
+    out->n_nodes = b->shrunk.n_nodes; out->n_edges = b->shrunk.n_edges; out->label_bytes = b->shrunk.label_bytes;
+    out->key_words = b->nw;
+    out->d_edge_src = b->shrunk.edge_src.as<u64>(); out->d_edge_dst = b->shrunk.edge_dst.as<u64>();
+    out->d_edge_weight = b->shrunk.edge_weight.as<u32>(); out->d_edge_kmers = b->shrunk.edge_kmers.as<u32>();
+    out->d_edge_label_off = b->shrunk.edge_label_off.as<u64>(); out->d_edge_label = b->shrunk.edge_label.as<uint8_t>();
+    out->d_node_key = b->shrunk.node_key.as<u64>();
     return KATOME_OK;
 }
 

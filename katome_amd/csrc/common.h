@@ -136,6 +136,17 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
 // Clean::remove_weak_edges with petgraph's retain_edges / retain_nodes numbering, same graph, in place
 int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t stream);
 
+// shrink.hip: Shrinkable::shrink (shrinker.rs:165-209) on a finalized graph; the result lives in its own buffers
+struct ShrinkInput {
+    const uint64_t *edge_src, *edge_dst; const uint32_t* edge_weight; const uint64_t *edge_key, *node_key;
+    uint64_t n_edges, n_nodes; uint32_t nw, k;
+};
+struct ShrinkOutput {
+    DevBuf edge_src, edge_dst, edge_weight, edge_kmers, edge_label_off, edge_label, node_key;
+    uint64_t n_edges = 0, n_nodes = 0, label_bytes = 0;
+};
+int dev_shrink(const ShrinkInput& g, ShrinkOutput& out, hipStream_t stream);
+
 // table.hip
 struct Table {
     DevBuf slots;          // NW=1: {u64 key|OCC, u32 count, u32 pad}; NW=2: {u64 hi|flags, u64 lo, u32 count, u32 pad[3]}

@@ -64,6 +64,34 @@ class DeviceGraph:
         self.node_key = _view(dg.d_node_key, (nn, nw), "<i8", builder, device)
 
 
+class DeviceContigs:
+    """result of Builder.shrink(): merged edges with labels of any length (compress_edge format, edge i at
+    edge_label[edge_label_off[i]:edge_label_off[i+1]])"""
+
+    def __init__(self, dc, builder, device):
+        self.n_nodes, self.n_edges, self.label_bytes, self.key_words = dc.n_nodes, dc.n_edges, dc.label_bytes, dc.key_words
+        ne, nn, nw = dc.n_edges, dc.n_nodes, dc.key_words
+        self.edge_src = _view(dc.d_edge_src, (ne,), "<i8", builder, device)
+        self.edge_dst = _view(dc.d_edge_dst, (ne,), "<i8", builder, device)
+        self.edge_weight = _view(dc.d_edge_weight, (ne,), "<i4", builder, device)
+        self.edge_kmers = _view(dc.d_edge_kmers, (ne,), "<i4", builder, device)
+        self.edge_label_off = _view(dc.d_edge_label_off, (ne + 1,), "<i8", builder, device)
+        self.edge_label = _view(dc.d_edge_label, (dc.label_bytes,), "|u1", builder, device)
+        self.node_key = _view(dc.d_node_key, (nn, nw), "<i8", builder, device)
+
+    def sequences(self):
+        """host: every merged edge decoded to its ACGT string (compress.rs:283-293 decompress_edge)"""
+        off = self.edge_label_off.cpu().numpy()
+        lab = self.edge_label.cpu().numpy()
+        out = []
+        for i in range(self.n_edges):
+            b = lab[off[i]:off[i + 1]]
+            pad = int(b[0])
+            bases = "".join("ACGT"[(int(x) >> s) & 3] for x in b[1:] for s in (6, 4, 2, 0))
+            out.append(bases[:len(bases) - pad])
+        return out
+
+
 class Builder:
     """one GPU's share of a build"""
 
@@ -187,6 +215,12 @@ class Builder:
         order: after the numbering, with petgraph's retain_edges / retain_nodes re-numbering).  On a finalized
         first-seen-order builder: applied now, same re-numbering; fetch the arrays again with graph()."""
         _check(_lib.lib().katome_dev_remove_weak_edges(self._h, threshold))
+
+    def shrink(self):
+        """Shrinkable::shrink (shrinker.rs:165-209) of the finalized graph as it stands -> DeviceContigs"""
+        dc = _lib.DevContigs()
+        _check(_lib.lib().katome_dev_shrink(self._h, C.byref(dc), _stream()))
+        return DeviceContigs(dc, self, self.tdev)
 
     def graph(self):
         """the finalized graph as it stands (after remove_dead_paths / remove_weak_edges)"""

@@ -1,4 +1,4 @@
-"""remove_dead_paths at scale: build a synthetic workload in first-seen order on one GPU, prune, print the stats.
+"""remove_dead_paths and shrink at scale: build a synthetic workload in first-seen order on one GPU, prune, shrink, print the stats.
 usage: python tools/bench_prune.py [--workload c3] [--reads N] [--cpu-reads M]
 With --cpu-reads the oracle (1 core) prunes the first M reads' graph for a CPU figure beside it."""
 import argparse
@@ -46,7 +46,15 @@ def main():
     dg, st = b.remove_dead_paths()
     torch.cuda.synchronize()
     t_prune = time.perf_counter() - t0
-    out = {"workload": wl.name, "reads": wl.reads, "k": wl.k, "rc": wl.reverse_complement, "build_ms": t_build * 1e3,
+    t0 = time.perf_counter()
+    dc = b.shrink()
+    torch.cuda.synchronize()
+    t_shrink = time.perf_counter() - t0
+    kmers = dc.edge_kmers
+    shrink = {"ms": t_shrink * 1e3, "nodes": dc.n_nodes, "edges": dc.n_edges, "label_bytes": dc.label_bytes,
+              "longest_path_kmers": int(kmers.max().item()) if dc.n_edges else 0,
+              "mean_path_kmers": float(kmers.double().mean().item()) if dc.n_edges else 0.0}
+    out = {"workload": wl.name, "shrink": shrink, "reads": wl.reads, "k": wl.k, "rc": wl.reverse_complement, "build_ms": t_build * 1e3,
            "prune_ms": t_prune * 1e3, "before": before, "after": (dg.n_nodes, dg.n_edges), "stats": st,
            "phases": {k: v for k, v in b.profile_read().items() if v[1]}}
     b.close()
@@ -59,8 +67,11 @@ def main():
         t1 = time.perf_counter()
         pruned = o.build_ascii(reads, wl.k, wl.reverse_complement, remove_dead_paths=True)
         t2 = time.perf_counter()
+        shrunk = o.build_ascii(reads, wl.k, wl.reverse_complement, stages="ds")
+        t3 = time.perf_counter()
         out["cpu"] = {"reads": n, "edges_before": full.n_edges, "edges_after": pruned.n_edges,
-                      "prune_s": (t2 - t1) - (t1 - t0), "passes": o.last_prune_passes()}
+                      "prune_s": (t2 - t1) - (t1 - t0), "passes": o.last_prune_passes(),
+                      "shrink_s": (t3 - t2) - (t2 - t1), "edges_shrunk": shrunk.n_edges}
     print(json.dumps(out))
 
 
