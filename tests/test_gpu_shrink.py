@@ -172,7 +172,8 @@ def test_tangled_graphs_where_the_traversal_order_cannot_matter(oracle, seed):
         b = _build(kd, packed, len(reads), L, k, rc)
         dc = b.shrink()
         got_all = _contigs(dc, k)
-        assert want and [c for c in got_all if c[0][:k - 1] in ok] == want
+        assert [c for c in got_all if c[0][:k - 1] in ok] == want
+        assert want or k <= 6                 # (at k = 5, 6 nearly every (k-1)-mer has a predecessor: nothing to start from)
         assert sum(dc.edge_kmers.cpu().tolist()) == full.n_edges          # every k-mer of the build is in exactly one merged edge
         b.close()
 
