@@ -1,0 +1,108 @@
+"""CPU sanitizer runs (GPU AddressSanitizer is not available on the pool): the oracle's C restatement -- petgraph lists,
+swap_remove, label merging -- and the product's host-only replay code, built with -fsanitize=address,undefined and
+driven from plain mains; the sanitized oracle must also reproduce the pinned constants."""
+import json
+import os
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SAN = ["-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-fno-omit-frame-pointer", "-g", "-O1"]
+ENV = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+
+
+def _have_sanitizers(tmp):
+    src = os.path.join(tmp, "t.c")
+    open(src, "w").write("int main(void){return 0;}\n")
+    try:
+        subprocess.check_call(["gcc"] + SAN + [src, "-o", os.path.join(tmp, "t")], stderr=subprocess.DEVNULL)
+        return subprocess.call([os.path.join(tmp, "t")], env=ENV) == 0
+    except (subprocess.CalledProcessError, OSError):
+        return False
+
+
+@pytest.fixture(scope="module")
+def oracle_selftest(tmp_path_factory):
+    tmp = str(tmp_path_factory.mktemp("san"))
+    if not _have_sanitizers(tmp):
+        pytest.skip("gcc sanitizer runtime not available")
+    exe = os.path.join(tmp, "oracle_selftest")
+    subprocess.check_call(["gcc", "-std=c11"] + SAN + [os.path.join(ROOT, "oracle", "katome_oracle.c"),
+                                                       os.path.join(ROOT, "oracle", "selftest.c"), "-o", exe, "-lm"])
+    return exe
+
+
+def _run(exe, k, rc, stages, thr, files):
+    out = subprocess.check_output([exe, str(k), str(int(rc)), stages or "-", str(thr)] + files, env=ENV, timeout=600)
+    return [int(x) for x in out.split()]
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_oracle_under_asan_reproduces_the_pins(oracle_selftest, golden_dir, i):
+    pinned = json.load(open(os.path.join(golden_dir, "pinned.json")))
+    f = [os.path.join(golden_dir, pinned["fixtures"][i])]
+    k = pinned["k"]
+    nodes, edges, read_bytes, _, _ = _run(oracle_selftest, k, False, "", 0, f)
+    assert [nodes, edges] == pinned["counts"]["values"][i]
+    assert read_bytes == pinned["read_bytes"]["values"][i]
+    assert _run(oracle_selftest, k, False, "d", 0, f)[:2] == pinned["remove_dead_paths"]["counts"][i]
+    assert _run(oracle_selftest, k, False, "w", pinned["remove_weak_edges"]["thresholds"][i], f)[:2] == pinned["remove_weak_edges"]["counts"][i]
+    assert _run(oracle_selftest, k, False, "s", 0, f)[:2] == pinned["shrink"]["counts"][i]
+
+
+@pytest.mark.parametrize("k,rc,stages", [(5, True, "ds"), (6, True, "wds"), (8, False, "sd"), (31, True, "dws"), (40, True, "ds")])
+def test_oracle_stage_chains_under_asan(oracle_selftest, golden_dir, k, rc, stages):
+    """small k makes tangled graphs (cycles, self-loops, merging tips): every removal and merge path runs clean"""
+    f = [os.path.join(golden_dir, "data2.txt"), os.path.join(golden_dir, "data1.txt")]
+    nodes, edges, _, _, seq = _run(oracle_selftest, k, rc, stages, 2, f)
+    assert nodes >= 0 and edges >= 0 and (seq >= edges * k)
+
+
+def test_replays_under_asan(tmp_path):
+    tmp = str(tmp_path)
+    if not _have_sanitizers(tmp):
+        pytest.skip("gcc sanitizer runtime not available")
+    exe = os.path.join(tmp, "replay_selftest")
+    subprocess.check_call(["g++", "-std=c++17"] + SAN + [os.path.join(HERE, "hostshim", "prune_replay_selftest.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], env=ENV, timeout=600)
+    assert out.split()[0] == b"ok" and int(out.split()[1]) == 300
+
+
+def _build_ingest(tmp, flags, name):
+    exe = os.path.join(tmp, name)
+    subprocess.check_call(["g++", "-std=c++17"] + flags + ["-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                                                          os.path.join(ROOT, "katome_amd", "csrc", "ingest.cpp"),
+                                                          os.path.join(HERE, "hostshim", "ingest_selftest.cpp"), "-o", exe, "-lpthread"])
+    return exe
+
+
+@pytest.mark.skipif(not os.path.isdir("/opt/rocm/include"), reason="HIP headers (for the shared declarations) not installed")
+def test_ingest_under_asan_and_tsan(tmp_path, golden_dir):
+    """the product's host ingest (file checks, record scan, ACGT filter, 2-bit packing) from a plain main: address /
+    undefined-behaviour / leak checks, then the threaded scan under ThreadSanitizer; one thread and many must agree"""
+    tmp = str(tmp_path)
+    if not _have_sanitizers(tmp):
+        pytest.skip("gcc sanitizer runtime not available")
+    files = [os.path.join(golden_dir, "data2.txt"), os.path.join(golden_dir, "data3.txt"), os.path.join(golden_dir, "data1.txt")]
+    exe = _build_ingest(tmp, SAN, "ingest_asan")
+    one = subprocess.check_output([exe, "40", "1"] + files, env=dict(ENV, KATOME_INGEST_THREADS="1"), timeout=300).split()
+    many = subprocess.check_output([exe, "40", "1"] + files, env=dict(ENV, KATOME_INGEST_THREADS="7", KATOME_INGEST_MIN_CHUNK="500"),
+                                   timeout=300).split()
+    assert one == many and int(one[0]) == 0
+    pinned = json.load(open(os.path.join(golden_dir, "pinned.json")))
+    assert int(one[3]) == sum(pinned["read_bytes"]["values"])   # bytes of the accepted reads (tests/build.rs:27; data2 holds 33 reads with an N)
+    assert int(one[2]) * 100 == int(one[3]) and int(one[6]) == 100
+    assert int(subprocess.check_output([exe, "40", "1", os.path.join(golden_dir, "data_too_short_read.txt")], env=ENV).split()[0]) == -6
+    assert int(subprocess.check_output([exe, "40", "1", golden_dir], env=ENV).split()[0]) == -2
+    tsan = ["-fsanitize=thread", "-g", "-O1"]
+    try:
+        exe = _build_ingest(tmp, tsan, "ingest_tsan")
+    except subprocess.CalledProcessError:
+        pytest.skip("ThreadSanitizer runtime not available")
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=1", KATOME_INGEST_THREADS="7", KATOME_INGEST_MIN_CHUNK="500")
+    r = subprocess.run([exe, "40", "1"] + files, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    if r.returncode != 0 and b"unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow in this container")
+    assert r.returncode == 0 and r.stdout.split() == one, r.stderr[-2000:]
