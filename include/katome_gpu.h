@@ -280,6 +280,22 @@ int katome_dev_remove_dead_paths(katome_builder *b, katome_dev_graph *graph, kat
 /* the finalized graph as it stands now (after katome_dev_remove_dead_paths / katome_dev_remove_weak_edges) */
 int katome_dev_current_graph(katome_builder *b, katome_dev_graph *out);
 
+/* host result of katome_shrink_files / katome_shrink_packed: the build (with the pruning the flags ask for) followed by
+ * Shrinkable::shrink, see katome_dev_shrink below for what the arrays mean.  Owned by the library until katome_contigs_free */
+typedef struct {
+    uint64_t n_nodes, n_edges, label_bytes, read_bytes;
+    uint32_t k, key_words;
+    const uint64_t *edge_src, *edge_dst;       /* [n_edges] ids into node_key                                  */
+    const uint32_t *edge_weight, *edge_kmers;  /* weight of the path's first k-mer; k-mers merged into the edge  */
+    const uint64_t *edge_label_off;            /* [n_edges + 1] byte offsets into edge_label                    */
+    const uint8_t  *edge_label;                /* compress_edge format, edge i = bytes [off[i], off[i+1])        */
+    const uint64_t *node_key;                  /* [n_nodes][key_words] packed (k-1)-mers                         */
+} katome_contigs;
+int  katome_shrink_files(const katome_settings *s, const char *const *paths, size_t n_paths, katome_contigs **out);
+int  katome_shrink_packed(const katome_settings *s, const uint8_t *packed, uint64_t n_reads, uint32_t read_len,
+                          const uint8_t *skip, katome_contigs **out);
+void katome_contigs_free(katome_contigs *c);
+
 /* Shrinkable::shrink for PtGraph (shrinker.rs:165-209; labels merged as EdgeSlice::merge does, slices.rs:23-34) on
  * the finalized graph as it stands: every maximal straight path (inner vertices with exactly one edge in and one out)
  * becomes ONE edge spelling the whole path, with the weight of the path's first edge (shrinker.rs:181,200); the inner

@@ -44,6 +44,12 @@ class PruneStats(C.Structure):
                 ("host_ms", C.c_double), ("total_ms", C.c_double)]
 
 
+class Contigs(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("label_bytes", C.c_uint64), ("read_bytes", C.c_uint64),
+                ("k", C.c_uint32), ("key_words", C.c_uint32), ("edge_src", u64p), ("edge_dst", u64p), ("edge_weight", u32p),
+                ("edge_kmers", u32p), ("edge_label_off", u64p), ("edge_label", u8p), ("node_key", u64p)]
+
+
 class DevContigs(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("label_bytes", C.c_uint64), ("key_words", C.c_uint32),
                 ("_pad", C.c_uint32), ("d_edge_src", C.c_void_p), ("d_edge_dst", C.c_void_p), ("d_edge_weight", C.c_void_p),
@@ -94,6 +100,9 @@ SYMBOLS = {
     "katome_dev_insert_tiles": (_i, [_vp, _vp, _u64, _u32, _vp]),
     "katome_dev_expand_tiles": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
     "katome_dev_finalize": (_i, [_vp, C.POINTER(DevGraph), _vp]),
+    "katome_shrink_files": (_i, [C.POINTER(Settings), _pp, _sz, C.POINTER(C.POINTER(Contigs))]),
+    "katome_shrink_packed": (_i, [C.POINTER(Settings), _vp, _u64, _u32, _vp, C.POINTER(C.POINTER(Contigs))]),
+    "katome_contigs_free": (None, [C.POINTER(Contigs)]),
     "katome_dev_shrink": (_i, [_vp, C.POINTER(DevContigs), _vp]),
     "katome_dev_current_graph": (_i, [_vp, C.POINTER(DevGraph)]),
     "katome_dev_remove_dead_paths": (_i, [_vp, C.POINTER(DevGraph), C.POINTER(PruneStats), _vp]),

@@ -223,6 +223,51 @@ class GpuGraph:
         return sorted(zip(self.kmer_strings(), (int(w) for w in self.edge_weight)))
 
 
+class GpuContigs:
+    """The build followed by Shrinkable::shrink (shrinker.rs:165-209): one edge per maximal straight path.
+
+    edge_seq: the paths as ACGT strings (decoded from the compress_edge labels); edge_weight: weight of each path's
+    first k-mer; edge_kmers: k-mers merged into each edge; edge_src/edge_dst: ids into node_key."""
+
+    def __init__(self, cptr):
+        c = cptr.contents
+        ne, nn, nw = c.n_edges, c.n_nodes, c.key_words
+        self.k, self.n_nodes, self.n_edges, self.read_bytes, self.key_words = c.k, nn, ne, c.read_bytes, nw
+
+        def arr(ptr, n, dtype):
+            return np.ctypeslib.as_array(ptr, (n,)).copy() if n else np.zeros(0, dtype)
+
+        self.edge_src, self.edge_dst = arr(c.edge_src, ne, np.uint64), arr(c.edge_dst, ne, np.uint64)
+        self.edge_weight, self.edge_kmers = arr(c.edge_weight, ne, np.uint32), arr(c.edge_kmers, ne, np.uint32)
+        self.edge_label_off = np.ctypeslib.as_array(c.edge_label_off, (ne + 1,)).copy()
+        self.edge_label = arr(c.edge_label, c.label_bytes, np.uint8)
+        self.node_key = arr(c.node_key, nn * nw, np.uint64).reshape(nn, nw)
+        self.edge_seq = []
+        for i in range(ne):
+            b = self.edge_label[int(self.edge_label_off[i]):int(self.edge_label_off[i + 1])]
+            bases = "".join("ACGT"[(int(x) >> sh) & 3] for x in b[1:] for sh in (6, 4, 2, 0))
+            self.edge_seq.append(bases[:len(bases) - int(b[0])])
+
+    @classmethod
+    def create(cls, input_files, ft, reverse_complement, minimal_weight_threshold=0, device=0, first_seen_order=False,
+               remove_dead_paths=False):
+        """Build::create, optionally remove_dead_paths, then shrink -- the start of assemble_with_graph
+        (asm/basic_assembler.rs:58-65) -> (GpuContigs, number_of_read_bytes)"""
+        s = make_settings(K_SIZE, ft, reverse_complement, minimal_weight_threshold, device,
+                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths)
+        cp = C.POINTER(_lib.Contigs)()
+        _check(_lib.lib().katome_shrink_files(C.byref(s), _paths(input_files), len(input_files), C.byref(cp)))
+        try:
+            c = cls(cp)
+        finally:
+            _lib.lib().katome_contigs_free(cp)
+        return c, c.read_bytes
+
+    def contigs(self):
+        """sorted (sequence, weight): the parity observable"""
+        return sorted(zip(self.edge_seq, (int(w) for w in self.edge_weight)))
+
+
 def _int_to_kmer(v, k):
     return "".join("ACGT"[(v >> (2 * (k - 1 - i))) & 3] for i in range(k))
 

@@ -713,9 +713,20 @@ void katome_graph_free(katome_graph* g) {
     delete o;
 }
 
+struct ContigsOwner {          // katome_contigs followed by what it owns
+    katome_contigs c;
+    std::vector<void*> mem;
+};
+void katome_contigs_free(katome_contigs* c) {
+    if (!c) return;
+    ContigsOwner* o = reinterpret_cast<ContigsOwner*>(c);
+    for (void* p : o->mem) free(p);
+    delete o;
+}
+
 }  // extern "C"
 
-template <class T> static int d2h(GraphOwner* o, const T** dst, const void* d_src, size_t count) {
+template <class T, class Owner> static int d2h(Owner* o, const T** dst, const void* d_src, size_t count) {
     T* h = (T*)malloc(std::max<size_t>(count, 1) * sizeof(T));
     if (!h) { set_error("out of host memory"); return KATOME_E_OOM; }
     o->mem.push_back(h);
@@ -747,6 +758,41 @@ static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** 
     return KATOME_OK;
 }
 
+// finalize (+ the pruning the flags ask for) + shrink, copied to host arrays
+static int contigs_to_host(katome_builder* b, uint64_t read_bytes, katome_contigs** out) {
+    katome_dev_graph dg;
+    KCHECK(katome_dev_finalize(b, &dg, nullptr));
+    if (b->s.flags & KATOME_FLAG_REMOVE_DEAD_PATHS) KCHECK(katome_dev_remove_dead_paths(b, &dg, nullptr, nullptr));
+    katome_dev_contigs dc;
+    KCHECK(katome_dev_shrink(b, &dc, nullptr));
+    ContigsOwner* o = new (std::nothrow) ContigsOwner();
+    if (!o) { set_error("out of host memory"); return KATOME_E_OOM; }
+    memset(&o->c, 0, sizeof o->c);
+    katome_contigs* c = &o->c;
+    c->n_nodes = dc.n_nodes; c->n_edges = dc.n_edges; c->label_bytes = dc.label_bytes; c->read_bytes = read_bytes;
+    c->k = b->s.k; c->key_words = dc.key_words;
+    int rc = KATOME_OK;
+    if ((rc = d2h(o, &c->edge_src, dc.d_edge_src, dc.n_edges)) || (rc = d2h(o, &c->edge_dst, dc.d_edge_dst, dc.n_edges)) ||
+        (rc = d2h(o, &c->edge_weight, dc.d_edge_weight, dc.n_edges)) || (rc = d2h(o, &c->edge_kmers, dc.d_edge_kmers, dc.n_edges)) ||
+        (rc = d2h(o, &c->edge_label_off, dc.d_edge_label_off, dc.n_edges ? dc.n_edges + 1 : 0)) ||
+        (rc = d2h(o, &c->edge_label, dc.d_edge_label, dc.label_bytes)) ||
+        (rc = d2h(o, &c->node_key, dc.d_node_key, dc.n_nodes * dc.key_words))) {
+        katome_contigs_free(c);
+        return rc;
+    }
+    if (dc.n_edges == 0) const_cast<uint64_t*>(c->edge_label_off)[0] = 0;       // (d2h hands out room for one entry even when asked for none)
+    *out = c;
+    return KATOME_OK;
+}
+
+// what a host entry hands back: the graph, or the graph after shrink
+struct Finish {
+    katome_graph** graph; katome_contigs** contigs;
+    int operator()(katome_builder* b, uint64_t read_bytes) const {
+        return contigs ? contigs_to_host(b, read_bytes, contigs) : graph_to_host(b, read_bytes, graph);
+    }
+};
+
 // records per extraction batch: bounded by a slice of free device memory
 static uint64_t batch_records(uint32_t nw) {
     size_t free_b = 0, total_b = 0;
@@ -758,10 +804,11 @@ static uint64_t batch_records(uint32_t nw) {
 
 extern "C" {
 
-int katome_build_packed(const katome_settings* s, const uint8_t* packed, uint64_t n_reads, uint32_t read_len,
-                        const uint8_t* skip, katome_graph** out) {
-    if (!s || !out || (!packed && n_reads)) { set_error("null argument"); return KATOME_E_ARG; }
-    *out = nullptr;
+}  // extern "C"
+
+static int build_packed_impl(const katome_settings* s, const uint8_t* packed, uint64_t n_reads, uint32_t read_len,
+                             const uint8_t* skip, const Finish& finish, const uint64_t* read_bytes_override = nullptr) {
+    if (!s || (!packed && n_reads)) { set_error("null argument"); return KATOME_E_ARG; }
     KCHECK(check_k(s->k));
     if (n_reads && read_len < s->k) {
         // only an ACCEPTED read can be too short (builder.rs:155-158 filters first)
@@ -804,10 +851,25 @@ int katome_build_packed(const katome_settings* s, const uint8_t* packed, uint64_
             if (rc) break;
         }
         d_rec.release(); d_packed.release(); d_skip.release();
-        rc = graph_to_host(b, read_bytes, out);
+        rc = finish(b, read_bytes_override ? *read_bytes_override : read_bytes);
     } while (0);
     katome_builder_destroy(b);
     return rc;
+}
+
+extern "C" {
+
+int katome_build_packed(const katome_settings* s, const uint8_t* packed, uint64_t n_reads, uint32_t read_len,
+                        const uint8_t* skip, katome_graph** out) {
+    if (!out) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    return build_packed_impl(s, packed, n_reads, read_len, skip, Finish{out, nullptr});
+}
+int katome_shrink_packed(const katome_settings* s, const uint8_t* packed, uint64_t n_reads, uint32_t read_len,
+                         const uint8_t* skip, katome_contigs** out) {
+    if (!out) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    return build_packed_impl(s, packed, n_reads, read_len, skip, Finish{nullptr, out});
 }
 
 int katome_ingest_files(const katome_settings* s, const char* const* paths, size_t n_paths, katome_reads** out) {
@@ -835,9 +897,10 @@ void katome_reads_free(katome_reads* r) {
     delete o;
 }
 
-int katome_build_files(const katome_settings* s, const char* const* paths, size_t n_paths, katome_graph** out) {
-    if (!s || !out || (!paths && n_paths)) { set_error("null argument"); return KATOME_E_ARG; }
-    *out = nullptr;
+}  // extern "C"
+
+static int build_files_impl(const katome_settings* s, const char* const* paths, size_t n_paths, const Finish& finish) {
+    if (!s || (!paths && n_paths)) { set_error("null argument"); return KATOME_E_ARG; }
     HostReads hr;
     KCHECK(ingest_files(s, paths, n_paths, hr));           // path / parse / short-read errors surface before any GPU work
     if (s->file_type == 2) {
@@ -858,23 +921,17 @@ int katome_build_files(const katome_settings* s, const char* const* paths, size_
                 if ((rc = katome_dev_insert_weighted(b, d_rec.as<u64>(), d_w.as<u32>(), hr.n_reads, nullptr))) break;
                 if (hipStreamSynchronize(nullptr) != hipSuccess) { set_error("device failure during build"); rc = KATOME_E_DEVICE; break; }
             }
-            rc = graph_to_host(b, hr.read_bytes, out);
+            rc = finish(b, hr.read_bytes);
         } while (0);
         katome_builder_destroy(b);
         return rc;
     }
-    if (hr.fixed_len) {
-        katome_graph* g = nullptr;
-        KCHECK(katome_build_packed(s, hr.packed, hr.n_reads, hr.fixed_len, nullptr, &g));
-        g->read_bytes = hr.read_bytes;
-        *out = g;
-        return KATOME_OK;
-    }
+    if (hr.fixed_len) return build_packed_impl(s, hr.packed, hr.n_reads, hr.fixed_len, nullptr, finish, &hr.read_bytes);
     katome_builder* b = nullptr;
     KCHECK(katome_builder_create(s, &b));
     int rc = KATOME_OK;
     do {
-        if (hr.n_reads == 0) { rc = graph_to_host(b, hr.read_bytes, out); break; }
+        if (hr.n_reads == 0) { rc = finish(b, hr.read_bytes); break; }
         DevBuf d_packed, d_off, d_len, d_pref, d_rec;
         if ((rc = d_packed.alloc(hr.packed_bytes + 32)) || (rc = d_off.alloc((hr.n_reads + 1) * 8)) || (rc = d_len.alloc(hr.n_reads * 4))) break;
         if (hipMemcpy(d_packed.p, hr.packed, hr.packed_bytes, hipMemcpyHostToDevice) != hipSuccess ||
@@ -901,10 +958,23 @@ int katome_build_files(const katome_settings* s, const char* const* paths, size_
         }
         if (rc) break;
         d_rec.release(); d_packed.release(); d_off.release(); d_len.release(); d_pref.release();
-        rc = graph_to_host(b, hr.read_bytes, out);
+        rc = finish(b, hr.read_bytes);
     } while (0);
     katome_builder_destroy(b);
     return rc;
+}
+
+extern "C" {
+
+int katome_build_files(const katome_settings* s, const char* const* paths, size_t n_paths, katome_graph** out) {
+    if (!out) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    return build_files_impl(s, paths, n_paths, Finish{out, nullptr});
+}
+int katome_shrink_files(const katome_settings* s, const char* const* paths, size_t n_paths, katome_contigs** out) {
+    if (!out) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    return build_files_impl(s, paths, n_paths, Finish{nullptr, out});
 }
 
 // Stats<CollectionStats> for PtGraph (stats/collections.rs:137-168), from the host arrays

@@ -178,6 +178,20 @@ def test_tangled_graphs_where_the_traversal_order_cannot_matter(oracle, seed):
         b.close()
 
 
+@pytest.mark.parametrize("name,k,rc,prune", [("data2.txt", 40, False, False), ("data3.txt", 40, True, True), ("data3.txt", 21, True, True),
+                                             ("data2.txt", 63, True, False)])
+def test_host_entry(oracle, golden_dir, name, k, rc, prune):
+    """katome_shrink_files: ingest, build, (first pruning,) shrink, host arrays"""
+    from katome_amd.build import GpuContigs, InputFileType, set_global_k_sizes
+    path = os.path.join(golden_dir, name)
+    set_global_k_sizes(k)
+    c, rb = GpuContigs.create([path], InputFileType.Fastq, rc, 0, first_seen_order=prune, remove_dead_paths=prune)
+    want = oracle.build_files([path], k, rc, stages="ds" if prune else "s")
+    assert rb == want.read_bytes and (c.n_nodes, c.n_edges) == (want.n_nodes, want.n_edges)
+    assert c.contigs() == want.contigs()
+    assert all(len(s) == k + int(m) - 1 for s, m in zip(c.edge_seq, c.edge_kmers))
+
+
 def test_before_finalize_is_an_error():
     from katome_amd import device as kd
     from katome_amd.build import KatomePanic
