@@ -60,6 +60,8 @@ def parse_args():
                     help="number edges and nodes in the reference's first-seen (petgraph) order (single GPU)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
+    ap.add_argument("--next-stages-reads", type=int, default=20_000_000,
+                    help="also time first-seen-order build + remove_dead_paths + shrink on this many reads (0 = skip; N = 1 only)")
     return ap.parse_args()
 
 
@@ -106,6 +108,49 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=Fa
         return dg.n_edges, dg.n_nodes
     finally:
         b.close()
+
+
+def next_stages(wl, sample_reads):
+    """Not part of the metric: the stages SURVEY 8(f) lists after the path, timed on a bounded prefix of the workload --
+    build in the reference's numbering, remove_dead_paths (pruner.rs:36-82), shrink (shrinker.rs:165-209)"""
+    import torch
+    from katome_amd import device as kd
+    w = wl.scaled(min(sample_reads, wl.reads))
+    packed, skip = kd.synth_reads(0, w.reads, w.read_len, w.genome_len, w.err_rate, w.n_inject_percent, device=0)
+    skip_arg = skip if w.n_inject_percent else None
+    b = kd.Builder(w.k, w.reverse_complement, table_slots_hint=int(w.expected_distinct_canonical() * 2.2), first_seen_order=True)
+    span = b.tile_span(w.read_len)
+    out = {"reads": w.reads}
+    try:
+        def timed(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) * 1e3, r
+
+        def build():
+            step = 16 << 20
+            for r0 in range(0, w.reads, step):
+                nr = min(step, w.reads - r0)
+                if span > 1:
+                    b.insert_tiles(b.extract_tiles(packed, nr, w.read_len, span, skip_arg, first_read=r0), span)
+                else:
+                    b.insert(b.extract_fixed(packed, nr, w.read_len, skip_arg, first_read=r0))
+            return b.finalize()
+        ms, dg = timed(build)
+        out["build_first_seen_order_ms"] = ms
+        out["edges"], out["nodes"] = dg.n_edges, dg.n_nodes
+        ms, (dg, st) = timed(b.remove_dead_paths)
+        out["remove_dead_paths_ms"] = ms
+        out["remove_dead_paths"] = {k: st[k] for k in ("passes", "removed_edges", "removed_nodes", "host_ms")}
+        out["edges_after_pruning"] = dg.n_edges
+        ms, dc = timed(b.shrink)
+        out["shrink_ms"] = ms
+        out["edges_after_shrink"] = dc.n_edges
+    finally:
+        b.close()
+    return out
 
 
 def cpu_baseline(wl, sample_reads):
@@ -289,6 +334,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
+        if world == 1 and not use_dist and args.next_stages_reads > 0:
+            line["next_stages"] = next_stages(wl, args.next_stages_reads)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
