@@ -1170,44 +1170,60 @@ static ko_graph *finish(build_ctx *c)
     return g;
 }
 
-/* PtGraph::from_edges + Shrinkable::shrink on hand-made graphs, the shape of shrinker.rs's in-file tests (237-488): SEQUENCES
- * slot i holds compress_edge(slot_ascii[i]) (slot 0 = scratch), edge j = (src, dst, (EdgeSlice(slot), weight)) */
-int ko_shrink_from_edges(const uint64_t *src, const uint64_t *dst, const uint64_t *slot, const uint32_t *w, size_t n_edges,
-                         const char *const *slot_ascii, size_t n_slots, size_t k, ko_graph **out)
+/* Hand-made graphs, the shape of the reference's in-file tests (shrinker.rs:237-488, pruner.rs:259-393): `n_nodes` add_node
+ * calls (more if an edge names a higher index, as PtGraph::from_edges does), then edge j = (src, dst, (EdgeSlice(slot), weight)),
+ * then `stages` in order: 's' shrink, 'd' remove_dead_paths, 'w' remove_weak_edges(threshold), 'v' remove_single_vertices.
+ * SEQUENCES slot i holds compress_edge(slot_ascii[i]) (slot 0 = scratch); slot_ascii may be NULL when no stage reads labels. */
+int ko_run_from_edges(size_t n_nodes, const uint64_t *src, const uint64_t *dst, const uint64_t *slot, const uint32_t *w, size_t n_edges,
+                      const char *const *slot_ascii, size_t n_slots, const char *stages, uint32_t threshold, size_t k, ko_graph **out)
 {
     *out = NULL; g_err[0] = 0;
     ko_set_global_k_sizes(k);
     pgraph_t p; pg_init(&p);
-    uint64_t max_node = 0;
-    for (size_t e = 0; e < n_edges; ++e) { if (src[e] > max_node) max_node = src[e]; if (dst[e] > max_node) max_node = dst[e]; }
-    if (n_edges) for (uint64_t n = 0; n <= max_node; ++n) pg_add_node(&p);        /* from_edges adds the missing nodes */
-    for (size_t e = 0; e < n_edges; ++e) pg_add_edge(&p, src[e], dst[e], slot[e], w[e]);
-    labels_t l; l.n = n_slots; l.bytes = (uint8_t **)calloc(n_slots ? n_slots : 1, sizeof(uint8_t *)); l.len = (size_t *)calloc(n_slots ? n_slots : 1, sizeof(size_t));
-    for (size_t i = 1; i < n_slots; ++i) {
+    uint64_t need = n_nodes;
+    for (size_t e = 0; e < n_edges; ++e) { if (src[e] + 1 > need) need = src[e] + 1; if (dst[e] + 1 > need) need = dst[e] + 1; }
+    for (uint64_t n = 0; n < need; ++n) pg_add_node(&p);
+    for (size_t e = 0; e < n_edges; ++e) pg_add_edge(&p, src[e], dst[e], slot ? slot[e] : 0, w[e]);
+    labels_t l; l.n = slot_ascii ? n_slots : 0;
+    l.bytes = (uint8_t **)calloc(l.n ? l.n : 1, sizeof(uint8_t *)); l.len = (size_t *)calloc(l.n ? l.n : 1, sizeof(size_t));
+    for (size_t i = 1; i < l.n; ++i) {
         size_t n = strlen(slot_ascii[i]);
         l.bytes[i] = (uint8_t *)xrealloc(NULL, n / 4 + 8);
         l.len[i] = ko_compress_edge((const uint8_t *)slot_ascii[i], n, l.bytes[i]);
     }
-    shrink(&p, &l);
+    for (const char *st = stages ? stages : ""; *st; ++st) {
+        if (*st == 's') {
+            if (!l.n) { snprintf(g_err, sizeof g_err, "oracle: shrink needs labels"); labels_free(&l); pg_free(&p); return KO_E_ARG; }
+            shrink(&p, &l);
+        }
+        else if (*st == 'd') remove_dead_paths(&p);
+        else if (*st == 'w') remove_weak_edges(&p, threshold);
+        else if (*st == 'v') remove_single_vertices(&p);
+    }
     ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
     g->n_nodes = p.n_nodes; g->n_edges = p.n_edges;
     g->edge_src = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8); g->edge_dst = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8);
     g->edge_slot = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8); g->edge_weight = (uint32_t *)xrealloc(NULL, (p.n_edges + 1) * 4);
     g->edge_seq_off = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8);
     size_t total = 0;
-    for (uint64_t e = 0; e < p.n_edges; ++e) total += l.len[p.edge_slot[e]] * 4;
+    for (uint64_t e = 0; e < p.n_edges && l.n; ++e) total += l.len[p.edge_slot[e]] * 4;
     g->edge_seq = (uint8_t *)xrealloc(NULL, total + 8);
     size_t at = 0;
     for (uint64_t e = 0; e < p.n_edges; ++e) {
         g->edge_src[e] = p.edge_node[0][e]; g->edge_dst[e] = p.edge_node[1][e]; g->edge_slot[e] = p.edge_slot[e]; g->edge_weight[e] = p.edge_w[e];
         g->edge_seq_off[e] = at;
-        at += ko_decompress_edge(l.bytes[p.edge_slot[e]], l.len[p.edge_slot[e]], g->edge_seq + at);
+        if (l.n && l.len[p.edge_slot[e]]) at += ko_decompress_edge(l.bytes[p.edge_slot[e]], l.len[p.edge_slot[e]], g->edge_seq + at);
     }
     g->edge_seq_off[p.n_edges] = at;
     pt_stats(&p, &g->stats);
     labels_free(&l); pg_free(&p);
     *out = g;
     return KO_OK;
+}
+int ko_shrink_from_edges(const uint64_t *src, const uint64_t *dst, const uint64_t *slot, const uint32_t *w, size_t n_edges,
+                         const char *const *slot_ascii, size_t n_slots, size_t k, ko_graph **out)
+{
+    return ko_run_from_edges(0, src, dst, slot, w, n_edges, slot_ascii, n_slots, "s", 0, k, out);
 }
 
 int ko_build_files(const char *const *paths, size_t n_paths, int file_type, int reverse_complement,

@@ -115,6 +115,9 @@ void ko_set_post_build(const char *stages, uint32_t weak_threshold);
  * weights and edge_seq of the shrunk graph (no fixed-stride labels) */
 int  ko_shrink_from_edges(const uint64_t *src, const uint64_t *dst, const uint64_t *slot, const uint32_t *w, size_t n_edges,
                           const char *const *slot_ascii, size_t n_slots, size_t k, ko_graph **out);
+/* general form: n_nodes add_node calls first (pruner.rs:277-285 style), any stage string ('s','d','w','v' = remove_single_vertices) */
+int  ko_run_from_edges(size_t n_nodes, const uint64_t *src, const uint64_t *dst, const uint64_t *slot, const uint32_t *w, size_t n_edges,
+                       const char *const *slot_ascii, size_t n_slots, const char *stages, uint32_t threshold, size_t k, ko_graph **out);
 void ko_graph_free(ko_graph *g);
 const char *ko_last_error(void);
 

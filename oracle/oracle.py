@@ -322,6 +322,24 @@ def shrink_from_edges(edges, slot_ascii, k):
         lib().ko_graph_free(gp)
 
 
+def run_from_edges(n_nodes, edges, stages, threshold=0, k=40):
+    """hand-made PtGraph (n_nodes add_node calls, edges = [(src, dst, weight)]) through `stages` -> OracleGraph"""
+    n = len(edges)
+    arr = lambda vals, t: (t * max(n, 1))(*vals)
+    gp = C.POINTER(KoGraph)()
+    L = lib()
+    L.ko_run_from_edges.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                    C.c_char_p, C.c_uint32, C.c_size_t, C.POINTER(C.POINTER(KoGraph))]
+    rc = L.ko_run_from_edges(n_nodes, arr([e[0] for e in edges], C.c_uint64), arr([e[1] for e in edges], C.c_uint64), None,
+                             arr([e[2] for e in edges], C.c_uint32), n, None, 0, stages.encode(), threshold, k, C.byref(gp))
+    if rc:
+        raise OracleError(rc, lib().ko_last_error().decode())
+    try:
+        return OracleGraph(gp, k)
+    finally:
+        lib().ko_graph_free(gp)
+
+
 def scan_files(paths, file_type=1):
     rp = C.POINTER(KoReads)()
     rc = lib().ko_scan_files(_paths(paths), len(paths), file_type, C.byref(rp))

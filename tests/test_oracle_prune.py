@@ -85,3 +85,26 @@ def test_model_reaches_the_quirks(oracle):
         loops += st["self_loops"]
         passes = max(passes, st["passes"])
     assert dup > 0 and passes > 2
+
+
+# the in-file tests of pruner.rs (259-393): hand-built graphs, counts after Clean's two operations
+PRUNER_KAT = [
+    # (name, lines, n_nodes, edges (src, dst, weight), stages, threshold, expected (nodes, edges))
+    ("prunes_single_graph", "266-274", 0, [], "w", 10, (0, 0)),
+    ("prunes_single_weak_edge", "289-298", 3, [(0, 1, 100), (1, 2, 1)], "w", 10, (2, 1)),
+    ("prunes_single_weak_edge_and_no_nodes", "300-311", 4, [(0, 1, 100), (1, 2, 1), (2, 3, 100)], "w", 10, (4, 2)),
+    ("prunes_strong_edges", "313-322", 3, [(0, 1, 100), (1, 2, 100)], "w", 10, (3, 2)),
+    ("prunes_cycle", "324-334", 3, [(0, 1, 1), (1, 2, 1), (2, 0, 1)], "w", 10, (0, 0)),
+    ("doesnt_remove_vertices", "339-348", 3, [(0, 1, 100), (1, 2, 1)], "v", 0, (3, 2)),
+    ("removes_one_vertex", "350-358", 3, [(0, 1, 100)], "v", 0, (2, 1)),
+    ("removes_two_vertices", "360-368", 3, [(0, 0, 100)], "v", 0, (1, 1)),
+    ("removes_all_vertices", "370-377", 3, [], "v", 0, (0, 0)),
+]
+
+
+@pytest.mark.parametrize("name,lines,n_nodes,edges,stages,thr,want", PRUNER_KAT, ids=[c[0] for c in PRUNER_KAT])
+def test_pruner_in_file_cases(oracle, name, lines, n_nodes, edges, stages, thr, want):
+    g = oracle.run_from_edges(n_nodes, edges, stages, thr)
+    assert (g.n_nodes, g.n_edges) == want
+    if name == "removes_two_vertices":          # the vertex that keeps its self-loop is re-labelled 0 by the swap_removes
+        assert g.edge_src.tolist() == g.edge_dst.tolist() == [0]
