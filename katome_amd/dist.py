@@ -198,6 +198,43 @@ def _exchange(send, send_counts, nw, group):
     return recv, recv_counts
 
 
+class _AsyncExchange:
+    """One all-to-all of records (and, aligned with them, of values) started now and waited for later, so that the links
+    work while this rank extracts / routes the next batch and counts the previous one.  Falls back to the blocking
+    `_exchange` when a message would exceed MAX_MESSAGE_BYTES (rounds) or the backend cannot move device tensors (gloo)."""
+
+    def __init__(self, parts, send_counts, group):
+        """parts: [(tensor grouped by destination, elements per record)], all with the same send_counts"""
+        world = dist.get_world_size(group)
+        self.group, self.parts, self.send_counts = group, parts, send_counts
+        dev = parts[0][0].device
+        sc = torch.tensor(send_counts, dtype=torch.int64, device=dev)
+        rc = torch.empty(world, dtype=torch.int64, device=dev)
+        _a2a(rc, sc, group=group)
+        self.recv_counts = [int(x) for x in rc.tolist()]
+        biggest = max(c * nw * t.element_size() for t, nw in parts for c in send_counts + self.recv_counts) if parts else 0
+        flag = torch.tensor([1 if biggest > MAX_MESSAGE_BYTES else 0], dtype=torch.int64, device=dev)
+        _all_reduce(flag, dist.ReduceOp.MAX, group)                 # every rank must take the same route
+        staged = dev.type == "cuda" and dist.get_backend(group) == "gloo"
+        self.work, self.recv = [], []
+        if int(flag.item()) or staged:
+            self.recv = [_exchange(t, send_counts, nw, group)[0] for t, nw in parts]
+            return
+        for t, nw in parts:
+            out = _empty(sum(self.recv_counts) * nw, t.dtype, dev)
+            inp = t[:sum(send_counts) * nw].contiguous()
+            w = dist.all_to_all_single(out, inp, output_split_sizes=[c * nw for c in self.recv_counts],
+                                       input_split_sizes=[c * nw for c in send_counts], group=group, async_op=True)
+            self.work.append((w, inp))                                # the input stays alive until the wait
+            self.recv.append(out)
+
+    def wait(self):
+        for w, _ in self.work:
+            w.wait()
+        self.work = []
+        return self.recv
+
+
 class RankGraph:
     """this rank's share of the graph: its edges (disjoint from every other rank's) with GLOBAL node ids,
     and the nodes it owns (global id = node_base + position)"""
@@ -231,6 +268,15 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
     # every rank must take part in every all-to-all: agree on the number of rounds
     nb = torch.tensor([n_batches], dtype=torch.int64, device=recbuf.device)
     _all_reduce(nb, dist.ReduceOp.MAX, group)
+    def count(recv):
+        if recv.numel():
+            if span > 1:
+                ops.insert_tiles(recv, span)
+            else:
+                ops.insert(recv)
+
+    # batch i travels while batch i+1 is extracted and routed and batch i-1 is counted
+    in_flight = None
     for i in range(int(nb.item())):
         r0 = i * batch_reads
         nr = max(0, min(batch_reads, n_reads - r0))
@@ -244,24 +290,42 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
         else:
             part, counts = recbuf[:0], [0] * world
         with phases("exchange_records"):
-            recv, _ = _exchange(part, counts, nwr, group)
-        if recv.numel():
-            if span > 1:
-                ops.insert_tiles(recv, span)
-            else:
-                ops.insert(recv)
+            started = _AsyncExchange([(part, nwr)], counts, group)
+            if in_flight is not None:
+                count(in_flight.wait()[0])
+            in_flight = started
+    if in_flight is not None:
+        with phases("exchange_records"):
+            last = in_flight.wait()[0]
+        count(last)
     if span > 1:
         keys, weights = ops.expand_tiles()               # this rank's distinct tiles as (k-mer, weight) records
-        with phases("route_kmers"):
-            if weights.numel():
-                pk, counts, pw = ops.partition(keys, world, key_words=ops.nw, values=weights, core=kmer_core)
-            else:
-                pk, counts, pw = keys, [0] * world, weights
-        with phases("exchange_kmers"):
-            rk, rcounts = _exchange(pk, counts, ops.nw, group)
-            rw, _ = _exchange(pw, counts, 1, group)
-        if rw.numel():
-            ops.insert(rk, rw)
+        # the same pipeline over slices of the record list (a slice never exceeds one message's size limit)
+        n_rec = weights.numel()
+        per_slice = max(1, MAX_MESSAGE_BYTES // (8 * ops.nw))
+        ns = torch.tensor([(n_rec + per_slice - 1) // per_slice], dtype=torch.int64, device=recbuf.device)
+        _all_reduce(ns, dist.ReduceOp.MAX, group)
+        in_flight = None
+        for j in range(int(ns.item())):
+            a, b = min(n_rec, j * per_slice), min(n_rec, (j + 1) * per_slice)
+            with phases("route_kmers"):
+                if b > a:
+                    pk, counts, pw = ops.partition(keys[a * ops.nw:b * ops.nw], world, key_words=ops.nw, values=weights[a:b],
+                                                   core=kmer_core)
+                else:
+                    pk, counts, pw = keys[:0], [0] * world, weights[:0]
+            with phases("exchange_kmers"):
+                started = _AsyncExchange([(pk, ops.nw), (pw, 1)], counts, group)
+                if in_flight is not None:
+                    rk, rw = in_flight.wait()
+                    if rw.numel():
+                        ops.insert(rk, rw)
+                in_flight = started
+        if in_flight is not None:
+            with phases("exchange_kmers"):
+                rk, rw = in_flight.wait()
+            if rw.numel():
+                ops.insert(rk, rw)
 
 
 def finalize_distributed(ops, group=None, phases=_NO_PHASES):
