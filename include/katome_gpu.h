@@ -351,6 +351,7 @@ int katome_dev_node_ids(int device, const uint64_t *d_edge_key, uint64_t n_edges
  * room for n_edges keys), and each edge's position among them                                          */
 int katome_dev_source_ids(int device, const uint64_t *d_edge_key, uint64_t n_edges, uint32_t k,
                           uint64_t *d_node_key, uint64_t *d_edge_src, uint64_t *n_sources, void *stream);
+/* source / target (k-1)-mer of every edge (either output may be NULL) */
 int katome_dev_endpoints(int device, const uint64_t *d_edge_key, uint64_t n, uint32_t k,
                          uint64_t *d_src_key, uint64_t *d_dst_key, void *stream);
 /* compress_edge-format labels (compress.rs:250-271) of packed k-mers                       */

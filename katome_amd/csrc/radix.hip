@@ -767,8 +767,8 @@ template <int NW>
 __global__ __launch_bounds__(BLOCK) void endpoints_kernel(const u64* __restrict__ ek, u64 n, u32 k, u64* __restrict__ src, u64* __restrict__ dst) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         Key<NW> key = load_key<NW>(ek, i);
-        store_key<NW>(src, i, source_node(key));
-        store_key<NW>(dst, i, target_node(key, k));
+        if (src) store_key<NW>(src, i, source_node(key));
+        if (dst) store_key<NW>(dst, i, target_node(key, k));
     }
 }
 int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream) {

@@ -312,10 +312,10 @@ def node_ids(edge_keys, k, device=0):
     return nodes[:nn.value * nw], src[:n], dst[:n]
 
 
-def endpoints(edge_keys, k, device=0):
+def endpoints(edge_keys, k, device=0, want_src=True):
     nw = record_words(k)
     n = edge_keys.numel() // nw
-    src, dst = torch.empty_like(edge_keys), torch.empty_like(edge_keys)
+    src, dst = (torch.empty_like(edge_keys) if want_src else None), torch.empty_like(edge_keys)
     _check(_lib.lib().katome_dev_endpoints(device, _ptr(edge_keys), n, k, _ptr(src), _ptr(dst), _stream()))
     return src, dst
 

@@ -71,7 +71,7 @@ class HipOps:
         return self.kd.source_ids(keys.reshape(-1), self.k, self.dev)
 
     def target_keys(self, keys):
-        return self.kd.endpoints(keys.reshape(-1), self.k, self.dev)[1]
+        return self.kd.endpoints(keys.reshape(-1), self.k, self.dev, want_src=False)[1]
 
     def sort_unique(self, keys, bits):
         self.kd.sort_keys(keys, bits, self.nw, device=self.dev)
@@ -376,12 +376,15 @@ def finalize_distributed(ops, group=None, phases=_NO_PHASES):
     base = int(bases[rank].item())
     total_nodes = int(all_n.sum().item())
     with phases("exchange_ids"):
-        ids_P, _ = _exchange(local + base, recv_counts, 1, group)     # reverse route: same split sizes, mirrored
-    del R, local
+        ids = local + base
+        if total_nodes < (1 << 31):
+            ids = ids.to(torch.int32)                                 # half the bytes on the links
+        ids_P, _ = _exchange(ids, recv_counts, 1, group)              # reverse route: same split sizes, mirrored
+    del R, local, ids
     if E:
         with phases("apply_ids"):
             edge_dst = _empty(E, torch.int64, dev)
-            edge_dst[origin[:E].to(torch.int64)] = ids_P             # ids_P is aligned with the routed targets
+            edge_dst[origin[:E].to(torch.int64)] = ids_P.to(torch.int64)   # ids_P is aligned with the routed targets
             edge_src = lsrc + base
         label = ops.labels(keys)
     else:
