@@ -3,9 +3,10 @@
 // hipMalloc / hipFree of multi-GiB buffers cost tens to hundreds of milliseconds each and hipFree
 // synchronises the device; a build allocates the table, the batch scratch, sort ping-pong buffers
 // and the result arrays.  Freed blocks are therefore kept per device and handed out again
-// (best fit, <= 25 % slack); everything is released on katome_dev_release_cache() or when a fresh
-// hipMalloc runs out of memory.  A block remembers the stream it was last used on: handing it to a
-// different stream first waits for that stream.
+// (best fit, <= 25 % slack).  When a fresh hipMalloc runs out of memory the smallest cached block that is big
+// enough is handed out whatever its slack (giving cached blocks back to the driver costs seconds once tens of
+// GiB are cached); only if there is none is the cache released (also on katome_dev_release_cache()).  A block
+// remembers the stream it was last used on: handing it to a different stream first waits for that stream.
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -61,9 +62,21 @@ int dev_malloc(void** out, size_t bytes, hipStream_t stream) {
     }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess) {                  // give the cached blocks back and try once more
+    if (e != hipSuccess) {                  // out of memory: any cached block that is big enough will do
         (void)hipGetLastError();
-        (void)hipDeviceSynchronize();
+        for (auto it = c.free_blocks.lower_bound(want); it != c.free_blocks.end(); ++it) {
+            if (it->second.device != device) continue;
+            Block b = it->second;
+            c.free_blocks.erase(it);
+            c.cached_bytes -= b.bytes;
+            if (b.stream != stream) (void)hipStreamSynchronize(b.stream);
+            b.stream = stream;
+            c.live[b.p] = b;
+            if (c.trace) fprintf(stderr, "[katome alloc] %.1f MiB served from a cached block of %.1f MiB\n", want / 1048576.0, b.bytes / 1048576.0);
+            *out = b.p;
+            return KATOME_OK;
+        }
+        (void)hipDeviceSynchronize();       // none: give the cached blocks back and try once more
         release_all_locked(c, device);
         e = hipMalloc(&p, want);
     }

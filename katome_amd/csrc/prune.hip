@@ -250,8 +250,16 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-int upload(DevBuf& d, const std::vector<u32>& h, hipStream_t stream) {
-    KCHECK(d.alloc(h.size() * 4 + 16, stream));
+// scratch that lives across the passes: re-allocated only when a pass needs more than any before it (the block sizes
+// differ from pass to pass, so handing them back each time defeats the caching allocator and hipMalloc/hipFree of
+// multi-GiB blocks cost 100s of ms under memory pressure)
+int ensure(DevBuf& d, size_t bytes, hipStream_t stream) {
+    if (d.bytes >= bytes && d.p) return KATOME_OK;
+    return d.alloc(bytes + bytes / 8 + 256, stream);
+}
+
+int upload(DevBuf& d, const U32Buf& h, hipStream_t stream) {
+    KCHECK(ensure(d, h.size() * 4 + 16, stream));
     if (!h.empty()) KCHECK_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * 4, hipMemcpyHostToDevice, stream));
     return KATOME_OK;
 }
@@ -279,7 +287,18 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     KCHECK(totals.alloc(32));
     PinnedU32 h_pos, h_mult, h_die;
     EdgeReplay er; NodeReplay nr;
+    DevBuf counts(stream), offs(stream), d_pos(stream), d_mult(stream), d_victims(stream), last_touch(stream), d_die(stream);
+    DevBuf to_e(stream), from_e(stream), to_n(stream), from_n(stream), tail_map(stream);
+    KCHECK(last_touch.alloc((N + 1) * 4));
     const bool trace = getenv("KATOME_TRACE_PRUNE") != nullptr;
+    double lap_t = now_ms();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(stream);
+        const double t = now_ms();
+        fprintf(stderr, "[prune]   %-18s %9.2f ms\n", what, t - lap_t);
+        lap_t = t;
+    };
     // adjacency summary, once
     KCHECK_HIP(hipMemsetAsync(node_deg.p, 0, N * 8, stream));
     KCHECK_HIP(hipMemsetAsync(first_out.p, 0, N * 8, stream));
@@ -287,6 +306,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     if (E) hipLaunchKernelGGL(degree_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, orig.as<u32>(), E,
                               node_deg.as<u64>(), first_out.as<u64>());
     KCHECK_HIP(hipGetLastError());
+    lap("adjacency");
     while (E) {
         const double pass_t0 = now_ms();
         double pass_host = 0;
@@ -298,6 +318,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         u64 h_tot[3] = {0, 0, 0};
         KCHECK_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
+        lap("walks");
         local.passes += 1;
         local.walks += h_tot[2];
         if (h_tot[0] == 0) break;                         // to_remove.is_empty() (pruner.rs:76)
@@ -305,14 +326,13 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         local.marked += h_tot[0];
         // (2) the marked indices, ascending (the reference sorts them descending; they are consumed from the top)
         const u64 nblocks = (E + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
-        DevBuf counts(stream), offs(stream), d_pos(stream), d_mult(stream);
-        KCHECK(counts.alloc(nblocks * 4 + 16)); KCHECK(offs.alloc((nblocks + 1) * 8 + 16));
+        KCHECK(ensure(counts, nblocks * 4 + 16, stream)); KCHECK(ensure(offs, (nblocks + 1) * 8 + 16, stream));
         hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, counts.as<u32>());
         KCHECK(dev_scan_counts(counts.as<u32>(), nblocks, offs.as<u64>(), stream));
         u64 u = 0;
         KCHECK_HIP(hipMemcpyAsync(&u, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
-        KCHECK(d_pos.alloc(u * 4 + 16)); KCHECK(d_mult.alloc(u * 4 + 16));
+        KCHECK(ensure(d_pos, u * 4 + 16, stream)); KCHECK(ensure(d_mult, u * 4 + 16, stream));
         hipLaunchKernelGGL(mark_write_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, offs.as<u64>(),
                            d_pos.as<u32>(), d_mult.as<u32>());
         if (u) hipLaunchKernelGGL(mark_clear_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos.as<u32>(), u, mult.as<u32>());
@@ -321,7 +341,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK_HIP(hipMemcpyAsync(h_pos.p, d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipMemcpyAsync(h_mult.p, d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
-        d_pos.release(); d_mult.release(); counts.release(); offs.release();
+        lap("marks to host");
         // (3) replay of remove_edge
         double t0 = now_ms();
         replay_edges(h_pos.p, h_mult.p, u, E, h_tot[0], er);
@@ -330,10 +350,10 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         const u64 m = er.victims.size();
         local.removed_edges += m;
         local.removed_by_duplicates += er.from_duplicates;
+        lap("replay edges");
         // (4) the nodes each removal isolates
-        DevBuf d_victims(stream), last_touch(stream), d_die(stream);
         KCHECK(upload(d_victims, er.victims, stream));
-        KCHECK(last_touch.alloc((N + 1) * 4)); KCHECK(d_die.alloc(2 * m * 4 + 16));
+        KCHECK(ensure(d_die, 2 * m * 4 + 16, stream));
         KCHECK_HIP(hipMemsetAsync(last_touch.p, 0, N * 4, stream));
         hipLaunchKernelGGL(death_count_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
                            node_deg.as<u64>(), first_out.as<u64>(), last_touch.as<u32>());
@@ -343,26 +363,26 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK(h_die.need(2 * m));
         KCHECK_HIP(hipMemcpyAsync(h_die.p, d_die.p, 2 * m * 4, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
-        d_victims.release(); last_touch.release(); d_die.release();
+        lap("deaths to host");
         // (5) replay of remove_node
         t0 = now_ms();
         replay_nodes(h_die.p, m, N, nr);
         const double t_nodes = now_ms() - t0;
         local.host_ms += t_nodes; pass_host += t_nodes;
         local.removed_nodes += N - nr.n_new;
+        lap("replay nodes");
         // (6) apply the moves, re-label the endpoints of the surviving edges
         {
-            DevBuf to(stream), from(stream), tail_map(stream);
-            KCHECK(upload(to, er.move_to, stream)); KCHECK(upload(from, er.move_from, stream));
+            KCHECK(upload(to_e, er.move_to, stream)); KCHECK(upload(from_e, er.move_from, stream));
             const u64 ne = er.move_to.size();
-            if (ne) hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(ne, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
-                                       from.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>());
+            if (ne) hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(ne, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_e.as<u32>(),
+                                       from_e.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>());
             E = er.n_new;
-            KCHECK(upload(to, nr.move_to, stream)); KCHECK(upload(from, nr.move_from, stream));
+            KCHECK(upload(to_n, nr.move_to, stream)); KCHECK(upload(from_n, nr.move_from, stream));
             const u64 nn = nr.move_to.size();
-            KCHECK(tail_map.alloc((N - nr.n_new + 1) * 4));
-            if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
-                                       from.as<u32>(), nn, nw, nr.n_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
+            KCHECK(ensure(tail_map, (N - nr.n_new + 1) * 4, stream));
+            if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
+                                       from_n.as<u32>(), nn, nw, nr.n_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
             if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, nr.n_new,
                                             tail_map.as<u32>());
             if (E) hipLaunchKernelGGL(first_out_redo_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, orig.as<u32>(), E,
@@ -371,6 +391,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             N = nr.n_new;
             KCHECK_HIP(hipStreamSynchronize(stream));      // the host vectors are reused by the next pass
         }
+        lap("apply");
         if (trace)
             fprintf(stderr, "[prune] pass %llu: E %llu N %llu walks %llu dead %llu marked %llu removed %llu (dup %llu) nodes %llu | %.2f ms, host %.2f (edges %.2f nodes %.2f)\n",
                     (unsigned long long)local.passes, (unsigned long long)E, (unsigned long long)N, (unsigned long long)h_tot[2],

@@ -3,12 +3,31 @@
 // Host-only, no HIP: included by prune.hip and by tests/hostshim.
 #pragma once
 #include <stdint.h>
-
-#include <vector>
+#include <stdlib.h>
+#include <string.h>
 
 namespace katome {
 
 constexpr uint32_t REPLAY_NONE = 0xFFFFFFFFu;
+
+// grow-only array of u32 without value-initialisation: the first pass of a big graph fills hundreds of MiB, and touching
+// that memory twice (zero-fill, then the real values) or copying it while a vector doubles costs as much as the replay
+struct U32Buf {
+    uint32_t* p = nullptr;
+    size_t cap = 0, n = 0;
+    U32Buf() {}
+    U32Buf(const U32Buf&) = delete;
+    U32Buf& operator=(const U32Buf&) = delete;
+    ~U32Buf() { free(p); }
+    void need(size_t c) {                  // contents are NOT kept
+        if (c > cap) { free(p); p = (uint32_t*)malloc((c + c / 8 + 64) * 4); cap = p ? c + c / 8 + 64 : 0; }
+        n = 0;
+    }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    const uint32_t* data() const { return p; }
+    uint32_t operator[](size_t i) const { return p[i]; }
+};
 
 // Edges (remove_paths, pruner.rs:199-217): the collected indices arrive ascending with multiplicities and are
 // consumed from the top, as the reference's descending sort does.  remove_edge(d) moves the edge at the last
@@ -16,16 +35,17 @@ constexpr uint32_t REPLAY_NONE = 0xFFFFFFFFu;
 // position both only move down, so the occupants that differ from the identity live in an array aligned with the
 // entries and everything streams.
 struct EdgeReplay {
-    std::vector<uint32_t> victims;     // identity (position at the start of the pass) of each removed edge, in order
-    std::vector<uint32_t> move_to, move_from;
-    std::vector<uint32_t> occ;
+    U32Buf victims;                    // identity (position at the start of the pass) of each removed edge, in order
+    U32Buf move_to, move_from;
+    U32Buf occ;
     uint64_t n_new = 0, from_duplicates = 0;
 };
 inline void replay_edges(const uint32_t* pos, const uint32_t* mult, uint64_t u, uint64_t n_edges, uint64_t marks, EdgeReplay& out) {
-    out.occ.assign(pos, pos + u);                      // occupant of position pos[j]
-    out.victims.resize(marks);
-    uint32_t* occ = out.occ.data();
-    uint32_t* victims = out.victims.data();
+    out.occ.need(u);                                   // occupant of position pos[j]
+    if (u) memcpy(out.occ.p, pos, u * 4);
+    out.victims.need(marks);
+    uint32_t* occ = out.occ.p;
+    uint32_t* victims = out.victims.p;
     uint64_t size = n_edges, nv = 0, dups = 0;
     long long q = (long long)u - 1;
     for (long long j = (long long)u - 1; j >= 0; --j) {
@@ -41,12 +61,16 @@ inline void replay_edges(const uint32_t* pos, const uint32_t* mult, uint64_t u, 
             --size;
         }
     }
-    out.victims.resize(nv);
+    out.victims.n = nv;
     out.n_new = size;
     out.from_duplicates = dups;
-    out.move_to.clear(); out.move_from.clear();
-    for (uint64_t j = 0; j < u && pos[j] < size; ++j)
-        if (occ[j] != pos[j]) { out.move_to.push_back(pos[j]); out.move_from.push_back(occ[j]); }
+    uint64_t below = 0;                                // entries under the new count: at most that many moves
+    while (below < u && pos[below] < size) ++below;
+    out.move_to.need(below); out.move_from.need(below);
+    uint64_t nm = 0;
+    for (uint64_t j = 0; j < below; ++j)
+        if (occ[j] != pos[j]) { out.move_to.p[nm] = pos[j]; out.move_from.p[nm] = occ[j]; ++nm; }
+    out.move_to.n = out.move_from.n = nm;
 }
 
 // Nodes (remove_single_node after every removed edge, pruner.rs:206-225): die[2t], die[2t+1] name the endpoints
@@ -54,17 +78,17 @@ inline void replay_edges(const uint32_t* pos, const uint32_t* mult, uint64_t u, 
 // CURRENT index goes first.  remove_node moves the last node into the freed index, so only nodes of the tail that
 // disappears are ever re-labelled: two arrays over that tail hold the whole state.
 struct NodeReplay {
-    std::vector<uint32_t> move_to, move_from;
-    std::vector<uint32_t> tail_pos, tail_occ;
+    U32Buf move_to, move_from;
+    U32Buf tail_pos, tail_occ;
     uint64_t n_new = 0;
 };
 inline void replay_nodes(const uint32_t* die, uint64_t m, uint64_t n_nodes, NodeReplay& out) {
     uint64_t n_die = 0;
     for (uint64_t i = 0; i < 2 * m; ++i) n_die += die[i] != REPLAY_NONE;
     const uint64_t base = n_nodes - n_die;
-    out.tail_pos.resize(n_die); out.tail_occ.resize(n_die);
-    uint32_t* tail_pos = out.tail_pos.data();          // current index of tail node base+i (REPLAY_NONE once removed)
-    uint32_t* tail_occ = out.tail_occ.data();          // node at tail index base+i
+    out.tail_pos.need(n_die); out.tail_occ.need(n_die);
+    uint32_t* tail_pos = out.tail_pos.p;               // current index of tail node base+i (REPLAY_NONE once removed)
+    uint32_t* tail_occ = out.tail_occ.p;               // node at tail index base+i
     for (uint64_t i = 0; i < n_die; ++i) tail_pos[i] = tail_occ[i] = (uint32_t)(base + i);
     uint64_t size = n_nodes;
     auto pos_of = [&](uint32_t v) -> uint32_t { return v < base ? v : tail_pos[v - base]; };
@@ -89,9 +113,11 @@ inline void replay_nodes(const uint32_t* die, uint64_t m, uint64_t n_nodes, Node
         }
     }
     out.n_new = size;
-    out.move_to.clear(); out.move_from.clear();
+    out.move_to.need(n_die); out.move_from.need(n_die);
+    uint64_t nm = 0;
     for (uint64_t i = 0; i < n_die; ++i)
-        if (tail_pos[i] != REPLAY_NONE) { out.move_to.push_back(tail_pos[i]); out.move_from.push_back((uint32_t)(base + i)); }
+        if (tail_pos[i] != REPLAY_NONE) { out.move_to.p[nm] = tail_pos[i]; out.move_from.p[nm] = (uint32_t)(base + i); ++nm; }
+    out.move_to.n = out.move_from.n = nm;
 }
 
 }  // namespace katome

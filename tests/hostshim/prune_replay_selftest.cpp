@@ -27,7 +27,7 @@ int main() {
         std::sort(todo.rbegin(), todo.rend());
         std::vector<uint32_t> victims;
         for (uint32_t d : todo) if (d < arr.size()) { victims.push_back(arr[d]); arr[d] = arr.back(); arr.pop_back(); }
-        if (victims != er.victims || arr.size() != er.n_new) { fprintf(stderr, "edge replay mismatch\n"); return 1; }
+        if (victims != std::vector<uint32_t>(er.victims.p, er.victims.p + er.victims.n) || arr.size() != er.n_new) { fprintf(stderr, "edge replay mismatch\n"); return 1; }
         for (size_t j = 0; j < er.move_to.size(); ++j) if (arr[er.move_to[j]] != er.move_from[j]) { fprintf(stderr, "edge move mismatch\n"); return 1; }
         // nodes: a random subset dies, in random pairs
         std::vector<uint32_t> dying;

@@ -30,7 +30,7 @@ def main():
                    first_seen_order=True)
     b.profile(True)
     span = b.tile_span(wl.read_len)
-    batch = 16 << 20
+    batch = 4 << 20
     t0 = time.perf_counter()
     for r0 in range(0, wl.reads, batch):
         nr = min(batch, wl.reads - r0)
@@ -50,6 +50,7 @@ def main():
     dc = b.shrink()
     torch.cuda.synchronize()
     t_shrink = time.perf_counter() - t0
+    kd.release_cache(0)                 # the library's cached blocks: torch needs room for the statistics below
     kmers = dc.edge_kmers
     shrink = {"ms": t_shrink * 1e3, "nodes": dc.n_nodes, "edges": dc.n_edges, "label_bytes": dc.label_bytes,
               "longest_path_kmers": int(kmers.max().item()) if dc.n_edges else 0,
