@@ -85,6 +85,11 @@ typedef struct {
     const uint8_t  *edge_label;   /* [n_edges][label_stride] compress_edge format               */
     const uint64_t *edge_key;     /* [n_edges][key_words] packed k-mer, right-aligned, w[0] = high word */
     const uint64_t *node_key;     /* [n_nodes][key_words] packed (k-1)-mer, right-aligned       */
+    /* FIRST_SEEN_ORDER graphs after remove_dead_paths / remove_weak_edges (NULL otherwise: age == index): the
+     * first-seen index every edge had BEFORE the removals re-numbered it.  petgraph's swap_remove re-labels edges but
+     * keeps every adjacency list in insertion order, so the reference's graph at this point is "these indices, lists
+     * ordered by age" (first_edge = the live edge with the largest age); see INTEGRATION.md                    */
+    const uint32_t *edge_age;
 } katome_graph;
 
 /* CollectionStats (stats/collections.rs:38-57) as computed for PtGraph (137-168) */
@@ -255,6 +260,7 @@ typedef struct {
     uint64_t *d_edge_src, *d_edge_dst;
     uint8_t  *d_edge_label;
     uint64_t *d_node_key;     /* [n_nodes][key_words]: sources ascending, then out-edge-less nodes ascending */
+    uint32_t *d_edge_age;     /* see katome_graph.edge_age; NULL while age == index */
 } katome_dev_graph;
 
 /* Table -> distinct oriented edges, sorted by packed k-mer (both strands when

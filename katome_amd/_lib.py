@@ -22,7 +22,7 @@ class Graph(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("read_bytes", C.c_uint64), ("k", C.c_uint32),
                 ("key_words", C.c_uint32), ("label_stride", C.c_uint32), ("_pad", C.c_uint32),
                 ("edge_src", u64p), ("edge_dst", u64p), ("edge_weight", u32p), ("edge_label", u8p),
-                ("edge_key", u64p), ("node_key", u64p)]
+                ("edge_key", u64p), ("node_key", u64p), ("edge_age", u32p)]
 
 
 class Stats(C.Structure):
@@ -61,7 +61,7 @@ class DevGraph(C.Structure):
     _fields_ = [("n_nodes", C.c_uint64), ("n_edges", C.c_uint64), ("key_words", C.c_uint32),
                 ("label_stride", C.c_uint32), ("d_edge_key", C.c_void_p), ("d_edge_weight", C.c_void_p),
                 ("d_edge_src", C.c_void_p), ("d_edge_dst", C.c_void_p), ("d_edge_label", C.c_void_p),
-                ("d_node_key", C.c_void_p)]
+                ("d_node_key", C.c_void_p), ("d_edge_age", C.c_void_p)]
 
 
 # every symbol include/katome_gpu.h declares: name -> (restype, argtypes)

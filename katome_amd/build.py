@@ -157,6 +157,8 @@ class GpuGraph:
         self.edge_label = arr(g.edge_label, (ne, g.label_stride), np.uint8)
         self.edge_key = arr(g.edge_key, (ne, nw), np.uint64)
         self.node_key = arr(g.node_key, (nn, nw), np.uint64)
+        # first-seen index each edge had before remove_dead_paths / remove_weak_edges re-numbered it (None: age == index)
+        self.edge_age = arr(g.edge_age, (ne,), np.uint32) if bool(g.edge_age) else None
         st = _lib.Stats()
         _check(_lib.lib().katome_graph_stats(gptr, C.byref(st)))
         self._stats = CollectionStats(

@@ -549,6 +549,7 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
         out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = cand;
+        out->d_edge_age = b->edge_age.p ? b->edge_age.as<u32>() : nullptr;
     }
     return KATOME_OK;
 }
@@ -578,6 +579,7 @@ int katome_dev_remove_dead_paths(katome_builder* b, katome_dev_graph* out, katom
         out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
         out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
         out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = b->node_key.as<u64>();
+        out->d_edge_age = b->edge_age.p ? b->edge_age.as<u32>() : nullptr;
     }
     return KATOME_OK;
 }
@@ -611,6 +613,7 @@ int katome_dev_current_graph(katome_builder* b, katome_dev_graph* out) {
     out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
     out->d_edge_src = b->edge_src.as<u64>(); out->d_edge_dst = b->edge_dst.as<u64>();
     out->d_edge_label = b->edge_label.as<uint8_t>(); out->d_node_key = b->node_key.as<u64>();
+        out->d_edge_age = b->edge_age.p ? b->edge_age.as<u32>() : nullptr;
     return KATOME_OK;
 }
 
@@ -750,7 +753,8 @@ static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** 
         (rc = d2h(o, &g->edge_weight, dg.d_edge_weight, dg.n_edges)) ||
         (rc = d2h(o, &g->edge_label, dg.d_edge_label, dg.n_edges * (size_t)dg.label_stride)) ||
         (rc = d2h(o, &g->edge_key, dg.d_edge_key, dg.n_edges * dg.key_words)) ||
-        (rc = d2h(o, &g->node_key, dg.d_node_key, dg.n_nodes * dg.key_words))) {
+        (rc = d2h(o, &g->node_key, dg.d_node_key, dg.n_nodes * dg.key_words)) ||
+        (dg.d_edge_age && (rc = d2h(o, &g->edge_age, dg.d_edge_age, dg.n_edges)))) {
         katome_graph_free(g);
         return rc;
     }

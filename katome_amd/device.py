@@ -62,6 +62,8 @@ class DeviceGraph:
         self.edge_dst = _view(dg.d_edge_dst, (ne,), "<i8", builder, device)
         self.edge_label = _view(dg.d_edge_label, (ne, dg.label_stride), "|u1", builder, device)
         self.node_key = _view(dg.d_node_key, (nn, nw), "<i8", builder, device)
+        # first-seen index each edge had before remove_* re-numbered it (None while age == index)
+        self.edge_age = _view(dg.d_edge_age, (ne,), "<i4", builder, device) if dg.d_edge_age else None
 
 
 class DeviceContigs:

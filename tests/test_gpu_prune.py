@@ -16,6 +16,9 @@ pytestmark = pytest.mark.gpu
 
 def _same(g, ref, k):
     assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    if getattr(g, "edge_age", None) is not None:
+        # the oracle hands SEQUENCES slots out in the order edges are first added (pt_graph.rs:176-194): slot = age + 1
+        assert np.array_equal(g.edge_age.astype(np.uint64) + 1, ref.edge_slot)
     assert np.array_equal(g.edge_label, ref.edge_label)
     assert np.array_equal(g.edge_weight, ref.edge_weight)
     assert np.array_equal(g.edge_src, ref.edge_src) and np.array_equal(g.edge_dst, ref.edge_dst)
@@ -195,6 +198,8 @@ def _dev_arrays(dg):
 
 def _assert_dev_same(dg, ref):
     assert (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
+    if dg.edge_age is not None:
+        assert np.array_equal(dg.edge_age.cpu().numpy().view(np.uint32).astype(np.uint64) + 1, ref.edge_slot)
     lab, w, s, d = _dev_arrays(dg)
     assert np.array_equal(lab, ref.edge_label) and np.array_equal(w, ref.edge_weight)
     assert np.array_equal(s, ref.edge_src) and np.array_equal(d, ref.edge_dst)
