@@ -92,13 +92,15 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=Fa
     b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint,
                    first_seen_order=first_seen)
     b.profile(True)
-    span = b.tile_span(wl.read_len)
+    span, tiles, rest = b.tile_plan(wl.read_len)
     try:
         for r0 in range(0, wl.reads, batch_reads):
             nr = min(batch_reads, wl.reads - r0)
-            if span > 1:      # tiled counting: (L-k+1)/span tile records per read, expanded before the edges are read out
+            if span > 1:      # tiled counting: tiles of `span` windows, expanded before the edges are read out (+ left-over windows)
                 rec = b.extract_tiles(packed, nr, wl.read_len, span, skip, out=recbuf, first_read=r0)
                 b.insert_tiles(rec, span)
+                if rest:
+                    b.insert(b.extract_remainder(packed, nr, wl.read_len, span, skip, out=recbuf, first_read=r0))
             else:
                 rec = b.extract_fixed(packed, nr, wl.read_len, skip, out=recbuf, first_read=r0)
                 b.insert(rec)
@@ -119,7 +121,6 @@ def next_stages(wl, sample_reads):
     packed, skip = kd.synth_reads(0, w.reads, w.read_len, w.genome_len, w.err_rate, w.n_inject_percent, device=0)
     skip_arg = skip if w.n_inject_percent else None
     b = kd.Builder(w.k, w.reverse_complement, table_slots_hint=int(w.expected_distinct_canonical() * 2.2), first_seen_order=True)
-    span = b.tile_span(w.read_len)
     out = {"reads": w.reads}
     try:
         def timed(fn):
@@ -130,13 +131,9 @@ def next_stages(wl, sample_reads):
             return (time.perf_counter() - t0) * 1e3, r
 
         def build():
-            step = 16 << 20
+            step = 4 << 20
             for r0 in range(0, w.reads, step):
-                nr = min(step, w.reads - r0)
-                if span > 1:
-                    b.insert_tiles(b.extract_tiles(packed, nr, w.read_len, span, skip_arg, first_read=r0), span)
-                else:
-                    b.insert(b.extract_fixed(packed, nr, w.read_len, skip_arg, first_read=r0))
+                b.count_reads(packed, min(step, w.reads - r0), w.read_len, skip_arg, first_read=r0)
             return b.finalize()
         ms, dg = timed(build)
         out["build_first_seen_order_ms"] = ms
@@ -250,15 +247,23 @@ def main():
         # algorithmic bytes: extraction = ceil(L/4) B read + 8*NW*W B written per read;
         # insertion = 8*NW B record + 16*NW B slot per insertion
         from katome_amd._lib import lib as _katome_lib
-        span = _katome_lib().katome_tile_span(wl.k, wl.read_len)
+        import ctypes as _C
+        if use_dist:          # the multi-GPU route only tiles reads whose windows are a whole number of tiles
+            span = _katome_lib().katome_tile_span(wl.k, wl.read_len)
+            tiles, rest = (W // span, 0) if span > 1 else (0, W)
+        else:
+            _sp, _t, _r = _C.c_uint32(), _C.c_uint32(), _C.c_uint32()
+            _katome_lib().katome_tile_plan(wl.k, wl.read_len, _C.byref(_sp), _C.byref(_t), _C.byref(_r))
+            span, tiles, rest = _sp.value, _t.value, _r.value
         nwt = _katome_lib().katome_tile_words(wl.k, span)
         # extraction writes one record per tile of `span` windows (span = 1: one per window);
         # an insertion moves a record (8*NW B) and touches a slot (16*NW B)
         cnt = timer.counts or {}
         steps = args.steps
-        alg = {"extract": lambda launches, reads: reads * (wl.stride + 8 * nwt * (W // span)),
-               "insert": lambda launches, reads: reads * W * (8 * nw + 16 * nw),
-               "insert_tiles": lambda launches, reads: reads * (W // span) * (8 * nwt + 16 * nwt)}
+        per_read_extract = (wl.stride + 8 * nwt * tiles + ((wl.stride + 8 * nw * rest) if rest else 0)) if span > 1 else (wl.stride + 8 * nw * W)
+        alg = {"extract": lambda launches, reads: reads * per_read_extract,
+               "insert": lambda launches, reads: reads * (rest if span > 1 else W) * (8 * nw + 16 * nw),
+               "insert_tiles": lambda launches, reads: reads * tiles * (8 * nwt + 16 * nwt)}
         if not use_dist and cnt:
             # expansion: one scan of the tile table + a 16*NW-byte slot touch per (distinct tile, k-mer) pair;
             # edge sort: ceil(2k/8) passes, each reading and writing every (key, weight) pair once

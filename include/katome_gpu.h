@@ -225,12 +225,21 @@ int katome_dev_insert_weighted(katome_builder *b, const uint64_t *d_records, con
  * span k-mers at once (same sums as `weight += 1` per window, pt_graph.rs:186-191; ~span x fewer atomics).
  * katome_tile_span: the span the library would use for these reads (1 = plain counting); spans above 16 are
  * broken into mid tiles first (two levels of the same expansion).
- * Records of katome_dev_extract_tiles: [n_reads*(read_len-k+1)/span][katome_tile_words(k, span)] u64.
+ * Records of katome_dev_extract_tiles: [n_reads*((read_len-k+1)/span)][katome_tile_words(k, span)] u64 (whole tiles only).
  * Tiles are expanded into the k-mer table by katome_dev_edges / katome_dev_finalize; the multi-GPU
  * driver takes them out with katome_dev_expand_tiles as (k-mer, weight) records (library-owned, valid until
  * the next insert) and routes those to the k-mers' owners (katome_dev_insert_weighted).            */
 uint32_t katome_tile_span(uint32_t k, uint32_t read_len);
 uint32_t katome_tile_words(uint32_t k, uint32_t span);
+/* Reads whose window count is not a multiple of a useful span (101 bp at k = 31: 71 windows) are counted as
+ * *tiles from the front plus the windows that are left over*: katome_tile_plan picks the span with the fewest table
+ * insertions per read (71 windows: 5 tiles of 14 + 1 single window = 6 instead of 71) and returns 1 if tiling
+ * pays; katome_dev_extract_tiles then yields `tiles` records per read and katome_dev_extract_remainder the
+ * `remainder` trailing windows of every read as plain k-mer records ([n_reads*remainder][katome_record_words(k)]),
+ * to be passed to katome_dev_insert right after the tiles of the same batch.                          */
+uint32_t katome_tile_plan(uint32_t k, uint32_t read_len, uint32_t *span, uint32_t *tiles, uint32_t *remainder);
+int katome_dev_extract_remainder(katome_builder *b, const uint8_t *d_packed, uint64_t n_reads, uint32_t read_len,
+                                 uint32_t span, const uint8_t *d_skip, uint64_t *d_records, void *stream);
 int katome_dev_extract_tiles(katome_builder *b, const uint8_t *d_packed, uint64_t n_reads, uint32_t read_len,
                              uint32_t span, const uint8_t *d_skip, uint64_t *d_records, void *stream);
 int katome_dev_insert_tiles(katome_builder *b, const uint64_t *d_records, uint64_t n_records, uint32_t span,

@@ -96,6 +96,8 @@ SYMBOLS = {
     "katome_dev_table_count": (_i, [_vp, u64p]),
     "katome_tile_span": (_u32, [_u32, _u32]),
     "katome_tile_words": (_u32, [_u32, _u32]),
+    "katome_tile_plan": (_u32, [_u32, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "katome_dev_extract_remainder": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp]),
     "katome_dev_extract_tiles": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp]),
     "katome_dev_insert_tiles": (_i, [_vp, _vp, _u64, _u32, _vp]),
     "katome_dev_expand_tiles": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),

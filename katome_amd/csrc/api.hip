@@ -55,6 +55,11 @@ struct katome_builder {
     bool first_seen = false;
     uint64_t reads_inserted = 0;       // reads whose records have been handed to an insert so far
     uint32_t seen_read_len = 0;        // read length of the last extraction (records per read follow from it)
+    // reads whose windows are not a whole number of tiles: the trailing windows come as plain k-mer records right after
+    // the batch's tiles (katome_dev_extract_remainder); first-seen order needs to know where they sit in their reads
+    bool rem_pending = false;
+    uint32_t rem_win0 = 0, rem_per_read = 0;
+    uint64_t last_batch_read0 = 0, last_batch_reads = 0;
     const uint64_t* var_prefix = nullptr;   // variable-length reads: window prefix of the last extraction (device), its reads
     uint64_t var_reads = 0, var_windows = 0;   // and windows; var_seq_base: sequence numbers handed out by earlier batches
     uint64_t var_seq_base = 0;
@@ -128,6 +133,30 @@ uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
     for (uint32_t s = 32; s >= 2; --s) if (W % s == 0 && k + s - 1 <= 63) return s;
     return 1;
 }
+// how a read of `read_len` bases is best counted: `tiles` tiles of `span` windows from the front, then `remainder`
+// single windows.  Fewest table insertions per read; spans above 16 without a divisor to break them into mid tiles
+// (two-level expansion) are charged a little.  Returns 0 (span 1) when tiling does not pay or is switched off.
+uint32_t katome_tile_plan(uint32_t k, uint32_t read_len, uint32_t* span, uint32_t* tiles, uint32_t* remainder) {
+    uint32_t best_s = 1, best_cost = 0xFFFFFFFFu;
+    const uint32_t W = read_len >= k ? read_len - k + 1 : 0;
+    if (W >= 2 && !getenv("KATOME_NO_TILES")) {
+        if (const char* e = getenv("KATOME_TILE_SPAN")) {
+            const uint32_t s = (uint32_t)atoi(e);
+            if (s >= 2 && s <= W && k + s - 1 <= 63) { best_s = s; best_cost = 0; }
+        }
+        for (uint32_t s = 2; best_cost != 0 && s <= 33 && s <= W && k + s - 1 <= 63; ++s) {
+            bool breakable = s <= 16;
+            for (uint32_t d = 3; d <= 8 && !breakable; ++d) breakable = s % d == 0;
+            const uint32_t cost = W / s + W % s + (breakable ? 0 : 2);
+            if (cost < best_cost || (cost == best_cost && s > best_s)) { best_cost = cost; best_s = s; }
+        }
+        if (best_cost != 0 && best_cost >= W) best_s = 1;
+    }
+    if (span) *span = best_s;
+    if (tiles) *tiles = best_s > 1 ? W / best_s : 0;
+    if (remainder) *remainder = best_s > 1 ? W % best_s : W;
+    return best_s > 1;
+}
 uint32_t katome_tile_words(uint32_t k, uint32_t span) { return (uint32_t)key_words_for_k(k + span - 1); }
 
 int katome_dev_extract_tiles(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len, uint32_t span,
@@ -138,6 +167,19 @@ int katome_dev_extract_tiles(katome_builder* b, const uint8_t* d_packed, uint64_
     b->seen_read_len = read_len;
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, span,
                                 b->first_seen && b->rc);
+}
+
+int katome_dev_extract_remainder(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len, uint32_t span,
+                                 const uint8_t* d_skip, uint64_t* d_records, void* stream) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (span < 1 || read_len < b->s.k) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    const uint32_t W = read_len - b->s.k + 1, first = (W / span) * span, rest = W - first;
+    if (rest == 0) return KATOME_OK;
+    PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
+    b->seen_read_len = read_len;
+    b->rem_pending = true; b->rem_win0 = first; b->rem_per_read = rest;
+    return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, 1,
+                                b->first_seen && b->rc, first, rest);
 }
 
 int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
@@ -308,9 +350,14 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
     } else if (b->first_seen) {
         if (b->var_seq_base) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
         if (b->seen_read_len < b->s.k) { set_error("first-seen order: extract the records with this builder first"); return KATOME_E_ARG; }
-        origin.windows = b->seen_read_len - b->s.k + 1; origin.per_read = origin.windows; origin.span = 1; origin.rc = b->rc;
-        origin.read0 = b->reads_inserted;
-        if (n_records % origin.per_read) { set_error("first-seen order: a batch must hold whole reads"); return KATOME_E_ARG; }
+        origin.windows = b->seen_read_len - b->s.k + 1; origin.span = 1; origin.rc = b->rc;
+        if (b->rem_pending) {           // the windows after the tiles of the batch that was just inserted
+            origin.per_read = b->rem_per_read; origin.win0 = b->rem_win0; origin.read0 = b->last_batch_read0;
+            if (n_records != b->last_batch_reads * origin.per_read) { set_error("first-seen order: insert the remainder of the batch whose tiles were inserted last"); return KATOME_E_ARG; }
+        } else {
+            origin.per_read = origin.windows; origin.read0 = b->reads_inserted;
+            if (n_records % origin.per_read) { set_error("first-seen order: a batch must hold whole reads"); return KATOME_E_ARG; }
+        }
     }
     const int passes = b->first_seen ? 0 : region_passes(b->table.cap * b->table.slot_bytes());
     if (passes > 0 && n_records >= (1u << 16)) {
@@ -333,9 +380,10 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
     if (b->first_seen && origin.win_prefix) {
         b->var_seq_base += 2 * n_records;
         b->var_prefix = nullptr; b->var_reads = b->var_windows = 0;
-    } else if (b->first_seen) {
+    } else if (b->first_seen && !b->rem_pending) {
         b->reads_inserted += n_records / origin.per_read;
     }
+    b->rem_pending = false;
     return KATOME_OK;
 }
 int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_records, void* stream) {
@@ -366,7 +414,10 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
         KCHECK(table_insert(b->tiles, d_records + done * nwt, nullptr, n, stream, b->first_seen ? &origin : nullptr));
         done += n;
     }
-    if (b->first_seen) b->reads_inserted += n_records / origin.per_read;
+    if (b->first_seen) {
+        b->last_batch_read0 = b->reads_inserted; b->last_batch_reads = n_records / origin.per_read;
+        b->reads_inserted += n_records / origin.per_read;
+    }
     return KATOME_OK;
 }
 
@@ -839,13 +890,19 @@ static int build_packed_impl(const katome_settings* s, const uint8_t* packed, ui
             uint64_t reads_per_batch = std::max<uint64_t>(batch_records(b->nw) / W, 64);
             reads_per_batch = (reads_per_batch / 64) * 64;       // keeps batch starts 16-byte aligned
             if ((rc = d_rec.alloc(std::min(reads_per_batch, n_reads) * W * 8 * b->nw + 16))) break;
-            const uint32_t span = katome_tile_span(s->k, read_len);
+            uint32_t span = 1, tiles = 0, rest = 0;
+            katome_tile_plan(s->k, read_len, &span, &tiles, &rest);
             for (uint64_t r0 = 0; r0 < n_reads && !rc; r0 += reads_per_batch) {
                 const uint64_t nr = std::min(reads_per_batch, n_reads - r0);
-                if (span > 1) {       // tiled counting: W/span tile records per read
+                if (span > 1) {       // tiled counting: W/span tile records per read, then the windows that are left over
                     rc = katome_dev_extract_tiles(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len, span,
                                                   skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);
-                    if (!rc) rc = katome_dev_insert_tiles(b, d_rec.as<u64>(), nr * (W / span), span, nullptr);
+                    if (!rc) rc = katome_dev_insert_tiles(b, d_rec.as<u64>(), nr * tiles, span, nullptr);
+                    if (!rc && rest) {
+                        rc = katome_dev_extract_remainder(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len, span,
+                                                          skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);
+                        if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), nr * rest, nullptr);
+                    }
                 } else {
                     rc = katome_dev_extract_fixed(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len,
                                                   skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);

@@ -94,7 +94,8 @@ inline unsigned grid_for(uint64_t work_items, unsigned per_block, unsigned cap =
 
 // ---- launchers implemented in the .hip files (all asynchronous on `stream`) -----------------
 int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
-                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span = 1, bool mark = false);
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span = 1, bool mark = false,
+                         uint32_t first_window = 0, uint32_t records_per_read = 0);
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                        const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                        uint64_t* d_records, hipStream_t stream, bool mark = false);
@@ -161,6 +162,7 @@ struct Table {
 // where a batch of records sits in the read-ordered stream (first-seen-order mode)
 struct SeenOrigin {
     uint64_t read0 = 0, rec0 = 0; uint32_t per_read = 1, span = 1, windows = 1; bool rc = false;
+    uint32_t win0 = 0;                 // first window the batch's records cover in every read (the windows after the tiles)
     // variable-length reads: record g of the batch is window g - win_prefix[r] of the read r with win_prefix[r] <= g;
     // seq_base = sequence numbers used by the batches before this one
     const uint64_t* win_prefix = nullptr; uint64_t n_reads = 0, seq_base = 0;

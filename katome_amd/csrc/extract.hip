@@ -25,9 +25,9 @@ constexpr u32 MARK_FLAG = 1u << 31;     // or-ed into `step`: tag records with R
 
 template <int NW, bool RC>
 __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t* lds_skip, u32 i, u32 W, u32 magicW,
-                                                    u32 stride_bytes, u32 k, u32 step) {
+                                                    u32 stride_bytes, u32 k, u32 step, u32 win0) {
     u32 r = W == 1 ? i : __umulhi(i, magicW);   // i / W (magic multiply, exact for i, W < 2^16; W = 1 has no 32-bit magic)
-    u32 w = (i - r * W) * (step & ~MARK_FLAG);
+    u32 w = win0 + (i - r * W) * (step & ~MARK_FLAG);
     if (lds_skip[r]) return key_invalid<NW>();
     u32 bit = r * stride_bytes * 8 + 2 * w;
     u32 di = bit >> 5, sh = bit & 31;
@@ -45,7 +45,7 @@ __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t
 
 template <int NW, bool RC>
 __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __restrict__ packed, u64 n_reads,
-                                                               u32 stride_bytes, u32 k, u32 W, u32 magicW, u32 step,
+                                                               u32 stride_bytes, u32 k, u32 W, u32 magicW, u32 step, u32 win0,
                                                                const uint8_t* __restrict__ skip, u64* __restrict__ out) {
     extern __shared__ u32 lds[];
     const u32 tile_bytes_max = TILE_READS * stride_bytes;
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
         if (NW == 1) {
             for (u32 p = tid; 2 * p < nrec; p += BLOCK) {
                 u32 i0 = 2 * p;
-                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i0, W, magicW, stride_bytes, k, step);
+                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i0, W, magicW, stride_bytes, k, step, win0);
                 if (i0 + 1 < nrec) {
-                    Key<NW> b = record_from_lds<NW, RC>(lds, lds_skip, i0 + 1, W, magicW, stride_bytes, k, step);
+                    Key<NW> b = record_from_lds<NW, RC>(lds, lds_skip, i0 + 1, W, magicW, stride_bytes, k, step, win0);
                     *reinterpret_cast<ulonglong2*>(out + out0 + i0) = make_ulonglong2(a.w[0], b.w[0]);
                 } else {
                     out[out0 + i0] = a.w[0];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
             }
         } else {
             for (u32 i = tid; i < nrec; i += BLOCK) {
-                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i, W, magicW, stride_bytes, k, step);
+                Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i, W, magicW, stride_bytes, k, step, win0);
                 *reinterpret_cast<ulonglong2*>(out + (out0 + i) * 2) = make_ulonglong2(a.w[0], a.w[NW - 1]);
             }
         }
@@ -121,11 +121,11 @@ struct ArrayAddr {
     __device__ __forceinline__ bool mark() const { return mark_; }
 };
 struct FixedAddr {
-    u64 stride_bytes; u64 W; const uint8_t* skip; u64 r; u32 step;
+    u64 stride_bytes; u64 W; const uint8_t* skip; u64 r; u32 step; u32 win0;
     __device__ __forceinline__ void locate(u64 i, u64& boff, u32& w) {
         r = i / W;
         boff = r * stride_bytes;
-        w = (u32)(i - r * W) * (step & ~MARK_FLAG);
+        w = win0 + (u32)(i - r * W) * (step & ~MARK_FLAG);
     }
     __device__ __forceinline__ bool mark() const { return (step & MARK_FLAG) != 0; }
     __device__ __forceinline__ bool skipped(u64) const { return skip && skip[r]; }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(BLOCK) void extract_general_kernel(const uint8_t* _
 // starts and W the records per read (step 1, W = L-k+1: every k-mer; step = span, W = (L-k0+1)/span with
 // k = k0+span-1: the tiles of `span` consecutive k0-mers that the tiled counting path stores).
 template <int NW, bool RC>
-static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u32 k, u32 step, u32 W, const uint8_t* d_skip,
+static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u32 k, u32 step, u32 W, u32 win0, const uint8_t* d_skip,
                            u64* d_records, hipStream_t stream) {
     const u32 stride = (read_len + 3) / 4;
     const u64 total = n_reads * (u64)W;
@@ -186,9 +186,9 @@ static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u
         const u64 n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
         unsigned grid = (unsigned)(n_tiles < 256u * 8u ? n_tiles : 256u * 8u);
         hipLaunchKernelGGL((extract_fixed_kernel<NW, RC>), dim3(grid), dim3(BLOCK), lds_bytes, stream, d_packed, n_reads,
-                           stride, k, W, magicW, step, d_skip, d_records);
+                           stride, k, W, magicW, step, win0, d_skip, d_records);
     } else {
-        FixedAddr a{stride, W, d_skip, 0, step};
+        FixedAddr a{stride, W, d_skip, 0, step, win0};
         hipLaunchKernelGGL((extract_general_kernel<NW, RC, FixedAddr>), dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, stream,
                            d_packed, n_reads * (u64)stride, a, total, k, d_records);
     }
@@ -196,17 +196,23 @@ static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u
     return KATOME_OK;
 }
 
+// Records of fixed-length reads.  Record j of a read covers `span` consecutive windows starting at window
+// first_window + j*span (as one (k+span-1)-mer); records_per_read = 0 means "as many as fit".
 int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
-                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span, bool mark) {
+                         const uint8_t* d_skip, uint64_t* d_records, hipStream_t stream, uint32_t span, bool mark,
+                         uint32_t first_window, uint32_t records_per_read) {
     if (read_len < k) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }   // pt_graph.rs:278
-    if (span == 0 || (read_len - k + 1) % span) { set_error("tile span %u does not divide the windows per read", span); return KATOME_E_ARG; }
-    const u32 kk = k + span - 1, W = (read_len - k + 1) / span;
+    const u32 windows = read_len - k + 1;
+    if (span == 0 || first_window > windows) { set_error("bad tile span %u / first window %u", span, first_window); return KATOME_E_ARG; }
+    const u32 kk = k + span - 1, W = records_per_read ? records_per_read : (windows - first_window) / span;
+    if (first_window + (u64)W * span > windows) { set_error("records reach past the last window of a read"); return KATOME_E_ARG; }
+    if (W == 0) return KATOME_OK;
     const int nw = key_words_for_k(kk);
     const u32 step = span | (mark ? MARK_FLAG : 0u);
-    if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream)
-                           : extract_fixed_t<1, false>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream);
-    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream)
-              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, step, W, d_skip, d_records, stream);
+    if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream)
+                           : extract_fixed_t<1, false>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream);
+    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream)
+              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream);
 }
 
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,

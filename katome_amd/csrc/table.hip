@@ -122,6 +122,7 @@ struct SeenParams {
     u32 span;             // windows per record
     u32 windows;          // W
     u32 rc;
+    u32 win0;             // first window covered in every read
     const u64* win_prefix; // variable-length reads (SeenOrigin): windows before each read of the batch, [n_reads + 1]
     u64 n_reads, seq_base;
 };
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
                 const u64 w0 = sp.win_prefix[lo], W = sp.win_prefix[lo + 1] - w0, i0 = g - w0;
                 P = sp.seq_base + 2 * w0 + i0; Q = sp.seq_base + 2 * w0 + 2 * W - i0 - 1;
             } else {
-                const u64 r = sp.read0 + g / sp.per_read, i0 = (g % sp.per_read) * sp.span;
+                const u64 r = sp.read0 + g / sp.per_read, i0 = sp.win0 + (g % sp.per_read) * sp.span;
                 P = r * 2 * sp.windows + i0; Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
             }
             if (sp.rc) {
@@ -376,7 +377,7 @@ int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights,
     if (t.track_seen) {
         if (!origin) { set_error("first-seen order: records must come with their position in the read stream"); return KATOME_E_ARG; }
         sp.seen = t.seen.as<u64>(); sp.read0 = origin->read0; sp.rec0 = origin->rec0; sp.per_read = origin->per_read;
-        sp.span = origin->span; sp.windows = origin->windows; sp.rc = origin->rc;
+        sp.span = origin->span; sp.windows = origin->windows; sp.rc = origin->rc; sp.win0 = origin->win0;
         sp.win_prefix = origin->win_prefix; sp.n_reads = origin->n_reads; sp.seq_base = origin->seq_base;
         if (t.nw == 1)
             hipLaunchKernelGGL((insert_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);

@@ -167,6 +167,35 @@ class Builder:
         _check(_lib.lib().katome_dev_extract_tiles(self._h, p, n_reads, read_len, span, sk, _ptr(out), _stream()))
         return out[:n_rec * nwt]
 
+    def tile_plan(self, read_len):
+        """(span, tiles per read, single windows left over per read); span 1 = count every window on its own"""
+        sp, t, r = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        _lib.lib().katome_tile_plan(self.k, read_len, C.byref(sp), C.byref(t), C.byref(r))
+        return sp.value, t.value, r.value
+
+    def extract_remainder(self, packed, n_reads, read_len, span, skip=None, out=None, first_read=0):
+        """the windows of every read that come after its last whole tile, as plain k-mer records"""
+        stride = (read_len + 3) // 4
+        W = read_len - self.k + 1
+        n_rec = n_reads * (W % span)
+        if out is None:
+            out = torch.empty(max(n_rec, 1) * self.nw, dtype=torch.int64, device=self.tdev)
+        assert out.numel() >= n_rec * self.nw
+        p = C.c_void_p(packed.data_ptr() + first_read * stride)
+        sk = C.c_void_p(skip.data_ptr() + first_read) if skip is not None else None
+        _check(_lib.lib().katome_dev_extract_remainder(self._h, p, n_reads, read_len, span, sk, _ptr(out), _stream()))
+        return out[:n_rec * self.nw]
+
+    def count_reads(self, packed, n_reads, read_len, skip=None, first_read=0):
+        """one batch through the library's plan: tiles (+ left-over windows), or every window on its own"""
+        span, tiles, rest = self.tile_plan(read_len)
+        if span > 1:
+            self.insert_tiles(self.extract_tiles(packed, n_reads, read_len, span, skip, first_read=first_read), span)
+            if rest:
+                self.insert(self.extract_remainder(packed, n_reads, read_len, span, skip, first_read=first_read))
+        else:
+            self.insert(self.extract_fixed(packed, n_reads, read_len, skip, first_read=first_read))
+
     def insert_tiles(self, records, span):
         n = records.numel() // self.tile_words(span)
         _check(_lib.lib().katome_dev_insert_tiles(self._h, _ptr(records), n, span, _stream()))

@@ -40,4 +40,7 @@ WORKLOADS = {
     "c3": Workload("c3", 200_000_000, 150, 31, 100_000_000, 1e-3, 0),
     # configs[4]: 1B reads, k=63 (128-bit keys), 8 GPUs
     "c5": Workload("c5", 1_000_000_000, 150, 63, 1_000_000_000, 5e-4, 0),
+    # not a BASELINE configuration: 101-bp reads, whose 71 windows are not a whole number of useful tiles
+    # (counted as 5 tiles of 14 windows + 1 window, katome_tile_plan)
+    "r101": Workload("r101", 100_000_000, 101, 31, 50_000_000, 1e-3, 0),
 }

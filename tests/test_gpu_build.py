@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-from helpers import kmer_to_int, pack_reads_ascii, windows_multiset  # noqa: E402
+from helpers import int_to_kmer, kmer_to_int, pack_reads_ascii, windows_multiset  # noqa: E402
 
 
 def _build_files(paths, k, rc, ft=None):
@@ -611,3 +611,47 @@ def test_multi_rank_on_one_gpu(oracle, tmp_path, world, k, rc, L):
                 assert node_of[int(p["src"][j])] == key >> 2 and node_of[int(p["dst"][j])] == key & mask
     assert sorted(merged.items()) == sorted((kmer_to_int(s), w) for s, w in ref.multiset())
     assert sorted(node_of) == list(range(ref.n_nodes)) and len(set(node_of.values())) == ref.n_nodes
+
+
+@pytest.mark.parametrize("k,L,rc,first_seen", [(31, 101, True, False), (31, 101, True, True), (21, 76, False, True), (40, 77, True, False),
+                                               (33, 126, True, True), (16, 50, True, False), (31, 150, True, True), (63, 150, True, False),
+                                               (31, 36, True, True), (12, 13, False, True)])
+def test_read_lengths_that_are_not_whole_tiles(oracle, k, L, rc, first_seen):
+    """the library's plan for any read length: tiles from the front + the windows left over (101 bp at k=31: 71 windows =
+    5 tiles of 14 + 1); same graph as the oracle, in the reference's numbering too; several batches"""
+    from katome_amd import device as kd
+    n = 3000
+    ascii_reads = oracle.synth_reads(0, n, L, 30000, 4e-3, 2)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("A")
+    packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+    skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+    b = kd.Builder(k, rc, first_seen_order=first_seen, table_slots_hint=1 << 14)
+    span, tiles, rest = b.tile_plan(L)
+    W = L - k + 1
+    assert (span == 1 and rest == W) or (tiles * span + rest == W and tiles + rest < W)
+    if (k, L) == (31, 101):
+        assert (span, tiles, rest) == (14, 5, 1)
+    for r0 in range(0, n, 1024):
+        b.count_reads(packed, min(1024, n - r0), L, skip, first_read=r0)
+    dg = b.finalize()
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
+    if first_seen:
+        assert np.array_equal(dg.edge_label.cpu().numpy(), ref.edge_label)
+        assert np.array_equal(dg.edge_weight.cpu().numpy().view(np.uint32), ref.edge_weight)
+        assert np.array_equal(dg.edge_src.cpu().numpy().view(np.uint64), ref.edge_src)
+        assert np.array_equal(dg.edge_dst.cpu().numpy().view(np.uint64), ref.edge_dst)
+    else:
+        nw = dg.key_words
+        ek = dg.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
+        keys = [int(r[0]) if nw == 1 else (int(r[0]) << 64) | int(r[1]) for r in ek]
+        got = list(zip([int_to_kmer(v, k) for v in keys], dg.edge_weight.cpu().numpy().view(np.uint32).tolist()))
+        assert got == ref.multiset()
+    b.close()
+    # the host entry takes the same route
+    from katome_amd.build import GpuGraph
+    g, _ = GpuGraph.create_from_packed(pack_reads_ascii(clean).reshape(-1), n, L, skip=has_n.astype(np.uint8),
+                                       reverse_complement=rc, k=k, first_seen_order=first_seen)
+    assert g.multiset() == ref.multiset()
