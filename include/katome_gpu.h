@@ -191,6 +191,20 @@ int katome_dev_extract_var(katome_builder *b, const uint8_t *d_packed, uint64_t 
                            const uint64_t *d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                            uint64_t *d_records, void *stream);
 
+/* variable-length reads counted as tiles: with one span for the whole batch, read r yields (len_r-k+1)/span whole tiles
+ * from its front (extract_var_tiles: d_tile_prefix[n_reads+1] = tiles before each read; records of
+ * katome_tile_words(k, span) words, to katome_dev_insert_tiles) and its (len_r-k+1) mod span trailing windows as plain
+ * k-mer records (extract_var_remainder: d_rest_prefix likewise; to katome_dev_insert, which also closes the batch --
+ * call it even when total_rest is 0 on a FIRST_SEEN_ORDER builder).  d_win_prefix / total_windows as above.          */
+int katome_dev_extract_var_tiles(katome_builder *b, const uint8_t *d_packed, uint64_t packed_bytes,
+                                 const uint64_t *d_byte_off, const uint32_t *d_len, const uint64_t *d_tile_prefix,
+                                 const uint64_t *d_win_prefix, uint64_t n_reads, uint64_t total_tiles,
+                                 uint64_t total_windows, uint32_t span, uint64_t *d_records, void *stream);
+int katome_dev_extract_var_remainder(katome_builder *b, const uint8_t *d_packed, uint64_t packed_bytes,
+                                     const uint64_t *d_byte_off, const uint32_t *d_len, const uint64_t *d_rest_prefix,
+                                     const uint64_t *d_win_prefix, uint64_t n_reads, uint64_t total_rest,
+                                     uint64_t total_windows, uint32_t span, uint64_t *d_records, void *stream);
+
 /* group records of `key_words` u64 words by owner rank = mulhi(mix(key), n_parts) (stable; invalid records are
  * dropped); optional u32 values travel with their records (both d_values and d_values_out, or neither).
  * d_out: same size as d_records; h_counts[n_parts] receives the records per part (synchronises)       */

@@ -86,6 +86,8 @@ SYMBOLS = {
     "katome_phase_name": (C.c_char_p, [_u32]),
     "katome_dev_extract_fixed": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
     "katome_dev_extract_var": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _u64, _u64, _vp, _vp]),
+    "katome_dev_extract_var_tiles": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u32, _vp, _vp]),
+    "katome_dev_extract_var_remainder": (_i, [_vp, _vp, _u64, _vp, _vp, _vp, _vp, _u64, _u64, _u64, _u32, _vp, _vp]),
     "katome_dev_partition": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp, _vp, u64p, _vp]),
     "katome_dev_partition_core": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _u32, _u32, _vp, _vp, u64p, _vp]),
     "katome_key_owner": (_u32, [u64p, _u32, _u32, _u32, _u32]),

@@ -63,6 +63,9 @@ struct katome_builder {
     const uint64_t* var_prefix = nullptr;   // variable-length reads: window prefix of the last extraction (device), its reads
     uint64_t var_reads = 0, var_windows = 0;   // and windows; var_seq_base: sequence numbers handed out by earlier batches
     uint64_t var_seq_base = 0;
+    const uint64_t* var_rec_prefix = nullptr;  // records before each read for the records just extracted (tiles / left-over windows)
+    uint64_t var_records = 0;                  // how many of them: the insert that follows must take exactly these
+    uint32_t var_mode = 0, var_span = 1;       // 0 every window, 1 whole tiles, 2 the windows after the last whole tile
     DevBuf edge_seq;                   // sequence number of each edge's first insertion, aligned with edge_key
     uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
     uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
@@ -182,17 +185,40 @@ int katome_dev_extract_remainder(katome_builder* b, const uint8_t* d_packed, uin
                                 b->first_seen && b->rc, first, rest);
 }
 
+static int extract_var_common(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
+                              const uint32_t* d_len, const uint64_t* d_rec_prefix, const uint64_t* d_win_prefix, uint64_t n_reads,
+                              uint64_t n_records, uint64_t total_windows, uint32_t span, uint32_t mode, uint64_t* d_records, void* stream) {
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (mode == 1 && (span < 2 || b->s.k + span - 1 > 63)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    if (b->first_seen) {
+        if (b->reads_inserted) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
+        // the insert that follows reads these
+        b->var_prefix = d_win_prefix; b->var_reads = n_reads; b->var_windows = total_windows;
+        b->var_rec_prefix = d_rec_prefix; b->var_records = n_records; b->var_mode = mode; b->var_span = span;
+    }
+    PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
+    return launch_extract_var(b->s.k, b->rc, d_packed, packed_bytes, d_byte_off, d_len, d_rec_prefix, n_reads, n_records,
+                              d_records, (hipStream_t)stream, b->first_seen && b->rc, span, mode);
+}
+
 int katome_dev_extract_var(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                            const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
                            uint64_t* d_records, void* stream) {
-    KCHECK_HIP(hipSetDevice(b->s.device));
-    if (b->first_seen) {
-        if (b->reads_inserted) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
-        b->var_prefix = d_win_prefix; b->var_reads = n_reads; b->var_windows = total_windows;   // the insert that follows reads them
-    }
-    PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
-    return launch_extract_var(b->s.k, b->rc, d_packed, packed_bytes, d_byte_off, d_len, d_win_prefix, n_reads, total_windows,
-                              d_records, (hipStream_t)stream, b->first_seen && b->rc);
+    return extract_var_common(b, d_packed, packed_bytes, d_byte_off, d_len, d_win_prefix, d_win_prefix, n_reads, total_windows,
+                              total_windows, 1, 0, d_records, stream);
+}
+int katome_dev_extract_var_tiles(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
+                                 const uint32_t* d_len, const uint64_t* d_tile_prefix, const uint64_t* d_win_prefix, uint64_t n_reads,
+                                 uint64_t total_tiles, uint64_t total_windows, uint32_t span, uint64_t* d_records, void* stream) {
+    return extract_var_common(b, d_packed, packed_bytes, d_byte_off, d_len, d_tile_prefix, d_win_prefix, n_reads, total_tiles,
+                              total_windows, span, 1, d_records, stream);
+}
+int katome_dev_extract_var_remainder(katome_builder* b, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
+                                     const uint32_t* d_len, const uint64_t* d_rest_prefix, const uint64_t* d_win_prefix, uint64_t n_reads,
+                                     uint64_t total_rest, uint64_t total_windows, uint32_t span, uint64_t* d_records, void* stream) {
+    if (span < 1) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    return extract_var_common(b, d_packed, packed_bytes, d_byte_off, d_len, d_rest_prefix, d_win_prefix, n_reads, total_rest,
+                              total_windows, span, 2, d_records, stream);
 }
 
 int katome_dev_partition(int device, const uint64_t* d_records, const uint32_t* d_values, uint64_t n_records, uint32_t key_words,
@@ -336,7 +362,13 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
     hipStream_t stream = (hipStream_t)stream_;
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
-    if (n_records == 0) return KATOME_OK;
+    if (n_records == 0) {
+        if (b->first_seen && b->var_prefix && b->var_mode != 1 && b->var_records == 0) {   // a batch whose reads are all whole tiles
+            b->var_seq_base += 2 * b->var_windows;
+            b->var_prefix = b->var_rec_prefix = nullptr; b->var_reads = b->var_windows = 0;
+        }
+        return KATOME_OK;
+    }
     uint64_t room = 0;
     KCHECK(ensure_table(b, n_records, &room, stream));
     // Optional: order the batch by table region first (streaming radix passes over the hash prefix), so
@@ -345,8 +377,9 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
     const uint64_t* k_in = d_records; const uint32_t* w_in = d_weights;
     SeenOrigin origin;
     if (b->first_seen && b->var_prefix) {
-        if (n_records != b->var_windows) { set_error("first-seen order: insert the whole batch katome_dev_extract_var produced"); return KATOME_E_ARG; }
+        if (b->var_mode == 1 || n_records != b->var_records) { set_error("first-seen order: insert exactly the records the last katome_dev_extract_var* call produced"); return KATOME_E_ARG; }
         origin.win_prefix = b->var_prefix; origin.n_reads = b->var_reads; origin.seq_base = b->var_seq_base; origin.rc = b->rc;
+        origin.rec_prefix = b->var_rec_prefix; origin.mode = b->var_mode; origin.span = b->var_span;
     } else if (b->first_seen) {
         if (b->var_seq_base) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
         if (b->seen_read_len < b->s.k) { set_error("first-seen order: extract the records with this builder first"); return KATOME_E_ARG; }
@@ -378,8 +411,8 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
         done += n;
     }
     if (b->first_seen && origin.win_prefix) {
-        b->var_seq_base += 2 * n_records;
-        b->var_prefix = nullptr; b->var_reads = b->var_windows = 0;
+        b->var_seq_base += 2 * b->var_windows;          // the batch is complete: its reads' windows, both strands
+        b->var_prefix = b->var_rec_prefix = nullptr; b->var_reads = b->var_windows = 0;
     } else if (b->first_seen && !b->rem_pending) {
         b->reads_inserted += n_records / origin.per_read;
     }
@@ -399,7 +432,13 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     b->span = span;
     const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
     SeenOrigin origin;
-    if (b->first_seen) {
+    const bool var_tiles = b->first_seen && b->var_prefix != nullptr;
+    if (var_tiles) {
+        if (b->var_mode != 1 || b->var_span != span || n_records != b->var_records) { set_error("first-seen order: insert exactly the tiles katome_dev_extract_var_tiles produced"); return KATOME_E_ARG; }
+        origin.win_prefix = b->var_prefix; origin.n_reads = b->var_reads; origin.seq_base = b->var_seq_base; origin.rc = b->rc;
+        origin.rec_prefix = b->var_rec_prefix; origin.mode = 1; origin.span = span;
+    } else if (b->first_seen) {
+        if (b->var_seq_base) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
         if (b->seen_read_len < b->s.k) { set_error("first-seen order: extract the records with this builder first"); return KATOME_E_ARG; }
         origin.windows = b->seen_read_len - b->s.k + 1; origin.per_read = origin.windows / span; origin.span = span; origin.rc = b->rc;
         origin.read0 = b->reads_inserted;
@@ -414,7 +453,7 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
         KCHECK(table_insert(b->tiles, d_records + done * nwt, nullptr, n, stream, b->first_seen ? &origin : nullptr));
         done += n;
     }
-    if (b->first_seen) {
+    if (b->first_seen && !var_tiles) {
         b->last_batch_read0 = b->reads_inserted; b->last_batch_reads = n_records / origin.per_read;
         b->reads_inserted += n_records / origin.per_read;
     }
@@ -1000,20 +1039,58 @@ static int build_files_impl(const katome_settings* s, const char* const* paths, 
             hipMemcpy(d_len.p, hr.len, hr.n_reads * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
         uint64_t cap = batch_records(b->nw);
         if (const char* e = getenv("KATOME_VAR_BATCH_RECORDS")) cap = std::max<uint64_t>(1, strtoull(e, nullptr, 10));   // tests: many small batches
-        std::vector<uint64_t> pref;
+        // one span for the whole input: the one with the fewest table insertions over all reads (tiles from the front of
+        // every read + the windows left over, as for fixed-length reads)
+        uint32_t span = 1;
+        if (!getenv("KATOME_NO_TILES")) {
+            std::vector<uint64_t> hist;
+            for (uint64_t r = 0; r < hr.n_reads; ++r) {
+                const uint32_t W = hr.len[r] - s->k + 1;
+                if (W >= hist.size()) hist.resize(W + 1, 0);
+                hist[W] += 1;
+            }
+            uint64_t best = hr.total_windows;
+            for (uint32_t sp = 2; sp <= 33 && s->k + sp - 1 <= 63; ++sp) {
+                bool breakable = sp <= 16;
+                for (uint32_t d = 3; d <= 8 && !breakable; ++d) breakable = sp % d == 0;
+                uint64_t cost = 0;
+                for (size_t W = 1; W < hist.size(); ++W) cost += hist[W] * (W / sp + W % sp + (breakable ? 0 : 2));
+                if (cost < best || (cost == best && span > 1)) { best = cost; span = sp; }
+            }
+            if (const char* e = getenv("KATOME_TILE_SPAN")) { const uint32_t sp = (uint32_t)atoi(e); if (sp >= 1 && s->k + sp - 1 <= 63) span = sp; }
+        }
+        DevBuf d_tpref, d_rpref;
+        std::vector<uint64_t> pref, tpref, rpref;
         for (uint64_t r0 = 0; r0 < hr.n_reads && !rc;) {
-            pref.assign(1, 0);
+            pref.assign(1, 0); tpref.assign(1, 0); rpref.assign(1, 0);
             uint64_t r1 = r0;
             while (r1 < hr.n_reads && (r1 == r0 || pref.back() + (hr.len[r1] - s->k + 1) <= cap)) {
-                pref.push_back(pref.back() + (hr.len[r1] - s->k + 1));
+                const uint64_t W = hr.len[r1] - s->k + 1;
+                pref.push_back(pref.back() + W);
+                tpref.push_back(tpref.back() + W / span);
+                rpref.push_back(rpref.back() + W % span);
                 ++r1;
             }
-            const uint64_t windows = pref.back();
+            const uint64_t windows = pref.back(), tiles = tpref.back(), rest = rpref.back(), nr = r1 - r0;
             if ((rc = d_pref.alloc(pref.size() * 8)) || (rc = d_rec.alloc(windows * 8 * b->nw + 16))) break;
             if (hipMemcpy(d_pref.p, pref.data(), pref.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
-            rc = katome_dev_extract_var(b, d_packed.as<uint8_t>(), hr.packed_bytes, d_off.as<u64>() + r0, d_len.as<u32>() + r0,
-                                        d_pref.as<u64>(), r1 - r0, windows, d_rec.as<u64>(), nullptr);
-            if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), windows, nullptr);
+            if (span > 1) {
+                if ((rc = d_tpref.alloc(tpref.size() * 8)) || (rc = d_rpref.alloc(rpref.size() * 8))) break;
+                if (hipMemcpy(d_tpref.p, tpref.data(), tpref.size() * 8, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(d_rpref.p, rpref.data(), rpref.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+                if (tiles) {
+                    rc = katome_dev_extract_var_tiles(b, d_packed.as<uint8_t>(), hr.packed_bytes, d_off.as<u64>() + r0, d_len.as<u32>() + r0,
+                                                      d_tpref.as<u64>(), d_pref.as<u64>(), nr, tiles, windows, span, d_rec.as<u64>(), nullptr);
+                    if (!rc) rc = katome_dev_insert_tiles(b, d_rec.as<u64>(), tiles, span, nullptr);
+                }
+                if (!rc) rc = katome_dev_extract_var_remainder(b, d_packed.as<uint8_t>(), hr.packed_bytes, d_off.as<u64>() + r0, d_len.as<u32>() + r0,
+                                                               d_rpref.as<u64>(), d_pref.as<u64>(), nr, rest, windows, span, d_rec.as<u64>(), nullptr);
+                if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), rest, nullptr);       // (also closes the batch when nothing is left over)
+            } else {
+                rc = katome_dev_extract_var(b, d_packed.as<uint8_t>(), hr.packed_bytes, d_off.as<u64>() + r0, d_len.as<u32>() + r0,
+                                            d_pref.as<u64>(), nr, windows, d_rec.as<u64>(), nullptr);
+                if (!rc) rc = katome_dev_insert(b, d_rec.as<u64>(), windows, nullptr);
+            }
             if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) { set_error("device failure during build"); rc = KATOME_E_DEVICE; }
             r0 = r1;
         }

@@ -98,7 +98,7 @@ int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t 
                          uint32_t first_window = 0, uint32_t records_per_read = 0);
 int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
                        const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
-                       uint64_t* d_records, hipStream_t stream, bool mark = false);
+                       uint64_t* d_records, hipStream_t stream, bool mark = false, uint32_t span = 1, uint32_t mode = 0);
 
 // radix.hip
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
@@ -166,6 +166,8 @@ struct SeenOrigin {
     // variable-length reads: record g of the batch is window g - win_prefix[r] of the read r with win_prefix[r] <= g;
     // seq_base = sequence numbers used by the batches before this one
     const uint64_t* win_prefix = nullptr; uint64_t n_reads = 0, seq_base = 0;
+    // ... whose records may be whole tiles (mode 1) or the windows after them (mode 2): rec_prefix = records before each read
+    const uint64_t* rec_prefix = nullptr; uint32_t mode = 0;
 };
 int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream);
 int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream,

@@ -107,15 +107,17 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
 // thread, read located by binary search over the window prefix sums, bytes fetched through L1/L2.
 // ---------------------------------------------------------------------------------------------
 struct ArrayAddr {
-    const u64* byte_off; const u32* len; const u64* win_prefix; u64 n_reads; bool mark_;
+    const u64* byte_off; const u32* len; const u64* rec_prefix; u64 n_reads; bool mark_;
+    u32 k0, span, mode;          // mode 0: every window; 1: whole tiles of `span` windows; 2: the windows after the last whole tile
     __device__ __forceinline__ void locate(u64 i, u64& boff, u32& w) const {
-        u64 lo = 0, hi = n_reads;            // largest r with win_prefix[r] <= i
+        u64 lo = 0, hi = n_reads;            // largest r with rec_prefix[r] <= i
         while (hi - lo > 1) {
             u64 mid = (lo + hi) >> 1;
-            if (win_prefix[mid] <= i) lo = mid; else hi = mid;
+            if (rec_prefix[mid] <= i) lo = mid; else hi = mid;
         }
         boff = byte_off[lo];
-        w = (u32)(i - win_prefix[lo]);
+        const u32 j = (u32)(i - rec_prefix[lo]);
+        w = mode == 1 ? j * span : mode == 2 ? ((len[lo] - k0 + 1) / span) * span + j : j;
     }
     __device__ __forceinline__ bool skipped(u64) const { return false; }
     __device__ __forceinline__ bool mark() const { return mark_; }
@@ -215,11 +217,14 @@ int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t 
               : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream);
 }
 
-int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
-                       const uint32_t* d_len, const uint64_t* d_win_prefix, uint64_t n_reads, uint64_t total_windows,
-                       uint64_t* d_records, hipStream_t stream, bool mark) {
+// d_rec_prefix: records before each read ([n_reads + 1]); mode / span as in ArrayAddr (mode 1 records are (k+span-1)-mers)
+int launch_extract_var(uint32_t k0, bool rc, const uint8_t* d_packed, uint64_t packed_bytes, const uint64_t* d_byte_off,
+                       const uint32_t* d_len, const uint64_t* d_rec_prefix, uint64_t n_reads, uint64_t total_windows,
+                       uint64_t* d_records, hipStream_t stream, bool mark, uint32_t span, uint32_t mode) {
     if (total_windows == 0 || n_reads == 0) return KATOME_OK;
-    ArrayAddr a{d_byte_off, d_len, d_win_prefix, n_reads, mark};
+    if (span == 0 || mode > 2) { set_error("bad span / mode"); return KATOME_E_ARG; }
+    ArrayAddr a{d_byte_off, d_len, d_rec_prefix, n_reads, mark, k0, span, mode};
+    const uint32_t k = mode == 1 ? k0 + span - 1 : k0;
     const int nw = key_words_for_k(k);
     dim3 grid(grid_for(total_windows, BLOCK)), block(BLOCK);
     if (nw == 1) {

@@ -125,6 +125,8 @@ struct SeenParams {
     u32 win0;             // first window covered in every read
     const u64* win_prefix; // variable-length reads (SeenOrigin): windows before each read of the batch, [n_reads + 1]
     u64 n_reads, seq_base;
+    const u64* rec_prefix; // records of this launch's kind before each read (== win_prefix for one record per window)
+    u32 mode;              // 0 every window, 1 whole tiles of `span` windows, 2 the windows after the last whole tile
 };
 
 template <int NW, bool SEEN>
@@ -146,9 +148,11 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
             u64 P, Q;
             if (sp.win_prefix) {        // a read's forward windows take 2*prefix + [0, W), its reverse complement's the next W
                 u64 lo = 0, hi = sp.n_reads;
-                while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (sp.win_prefix[mid] <= g) lo = mid; else hi = mid; }
-                const u64 w0 = sp.win_prefix[lo], W = sp.win_prefix[lo + 1] - w0, i0 = g - w0;
-                P = sp.seq_base + 2 * w0 + i0; Q = sp.seq_base + 2 * w0 + 2 * W - i0 - 1;
+                while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (sp.rec_prefix[mid] <= g) lo = mid; else hi = mid; }
+                const u64 w0 = sp.win_prefix[lo], W = sp.win_prefix[lo + 1] - w0, j = g - sp.rec_prefix[lo];
+                const u64 i0 = sp.mode == 1 ? j * sp.span : sp.mode == 2 ? (W / sp.span) * sp.span + j : j;
+                const u64 width = sp.mode == 1 ? sp.span : 1;
+                P = sp.seq_base + 2 * w0 + i0; Q = sp.seq_base + 2 * w0 + 2 * W - i0 - width;
             } else {
                 const u64 r = sp.read0 + g / sp.per_read, i0 = sp.win0 + (g % sp.per_read) * sp.span;
                 P = r * 2 * sp.windows + i0; Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
@@ -379,6 +383,7 @@ int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights,
         sp.seen = t.seen.as<u64>(); sp.read0 = origin->read0; sp.rec0 = origin->rec0; sp.per_read = origin->per_read;
         sp.span = origin->span; sp.windows = origin->windows; sp.rc = origin->rc; sp.win0 = origin->win0;
         sp.win_prefix = origin->win_prefix; sp.n_reads = origin->n_reads; sp.seq_base = origin->seq_base;
+        sp.rec_prefix = origin->rec_prefix ? origin->rec_prefix : origin->win_prefix; sp.mode = origin->mode;
         if (t.nw == 1)
             hipLaunchKernelGGL((insert_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
         else

@@ -173,8 +173,9 @@ def _variable_length_fastq(path, seed, n_reads, k, genome_len=3000, err=0.01):
         f.write("\n".join(lines) + "\n")
 
 
+@pytest.mark.parametrize("tiles", [True, False])
 @pytest.mark.parametrize("k,rc,n_reads", [(11, True, 900), (12, False, 700), (31, True, 1500), (40, True, 800), (5, True, 200)])
-def test_variable_length_reads_in_reference_order(oracle, tmp_path, monkeypatch, k, rc, n_reads):
+def test_variable_length_reads_in_reference_order(oracle, tmp_path, monkeypatch, k, rc, n_reads, tiles):
     """first-seen numbering and remove_dead_paths for reads of unequal length (the general file route: one record
     per window, sequence numbers from the per-read window prefix), in one batch and in many"""
     from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
@@ -183,6 +184,8 @@ def test_variable_length_reads_in_reference_order(oracle, tmp_path, monkeypatch,
     set_global_k_sizes(k)
     if n_reads % 200:
         monkeypatch.setenv("KATOME_VAR_BATCH_RECORDS", "1500")
+    if not tiles:                          # every window on its own instead of tiles + left-over windows
+        monkeypatch.setenv("KATOME_NO_TILES", "1")
     g, rb = GpuGraph.create([fq], InputFileType.Fastq, rc, 0, first_seen_order=True)
     ref = oracle.build_files([fq], k, rc)
     assert rb == ref.read_bytes
