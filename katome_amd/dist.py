@@ -55,6 +55,12 @@ class HipOps:
     def tile_words(self, span):
         return self.b.tile_words(span)
 
+    def tile_plan(self, read_len):
+        return self.b.tile_plan(read_len)
+
+    def extract_remainder(self, packed, n_reads, read_len, span, skip, first_read):
+        return self.b.extract_remainder(packed, n_reads, read_len, span, skip, first_read=first_read)
+
     def extract_tiles(self, packed, n_reads, read_len, span, skip, out, first_read):
         return self.b.extract_tiles(packed, n_reads, read_len, span, skip, out=out, first_read=first_read)
 
@@ -258,11 +264,13 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
     smaller all-to-all brings those to the k-mers' owners."""
     world = dist.get_world_size(group)
     W = read_len - ops.k + 1
-    span = ops.tile_span(read_len)
-    # the span must be the same on every rank (it is a function of k and the read length)
+    # the plan is the same on every rank (a function of k and the read length): `span` windows per tile, `per_read` tiles
+    # from the front of every read, `rest` windows left over (those travel as plain k-mer records)
+    span, per_read, rest = ops.tile_plan(read_len)
+    if span <= 1:
+        span, per_read, rest = 1, W, 0
     nwr = ops.tile_words(span) if span > 1 else ops.nw
     kmer_core = (2, ops.k - 2)                # owner of a k-mer: its canonical middle (see the module docstring)
-    per_read = W // span
     recbuf = ops.empty(max(1, min(batch_reads, max(n_reads, 1)) * per_read * nwr))
     n_batches = (n_reads + batch_reads - 1) // batch_reads
     # every rank must take part in every all-to-all: agree on the number of rounds
@@ -294,6 +302,17 @@ def build_shard(ops, packed, skip, n_reads, read_len, batch_reads, group=None, p
             if in_flight is not None:
                 count(in_flight.wait()[0])
             in_flight = started
+        if rest:                                          # the windows after the last whole tile of every read
+            if nr:
+                rem = ops.extract_remainder(packed, nr, read_len, span, skip, r0)
+                with phases("route_records"):
+                    rpart, rcounts = ops.partition(rem, world, key_words=ops.nw, core=kmer_core)
+            else:
+                rpart, rcounts = recbuf[:0], [0] * world
+            with phases("exchange_records"):
+                got = _AsyncExchange([(rpart, ops.nw)], rcounts, group).wait()[0]
+            if got.numel():
+                ops.insert(got)
     if in_flight is not None:
         with phases("exchange_records"):
             last = in_flight.wait()[0]

@@ -96,6 +96,31 @@ class NumpyOps:
     def tile_words(self, span):
         return 1 if 2 * (self.k + span - 1) <= 62 else 2
 
+    def tile_plan(self, read_len):
+        import ctypes as C_
+        from katome_amd import _lib
+        sp, t, r = C_.c_uint32(), C_.c_uint32(), C_.c_uint32()
+        _lib.lib().katome_tile_plan(self.k, read_len, C_.byref(sp), C_.byref(t), C_.byref(r))     # pure host function
+        return sp.value, t.value, r.value
+
+    def extract_remainder(self, packed, n_reads, read_len, span, skip, first_read):
+        stride = (read_len + 3) // 4
+        W = read_len - self.k + 1
+        p = packed.numpy()
+        recs = []
+        for r in range(first_read, first_read + n_reads):
+            row = p[r * stride:(r + 1) * stride]
+            bases = [(int(b) >> s) & 3 for b in row for s in (6, 4, 2, 0)][:read_len]
+            for w in range((W // span) * span, W):
+                if skip is not None and int(skip[r]):
+                    recs.append(INVALID)
+                    continue
+                v = 0
+                for c in bases[w:w + self.k]:
+                    v = (v << 2) | c
+                recs.append(min(v, _rc(v, self.k)) if self.rc else v)
+        return self._to_tensor(recs)
+
     def extract_tiles(self, packed, n_reads, read_len, span, skip, out, first_read):
         stride = (read_len + 3) // 4
         kk = self.k + span - 1

@@ -56,11 +56,13 @@ def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
         dist.destroy_process_group()
 
 
-# read_len 50: k=11 -> 40 windows, tiles of 8; k=33 -> 18 windows, tiles of 6 (128-bit); k=12 -> 39 windows, tiles of 3;
-# k=6 -> 45 windows, tiles of 5; read_len 53 with k=11: 43 windows (prime) -> the plain, untiled route
+# katome_tile_plan: read_len 50: k=11 -> 40 windows = 2 tiles of 20; k=33 -> 18 windows = 1 tile of 18 (128-bit);
+# k=12 -> 39 windows = 3 tiles of 13; k=6 -> 45 windows = 3 tiles of 15; read_len 53 with k=11: 43 windows (prime) =
+# 2 tiles of 21 + 1 window left over (the left-over windows travel as plain k-mer records); k=60: no span fits 63 bases
 @pytest.mark.parametrize("world,k,rc,n_reads,batch,read_len", [(2, 11, True, 260, 64, 50), (2, 33, True, 130, 1000, 50),
                                                                 (3, 12, False, 200, 64, 50), (2, 6, True, 70, 64, 50),
-                                                                (2, 11, True, 130, 64, 53)])
+                                                                (2, 11, True, 130, 64, 53), (3, 11, False, 150, 40, 57),
+                                                                (2, 60, True, 60, 64, 75)])
 def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads, batch, read_len):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, k, rc, n_reads, read_len, batch, str(tmp_path)), nprocs=world, join=True)
