@@ -573,6 +573,15 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         // insertion, nodes by the first insertion that touches them (source of a strand's first window: 2*seq;
         // target: 2*seq + 1).  petgraph hands out indices in exactly that order (pt_graph.rs:149,194).
         PhaseScope ps(b->prof, PH_FIRST_SEEN, stream);
+        const bool trace = getenv("KATOME_TRACE_FINALIZE") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!trace) return;
+            (void)hipStreamSynchronize(stream);
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "[finalize] %-22s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+            t_last = t;
+        };
         const uint64_t N = b->n_nodes;
         if (N >= (1ull << 32)) { set_error("first-seen order: more than 2^32 nodes on one GPU"); return KATOME_E_UNSUPPORTED; }
         const uint64_t max_seq = b->var_seq_base ? 2 * b->var_seq_base + 2
@@ -587,41 +596,56 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
             KCHECK(node_first.alloc((N + 1) * 8)); KCHECK(nperm.alloc((N + 1) * 4));
             KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
             KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
+            lap("node_first");
             KCHECK(dev_iota(nperm.as<u32>(), N, stream));
             KCHECK(dev_sort(node_first.as<u64>(), nperm.as<u32>(), N, 1, bits, stream));        // nperm[new] = old
+            lap("sort nodes");
             node_first.release();
             KCHECK(dev_invert(nperm.as<u32>(), N, new_id.as<u64>(), stream));                   // new_id[old] = new
             KCHECK(onode.alloc((N + 1) * 8 * nw));
             KCHECK(dev_gather_keys(b->node_key.as<u64>(), nperm.as<u32>(), N, nw, onode.as<u64>(), stream));
             const size_t n = onode.bytes; b->node_key.adopt(onode.take(), n);
+            lap("invert + node keys");
         }
         KCHECK(eperm.alloc((E + 1) * 4));
         KCHECK(dev_iota(eperm.as<u32>(), E, stream));
         KCHECK(dev_sort(b->edge_seq.as<u64>(), eperm.as<u32>(), E, 1, bits, stream));           // eperm[new] = old; edge_seq now ascending
+        lap("sort edges by seq");
         {
-            DevBuf o(stream);
-            KCHECK(o.alloc((E + 1) * 8 * nw));
-            KCHECK(dev_gather_keys(b->edge_key.as<u64>(), eperm.as<u32>(), E, nw, o.as<u64>(), stream));
-            const size_t n = o.bytes; b->edge_key.adopt(o.take(), n);
+            // one 32-byte record per edge, read once at random (radix.hip dev_permute_edges); if that much scratch is not
+            // to be had, the four separate gathers
+            DevBuf aos(stream);
+            if (aos.alloc(E * 32 + 64) == KATOME_OK) {
+                KCHECK(dev_permute_edges(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->edge_src.as<u64>(), b->edge_dst.as<u64>(),
+                                         new_id.as<u64>(), eperm.as<u32>(), E, nw, aos.p, stream));
+            } else {
+                {
+                    DevBuf o(stream);
+                    KCHECK(o.alloc((E + 1) * 8 * nw));
+                    KCHECK(dev_gather_keys(b->edge_key.as<u64>(), eperm.as<u32>(), E, nw, o.as<u64>(), stream));
+                    const size_t n = o.bytes; b->edge_key.adopt(o.take(), n);
+                }
+                {
+                    DevBuf o(stream);
+                    KCHECK(o.alloc((E + 1) * 4));
+                    KCHECK(dev_gather_u32(b->edge_weight.as<u32>(), eperm.as<u32>(), E, o.as<u32>(), stream));
+                    const size_t n = o.bytes; b->edge_weight.adopt(o.take(), n);
+                }
+                {
+                    DevBuf o(stream);
+                    KCHECK(o.alloc((E + 1) * 8));
+                    KCHECK(dev_gather_mapped(b->edge_src.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, o.as<u64>(), stream));
+                    const size_t n = o.bytes; b->edge_src.adopt(o.take(), n);
+                }
+                {
+                    DevBuf o(stream);
+                    KCHECK(o.alloc((E + 1) * 8));
+                    KCHECK(dev_gather_mapped(b->edge_dst.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, o.as<u64>(), stream));
+                    const size_t n = o.bytes; b->edge_dst.adopt(o.take(), n);
+                }
+            }
         }
-        {
-            DevBuf o(stream);
-            KCHECK(o.alloc((E + 1) * 4));
-            KCHECK(dev_gather_u32(b->edge_weight.as<u32>(), eperm.as<u32>(), E, o.as<u32>(), stream));
-            const size_t n = o.bytes; b->edge_weight.adopt(o.take(), n);
-        }
-        {
-            DevBuf o(stream);
-            KCHECK(o.alloc((E + 1) * 8));
-            KCHECK(dev_gather_mapped(b->edge_src.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, o.as<u64>(), stream));
-            const size_t n = o.bytes; b->edge_src.adopt(o.take(), n);
-        }
-        {
-            DevBuf o(stream);
-            KCHECK(o.alloc((E + 1) * 8));
-            KCHECK(dev_gather_mapped(b->edge_dst.as<u64>(), eperm.as<u32>(), new_id.as<u64>(), E, o.as<u64>(), stream));
-            const size_t n = o.bytes; b->edge_dst.adopt(o.take(), n);
-        }
+        lap("edges to seq order");
         if (b->prune_weight) KCHECK(weak_edges_ordered(b, b->prune_weight, stream));
         cand = b->node_key.as<u64>();
     }

@@ -119,6 +119,8 @@ int dev_gather_u64(const uint64_t* src, const uint32_t* idx, uint64_t n, uint64_
 int dev_gather_keys(const uint64_t* src, const uint32_t* idx, uint64_t n, uint32_t nw, uint64_t* dst, hipStream_t stream);
 int dev_gather_mapped(const uint64_t* src, const uint32_t* idx, const uint64_t* map, uint64_t n, uint64_t* dst, hipStream_t stream);
 int dev_invert(const uint32_t* perm, uint64_t n, uint64_t* inv, hipStream_t stream);
+int dev_permute_edges(uint64_t* key, uint32_t* weight, uint64_t* src, uint64_t* dst, const uint64_t* new_id, const uint32_t* idx,
+                      uint64_t n, uint32_t nw, void* scratch, hipStream_t stream);
 int dev_node_first(const uint64_t* src, const uint64_t* dst, const uint64_t* seq, uint64_t n, uint64_t* node_first, hipStream_t stream);
 int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream);
 int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream);

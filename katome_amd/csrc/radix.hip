@@ -709,6 +709,51 @@ __global__ __launch_bounds__(BLOCK) void gather_mapped_kernel(const u64* __restr
                                                                u64 n, u64* __restrict__ dst) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) dst[i] = map[src[idx[i]]];
 }
+// first-seen order: the edges leave key order for sequence order.  Four separate gathers cost six random reads per edge
+// (two of them through the node map); packing each edge into one 32-byte record first (its end points already mapped,
+// the source map read nearly in order because sources ascend with the keys) leaves two.
+struct PackedEdge { u64 k0, k1; u32 src, dst, weight, pad; };
+static_assert(sizeof(PackedEdge) == 32, "packed edge layout");
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void pack_edges_kernel(const u64* __restrict__ key, const u32* __restrict__ weight, const u64* __restrict__ src,
+                                                            const u64* __restrict__ dst, const u64* __restrict__ new_id, u64 n,
+                                                            PackedEdge* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        PackedEdge e;
+        e.k0 = key[i * NW]; e.k1 = NW == 2 ? key[i * NW + 1] : 0;
+        e.src = (u32)new_id[src[i]]; e.dst = (u32)new_id[dst[i]]; e.weight = weight[i]; e.pad = 0;
+        out[i] = e;
+    }
+}
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void unpack_edges_kernel(const PackedEdge* __restrict__ in, const u32* __restrict__ idx, u64 n,
+                                                              u64* __restrict__ key, u32* __restrict__ weight, u64* __restrict__ src,
+                                                              u64* __restrict__ dst) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const PackedEdge e = in[idx[i]];
+        key[i * NW] = e.k0;
+        if (NW == 2) key[i * NW + 1] = e.k1;
+        weight[i] = e.weight; src[i] = e.src; dst[i] = e.dst;
+    }
+}
+// in place: edge arrays permuted by idx (new position i <- old position idx[i]) with end points mapped through new_id;
+// `scratch` needs n * 32 bytes
+int dev_permute_edges(uint64_t* key, uint32_t* weight, uint64_t* src, uint64_t* dst, const uint64_t* new_id, const uint32_t* idx,
+                      uint64_t n, uint32_t nw, void* scratch, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    PackedEdge* aos = (PackedEdge*)scratch;
+    const dim3 grid(grid_for(n, BLOCK, 256u * 32u)), blk(BLOCK);
+    if (nw == 1) {
+        hipLaunchKernelGGL(pack_edges_kernel<1>, grid, blk, 0, stream, key, weight, src, dst, new_id, n, aos);
+        hipLaunchKernelGGL(unpack_edges_kernel<1>, grid, blk, 0, stream, aos, idx, n, key, weight, src, dst);
+    } else {
+        hipLaunchKernelGGL(pack_edges_kernel<2>, grid, blk, 0, stream, key, weight, src, dst, new_id, n, aos);
+        hipLaunchKernelGGL(unpack_edges_kernel<2>, grid, blk, 0, stream, aos, idx, n, key, weight, src, dst);
+    }
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
 // inverse of a permutation: inv[perm[i]] = i
 __global__ __launch_bounds__(BLOCK) void invert_kernel(const u32* __restrict__ perm, u64 n, u64* __restrict__ inv) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) inv[perm[i]] = i;
