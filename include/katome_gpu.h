@@ -309,6 +309,17 @@ int katome_dev_remove_dead_paths(katome_builder *b, katome_dev_graph *graph, kat
 /* the finalized graph as it stands now (after katome_dev_remove_dead_paths / katome_dev_remove_weak_edges) */
 int katome_dev_current_graph(katome_builder *b, katome_dev_graph *out);
 
+/* Standardizable for PtGraph (standardizer.rs:41-128), the two weight passes assemble_with_graph runs between its
+ * prunings (asm/basic_assembler.rs:63-70), in place on the finalized graph as it stands:
+ *  - standardize_contigs (72-122): every contig -- an out-edge of an ambiguous vertex (pt_graph.rs:54-62) followed while
+ *    the vertex reached has one out-edge and is not ambiguous -- gets the rounded mean of its weights; no re-numbering;
+ *  - standardize_edges (42-70): weights scaled by (original_genome_length - k) / (sum of weights - sum of the weights
+ *    under `threshold`), rounded, then remove_weak_edges(1) (same numbering rules as katome_dev_remove_weak_edges).
+ * With katome_dev_remove_dead_paths / katome_dev_remove_weak_edges this covers every stage of the reference up to
+ * `collapse`, index for index on a FIRST_SEEN_ORDER builder (fetch the arrays with katome_dev_current_graph).      */
+int katome_dev_standardize_contigs(katome_builder *b, void *stream);
+int katome_dev_standardize_edges(katome_builder *b, uint64_t original_genome_length, uint32_t threshold, void *stream);
+
 /* host result of katome_shrink_files / katome_shrink_packed: the build (with the pruning the flags ask for) followed by
  * Shrinkable::shrink, see katome_dev_shrink below for what the arrays mean.  Owned by the library until katome_contigs_free */
 typedef struct {

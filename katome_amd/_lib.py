@@ -107,6 +107,8 @@ SYMBOLS = {
     "katome_shrink_files": (_i, [C.POINTER(Settings), _pp, _sz, C.POINTER(C.POINTER(Contigs))]),
     "katome_shrink_packed": (_i, [C.POINTER(Settings), _vp, _u64, _u32, _vp, C.POINTER(C.POINTER(Contigs))]),
     "katome_contigs_free": (None, [C.POINTER(Contigs)]),
+    "katome_dev_standardize_contigs": (_i, [_vp, _vp]),
+    "katome_dev_standardize_edges": (_i, [_vp, _u64, _u32, _vp]),
     "katome_dev_shrink": (_i, [_vp, C.POINTER(DevContigs), _vp]),
     "katome_dev_current_graph": (_i, [_vp, C.POINTER(DevGraph)]),
     "katome_dev_remove_dead_paths": (_i, [_vp, C.POINTER(DevGraph), C.POINTER(PruneStats), _vp]),

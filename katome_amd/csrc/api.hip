@@ -698,6 +698,28 @@ int katome_dev_remove_dead_paths(katome_builder* b, katome_dev_graph* out, katom
     return KATOME_OK;
 }
 
+int katome_dev_standardize_contigs(katome_builder* b, void* stream_) {
+    if (!b) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (!b->finalized) { set_error("standardize_contigs: call katome_dev_finalize first"); return KATOME_E_ARG; }
+    KCHECK(dev_standardize_contigs(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->n_nodes, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+int katome_dev_standardize_edges(katome_builder* b, uint64_t original_genome_length, uint32_t threshold, void* stream_) {
+    if (!b) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (!b->finalized) { set_error("standardize_edges: call katome_dev_finalize first"); return KATOME_E_ARG; }
+    KCHECK(dev_standardize_scale(b->edge_weight.as<u32>(), b->n_edges, original_genome_length, b->s.k, threshold, stream));
+    KCHECK(weak_edges_ordered(b, 1, stream));          // "remove edges with weight 0" (standardizer.rs:68-69)
+    KCHECK(dev_labels(b->edge_key.as<u64>(), b->n_edges, b->s.k, b->edge_label.as<uint8_t>(), stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
 int katome_dev_shrink(katome_builder* b, katome_dev_contigs* out, void* stream_) {
     if (!b || !out) { set_error("null argument"); return KATOME_E_ARG; }
     hipStream_t stream = (hipStream_t)stream_;

@@ -139,6 +139,10 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
 // Clean::remove_weak_edges with petgraph's retain_edges / retain_nodes numbering, same graph, in place
 int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t stream);
 
+// standardize.hip: Standardizable (standardizer.rs:41-128)
+int dev_standardize_contigs(const uint64_t* src, const uint64_t* dst, uint32_t* weight, uint64_t E, uint64_t N, hipStream_t stream);
+int dev_standardize_scale(uint32_t* weight, uint64_t E, uint64_t original_genome_length, uint32_t k, uint32_t threshold, hipStream_t stream);
+
 // shrink.hip: Shrinkable::shrink (shrinker.rs:165-209) on a finalized graph; the result lives in its own buffers
 struct ShrinkInput {
     const uint64_t *edge_src, *edge_dst; const uint32_t* edge_weight; const uint64_t *edge_key, *node_key;

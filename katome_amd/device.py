@@ -247,6 +247,14 @@ class Builder:
         first-seen-order builder: applied now, same re-numbering; fetch the arrays again with graph()."""
         _check(_lib.lib().katome_dev_remove_weak_edges(self._h, threshold))
 
+    def standardize_contigs(self):
+        """Standardizable::standardize_contigs (standardizer.rs:72-122) on the finalized graph, in place"""
+        _check(_lib.lib().katome_dev_standardize_contigs(self._h, _stream()))
+
+    def standardize_edges(self, original_genome_length, threshold):
+        """Standardizable::standardize_edges (standardizer.rs:42-70): scale, round, remove_weak_edges(1)"""
+        _check(_lib.lib().katome_dev_standardize_edges(self._h, original_genome_length, threshold, _stream()))
+
     def shrink(self):
         """Shrinkable::shrink (shrinker.rs:165-209) of the finalized graph as it stands -> DeviceContigs"""
         dc = _lib.DevContigs()

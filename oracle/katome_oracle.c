@@ -24,6 +24,7 @@
 #include "katome_oracle.h"
 
 #include <limits.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -977,6 +978,56 @@ static void remove_weak_edges(pgraph_t *g, uint32_t threshold)      /* pruner.rs
     remove_single_vertices(g);
 }
 
+/* ============================ standardizer.rs:41-128 (PtGraph) ====================== */
+static uint64_t pg_degree_exact(const pgraph_t *g, uint64_t n, int dir);
+static void remove_weak_edges(pgraph_t *g, uint32_t threshold);
+static int is_ambiguous(const pgraph_t *g, uint64_t n)               /* pt_graph.rs:54-62 */
+{
+    uint64_t in = pg_degree_exact(g, n, 1), out = pg_degree_exact(g, n, 0);
+    return (in > 1 || out > 1) || (in == 0 && out >= 1);
+}
+/* Standardizable::standardize_contigs (standardizer.rs:72-82) with get_contigs_from_node (84-107) and
+ * standardize_contig (109-122).  The reference walks a HashSet of ambiguous nodes; contigs never share an edge, so the
+ * order does not matter. */
+static void standardize_contigs(pgraph_t *g)
+{
+    uint8_t *amb = (uint8_t *)calloc(g->n_nodes ? g->n_nodes : 1, 1);
+    for (uint64_t n = 0; n < g->n_nodes; ++n) amb[n] = (uint8_t)is_ambiguous(g, n);
+    evec_t contig = {0, 0, 0};
+    for (uint64_t start = 0; start < g->n_nodes; ++start) {
+        if (!amb[start]) continue;
+        for (uint64_t e0 = g->node_next[0][start]; e0 != END; e0 = g->edge_next[0][e0]) {     /* neighbors_directed(start, Outgoing) */
+            uint64_t current_node = g->edge_node[1][e0];
+            uint64_t current_edge = pg_find_edge(g, start, current_node);
+            contig.n = 0;
+            for (;;) {
+                evec_push(&contig, current_edge);
+                if (pg_degree_exact(g, current_node, 0) != 1 || amb[current_node]) break;
+                current_edge = g->node_next[0][current_node];
+                current_node = g->edge_node[1][current_edge];
+            }
+            uint64_t sum = 0;
+            for (size_t i = 0; i < contig.n; ++i) sum += g->edge_w[contig.v[i]];
+            const uint32_t w = (uint32_t)round((double)sum / (double)contig.n);
+            for (size_t i = 0; i < contig.n; ++i) g->edge_w[contig.v[i]] = w;
+        }
+    }
+    free(contig.v); free(amb);
+}
+/* Standardizable::standardize_edges (standardizer.rs:42-70) */
+static void standardize_edges(pgraph_t *g, uint64_t original_genome_length, uint64_t k_size, uint32_t threshold)
+{
+    uint64_t s = 0, l = 0;
+    for (uint64_t e = 0; e < g->n_edges; ++e) { s += g->edge_w[e]; if (g->edge_w[e] < threshold) l += g->edge_w[e]; }
+    const double p = (double)(original_genome_length - k_size) / (double)(s - l);      /* calculate_standardization_ratio (124-128) */
+    for (uint64_t e = 0; e < g->n_edges; ++e) {
+        const double scaled = round((double)g->edge_w[e] * p);
+        uint32_t nw = scaled >= 4294967295.0 ? 4294967295u : scaled > 0 ? (uint32_t)scaled : 0u;   /* `as EdgeWeight` saturates */
+        g->edge_w[e] = (nw == 0 && g->edge_w[e] >= threshold) ? 1 : nw;
+    }
+    remove_weak_edges(g, 1);
+}
+
 /* ============================ shrinker.rs:38-209 (PtGraph) ========================== */
 /* After PtGraph::create every SEQUENCES slot holds one edge in compress_edge format (pt_graph.rs:339-343); shrink
  * merges them (EdgeSlice::merge, slices.rs:23-34), so slots get their own growable byte strings here. */
@@ -1102,6 +1153,8 @@ static void shrink(pgraph_t *g, labels_t *l)
  * 'w' = remove_weak_edges(threshold), 's' = shrink */
 static char g_stages[8] = "";
 static uint32_t g_weak_threshold = 0;
+static uint64_t g_genome_length = 0;          /* original_genome_length of standardize_edges ('e') */
+void ko_set_genome_length(uint64_t n) { g_genome_length = n; }
 void ko_set_post_build(const char *stages, uint32_t weak_threshold)
 {
     size_t n = stages ? strlen(stages) : 0;
@@ -1117,6 +1170,8 @@ static ko_graph *finish(build_ctx *c)
     for (const char *st = g_stages; *st; ++st) {
         if (*st == 'd') remove_dead_paths(&c->b.graph);
         else if (*st == 'w') remove_weak_edges(&c->b.graph, g_weak_threshold);
+        else if (*st == 'c') standardize_contigs(&c->b.graph);
+        else if (*st == 'e') standardize_edges(&c->b.graph, g_genome_length, K_SIZE, g_weak_threshold);
         else if (*st == 's') {
             if (!labels.bytes) {                       /* the post-pass of PtGraph::create (pt_graph.rs:339-343): slots -> edge format */
                 labels.n = c->b.seqs.len;
@@ -1199,6 +1254,8 @@ int ko_run_from_edges(size_t n_nodes, const uint64_t *src, const uint64_t *dst, 
         else if (*st == 'd') remove_dead_paths(&p);
         else if (*st == 'w') remove_weak_edges(&p, threshold);
         else if (*st == 'v') remove_single_vertices(&p);
+        else if (*st == 'c') standardize_contigs(&p);
+        else if (*st == 'e') standardize_edges(&p, g_genome_length, k, threshold);
     }
     ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
     g->n_nodes = p.n_nodes; g->n_edges = p.n_edges;

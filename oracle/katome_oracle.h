@@ -110,6 +110,9 @@ uint64_t ko_last_prune_passes(void);
  * indices visited in descending order, rejected ones swap_removed), 's' = Shrinkable::shrink (shrinker.rs:38-209,
  * with EdgeSlice::merge slices.rs:23-34); "" = none */
 void ko_set_post_build(const char *stages, uint32_t weak_threshold);
+/* further stages: 'c' = Standardizable::standardize_contigs (standardizer.rs:72-122), 'e' = standardize_edges
+ * (standardizer.rs:42-70) with original_genome_length set here, k = the build's k and threshold = weak_threshold */
+void ko_set_genome_length(uint64_t original_genome_length);
 /* PtGraph::from_edges + shrink on a hand-made graph (the in-file tests of shrinker.rs:237-488): slot i of SEQUENCES =
  * compress_edge(slot_ascii[i]) (slot 0 unused); edge j = (src[j], dst[j], (EdgeSlice(slot[j]), w[j])).  Result: endpoints,
  * weights and edge_seq of the shrunk graph (no fixed-stride labels) */

@@ -249,9 +249,16 @@ def _paths(paths):
     return arr
 
 
+def set_genome_length(n):
+    """original_genome_length for the 'e' (standardize_edges) stage"""
+    lib().ko_set_genome_length.argtypes = [C.c_uint64]
+    lib().ko_set_genome_length(int(n))
+
+
 def _stages(remove_weak_edges, remove_dead_paths, stages):
     """post-build stages on the PtGraph, in order: 'w' = Clean::remove_weak_edges(threshold) (pruner.rs:84-93),
-    'd' = Prunable::remove_dead_paths (pruner.rs:36-82), 's' = Shrinkable::shrink (shrinker.rs:165-176);
+    'd' = Prunable::remove_dead_paths (pruner.rs:36-82), 's' = Shrinkable::shrink (shrinker.rs:165-176),
+    'c' = standardize_contigs, 'e' = standardize_edges(genome length via set_genome_length, threshold = remove_weak_edges);
     default: weak edges first if both are asked for"""
     if stages is None:
         stages = ("w" if remove_weak_edges is not None else "") + ("d" if remove_dead_paths else "")

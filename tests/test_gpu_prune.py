@@ -246,3 +246,59 @@ def test_remove_weak_edges_in_reference_order(oracle, k, rc, thr):
     b.remove_weak_edges(thr)                       # the assembler's order (asm/basic_assembler.rs:58-66, without the shrink between)
     _assert_dev_same(b.graph(), oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=thr, remove_dead_paths=True, stages="dw"))
     b.close()
+
+
+@pytest.mark.parametrize("k,rc,thr,glen", [(31, True, 2, 15000), (21, False, 2, 15000), (12, True, 3, 4000), (40, True, 2, 20000),
+                                           (8, True, 4, 1500)])
+def test_every_stage_up_to_collapse(oracle, k, rc, thr, glen):
+    """assemble_with_graph (asm/basic_assembler.rs:58-72) on the device, stage by stage against the oracle: remove_dead_paths,
+    standardize_contigs, remove_weak_edges(threshold), standardize_contigs, standardize_edges(genome length, k, threshold),
+    remove_dead_paths -- the graph `collapse` receives, index for index (weights, labels, end points, ages)"""
+    from katome_amd import device as kd
+    n, L = 2500, 110
+    ascii_reads = oracle.synth_reads(0, n, L, glen, 8e-3, 0)
+    packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc, first_seen_order=True)
+    b.count_reads(packed, n, L)
+    b.finalize()
+    oracle.set_genome_length(glen)
+
+    def ref(stages):
+        return oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=thr, stages=stages)
+
+    b.remove_dead_paths()
+    b.standardize_contigs()
+    _assert_dev_same(b.graph(), ref("dc"))
+    b.remove_weak_edges(thr)
+    b.standardize_contigs()
+    _assert_dev_same(b.graph(), ref("dcwc"))
+    b.standardize_edges(glen, thr)
+    _assert_dev_same(b.graph(), ref("dcwce"))
+    dg, _ = b.remove_dead_paths()
+    final = ref("dcwced")
+    _assert_dev_same(dg, final)
+    full = oracle.build_ascii(ascii_reads, k, rc)
+    assert final.n_edges < full.n_edges
+    b.close()
+
+
+@pytest.mark.parametrize("k,rc", [(21, True), (9, True), (16, False)])
+def test_standardize_contigs_on_any_numbering(oracle, golden_dir, k, rc):
+    """no re-numbering is involved, so the default (by packed key) order gets the same weight per k-mer"""
+    from katome_amd import device as kd
+    from katome_amd.build import ingest_files, InputFileType
+    path = os.path.join(golden_dir, "data3.txt")
+    r = ingest_files([path], InputFileType.Fastq, k)
+    packed = torch.from_numpy(r["packed"].copy()).cuda()
+    b = kd.Builder(k, rc)
+    b.count_reads(packed, r["n_reads"], r["fixed_len"])
+    b.finalize()
+    b.standardize_contigs()
+    dg = b.graph()
+    nw = dg.key_words
+    ek = dg.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
+    keys = [int(x[0]) if nw == 1 else (int(x[0]) << 64) | int(x[1]) for x in ek]
+    from helpers import int_to_kmer
+    got = sorted(zip([int_to_kmer(v, k) for v in keys], dg.edge_weight.cpu().numpy().view(np.uint32).tolist()))
+    assert got == oracle.build_files([path], k, rc, stages="c").multiset()
+    b.close()
