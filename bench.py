@@ -114,7 +114,8 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=Fa
 
 def next_stages(wl, sample_reads):
     """Not part of the metric: the stages SURVEY 8(f) lists after the path, timed on a bounded prefix of the workload --
-    build in the reference's numbering, remove_dead_paths (pruner.rs:36-82), shrink (shrinker.rs:165-209)"""
+    build in the reference's numbering, remove_dead_paths (pruner.rs:36-82), shrink (shrinker.rs:165-209; of the pruned
+    graph, which it leaves untouched), then the remaining stages of assemble_with_graph up to collapse"""
     import torch
     from katome_amd import device as kd
     w = wl.scaled(min(sample_reads, wl.reads))
@@ -145,6 +146,15 @@ def next_stages(wl, sample_reads):
         ms, dc = timed(b.shrink)
         out["shrink_ms"] = ms
         out["edges_after_shrink"] = dc.n_edges
+        # the rest of assemble_with_graph up to collapse (asm/basic_assembler.rs:63-72), threshold 2
+        ms1, _ = timed(b.standardize_contigs)
+        ms2, _ = timed(lambda: b.remove_weak_edges(2))
+        ms3, _ = timed(b.standardize_contigs)
+        ms4, _ = timed(lambda: b.standardize_edges(w.genome_len, 2))
+        ms5, (dg, st2) = timed(b.remove_dead_paths)
+        out["up_to_collapse_ms"] = {"standardize_contigs": ms1, "remove_weak_edges": ms2, "standardize_contigs_2": ms3,
+                                    "standardize_edges": ms4, "remove_dead_paths_2": ms5}
+        out["edges_before_collapse"] = dg.n_edges
     finally:
         b.close()
     return out
