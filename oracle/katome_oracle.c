@@ -1149,6 +1149,197 @@ static void shrink(pgraph_t *g, labels_t *l)
     free(t.fb); free(t.stack);
 }
 
+/* ============================ collapser.rs:29-273 (PtGraph) ========================= */
+/* petgraph 0.4.13 tarjan_scc, restated from its published source (crate absent): recursive visit in node_identifiers()
+ * order, neighbours in adjacency-list order; each SCC is pushed when its root is finished, its nodes in pop order */
+typedef struct { int64_t *index; uint64_t *lowlink; uint8_t *on_stack; uint64_t *stack; size_t sp; uint64_t counter;
+                 uint64_t *scc_nodes; size_t scc_n; size_t *scc_start; size_t n_sccs; } tarjan_t;
+static void scc_visit(const pgraph_t *g, tarjan_t *d, uint64_t v)
+{
+    if (d->index[v] >= 0) return;
+    const uint64_t v_index = d->counter;
+    d->index[v] = (int64_t)v_index; d->lowlink[v] = v_index; d->on_stack[v] = 1;
+    d->stack[d->sp++] = v;
+    d->counter += 1;
+    for (uint64_t e = g->node_next[0][v]; e != END; e = g->edge_next[0][e]) {       /* g.neighbors(v) */
+        const uint64_t w = g->edge_node[1][e];
+        if (d->index[w] < 0) {
+            scc_visit(g, d, w);
+            if (d->lowlink[w] < d->lowlink[v]) d->lowlink[v] = d->lowlink[w];
+        } else if (d->on_stack[w]) {
+            if ((uint64_t)d->index[w] < d->lowlink[v]) d->lowlink[v] = (uint64_t)d->index[w];
+        }
+    }
+    if (d->lowlink[v] == v_index) {
+        d->scc_start[d->n_sccs++] = d->scc_n;
+        for (;;) {
+            const uint64_t w = d->stack[--d->sp];
+            d->on_stack[w] = 0;
+            d->scc_nodes[d->scc_n++] = w;
+            if (w == v) break;
+        }
+    }
+}
+/* unwrap!(tarjan_scc(&self).iter().last())[0] (collapser.rs:63) */
+static uint64_t last_scc_first_node(const pgraph_t *g)
+{
+    const size_t n = g->n_nodes;
+    tarjan_t d; memset(&d, 0, sizeof d);
+    d.index = (int64_t *)xrealloc(NULL, n * 8); d.lowlink = (uint64_t *)xrealloc(NULL, n * 8); d.on_stack = (uint8_t *)calloc(n, 1);
+    d.stack = (uint64_t *)xrealloc(NULL, n * 8); d.scc_nodes = (uint64_t *)xrealloc(NULL, n * 8); d.scc_start = (size_t *)xrealloc(NULL, n * sizeof(size_t));
+    for (size_t i = 0; i < n; ++i) d.index[i] = -1;
+    for (uint64_t v = 0; v < n; ++v) scc_visit(g, &d, v);
+    const uint64_t r = d.scc_nodes[d.scc_start[d.n_sccs - 1]];
+    free(d.index); free(d.lowlink); free(d.on_stack); free(d.stack); free(d.scc_nodes); free(d.scc_start);
+    return r;
+}
+
+typedef struct { char **v; size_t n, cap; } strvec_t;
+static void strvec_push(strvec_t *s, const char *str, size_t len)
+{
+    if (s->n == s->cap) { s->cap = s->cap ? s->cap * 2 : 64; s->v = (char **)xrealloc(s->v, s->cap * sizeof(char *)); }
+    s->v[s->n] = (char *)xrealloc(NULL, len + 1); memcpy(s->v[s->n], str, len); s->v[s->n][len] = 0; s->n++;
+}
+typedef struct { char *p; size_t n, cap; } str_t;
+static void str_append(str_t *s, const uint8_t *b, size_t len)
+{
+    if (s->n + len + 1 > s->cap) { s->cap = (s->n + len + 1) * 2; s->p = (char *)xrealloc(s->p, s->cap); }
+    memcpy(s->p + s->n, b, len); s->n += len; s->p[s->n] = 0;
+}
+/* EdgeSlice::name (decompress_edge of the slot) appended whole, or from K1_SIZE on (remainder, slices.rs:36-42) */
+static void append_edge_name(str_t *contig, const labels_t *l, uint64_t slot, int remainder_only)
+{
+    uint8_t *ascii = (uint8_t *)xrealloc(NULL, l->len[slot] * 4 + 8);
+    const size_t an = ko_decompress_edge(l->bytes[slot], l->len[slot], ascii);
+    if (remainder_only) str_append(contig, ascii + K1_SIZE, an - K1_SIZE); else str_append(contig, ascii, an);
+    free(ascii);
+}
+static uint64_t self_loop(const pgraph_t *g, uint64_t node)           /* collapser.rs:213-224 */
+{
+    if (pg_degree_exact(g, node, 1) > 2) return END;
+    for (uint64_t e = g->node_next[0][node]; e != END; e = g->edge_next[0][e]) if (g->edge_node[1][e] == g->edge_node[0][e]) return e;
+    return END;
+}
+static uint64_t simple_loop(const pgraph_t *g, uint64_t edge)          /* collapser.rs:234-259 */
+{
+    const uint64_t source = g->edge_node[0][edge], target = g->edge_node[1][edge];
+    const uint64_t in_source = pg_degree_exact(g, source, 1);
+    if (in_source == 0 || in_source > 2) return END;
+    if (pg_degree_exact(g, target, 1) != 1 || pg_degree_exact(g, target, 0) != 2) return END;
+    for (uint64_t e = g->node_next[0][target]; e != END; e = g->edge_next[0][e])
+        if (g->edge_node[1][e] == source && g->edge_w[e] < g->edge_w[edge]) return e;
+    return END;
+}
+static void decrease_weight(pgraph_t *g, uint64_t edge)                /* collapser.rs:261-273 */
+{
+    g->edge_w[edge] -= 1;
+    if (g->edge_w[edge] > 0) return;
+    pg_remove_edge(g, edge);
+}
+static void remove_single_with_ambiguity(pgraph_t *g, evec_t *to_remove, uint8_t *ambiguous)   /* collapser.rs:84-97 */
+{
+    qsort(to_remove->v, to_remove->n, 8, cmp_desc);
+    uint64_t last_node = g->n_nodes;
+    for (size_t i = 0; i < to_remove->n; ++i) {
+        last_node -= 1;
+        ambiguous[to_remove->v[i]] = ambiguous[last_node];            /* copy_bit(last_node, node.index()) */
+        pg_remove_node(g, to_remove->v[i]);
+    }
+    to_remove->n = 0;
+}
+static void contigs_from_vertex(pgraph_t *g, const labels_t *l, uint64_t v, uint8_t *ambiguous, evec_t *single_vertices,
+                                strvec_t *contigs)                     /* collapser.rs:99-203 */
+{
+    str_t contig = {0, 0, 0};
+    uint64_t current_vertex = v, current_edge_index, simple_loop_;
+    uint64_t num_in = pg_degree_exact(g, current_vertex, 1), num_out = pg_degree_exact(g, current_vertex, 0);
+    for (;;) {
+        simple_loop_ = END;
+        if (num_out == 0) {
+            if (num_in == 0) evec_push(single_vertices, current_vertex);
+            if (contig.n) strvec_push(contigs, contig.p, contig.n);
+            free(contig.p);
+            return;
+        }
+        current_edge_index = g->node_next[0][current_vertex];          /* first_edge(current_vertex, Outgoing) */
+        if (ambiguous[current_vertex]) {
+            if (contig.n) { strvec_push(contigs, contig.p, contig.n); contig.n = 0; }
+        } else {
+            int make_ambiguous = 0;
+            if (num_in == 2 && num_out == 1) {
+                if (self_loop(g, current_vertex) == END) {
+                    simple_loop_ = simple_loop(g, current_edge_index);
+                    if (simple_loop_ == END) make_ambiguous = 1;
+                }
+            } else if ((num_in == 1 && num_out == 2) || (num_in == 2 && num_out == 2)) {
+                const uint64_t e = self_loop(g, current_vertex);
+                if (e != END) current_edge_index = e; else make_ambiguous = 1;
+            } else if ((num_in == 0 && num_out == 1) || (num_in == 1 && num_out == 1)) {
+            } else {
+                make_ambiguous = 1;
+            }
+            if (make_ambiguous) {
+                ambiguous[current_vertex] = 1;
+                if (contig.n) { strvec_push(contigs, contig.p, contig.n); contig.n = 0; }
+            }
+        }
+        append_edge_name(&contig, l, g->edge_slot[current_edge_index], contig.n != 0);
+        const uint64_t target = g->edge_node[1][current_edge_index];
+        num_in = pg_degree_exact(g, target, 1);
+        if (simple_loop_ != END) {
+            append_edge_name(&contig, l, g->edge_slot[simple_loop_], 1);
+            if (current_edge_index < simple_loop_) { decrease_weight(g, simple_loop_); decrease_weight(g, current_edge_index); }
+            else { decrease_weight(g, current_edge_index); decrease_weight(g, simple_loop_); }
+        } else {
+            decrease_weight(g, current_edge_index);
+        }
+        num_out = pg_degree_exact(g, target, 0);
+        if (pg_degree_exact(g, current_vertex, 1) == 0 && pg_degree_exact(g, current_vertex, 0) == 0) evec_push(single_vertices, current_vertex);
+        current_vertex = target;
+    }
+}
+/* Collapsable::collapse (collapser.rs:29-82) */
+static void collapse(pgraph_t *g, labels_t *l, strvec_t *contigs)
+{
+    shrink(g, l);
+    uint8_t *ambiguous = (uint8_t *)calloc(g->n_nodes ? g->n_nodes : 1, 1);
+    evec_t single_vertices = {0, 0, 0}, externals = {0, 0, 0};
+    for (;;) {
+        for (;;) {
+            externals.n = 0;
+            for (uint64_t n = 0; n < g->n_nodes; ++n) if (g->node_next[1][n] == END) evec_push(&externals, n);
+            if (externals.n == 0) break;
+            for (size_t i = 0; i < externals.n; ++i) contigs_from_vertex(g, l, externals.v[i], ambiguous, &single_vertices, contigs);
+            remove_single_with_ambiguity(g, &single_vertices, ambiguous);
+        }
+        if (g->n_nodes != 0) {
+            const uint64_t node_in_cycle = last_scc_first_node(g);
+            contigs_from_vertex(g, l, node_in_cycle, ambiguous, &single_vertices, contigs);
+            remove_single_with_ambiguity(g, &single_vertices, ambiguous);
+        } else {
+            break;
+        }
+    }
+    free(ambiguous); free(single_vertices.v); free(externals.v);
+}
+
+static void store_contigs(ko_graph *g, strvec_t *contigs)
+{
+    g->n_contigs = contigs->n;
+    g->contig_off = (uint64_t *)xrealloc(NULL, (contigs->n + 1) * 8);
+    size_t total = 0;
+    for (size_t i = 0; i < contigs->n; ++i) total += strlen(contigs->v[i]);
+    g->contig_seq = (uint8_t *)xrealloc(NULL, total + 8);
+    size_t at = 0;
+    for (size_t i = 0; i < contigs->n; ++i) {
+        const size_t n = strlen(contigs->v[i]);
+        g->contig_off[i] = at; memcpy(g->contig_seq + at, contigs->v[i], n); at += n;
+        free(contigs->v[i]);
+    }
+    g->contig_off[contigs->n] = at;
+    free(contigs->v); contigs->v = NULL; contigs->n = contigs->cap = 0;
+}
+
 /* stages run on the finished PtGraph before the result is read out, in the order given: 'd' = remove_dead_paths,
  * 'w' = remove_weak_edges(threshold), 's' = shrink */
 static char g_stages[8] = "";
@@ -1167,12 +1358,14 @@ void ko_set_prune_dead_paths(int on) { ko_set_post_build(on ? "d" : "", 0); }
 static ko_graph *finish(build_ctx *c)
 {
     labels_t labels = {0, 0, 0};
+    strvec_t contigs = {0, 0, 0};
+    int collapsed = 0;
     for (const char *st = g_stages; *st; ++st) {
         if (*st == 'd') remove_dead_paths(&c->b.graph);
         else if (*st == 'w') remove_weak_edges(&c->b.graph, g_weak_threshold);
         else if (*st == 'c') standardize_contigs(&c->b.graph);
         else if (*st == 'e') standardize_edges(&c->b.graph, g_genome_length, K_SIZE, g_weak_threshold);
-        else if (*st == 's') {
+        else if (*st == 's' || *st == 'C') {
             if (!labels.bytes) {                       /* the post-pass of PtGraph::create (pt_graph.rs:339-343): slots -> edge format */
                 labels.n = c->b.seqs.len;
                 labels.bytes = (uint8_t **)calloc(labels.n, sizeof(uint8_t *));
@@ -1183,10 +1376,12 @@ static ko_graph *finish(build_ctx *c)
                     labels.len[i] = ko_kmer_to_edge(c->b.seqs.data + i * c->b.seqs.slot, c->b.seqs.slot, labels.bytes[i]);
                 }
             }
-            shrink(&c->b.graph, &labels);
+            if (*st == 's') shrink(&c->b.graph, &labels);
+            else { collapse(&c->b.graph, &labels, &contigs); collapsed = 1; }
         }
     }
     ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
+    if (collapsed) store_contigs(g, &contigs);
     pgraph_t *p = &c->b.graph;
     g->n_nodes = p->n_nodes; g->n_edges = p->n_edges; g->read_bytes = c->total;
     g->label_stride = (uint32_t)(1 + ceil_div(K_SIZE, CHARS_PER_CARRIER));
@@ -1246,6 +1441,8 @@ int ko_run_from_edges(size_t n_nodes, const uint64_t *src, const uint64_t *dst, 
         l.bytes[i] = (uint8_t *)xrealloc(NULL, n / 4 + 8);
         l.len[i] = ko_compress_edge((const uint8_t *)slot_ascii[i], n, l.bytes[i]);
     }
+    strvec_t contigs = {0, 0, 0};
+    int collapsed = 0;
     for (const char *st = stages ? stages : ""; *st; ++st) {
         if (*st == 's') {
             if (!l.n) { snprintf(g_err, sizeof g_err, "oracle: shrink needs labels"); labels_free(&l); pg_free(&p); return KO_E_ARG; }
@@ -1256,8 +1453,13 @@ int ko_run_from_edges(size_t n_nodes, const uint64_t *src, const uint64_t *dst, 
         else if (*st == 'v') remove_single_vertices(&p);
         else if (*st == 'c') standardize_contigs(&p);
         else if (*st == 'e') standardize_edges(&p, g_genome_length, k, threshold);
+        else if (*st == 'C') {
+            if (!l.n) { snprintf(g_err, sizeof g_err, "oracle: collapse needs labels"); labels_free(&l); pg_free(&p); return KO_E_ARG; }
+            collapse(&p, &l, &contigs); collapsed = 1;
+        }
     }
     ko_graph *g = (ko_graph *)calloc(1, sizeof *g);
+    if (collapsed) store_contigs(g, &contigs);
     g->n_nodes = p.n_nodes; g->n_edges = p.n_edges;
     g->edge_src = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8); g->edge_dst = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8);
     g->edge_slot = (uint64_t *)xrealloc(NULL, (p.n_edges + 1) * 8); g->edge_weight = (uint32_t *)xrealloc(NULL, (p.n_edges + 1) * 4);
@@ -1346,7 +1548,7 @@ void ko_graph_free(ko_graph *g)
 {
     if (!g) return;
     free(g->edge_src); free(g->edge_dst); free(g->edge_slot); free(g->edge_weight); free(g->edge_label);
-    free(g->edge_seq_off); free(g->edge_seq);
+    free(g->edge_seq_off); free(g->edge_seq); free(g->contig_off); free(g->contig_seq);
     free(g);
 }
 

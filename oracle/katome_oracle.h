@@ -76,6 +76,11 @@ typedef struct {
      * edge_seq_off[e+1]); edge_label then only holds meaningful bytes for edges that were never merged        */
     uint64_t *edge_seq_off;
     uint8_t  *edge_seq;
+    /* after a 'C' (collapse) stage: the serialized contigs in the order collapse() returns them (collapser.rs:29-82);
+     * the graph itself is then what collapse left of it (normally nothing) */
+    uint64_t  n_contigs;
+    uint64_t *contig_off;
+    uint8_t  *contig_seq;
 } ko_graph;
 
 /* error codes mirror the reference's panics */
@@ -106,6 +111,7 @@ int  ko_build_ascii(const uint8_t *reads, size_t n_reads, size_t read_len,
 void ko_set_prune_dead_paths(int on);
 uint64_t ko_last_prune_passes(void);
 /* general form: `stages` is applied in order to the finished PtGraph of every ko_build_*: 'd' = remove_dead_paths,
+ * 'C' = Collapsable::collapse (collapser.rs:29-273, over a restated petgraph tarjan_scc),
  * 'w' = Clean::remove_weak_edges(weak_threshold) (pruner.rs:84-93, over petgraph's retain_edges / retain_nodes:
  * indices visited in descending order, rejected ones swap_removed), 's' = Shrinkable::shrink (shrinker.rs:38-209,
  * with EdgeSlice::merge slices.rs:23-34); "" = none */

@@ -38,7 +38,8 @@ class KoGraph(C.Structure):
                 ("edge_label", C.POINTER(C.c_uint8)), ("label_stride", C.c_uint32),
                 ("n_sequences", C.c_uint64), ("stats", KoStats),
                 ("gir_node_count", C.c_uint64), ("gir_edge_count", C.c_uint64),
-                ("edge_seq_off", C.POINTER(C.c_uint64)), ("edge_seq", C.POINTER(C.c_uint8))]
+                ("edge_seq_off", C.POINTER(C.c_uint64)), ("edge_seq", C.POINTER(C.c_uint8)),
+                ("n_contigs", C.c_uint64), ("contig_off", C.POINTER(C.c_uint64)), ("contig_seq", C.POINTER(C.c_uint8))]
 
 
 class KoReads(C.Structure):
@@ -231,6 +232,13 @@ class OracleGraph:
             raw = bytes(np.ctypeslib.as_array(g.edge_seq, (max(int(off[-1]), 1),))[:int(off[-1])])
             self.edge_seq = [raw[int(off[i]):int(off[i + 1])].decode() for i in range(ne)]
 
+        self.collapsed = None                # after a collapse stage: the serialized contigs, in order
+        if bool(g.contig_off):
+            nc = g.n_contigs
+            off = np.ctypeslib.as_array(g.contig_off, (nc + 1,)).copy()
+            raw = bytes(np.ctypeslib.as_array(g.contig_seq, (max(int(off[-1]), 1),))[:int(off[-1])])
+            self.collapsed = [raw[int(off[i]):int(off[i + 1])].decode() for i in range(nc)]
+
     def contigs(self):
         """after shrink: sorted (sequence, weight) of every edge; the endpoints are its first and last k-1 bases"""
         return sorted(zip(self.edge_seq, (int(w) for w in self.edge_weight)))
@@ -329,16 +337,20 @@ def shrink_from_edges(edges, slot_ascii, k):
         lib().ko_graph_free(gp)
 
 
-def run_from_edges(n_nodes, edges, stages, threshold=0, k=40):
-    """hand-made PtGraph (n_nodes add_node calls, edges = [(src, dst, weight)]) through `stages` -> OracleGraph"""
+def run_from_edges(n_nodes, edges, stages, threshold=0, k=40, slot_ascii=None):
+    """hand-made PtGraph (n_nodes add_node calls; edges = [(src, dst, weight)] or, with slot_ascii (slot 0 unused),
+    [(src, dst, weight, slot)]) through `stages` -> OracleGraph"""
     n = len(edges)
     arr = lambda vals, t: (t * max(n, 1))(*vals)
     gp = C.POINTER(KoGraph)()
     L = lib()
     L.ko_run_from_edges.argtypes = [C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                     C.c_char_p, C.c_uint32, C.c_size_t, C.POINTER(C.POINTER(KoGraph))]
-    rc = L.ko_run_from_edges(n_nodes, arr([e[0] for e in edges], C.c_uint64), arr([e[1] for e in edges], C.c_uint64), None,
-                             arr([e[2] for e in edges], C.c_uint32), n, None, 0, stages.encode(), threshold, k, C.byref(gp))
+    slots = (C.c_char_p * len(slot_ascii))(*[x.encode() if x else b"" for x in slot_ascii]) if slot_ascii else None
+    slot_arr = arr([e[3] for e in edges], C.c_uint64) if slot_ascii else None
+    rc = L.ko_run_from_edges(n_nodes, arr([e[0] for e in edges], C.c_uint64), arr([e[1] for e in edges], C.c_uint64), slot_arr,
+                             arr([e[2] for e in edges], C.c_uint32), n, slots, len(slot_ascii) if slot_ascii else 0,
+                             stages.encode(), threshold, k, C.byref(gp))
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:

@@ -302,3 +302,65 @@ def test_standardize_contigs_on_any_numbering(oracle, golden_dir, k, rc):
     got = sorted(zip([int_to_kmer(v, k) for v in keys], dg.edge_weight.cpu().numpy().view(np.uint32).tolist()))
     assert got == oracle.build_files([path], k, rc, stages="c").multiset()
     b.close()
+
+
+def _collapse_from_device_graph(oracle, dg, k):
+    """rebuild a PtGraph from the device arrays the way INTEGRATION.md prescribes (edges added in ascending age, so that
+    petgraph's adjacency lists come out as the reference has them) and run the oracle's restated collapse on it"""
+    from helpers import int_to_kmer
+    nw = dg.key_words
+    ek = dg.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
+    seqs = [int_to_kmer(int(x[0]) if nw == 1 else (int(x[0]) << 64) | int(x[1]), k) for x in ek]
+    src = dg.edge_src.cpu().numpy().view(np.uint64).tolist()
+    dst = dg.edge_dst.cpu().numpy().view(np.uint64).tolist()
+    w = dg.edge_weight.cpu().numpy().view(np.uint32).tolist()
+    age = dg.edge_age.cpu().numpy().view(np.uint32).tolist() if dg.edge_age is not None else list(range(dg.n_edges))
+    order = sorted(range(dg.n_edges), key=lambda e: age[e])
+    edges = [(src[e], dst[e], w[e], i + 1) for i, e in enumerate(order)]
+    slots = [None] + [seqs[e] for e in order]
+    return oracle.run_from_edges(dg.n_nodes, edges, "C", 0, k, slots).collapsed
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_contigs_from_the_gpu_graph_pinned(oracle, golden_dir, i):
+    """tests/collapser.rs:32 ([2, 92, 233] contigs) with the GRAPH coming from the GPU build (reference numbering) and only
+    collapse run by the oracle: the same contigs, in the same order, as the all-CPU pipeline"""
+    from katome_amd import device as kd
+    from katome_amd.build import ingest_files, InputFileType
+    pinned = json.load(open(os.path.join(golden_dir, "pinned.json")))
+    path, k = os.path.join(golden_dir, pinned["fixtures"][i]), pinned["k"]
+    r = ingest_files([path], InputFileType.Fastq, k)
+    packed = torch.from_numpy(r["packed"].copy()).cuda()
+    b = kd.Builder(k, False, first_seen_order=True)
+    b.count_reads(packed, r["n_reads"], r["fixed_len"])
+    dg = b.finalize()
+    got = _collapse_from_device_graph(oracle, dg, k)
+    assert len(got) == pinned["collapse"]["contigs"][i]
+    assert got == oracle.build_files([path], k, False, stages="C").collapsed
+    b.close()
+
+
+@pytest.mark.parametrize("k,rc,thr,glen", [(31, True, 2, 15000), (21, False, 2, 15000), (12, True, 3, 4000), (8, True, 4, 1500)])
+def test_contigs_of_the_whole_pipeline(oracle, k, rc, thr, glen):
+    """assemble_with_graph end to end: every stage before collapse on the device, collapse itself by the oracle on the
+    graph rebuilt from the device arrays -- the contigs equal those of the oracle's all-CPU pipeline, string for string and
+    in the same order"""
+    from katome_amd import device as kd
+    n, L = 2500, 110
+    ascii_reads = oracle.synth_reads(0, n, L, glen, 8e-3, 0)
+    packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc, first_seen_order=True)
+    b.count_reads(packed, n, L)
+    b.finalize()
+    b.remove_dead_paths()
+    b.standardize_contigs()
+    b.remove_weak_edges(thr)
+    b.standardize_contigs()
+    b.standardize_edges(glen, thr)
+    dg, _ = b.remove_dead_paths()
+    got = _collapse_from_device_graph(oracle, dg, k)
+    oracle.set_genome_length(glen)
+    want = oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=thr, stages="dcwcedC").collapsed
+    assert len(want) > 10 and sum(map(len, want)) > 2000
+    assert got == want
+    b.close()
