@@ -1238,7 +1238,7 @@ static void decrease_weight(pgraph_t *g, uint64_t edge)                /* collap
 }
 static void remove_single_with_ambiguity(pgraph_t *g, evec_t *to_remove, uint8_t *ambiguous)   /* collapser.rs:84-97 */
 {
-    qsort(to_remove->v, to_remove->n, 8, cmp_desc);
+    if (to_remove->n) qsort(to_remove->v, to_remove->n, 8, cmp_desc);
     uint64_t last_node = g->n_nodes;
     for (size_t i = 0; i < to_remove->n; ++i) {
         last_node -= 1;

@@ -52,12 +52,13 @@ def test_oracle_under_asan_reproduces_the_pins(oracle_selftest, golden_dir, i):
     assert _run(oracle_selftest, k, False, "s", 0, f)[:2] == pinned["shrink"]["counts"][i]
 
 
-@pytest.mark.parametrize("k,rc,stages", [(5, True, "ds"), (6, True, "wds"), (8, False, "sd"), (31, True, "dws"), (40, True, "ds")])
+@pytest.mark.parametrize("k,rc,stages", [(5, True, "ds"), (6, True, "wds"), (8, False, "sd"), (31, True, "dws"), (40, True, "ds"),
+                                         (6, True, "dcwcC"), (9, False, "cC"), (40, False, "dcC"), (4, True, "C")])
 def test_oracle_stage_chains_under_asan(oracle_selftest, golden_dir, k, rc, stages):
     """small k makes tangled graphs (cycles, self-loops, merging tips): every removal and merge path runs clean"""
     f = [os.path.join(golden_dir, "data2.txt"), os.path.join(golden_dir, "data1.txt")]
     nodes, edges, _, _, seq = _run(oracle_selftest, k, rc, stages, 2, f)
-    assert nodes >= 0 and edges >= 0 and (seq >= edges * k)
+    assert nodes >= 0 and edges >= 0 and (seq >= edges * k or "C" in stages)
 
 
 def test_replays_under_asan(tmp_path):
