@@ -110,6 +110,13 @@ typedef struct {
  * the GPU, copy the graph back. */
 int katome_build_files(const katome_settings *s, const char *const *paths, size_t n_paths,
                        katome_graph **out);
+/* the build followed by stages of assemble_with_graph (asm/basic_assembler.rs:58-72), on the device, in the order
+ * `stages` names them: 'd' Prunable::remove_dead_paths, 'c' Standardizable::standardize_contigs, 'w'
+ * Clean::remove_weak_edges(settings.min_weight), 'e' standardize_edges(original_genome_length, k, settings.min_weight).
+ * "dcwced" is everything the reference does before collapse().  Needs KATOME_FLAG_FIRST_SEEN_ORDER; the result carries
+ * edge_age (see katome_graph).                                                                              */
+int katome_build_files_staged(const katome_settings *s, const char *const *paths, size_t n_paths, const char *stages,
+                              uint64_t original_genome_length, katome_graph **out);
 
 /* Same build from reads that are already 2-bit packed (A0 C1 G2 T3, 4 bases per byte, first
  * base in the two most significant bits: the bit order of compress_node, compress.rs:55-73).

@@ -69,6 +69,7 @@ _vp, _sz, _i, _u32, _u64, _dbl = C.c_void_p, C.c_size_t, C.c_int, C.c_uint32, C.
 _pp = C.POINTER(C.c_char_p)
 SYMBOLS = {
     "katome_build_files": (_i, [C.POINTER(Settings), _pp, _sz, C.POINTER(C.POINTER(Graph))]),
+    "katome_build_files_staged": (_i, [C.POINTER(Settings), _pp, _sz, C.c_char_p, _u64, C.POINTER(C.POINTER(Graph))]),
     "katome_build_packed": (_i, [C.POINTER(Settings), _vp, _u64, _u32, _vp, C.POINTER(C.POINTER(Graph))]),
     "katome_graph_free": (None, [C.POINTER(Graph)]),
     "katome_graph_stats": (_i, [C.POINTER(Graph), C.POINTER(Stats)]),

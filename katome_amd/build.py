@@ -170,15 +170,22 @@ class GpuGraph:
     # ---- Build::create (builder.rs:42-54) ----------------------------------------------------
     @classmethod
     def create(cls, input_files, ft, reverse_complement, minimal_weight_threshold=0, device=0, first_seen_order=False,
-               remove_dead_paths=False):
+               remove_dead_paths=False, stages=None, original_genome_length=0):
         """-> (GpuGraph, number_of_read_bytes); uses the global k set by set_global_k_sizes.
+        stages: stages of assemble_with_graph to run on the device after the build, e.g. "dcwced" = everything before
+        collapse (d remove_dead_paths, c standardize_contigs, w remove_weak_edges(minimal_weight_threshold),
+        e standardize_edges(original_genome_length, k, minimal_weight_threshold)); needs first_seen_order.
         first_seen_order: number edges and nodes as the reference's petgraph does (order of first insertion).
         remove_dead_paths: also run Prunable::remove_dead_paths (pruner.rs:36-82) as assemble() does next
         (asm/basic_assembler.rs:58-62); needs first_seen_order."""
         s = make_settings(K_SIZE, ft, reverse_complement, minimal_weight_threshold, device,
                           first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths)
         gp = C.POINTER(_lib.Graph)()
-        _check(_lib.lib().katome_build_files(C.byref(s), _paths(input_files), len(input_files), C.byref(gp)))
+        if stages:
+            _check(_lib.lib().katome_build_files_staged(C.byref(s), _paths(input_files), len(input_files), stages.encode(),
+                                                        original_genome_length, C.byref(gp)))
+        else:
+            _check(_lib.lib().katome_build_files(C.byref(s), _paths(input_files), len(input_files), C.byref(gp)))
         try:
             g = cls(gp)
         finally:

@@ -874,10 +874,29 @@ template <class T, class Owner> static int d2h(Owner* o, const T** dst, const vo
     return KATOME_OK;
 }
 
-static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** out) {
+// the stages of assemble_with_graph (asm/basic_assembler.rs:58-72) a host entry may ask for after the build, in the
+// order given: d = remove_dead_paths, c = standardize_contigs, w = remove_weak_edges(min_weight),
+// e = standardize_edges(original_genome_length, k, min_weight)
+static int run_stages(katome_builder* b, const char* stages, uint64_t genome_len) {
+    for (const char* st = stages ? stages : ""; *st; ++st) {
+        switch (*st) {
+            case 'd': KCHECK(katome_dev_remove_dead_paths(b, nullptr, nullptr, nullptr)); break;
+            case 'c': KCHECK(katome_dev_standardize_contigs(b, nullptr)); break;
+            case 'w': KCHECK(katome_dev_remove_weak_edges(b, b->s.min_weight)); break;
+            case 'e': KCHECK(katome_dev_standardize_edges(b, genome_len, b->s.min_weight, nullptr)); break;
+            default: set_error("unknown stage '%c' (d, c, w, e)", *st); return KATOME_E_ARG;
+        }
+    }
+    return KATOME_OK;
+}
+
+static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** out, const char* stages = nullptr, uint64_t genome_len = 0) {
     katome_dev_graph dg;
+    if (stages && *stages && !b->first_seen) { set_error("stages after the build need KATOME_FLAG_FIRST_SEEN_ORDER"); return KATOME_E_ARG; }
     KCHECK(katome_dev_finalize(b, &dg, nullptr));
     if (b->s.flags & KATOME_FLAG_REMOVE_DEAD_PATHS) KCHECK(katome_dev_remove_dead_paths(b, &dg, nullptr, nullptr));
+    KCHECK(run_stages(b, stages, genome_len));
+    KCHECK(katome_dev_current_graph(b, &dg));
     GraphOwner* o = new (std::nothrow) GraphOwner();
     if (!o) { set_error("out of host memory"); return KATOME_E_OOM; }
     memset(&o->g, 0, sizeof o->g);
@@ -928,8 +947,9 @@ static int contigs_to_host(katome_builder* b, uint64_t read_bytes, katome_contig
 // what a host entry hands back: the graph, or the graph after shrink
 struct Finish {
     katome_graph** graph; katome_contigs** contigs;
+    const char* stages = nullptr; uint64_t genome_len = 0;
     int operator()(katome_builder* b, uint64_t read_bytes) const {
-        return contigs ? contigs_to_host(b, read_bytes, contigs) : graph_to_host(b, read_bytes, graph);
+        return contigs ? contigs_to_host(b, read_bytes, contigs) : graph_to_host(b, read_bytes, graph, stages, genome_len);
     }
 };
 
@@ -1154,6 +1174,14 @@ int katome_build_files(const katome_settings* s, const char* const* paths, size_
     if (!out) { set_error("null argument"); return KATOME_E_ARG; }
     *out = nullptr;
     return build_files_impl(s, paths, n_paths, Finish{out, nullptr});
+}
+int katome_build_files_staged(const katome_settings* s, const char* const* paths, size_t n_paths, const char* stages,
+                              uint64_t original_genome_length, katome_graph** out) {
+    if (!out) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    Finish f{out, nullptr};
+    f.stages = stages; f.genome_len = original_genome_length;
+    return build_files_impl(s, paths, n_paths, f);
 }
 int katome_shrink_files(const katome_settings* s, const char* const* paths, size_t n_paths, katome_contigs** out) {
     if (!out) { set_error("null argument"); return KATOME_E_ARG; }

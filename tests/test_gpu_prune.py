@@ -364,3 +364,19 @@ def test_contigs_of_the_whole_pipeline(oracle, k, rc, thr, glen):
     assert len(want) > 10 and sum(map(len, want)) > 2000
     assert got == want
     b.close()
+
+
+@pytest.mark.parametrize("name,k,rc,thr,glen,stages", [("data3.txt", 21, True, 2, 3000, "dcwced"), ("data2.txt", 12, False, 2, 2500, "dcwced"),
+                                                       ("data3.txt", 40, False, 1, 20000, "cwe"), ("data2.txt", 9, True, 3, 800, "wdc")])
+def test_host_entry_with_stages(oracle, golden_dir, name, k, rc, thr, glen, stages):
+    """katome_build_files_staged: files in, the graph after the named stages out (host arrays, ages included)"""
+    from katome_amd.build import GpuGraph, InputFileType, KatomePanic, set_global_k_sizes
+    path = os.path.join(golden_dir, name)
+    set_global_k_sizes(k)
+    g, rb = GpuGraph.create([path], InputFileType.Fastq, rc, thr, first_seen_order=True, stages=stages, original_genome_length=glen)
+    oracle.set_genome_length(glen)
+    ref = oracle.build_files([path], k, rc, remove_weak_edges=thr, stages=stages)
+    assert rb == ref.read_bytes
+    _same(g, ref, k)
+    with pytest.raises(KatomePanic):          # the stages walk petgraph's numbering
+        GpuGraph.create([path], InputFileType.Fastq, rc, thr, stages=stages, original_genome_length=glen)
