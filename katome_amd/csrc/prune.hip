@@ -403,24 +403,106 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     return KATOME_OK;
 }
 
-// flagged indices ascending (flag[i] != 0) -> host; then the swap_remove replay over them from the top
-static int flagged_replay(const u32* d_flag, u64 n, PinnedU32& h_pos, PinnedU32& h_mult, EdgeReplay& er, hipStream_t stream) {
+// ---- retain_edges / retain_nodes on the device ---------------------------------------------------------------------
+// petgraph's retain_* visit the indices in descending order and swap_remove the rejected ones; every index is listed
+// once, and then the replay has a parallel form.  With u of n indices flagged, the j-th removal (descending) happens
+// when position n - j is the last one, and what sits there moves into the removed index.  So for a flagged index p with
+// c flagged indices below it (j = u - c): next(p) = n - (u - c) is where its new occupant comes from, and that
+// occupant is whatever ended up at next(p) before -- itself if next(p) is not flagged, else recursively the occupant of
+// next(next(p)) (always a larger position).  The flagged indices under the new count M = n - u are the holes that get
+// filled: hole p <- f(next(p)), f followed to an unflagged position by pointer jumping over the tail [M, n).
+__global__ __launch_bounds__(BLOCK) void retain_links_kernel(const u32* __restrict__ flag, u64 n, u64 u, const u64* __restrict__ block_offs,
+                                                             u32* __restrict__ jump /* [u]: tail position q -> jump[q - M] */,
+                                                             u32* __restrict__ hole_to, u32* __restrict__ hole_from) {
+    __shared__ u32 wsum[BLOCK / 64];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = ((u64)blockIdx.x * BLOCK + tid) * MARK_ITEMS, M = n - u;
+    bool f[MARK_ITEMS]; u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j) { f[j] = base + j < n && flag[base + j] != 0; c += f[j]; }
+    u32 incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < wave; ++w) woff += wsum[w];
+    u64 before = block_offs[blockIdx.x] + woff + incl - c;          // flagged indices below base
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j) {
+        const u64 p = base + j;
+        if (p >= n) break;
+        if (f[j]) {
+            const u64 next = n - (u - before);
+            if (p >= M) jump[p - M] = (u32)next;
+            else { hole_to[before] = (u32)p; hole_from[before] = (u32)next; }   // the holes are the first flagged indices
+            ++before;
+        } else if (p >= M) {
+            jump[p - M] = (u32)p;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void retain_jump_kernel(u32* __restrict__ jump, u64 u, u64 M, u32* __restrict__ changed) {
+    bool any = false;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < u; i += (u64)gridDim.x * BLOCK) {
+        const u32 v = jump[i];
+        if (v == (u32)(M + i)) continue;                             // not flagged, or removed while last: a fixed point
+        const u32 w = jump[v - M];
+        if (w != v) { jump[i] = w; any = true; }
+    }
+    if (any) *changed = 1;
+}
+__global__ __launch_bounds__(BLOCK) void retain_resolve_kernel(const u32* __restrict__ jump, u64 M, u64 holes, u32* __restrict__ hole_from) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < holes; i += (u64)gridDim.x * BLOCK) hole_from[i] = jump[hole_from[i] - M];
+}
+
+// flag[i] != 0: index i is rejected.  -> moves (to[k] <- from[k], k < *n_moves) on the device and the new count
+static int retain_on_device(const u32* d_flag, u64 n, DevBuf& to, DevBuf& from, u64* n_moves, u64* n_new, hipStream_t stream) {
     const u64 nblocks = (n + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
-    DevBuf counts(stream), offs(stream), d_pos(stream), d_mult(stream);
-    KCHECK(counts.alloc(nblocks * 4 + 16)); KCHECK(offs.alloc((nblocks + 1) * 8 + 16));
+    DevBuf counts(stream), offs(stream), jump(stream), changed(stream);
+    KCHECK(counts.alloc(nblocks * 4 + 16)); KCHECK(offs.alloc((nblocks + 1) * 8 + 16)); KCHECK(changed.alloc(16));
     hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_flag, n, counts.as<u32>());
     KCHECK(dev_scan_counts(counts.as<u32>(), nblocks, offs.as<u64>(), stream));
     u64 u = 0;
     KCHECK_HIP(hipMemcpyAsync(&u, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
-    KCHECK(d_pos.alloc(u * 4 + 16)); KCHECK(d_mult.alloc(u * 4 + 16));
-    hipLaunchKernelGGL(mark_write_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_flag, n, offs.as<u64>(), d_pos.as<u32>(), d_mult.as<u32>());
+    const u64 M = n - u;
+    *n_new = M; *n_moves = 0;
+    if (u == 0 || M == 0) return KATOME_OK;
+    // how many holes: flagged indices below M.  Everything flagged is either a hole or in the tail; the tail holds u
+    // positions of which (u - holes) are flagged, so holes = unflagged tail positions = survivors that move
+    KCHECK(jump.alloc(u * 4 + 16));
+    KCHECK(ensure(to, std::min(u, M) * 4 + 16, stream)); KCHECK(ensure(from, std::min(u, M) * 4 + 16, stream));
+    hipLaunchKernelGGL(retain_links_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_flag, n, u, offs.as<u64>(), jump.as<u32>(),
+                       to.as<u32>(), from.as<u32>());
+    // holes = flagged below M = prefix count at M: read it off the block offsets is not exact, so count it from the scan
+    // of the block that holds M: simpler, ask the device for the number of flagged indices below M
+    u64 holes = 0;
+    {
+        // flagged below M = u - flagged in [M, n); the tail is u positions long: count its flagged ones with the same kernels
+        DevBuf tcounts(stream), toffs(stream);
+        const u64 tblocks = (u + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
+        KCHECK(tcounts.alloc(tblocks * 4 + 16)); KCHECK(toffs.alloc((tblocks + 1) * 8 + 16));
+        hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)tblocks), dim3(BLOCK), 0, stream, d_flag + M, u, tcounts.as<u32>());
+        KCHECK(dev_scan_counts(tcounts.as<u32>(), tblocks, toffs.as<u64>(), stream));
+        u64 in_tail = 0;
+        KCHECK_HIP(hipMemcpyAsync(&in_tail, toffs.as<u64>() + tblocks, 8, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        holes = u - in_tail;
+    }
+    // pointer jumping: chains only run upwards and end at an unflagged position
+    for (int round = 0; round < 64; ++round) {
+        KCHECK_HIP(hipMemsetAsync(changed.p, 0, 4, stream));
+        for (int rep = 0; rep < 2; ++rep)
+            hipLaunchKernelGGL(retain_jump_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<u32>(), u, M, changed.as<u32>());
+        u32 h = 0;
+        KCHECK_HIP(hipMemcpyAsync(&h, changed.p, 4, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        if (!h) break;
+    }
+    if (holes) hipLaunchKernelGGL(retain_resolve_kernel, dim3(grid_for(holes, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<u32>(), M, holes, from.as<u32>());
     KCHECK_HIP(hipGetLastError());
-    KCHECK(h_pos.need(u)); KCHECK(h_mult.need(u));
-    KCHECK_HIP(hipMemcpyAsync(h_pos.p, d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
-    KCHECK_HIP(hipMemcpyAsync(h_mult.p, d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
-    KCHECK_HIP(hipStreamSynchronize(stream));
-    replay_edges(h_pos.p, h_mult.p, u, n, u, er);
+    *n_moves = holes;
     return KATOME_OK;
 }
 
@@ -437,8 +519,6 @@ int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t
     if (E == 0) return KATOME_OK;
     u64* src = g.edge_src->as<u64>(); u64* dst = g.edge_dst->as<u64>();
     u32* weight = g.edge_weight->as<u32>(); u64* key = g.edge_key->as<u64>(); u64* node_key = g.node_key->as<u64>();
-    PinnedU32 h_pos, h_mult;
-    EdgeReplay er;
     DevBuf flag(stream), to(stream), from(stream);
     KCHECK(flag.alloc((std::max(E, N) + 1) * 4));
     DevBuf& orig = *g.edge_age;                            // the edges' ages move with them: remove_dead_paths may follow
@@ -446,20 +526,20 @@ int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t
         KCHECK(orig.alloc((E + 1) * 4, stream));
         KCHECK(dev_iota(orig.as<u32>(), E, stream));
     }
+    // retain_edges(|e| weight >= threshold)
     hipLaunchKernelGGL(weak_flag_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, weight, E, threshold, flag.as<u32>());
-    KCHECK(flagged_replay(flag.as<u32>(), E, h_pos, h_mult, er, stream));
-    KCHECK(upload(to, er.move_to, stream)); KCHECK(upload(from, er.move_from, stream));
-    if (!er.move_to.empty())
-        hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(er.move_to.size(), BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
-                           from.as<u32>(), (u64)er.move_to.size(), nw, src, dst, weight, orig.as<u32>(), key, (u64*)nullptr);
-    E = er.n_new;
+    u64 n_moves = 0, E_new = E;
+    KCHECK(retain_on_device(flag.as<u32>(), E, to, from, &n_moves, &E_new, stream));
+    if (n_moves)
+        hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(n_moves, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
+                           from.as<u32>(), n_moves, nw, src, dst, weight, orig.as<u32>(), key, (u64*)nullptr);
+    E = E_new;
     // retain_nodes(|n| has a neighbour)
     hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, flag.as<u32>(), N, 1u);
     if (E) hipLaunchKernelGGL(touch_nodes_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, flag.as<u32>());
     KCHECK_HIP(hipGetLastError());
-    KCHECK(flagged_replay(flag.as<u32>(), N, h_pos, h_mult, er, stream));
-    KCHECK(upload(to, er.move_to, stream)); KCHECK(upload(from, er.move_from, stream));
-    const u64 nn = er.move_to.size(), N_new = er.n_new;
+    u64 nn = 0, N_new = N;
+    KCHECK(retain_on_device(flag.as<u32>(), N, to, from, &nn, &N_new, stream));
     DevBuf tail_map(stream);
     KCHECK(tail_map.alloc((N - N_new + 1) * 4));
     if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(), from.as<u32>(),
