@@ -62,7 +62,9 @@ def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
 @pytest.mark.parametrize("world,k,rc,n_reads,batch,read_len", [(2, 11, True, 260, 64, 50), (2, 33, True, 130, 1000, 50),
                                                                 (3, 12, False, 200, 64, 50), (2, 6, True, 70, 64, 50),
                                                                 (2, 11, True, 130, 64, 53), (3, 11, False, 150, 40, 57),
-                                                                (2, 60, True, 60, 64, 75)])
+                                                                (2, 60, True, 60, 64, 75),
+                                                                (3, 11, True, 100, 40, 53),      # the third rank gets no reads at all
+                                                                (3, 12, False, 60, 64, 50)])     # two ranks without reads
 def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads, batch, read_len):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, k, rc, n_reads, read_len, batch, str(tmp_path)), nprocs=world, join=True)
