@@ -259,6 +259,11 @@ uint32_t katome_tile_words(uint32_t k, uint32_t span);
  * `remainder` trailing windows of every read as plain k-mer records ([n_reads*remainder][katome_record_words(k)]),
  * to be passed to katome_dev_insert right after the tiles of the same batch.                          */
 uint32_t katome_tile_plan(uint32_t k, uint32_t read_len, uint32_t *span, uint32_t *tiles, uint32_t *remainder);
+/* same with tiles of at most max_tile_words u64 words (1: 31 bases, 2: 63, 3: 95 -- three-word tiles are what lets
+ * k = 63 be tiled at all; katome_tile_plan = limit 3; the multi-GPU route, whose partition passes take one- and
+ * two-word records, asks for 2)                                                                          */
+uint32_t katome_tile_plan_limited(uint32_t k, uint32_t read_len, uint32_t max_tile_words, uint32_t *span,
+                                  uint32_t *tiles, uint32_t *remainder);
 int katome_dev_extract_remainder(katome_builder *b, const uint8_t *d_packed, uint64_t n_reads, uint32_t read_len,
                                  uint32_t span, const uint8_t *d_skip, uint64_t *d_records, void *stream);
 int katome_dev_extract_tiles(katome_builder *b, const uint8_t *d_packed, uint64_t n_reads, uint32_t read_len,

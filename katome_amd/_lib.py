@@ -100,6 +100,7 @@ SYMBOLS = {
     "katome_tile_span": (_u32, [_u32, _u32]),
     "katome_tile_words": (_u32, [_u32, _u32]),
     "katome_tile_plan": (_u32, [_u32, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "katome_tile_plan_limited": (_u32, [_u32, _u32, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "katome_dev_extract_remainder": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp]),
     "katome_dev_extract_tiles": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp]),
     "katome_dev_insert_tiles": (_i, [_vp, _vp, _u64, _u32, _vp]),

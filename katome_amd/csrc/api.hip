@@ -138,19 +138,22 @@ uint32_t katome_tile_span(uint32_t k, uint32_t read_len) {
 }
 // how a read of `read_len` bases is best counted: `tiles` tiles of `span` windows from the front, then `remainder`
 // single windows.  Fewest table insertions per read; spans above 16 without a divisor to break them into mid tiles
-// (two-level expansion) are charged a little.  Returns 0 (span 1) when tiling does not pay or is switched off.
-uint32_t katome_tile_plan(uint32_t k, uint32_t read_len, uint32_t* span, uint32_t* tiles, uint32_t* remainder) {
+// (two-level expansion) are charged for it.  Tiles may take up to `max_tile_words` u64 words (3: 95 bases, which is what
+// lets k = 63 be tiled at all).  Returns 0 (span 1) when tiling does not pay or is switched off.
+uint32_t katome_tile_plan_limited(uint32_t k, uint32_t read_len, uint32_t max_tile_words, uint32_t* span, uint32_t* tiles,
+                                  uint32_t* remainder) {
     uint32_t best_s = 1, best_cost = 0xFFFFFFFFu;
     const uint32_t W = read_len >= k ? read_len - k + 1 : 0;
+    const uint32_t max_bases = max_tile_words >= 3 ? 95u : max_tile_words == 2 ? 63u : 31u;
     if (W >= 2 && !getenv("KATOME_NO_TILES")) {
         if (const char* e = getenv("KATOME_TILE_SPAN")) {
             const uint32_t s = (uint32_t)atoi(e);
-            if (s >= 2 && s <= W && k + s - 1 <= 63) { best_s = s; best_cost = 0; }
+            if (s >= 2 && s <= W && k + s - 1 <= max_bases) { best_s = s; best_cost = 0; }
         }
-        for (uint32_t s = 2; best_cost != 0 && s <= 33 && s <= W && k + s - 1 <= 63; ++s) {
+        for (uint32_t s = 2; best_cost != 0 && s <= 33 && s <= W && k + s - 1 <= max_bases; ++s) {
             bool breakable = s <= 16;
             for (uint32_t d = 3; d <= 8 && !breakable; ++d) breakable = s % d == 0;
-            const uint32_t cost = W / s + W % s + (breakable ? 0 : 2);
+            const uint32_t cost = W / s + W % s + (breakable ? 0 : 4);
             if (cost < best_cost || (cost == best_cost && s > best_s)) { best_cost = cost; best_s = s; }
         }
         if (best_cost != 0 && best_cost >= W) best_s = 1;
@@ -160,12 +163,15 @@ uint32_t katome_tile_plan(uint32_t k, uint32_t read_len, uint32_t* span, uint32_
     if (remainder) *remainder = best_s > 1 ? W % best_s : W;
     return best_s > 1;
 }
+uint32_t katome_tile_plan(uint32_t k, uint32_t read_len, uint32_t* span, uint32_t* tiles, uint32_t* remainder) {
+    return katome_tile_plan_limited(k, read_len, 3, span, tiles, remainder);
+}
 uint32_t katome_tile_words(uint32_t k, uint32_t span) { return (uint32_t)key_words_for_k(k + span - 1); }
 
 int katome_dev_extract_tiles(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len, uint32_t span,
                              const uint8_t* d_skip, uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
-    if (span < 1 || b->s.k + span - 1 > 63) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    if (span < 1 || b->s.k + span - 1 > 95) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     b->seen_read_len = read_len;
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, span,
@@ -427,7 +433,8 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     hipStream_t stream = (hipStream_t)stream_;
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
-    if (span < 2 || b->s.k + span - 1 > 63 || (b->tiles_ready && span != b->span)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    if (span < 2 || b->s.k + span - 1 > 95 || (b->tiles_ready && span != b->span)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    if (b->first_seen && b->var_prefix && b->s.k + span - 1 > 63) { set_error("variable-length reads: tiles of at most 63 bases"); return KATOME_E_ARG; }
     if (n_records == 0) return KATOME_OK;
     b->span = span;
     const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);

@@ -95,7 +95,12 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
         } else {
             for (u32 i = tid; i < nrec; i += BLOCK) {
                 Key<NW> a = record_from_lds<NW, RC>(lds, lds_skip, i, W, magicW, stride_bytes, k, step, win0);
-                *reinterpret_cast<ulonglong2*>(out + (out0 + i) * 2) = make_ulonglong2(a.w[0], a.w[NW - 1]);
+                if (NW == 2) {
+                    *reinterpret_cast<ulonglong2*>(out + (out0 + i) * 2) = make_ulonglong2(a.w[0], a.w[NW - 1]);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NW; ++j) out[(out0 + i) * NW + j] = a.w[j];
+                }
             }
         }
         __syncthreads();
@@ -213,8 +218,10 @@ int launch_extract_fixed(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t 
     const u32 step = span | (mark ? MARK_FLAG : 0u);
     if (nw == 1) return rc ? extract_fixed_t<1, true>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream)
                            : extract_fixed_t<1, false>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream);
-    return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream)
-              : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream);
+    if (nw == 2) return rc ? extract_fixed_t<2, true>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream)
+                           : extract_fixed_t<2, false>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream);
+    return rc ? extract_fixed_t<3, true>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream)
+              : extract_fixed_t<3, false>(d_packed, n_reads, read_len, kk, step, W, first_window, d_skip, d_records, stream);
 }
 
 // d_rec_prefix: records before each read ([n_reads + 1]); mode / span as in ArrayAddr (mode 1 records are (k+span-1)-mers)

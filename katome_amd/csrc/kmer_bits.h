@@ -33,7 +33,9 @@ constexpr u64 RC_MARK = 1ull << 62;
 
 template <int NW> struct Key { u64 w[NW]; };
 
-KD int key_words_for_k(u32 k) { return 2 * k <= 62 ? 1 : 2; }
+// k-mers are at most 63 bases (two words); TILES of k-mers may take three (up to 95 bases: 190 bits, w[0] keeps its two
+// top bits free for the table's flags, as it does for one and two words)
+KD int key_words_for_k(u32 k) { return 2 * k <= 62 ? 1 : 2 * k <= 126 ? 2 : 3; }
 
 // ---- hashing ------------------------------------------------------------------------------
 KD u64 mix64(u64 x) {
@@ -44,6 +46,7 @@ KD u64 mix64(u64 x) {
 }
 KD u64 hash_key(const Key<1>& k) { return mix64(k.w[0]); }
 KD u64 hash_key(const Key<2>& k) { return mix64(k.w[1] ^ mix64(k.w[0] + 0x9E3779B97F4A7C15ull)); }
+KD u64 hash_key(const Key<3>& k) { return mix64(k.w[2] ^ mix64(k.w[1] ^ mix64(k.w[0] + 0x9E3779B97F4A7C15ull))); }
 
 KD u64 mulhi64(u64 a, u64 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -58,8 +61,14 @@ KD u64 hash_to_range(u64 h, u64 n) { return mulhi64(h, n); }
 // ---- comparisons --------------------------------------------------------------------------
 KD bool key_eq(const Key<1>& a, const Key<1>& b) { return a.w[0] == b.w[0]; }
 KD bool key_eq(const Key<2>& a, const Key<2>& b) { return a.w[0] == b.w[0] && a.w[1] == b.w[1]; }
+KD bool key_eq(const Key<3>& a, const Key<3>& b) { return a.w[0] == b.w[0] && a.w[1] == b.w[1] && a.w[2] == b.w[2]; }
 KD bool key_lt(const Key<1>& a, const Key<1>& b) { return a.w[0] < b.w[0]; }
 KD bool key_lt(const Key<2>& a, const Key<2>& b) { return a.w[0] < b.w[0] || (a.w[0] == b.w[0] && a.w[1] < b.w[1]); }
+KD bool key_lt(const Key<3>& a, const Key<3>& b) {
+    if (a.w[0] != b.w[0]) return a.w[0] < b.w[0];
+    if (a.w[1] != b.w[1]) return a.w[1] < b.w[1];
+    return a.w[2] < b.w[2];
+}
 template <int NW> KD bool key_valid(const Key<NW>& a) { return a.w[0] != INVALID_WORD; }
 template <int NW> KD Key<NW> key_invalid() { Key<NW> r; for (int i = 0; i < NW; ++i) r.w[i] = INVALID_WORD; return r; }
 
@@ -76,6 +85,20 @@ KD Key<2> key_shr(const Key<2>& a, u32 s) {
     else { r.w[0] = a.w[0] >> s; r.w[1] = (a.w[1] >> s) | (a.w[0] << (64 - s)); }
     return r;
 }
+KD Key<3> key_shr(const Key<3>& a, u32 s) {
+    if (s == 0) return a;
+    Key<3> r; r.w[0] = r.w[1] = r.w[2] = 0;
+    if (s >= 192) return r;
+    const u32 ws = s >> 6, bs = s & 63;               // whole words, then bits
+    for (int i = 2; i >= 0; --i) {
+        const int j = i - (int)ws;                    // source word of the low part
+        if (j < 0) break;
+        u64 v = a.w[j] >> bs;
+        if (bs && j - 1 >= 0) v |= a.w[j - 1] << (64 - bs);
+        r.w[i] = v;
+    }
+    return r;
+}
 // keep the low `bits` bits
 KD Key<1> key_low_bits(const Key<1>& a, u32 bits) { Key<1> r; r.w[0] = bits >= 64 ? a.w[0] : a.w[0] & ((1ull << bits) - 1); return r; }
 KD Key<2> key_low_bits(const Key<2>& a, u32 bits) {
@@ -85,9 +108,19 @@ KD Key<2> key_low_bits(const Key<2>& a, u32 bits) {
     else { r.w[0] = 0; r.w[1] = a.w[1] & ((1ull << bits) - 1); }
     return r;
 }
+KD Key<3> key_low_bits(const Key<3>& a, u32 bits) {
+    Key<3> r = a;
+    if (bits >= 192) return r;
+    if (bits >= 128) { r.w[0] = bits == 128 ? 0 : a.w[0] & ((1ull << (bits - 128)) - 1); return r; }
+    r.w[0] = 0;
+    if (bits >= 64) { r.w[1] = bits == 64 ? 0 : a.w[1] & ((1ull << (bits - 64)) - 1); return r; }
+    r.w[1] = 0; r.w[2] = a.w[2] & ((1ull << bits) - 1);
+    return r;
+}
 // bits [shift, shift+nbits) of the key, nbits <= 32
 KD u32 key_digit(const Key<1>& a, u32 shift, u32 nbits) { return (u32)(shift >= 64 ? 0 : (a.w[0] >> shift)) & ((1u << nbits) - 1); }
 KD u32 key_digit(const Key<2>& a, u32 shift, u32 nbits) { return (u32)key_shr(a, shift).w[1] & ((1u << nbits) - 1); }
+KD u32 key_digit(const Key<3>& a, u32 shift, u32 nbits) { return (u32)key_shr(a, shift).w[2] & ((1u << nbits) - 1); }
 
 // ---- window extraction --------------------------------------------------------------------
 // `d` holds 2*NW+1 consecutive 32-bit words of the packed read, each already byte-swapped so
@@ -102,6 +135,12 @@ KD Key<2> extract_window(const u32* d, u32 sh, u32 k, Key<2>*) {
     u64 w0 = ((u64)d[0] << 32) | d[1], w1 = ((u64)d[2] << 32) | d[3], w2 = (u64)d[4] << 32;
     Key<2> x; x.w[0] = shl_fill(w0, w1, sh); x.w[1] = shl_fill(w1, w2, sh);
     return key_shr(x, 128 - 2 * k);
+}
+
+KD Key<3> extract_window(const u32* d, u32 sh, u32 k, Key<3>*) {
+    u64 w0 = ((u64)d[0] << 32) | d[1], w1 = ((u64)d[2] << 32) | d[3], w2 = ((u64)d[4] << 32) | d[5], w3 = (u64)d[6] << 32;
+    Key<3> x; x.w[0] = shl_fill(w0, w1, sh); x.w[1] = shl_fill(w1, w2, sh); x.w[2] = shl_fill(w2, w3, sh);
+    return key_shr(x, 192 - 2 * k);
 }
 
 // ---- reverse complement -------------------------------------------------------------------
@@ -127,6 +166,10 @@ KD Key<1> revcomp(const Key<1>& a, u32 k) {
 KD Key<2> revcomp(const Key<2>& a, u32 k) {
     Key<2> x; x.w[0] = ~rev_groups64(a.w[1]); x.w[1] = ~rev_groups64(a.w[0]);
     return key_shr(x, 128 - 2 * k);
+}
+KD Key<3> revcomp(const Key<3>& a, u32 k) {
+    Key<3> x; x.w[0] = ~rev_groups64(a.w[2]); x.w[1] = ~rev_groups64(a.w[1]); x.w[2] = ~rev_groups64(a.w[0]);
+    return key_shr(x, 192 - 2 * k);
 }
 template <int NW> KD Key<NW> canonical(const Key<NW>& a, u32 k) {
     Key<NW> rc = revcomp(a, k);
@@ -157,6 +200,9 @@ template <int NW> KD Key<NW> target_node(const Key<NW>& kmer, u32 k) { return ke
 KD Key<1> narrow_key(const Key<1>& a, Key<1>*) { return a; }
 KD Key<2> narrow_key(const Key<2>& a, Key<2>*) { return a; }
 KD Key<1> narrow_key(const Key<2>& a, Key<1>*) { Key<1> r; r.w[0] = a.w[1]; return r; }
+KD Key<3> narrow_key(const Key<3>& a, Key<3>*) { return a; }
+KD Key<2> narrow_key(const Key<3>& a, Key<2>*) { Key<2> r; r.w[0] = a.w[1]; r.w[1] = a.w[2]; return r; }
+KD Key<1> narrow_key(const Key<3>& a, Key<1>*) { Key<1> r; r.w[0] = a.w[2]; return r; }
 // the o-th sub-window (o = 0 is the leftmost) of a tile made of n_sub windows of sub_len bases whose starts are
 // `stride` bases apart (k-mers of a tile: sub_len = k, stride = 1; the smaller tiles of a big tile: stride = their span)
 template <int NWT, int NWK> KD Key<NWK> sub_window(const Key<NWT>& tile, u32 sub_len, u32 n_sub, u32 stride, u32 o) {

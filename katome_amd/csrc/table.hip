@@ -19,7 +19,8 @@ constexpr u64 KEYBITS = ~(OCC | LOCK);
 
 struct Slot1 { u64 key; u32 count; u32 pad; };
 struct Slot2 { u64 hi; u64 lo; u32 count; u32 pad[3]; };
-static_assert(sizeof(Slot1) == 16 && sizeof(Slot2) == 32, "slot layout");
+struct Slot3 { u64 hi; u64 mid; u64 lo; u32 count; u32 pad; };     // tiles of 64..95 bases (k > 32 with a useful span)
+static_assert(sizeof(Slot1) == 16 && sizeof(Slot2) == 32 && sizeof(Slot3) == 32, "slot layout");
 
 __device__ __forceinline__ u64 ld_agent(const u64* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_agent(u64* p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -94,11 +95,53 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
     return 0;
 }
 
+// three-word keys: the same claim / publish protocol with two payload words
+__device__ __forceinline__ u32 upsert(Slot3* slots, u64 cap, Key<3> key, u32 add, u32* err, u64* slot_out = nullptr) {
+    u64 s = hash_to_range(hash_key(key), cap);
+    u64 spins = 0;
+    for (u64 probes = 0; probes < cap;) {
+        u64 cur = slots[s].hi;
+        bool cached_view = true;
+        if (!(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
+        if (cur == 0) {
+            cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
+            if (cur == 0) {
+                st_agent(&slots[s].mid, key.w[1]);
+                st_agent(&slots[s].lo, key.w[2]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                st_agent(&slots[s].hi, key.w[0] | OCC);
+                atomicAdd(&slots[s].count, add);
+                if (slot_out) *slot_out = s;
+                return 1;
+            }
+        }
+        if ((cur & KEYBITS) == key.w[0]) {
+            if (cur & LOCK) {
+                if (++spins > (1ull << 24)) { *err = 2; return 0; }
+                __builtin_amdgcn_s_sleep(1);
+                continue;
+            }
+            const u64 mid = cached_view ? slots[s].mid : ld_agent(&slots[s].mid);
+            const u64 lo = cached_view ? slots[s].lo : ld_agent(&slots[s].lo);
+            if (mid == key.w[1] && lo == key.w[2]) {
+                atomicAdd(&slots[s].count, add);
+                if (slot_out) *slot_out = s;
+                return 0;
+            }
+        }
+        if (++s == cap) s = 0;
+        ++probes;
+    }
+    *err = 1;
+    return 0;
+}
+
 struct TableAux { u64 occupied; u32 err; u32 pad; };
 
 template <int NW> struct SlotOf;
 template <> struct SlotOf<1> { typedef Slot1 type; };
 template <> struct SlotOf<2> { typedef Slot2 type; };
+template <> struct SlotOf<3> { typedef Slot3 type; };
 
 __device__ __forceinline__ u32 wave_sum(u32 v) {
 #pragma unroll
@@ -174,6 +217,7 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
 // move every (key, weight) of an old table into a bigger one
 __device__ __forceinline__ bool slot_key(const Slot1& s, Key<1>& k) { k.w[0] = s.key & KEYBITS; return (s.key & OCC) != 0; }
 __device__ __forceinline__ bool slot_key(const Slot2& s, Key<2>& k) { k.w[0] = s.hi & KEYBITS; k.w[1] = s.lo; return (s.hi & OCC) != 0; }
+__device__ __forceinline__ bool slot_key(const Slot3& s, Key<3>& k) { k.w[0] = s.hi & KEYBITS; k.w[1] = s.mid; k.w[2] = s.lo; return (s.hi & OCC) != 0; }
 
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void rehash_kernel(const typename SlotOf<NW>::type* __restrict__ old_slots, u64 old_cap,
@@ -386,12 +430,16 @@ int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights,
         sp.rec_prefix = origin->rec_prefix ? origin->rec_prefix : origin->win_prefix; sp.mode = origin->mode;
         if (t.nw == 1)
             hipLaunchKernelGGL((insert_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
-        else
+        else if (t.nw == 2)
             hipLaunchKernelGGL((insert_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
+        else
+            hipLaunchKernelGGL((insert_kernel<3, true>), grid, block, 0, stream, t.slots.as<Slot3>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
     } else if (t.nw == 1)
         hipLaunchKernelGGL((insert_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
-    else
+    else if (t.nw == 2)
         hipLaunchKernelGGL((insert_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
+    else
+        hipLaunchKernelGGL((insert_kernel<3, false>), grid, block, 0, stream, t.slots.as<Slot3>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
@@ -405,8 +453,10 @@ int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
     const u64* os = t.track_seen ? t.seen.as<u64>() : nullptr; u64* ns = t.track_seen ? nt.seen.as<u64>() : nullptr;
     if (t.nw == 1)
         hipLaunchKernelGGL(rehash_kernel<1>, grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, nt.slots.as<Slot1>(), nt.cap, &aux->occupied, &aux->err, os, ns);
-    else
+    else if (t.nw == 2)
         hipLaunchKernelGGL(rehash_kernel<2>, grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, nt.slots.as<Slot2>(), nt.cap, &aux->occupied, &aux->err, os, ns);
+    else
+        hipLaunchKernelGGL(rehash_kernel<3>, grid, block, 0, stream, t.slots.as<Slot3>(), t.cap, nt.slots.as<Slot3>(), nt.cap, &aux->occupied, &aux->err, os, ns);
     KCHECK_HIP(hipGetLastError());
     t.slots.adopt(nt.slots.take(), new_cap * t.slot_bytes());
     t.counter.adopt(nt.counter.take(), sizeof(TableAux));
@@ -430,8 +480,14 @@ static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint3
                        (kmers && kmers->track_seen) ? tiles.seen.as<u64>() : nullptr,                                          \
                        (kmers && kmers->track_seen) ? kmers->seen.as<u64>() : nullptr)
     if (tiles.nw == 1) { if (rc) KATOME_EXPAND(1, 1, true); else KATOME_EXPAND(1, 1, false); }
-    else if (nwk == 1) { if (rc) KATOME_EXPAND(2, 1, true); else KATOME_EXPAND(2, 1, false); }
-    else               { if (rc) KATOME_EXPAND(2, 2, true); else KATOME_EXPAND(2, 2, false); }
+    else if (tiles.nw == 2) {
+        if (nwk == 1) { if (rc) KATOME_EXPAND(2, 1, true); else KATOME_EXPAND(2, 1, false); }
+        else          { if (rc) KATOME_EXPAND(2, 2, true); else KATOME_EXPAND(2, 2, false); }
+    } else {                   // three-word tiles: into mid tiles of three or two words, or into k-mers of two
+        if (nwk == 3)      { if (rc) KATOME_EXPAND(3, 3, true); else KATOME_EXPAND(3, 3, false); }
+        else if (nwk == 2) { if (rc) KATOME_EXPAND(3, 2, true); else KATOME_EXPAND(3, 2, false); }
+        else { set_error("expand: three-word tiles of one-word windows"); return KATOME_E_ARG; }
+    }
 #undef KATOME_EXPAND
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;

@@ -167,10 +167,10 @@ class Builder:
         _check(_lib.lib().katome_dev_extract_tiles(self._h, p, n_reads, read_len, span, sk, _ptr(out), _stream()))
         return out[:n_rec * nwt]
 
-    def tile_plan(self, read_len):
+    def tile_plan(self, read_len, max_tile_words=3):
         """(span, tiles per read, single windows left over per read); span 1 = count every window on its own"""
         sp, t, r = C.c_uint32(), C.c_uint32(), C.c_uint32()
-        _lib.lib().katome_tile_plan(self.k, read_len, C.byref(sp), C.byref(t), C.byref(r))
+        _lib.lib().katome_tile_plan_limited(self.k, read_len, max_tile_words, C.byref(sp), C.byref(t), C.byref(r))
         return sp.value, t.value, r.value
 
     def extract_remainder(self, packed, n_reads, read_len, span, skip=None, out=None, first_read=0):

@@ -56,7 +56,7 @@ class HipOps:
         return self.b.tile_words(span)
 
     def tile_plan(self, read_len):
-        return self.b.tile_plan(read_len)
+        return self.b.tile_plan(read_len, max_tile_words=2)      # the partition passes take one- and two-word records
 
     def extract_remainder(self, packed, n_reads, read_len, span, skip, first_read):
         return self.b.extract_remainder(packed, n_reads, read_len, span, skip, first_read=first_read)

@@ -29,12 +29,14 @@ template <int NW> static void st(uint64_t* p, const Key<NW>& k) { for (int i = 0
 extern "C" {
 int hs_key_words(uint32_t k) { return key_words_for_k(k); }
 void hs_extract(const uint8_t* packed, uint64_t nbytes, uint64_t byte_off, uint32_t w, uint32_t k, uint64_t* out) {
-    if (key_words_for_k(k) == 1) extract_t<1>(packed, nbytes, byte_off, w, k, out); else extract_t<2>(packed, nbytes, byte_off, w, k, out);
+    const int nw = key_words_for_k(k);
+    if (nw == 1) extract_t<1>(packed, nbytes, byte_off, w, k, out); else if (nw == 2) extract_t<2>(packed, nbytes, byte_off, w, k, out);
+    else extract_t<3>(packed, nbytes, byte_off, w, k, out);
 }
 // dword-aligned variant: what extract_fixed_kernel does with its LDS image
 void hs_extract_aligned(const uint8_t* packed, uint64_t nbytes, uint64_t bit_off, uint32_t k, uint64_t* out) {
     uint32_t di = (uint32_t)(bit_off >> 5), sh = (uint32_t)(bit_off & 31);
-    uint32_t d[5];
+    uint32_t d[7];
     int nw = key_words_for_k(k);
     for (int j = 0; j < 2 * nw + 1; ++j) {
         uint32_t v = 0;
@@ -42,13 +44,25 @@ void hs_extract_aligned(const uint8_t* packed, uint64_t nbytes, uint64_t bit_off
         d[j] = v;
     }
     if (nw == 1) { Key<1> key = extract_window(d, sh, k, (Key<1>*)nullptr); out[0] = key.w[0]; }
-    else { Key<2> key = extract_window(d, sh, k, (Key<2>*)nullptr); out[0] = key.w[0]; out[1] = key.w[1]; }
+    else if (nw == 2) { Key<2> key = extract_window(d, sh, k, (Key<2>*)nullptr); out[0] = key.w[0]; out[1] = key.w[1]; }
+    else { Key<3> key = extract_window(d, sh, k, (Key<3>*)nullptr); out[0] = key.w[0]; out[1] = key.w[1]; out[2] = key.w[2]; }
 }
 void hs_revcomp(const uint64_t* in, uint32_t k, uint64_t* out) {
-    if (key_words_for_k(k) == 1) st<1>(out, revcomp(ld<1>(in), k)); else st<2>(out, revcomp(ld<2>(in), k));
+    const int nw = key_words_for_k(k);
+    if (nw == 1) st<1>(out, revcomp(ld<1>(in), k)); else if (nw == 2) st<2>(out, revcomp(ld<2>(in), k)); else st<3>(out, revcomp(ld<3>(in), k));
 }
 void hs_canonical(const uint64_t* in, uint32_t k, uint64_t* out) {
-    if (key_words_for_k(k) == 1) st<1>(out, canonical(ld<1>(in), k)); else st<2>(out, canonical(ld<2>(in), k));
+    const int nw = key_words_for_k(k);
+    if (nw == 1) st<1>(out, canonical(ld<1>(in), k)); else if (nw == 2) st<2>(out, canonical(ld<2>(in), k)); else st<3>(out, canonical(ld<3>(in), k));
+}
+// sub-window o of a tile of n_sub windows of sub_len bases, `stride` bases apart (kmer_bits.h sub_window); nwt / nwk words
+void hs_sub_window(const uint64_t* tile, int nwt, int nwk, uint32_t sub_len, uint32_t n_sub, uint32_t stride, uint32_t o, uint64_t* out) {
+    if (nwt == 3 && nwk == 3) st<3>(out, sub_window<3, 3>(ld<3>(tile), sub_len, n_sub, stride, o));
+    else if (nwt == 3 && nwk == 2) st<2>(out, sub_window<3, 2>(ld<3>(tile), sub_len, n_sub, stride, o));
+    else if (nwt == 3 && nwk == 1) st<1>(out, sub_window<3, 1>(ld<3>(tile), sub_len, n_sub, stride, o));
+    else if (nwt == 2 && nwk == 2) st<2>(out, sub_window<2, 2>(ld<2>(tile), sub_len, n_sub, stride, o));
+    else if (nwt == 2 && nwk == 1) st<1>(out, sub_window<2, 1>(ld<2>(tile), sub_len, n_sub, stride, o));
+    else st<1>(out, sub_window<1, 1>(ld<1>(tile), sub_len, n_sub, stride, o));
 }
 void hs_endpoints(const uint64_t* in, uint32_t k, uint64_t* src, uint64_t* dst) {
     if (key_words_for_k(k) == 1) { st<1>(src, source_node(ld<1>(in))); st<1>(dst, target_node(ld<1>(in), k)); }
@@ -59,7 +73,7 @@ void hs_label(const uint64_t* in, uint32_t k, uint8_t* out) {
     out[0] = (uint8_t)label_pad_for_k(k);
     for (uint32_t i = 0; i < nb; ++i) out[1 + i] = key_words_for_k(k) == 1 ? label_byte(ld<1>(in), k, i) : label_byte(ld<2>(in), k, i);
 }
-uint64_t hs_hash(const uint64_t* in, int nw) { return nw == 1 ? hash_key(ld<1>(in)) : hash_key(ld<2>(in)); }
+uint64_t hs_hash(const uint64_t* in, int nw) { return nw == 1 ? hash_key(ld<1>(in)) : nw == 2 ? hash_key(ld<2>(in)) : hash_key(ld<3>(in)); }
 uint64_t hs_owner(const uint64_t* in, int nw, uint64_t n) { return hash_to_range(hs_hash(in, nw), n); }
 uint64_t hs_core_owner(const uint64_t* in, int nw, uint32_t shift, uint32_t core, uint64_t n) {
     return nw == 1 ? core_owner(ld<1>(in), shift, core, n) : core_owner(ld<2>(in), shift, core, n);

@@ -100,7 +100,7 @@ class NumpyOps:
         import ctypes as C_
         from katome_amd import _lib
         sp, t, r = C_.c_uint32(), C_.c_uint32(), C_.c_uint32()
-        _lib.lib().katome_tile_plan(self.k, read_len, C_.byref(sp), C_.byref(t), C_.byref(r))     # pure host function
+        _lib.lib().katome_tile_plan_limited(self.k, read_len, 2, C_.byref(sp), C_.byref(t), C_.byref(r))     # pure host function
         return sp.value, t.value, r.value
 
     def extract_remainder(self, packed, n_reads, read_len, span, skip, first_read):

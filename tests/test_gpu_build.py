@@ -615,7 +615,10 @@ def test_multi_rank_on_one_gpu(oracle, tmp_path, world, k, rc, L):
 
 @pytest.mark.parametrize("k,L,rc,first_seen", [(31, 101, True, False), (31, 101, True, True), (21, 76, False, True), (40, 77, True, False),
                                                (33, 126, True, True), (16, 50, True, False), (31, 150, True, True), (63, 150, True, False),
-                                               (31, 36, True, True), (12, 13, False, True)])
+                                               (31, 36, True, True), (12, 13, False, True),
+                                               # three-word tiles (64..95 bases): k = 63 -> 3 tiles of 28 + 4 windows, mid tiles of 69
+                                               # bases; k = 40 -> tiles of 66 bases broken into two-word mid tiles; k = 47, plain order
+                                               (63, 150, True, True), (40, 150, True, True), (47, 150, False, False), (62, 131, True, True)])
 def test_read_lengths_that_are_not_whole_tiles(oracle, k, L, rc, first_seen):
     """the library's plan for any read length: tiles from the front + the windows left over (101 bp at k=31: 71 windows =
     5 tiles of 14 + 1); same graph as the oracle, in the reference's numbering too; several batches"""
@@ -633,6 +636,8 @@ def test_read_lengths_that_are_not_whole_tiles(oracle, k, L, rc, first_seen):
     assert (span == 1 and rest == W) or (tiles * span + rest == W and tiles + rest < W)
     if (k, L) == (31, 101):
         assert (span, tiles, rest) == (14, 5, 1)
+    if (k, L) == (63, 150):
+        assert (span, tiles, rest) == (28, 3, 4) and b.tile_words(span) == 3
     for r0 in range(0, n, 1024):
         b.count_reads(packed, min(1024, n - r0), L, skip, first_read=r0)
     dg = b.finalize()

@@ -136,3 +136,50 @@ def test_core_owner_keeps_a_node_with_its_out_edges(k):
         owners = {L.hs_core_owner(shim_words((node << 2) | b, nw), nw, 2, k - 2, 8) for b in range(4)}
         assert len(owners) == 1
     assert len(seen) >= (2 if k <= 4 else 6)
+
+
+@pytest.mark.parametrize("kk", [64, 65, 73, 84, 94, 95])
+def test_three_word_tiles(kk):
+    """tiles of k-mers may take three words (64..95 bases): extraction, reverse complement, canonical form and the
+    sub-windows the expansion kernels take out of them, against plain string arithmetic"""
+    from helpers import pack_reads_ascii
+    import numpy as np
+    L = hostshim()
+    L.hs_sub_window.argtypes = [C.POINTER(C.c_uint64), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    assert L.hs_key_words(kk) == 3 and L.hs_key_words(63) == 2 and L.hs_key_words(31) == 1
+    rng = random.Random(kk)
+    for _ in range(12):
+        n = rng.randrange(kk, kk + 60)
+        read = "".join(rng.choice("ACGT") for _ in range(n))
+        packed = pack_reads_ascii(np.frombuffer(read.encode(), np.uint8).reshape(1, -1)).reshape(-1).tobytes()
+        for w in range(0, n - kk + 1, 3):
+            out = (C.c_uint64 * 3)()
+            L.hs_extract(packed, len(packed), 0, w, kk, out)
+            tile = words_to_int(out)
+            assert tile == kmer_to_int(read[w:w + kk]), (kk, w)
+            out2 = (C.c_uint64 * 3)()
+            L.hs_extract_aligned(packed, len(packed), 2 * w, kk, out2)
+            assert words_to_int(out2) == tile
+            rc = (C.c_uint64 * 3)()
+            L.hs_revcomp(out, kk, rc)
+            assert int_to_kmer(words_to_int(rc), kk) == revcomp_str(read[w:w + kk])
+            can = (C.c_uint64 * 3)()
+            L.hs_canonical(out, kk, can)
+            assert words_to_int(can) == min(tile, words_to_int(rc))
+    # sub-windows: a tile of `span` k-mers -> its k-mers (two words or one), and a big tile -> its mid tiles (three words)
+    for k, span in ((63, kk - 62), (40, kk - 39), (kk - 32, 33)):
+        if span < 2 or k + span - 1 != kk or k > 63:
+            continue
+        s = "".join(rng.choice("ACGT") for _ in range(kk))
+        tile = shim_words(kmer_to_int(s), 3)
+        nwk = nw_of(k)
+        for o in range(span):
+            out = (C.c_uint64 * nwk)()
+            L.hs_sub_window(tile, 3, nwk, k, span, 1, o, out)
+            assert int_to_kmer(words_to_int(out), k) == s[o:o + k]
+        for s2 in range(2, span):
+            if span % s2 == 0 and k + s2 - 1 >= 64:           # mid tiles that still need three words
+                for o in range(span // s2):
+                    out = (C.c_uint64 * 3)()
+                    L.hs_sub_window(tile, 3, 3, k + s2 - 1, span // s2, s2, o, out)
+                    assert int_to_kmer(words_to_int(out), k + s2 - 1) == s[o * s2:o * s2 + k + s2 - 1]
