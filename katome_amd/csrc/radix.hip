@@ -246,6 +246,93 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
     return KATOME_OK;
 }
 
+// After a stable sort on the TOP bits only (bits [low, key_bits)) the keys are in order except inside the runs that share
+// those bits; where the keys are (nearly) distinct such runs are a handful of records.  The first record of every run
+// sorts its run in place by the full key (stable insertion sort: equal keys keep the order the passes gave them); a run
+// longer than TIE_RUN_MAX raises `overflow` and the caller falls back to the remaining passes.
+constexpr u32 TIE_RUN_MAX = 48;
+constexpr u32 TIE_TILE = 2048;                         // positions whose runs a workgroup puts right
+// A workgroup owns the runs that START in its tile; it stages the tile plus enough of what follows to hold the last such
+// run in LDS (coalesced), the first record of every run sorts its run there, and the owned range is written back.
+template <int NW, bool HAS_VAL>
+__global__ __launch_bounds__(BLOCK) void tie_fix_kernel(u64* __restrict__ keys, u32* __restrict__ vals, u64 n, u32 low, u32* __restrict__ overflow) {
+    constexpr u32 SPAN = TIE_TILE + TIE_RUN_MAX + 1;   // [t0 - 1, t0 + TIE_TILE + TIE_RUN_MAX)
+    __shared__ u64 lk[SPAN * NW];
+    __shared__ u32 lv[HAS_VAL ? SPAN : 1];
+    __shared__ u32 first_owned, last_end;
+    const u64 n_tiles = (n + TIE_TILE - 1) / TIE_TILE;
+    for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const u64 t0 = tile * TIE_TILE;
+        const u64 g0 = t0 ? t0 - 1 : 0;                // global position of lk[0]
+        const u32 off = (u32)(t0 - g0);                // index of t0 in LDS (1, or 0 for the first tile)
+        const u32 cnt = (u32)((n - g0) < (u64)SPAN - (1 - off) ? (n - g0) : (u64)SPAN - (1 - off));
+        if (threadIdx.x == 0) { first_owned = 0xFFFFFFFFu; last_end = 0; }
+        for (u32 j = threadIdx.x; j < cnt; j += BLOCK) {
+            const Key<NW> kj = load_key<NW>(keys, g0 + j);
+#pragma unroll
+            for (int q = 0; q < NW; ++q) lk[j * NW + q] = kj.w[q];
+            if (HAS_VAL) lv[j] = vals[g0 + j];
+        }
+        __syncthreads();
+        const u32 tile_end = (u32)((n - t0) < (u64)TIE_TILE ? (n - t0) : (u64)TIE_TILE) + off;    // LDS index one past the tile
+        for (u32 j = off + threadIdx.x; j < tile_end; j += BLOCK) {
+            Key<NW> head;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) head.w[q] = lk[j * NW + q];
+            head = key_shr(head, low);
+            if (g0 + j > 0) {
+                Key<NW> prev;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) prev.w[q] = lk[(j - 1) * NW + q];
+                if (key_eq(key_shr(prev, low), head)) continue;                   // not the first of its run
+            }
+            atomicMin(&first_owned, j);
+            u32 end = j + 1;
+            for (; end < cnt && end - j <= TIE_RUN_MAX; ++end) {
+                Key<NW> x;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) x.w[q] = lk[end * NW + q];
+                if (!key_eq(key_shr(x, low), head)) break;
+            }
+            if (end - j > TIE_RUN_MAX) { *overflow = 1; end = j + 1; }
+            atomicMax(&last_end, end);
+            for (u32 a = j + 1; a < end; ++a) {
+                Key<NW> ka;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) ka.w[q] = lk[a * NW + q];
+                const u32 va = HAS_VAL ? lv[a] : 0;
+                u32 b = a;
+                for (; b > j; --b) {
+                    Key<NW> kb;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) kb.w[q] = lk[(b - 1) * NW + q];
+                    if (!key_lt(ka, kb)) break;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) lk[b * NW + q] = kb.w[q];
+                    if (HAS_VAL) lv[b] = lv[b - 1];
+                }
+                if (b != a) {
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) lk[b * NW + q] = ka.w[q];
+                    if (HAS_VAL) lv[b] = va;
+                }
+            }
+        }
+        __syncthreads();
+        const u32 w0 = first_owned, w1 = last_end;      // owned range in LDS indices
+        if (w0 != 0xFFFFFFFFu) {
+            for (u32 j = w0 + threadIdx.x; j < w1; j += BLOCK) {
+                Key<NW> kj;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) kj.w[q] = lk[j * NW + q];
+                store_key<NW>(keys, g0 + j, kj);
+                if (HAS_VAL) vals[g0 + j] = lv[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <int NW, bool HAS_VAL>
 static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream) {
     if (n < 2) return KATOME_OK;
@@ -256,11 +343,33 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
     if (HAS_VAL) KCHECK(tv.alloc(n * 4));
     u64* kin = d_keys; u64* kout = tk.as<u64>();
     u32* vin = d_vals; u32* vout = tv.as<u32>();
-    for (u32 shift = 0; shift < key_bits; shift += RADIX_BITS) {
+    auto pass = [&](u32 shift) -> int {
         RadixDigit<NW> dg{shift, (key_bits - shift) < (u32)RADIX_BITS ? (key_bits - shift) : (u32)RADIX_BITS};
         KCHECK((radix_pass<NW, HAS_VAL>(kin, vin, n, dg, kout, vout, pb, stream)));
         u64* t = kin; kin = kout; kout = t;
         u32* tv2 = vin; vin = vout; vout = tv2;
+        return KATOME_OK;
+    };
+    // Enough top bits to tell (nearly) all of n keys apart -- log2(n) + 9, in whole digits -- then the short runs that
+    // share them are put right by tie_fix_kernel.  Long keys save most: 2k = 62 bits: 5 passes instead of 8; 126: 5 of 16.
+    u32 need = 9;
+    while (need < 64 && (n >> (need - 9))) ++need;
+    const u32 top_passes = (need + RADIX_BITS - 1) / RADIX_BITS, all_passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
+    u32 low = 0;                                            // bits below `low` are left to the tie fix
+    if (top_passes + 1 < all_passes && n >= (1u << 16) && !getenv("KATOME_FULL_SORT")) low = (all_passes - top_passes) * RADIX_BITS;
+    for (u32 shift = low; shift < key_bits; shift += RADIX_BITS) KCHECK(pass(shift));
+    if (low) {
+        DevBuf overflow(stream);
+        KCHECK(overflow.alloc(16));
+        KCHECK_HIP(hipMemsetAsync(overflow.p, 0, 4, stream));
+        hipLaunchKernelGGL((tie_fix_kernel<NW, HAS_VAL>), dim3(grid_for(n, TIE_TILE, 256u * 16u)), dim3(BLOCK), 0, stream, kin, vin, n, low, overflow.as<u32>());
+        KCHECK_HIP(hipGetLastError());
+        u32 h = 0;
+        KCHECK_HIP(hipMemcpyAsync(&h, overflow.p, 4, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        if (h) {                                            // many keys share their top bits: the plain LSD sort, all passes
+            for (u32 shift = 0; shift < key_bits; shift += RADIX_BITS) KCHECK(pass(shift));
+        }
     }
     if (kin != d_keys) {
         KCHECK_HIP(hipMemcpyAsync(d_keys, kin, n * 8 * NW, hipMemcpyDeviceToDevice, stream));

@@ -228,3 +228,38 @@ def test_synth_reads_match_cpu_definition(oracle, L, npct):
     assert np.array_equal(got[ok], pack_reads_ascii(clean[ok]))
     if npct:
         assert 0 < has_n.sum() < n
+
+
+@pytest.mark.parametrize("nw,bits", [(1, 62), (2, 126), (2, 80)])
+@pytest.mark.parametrize("shape", ["shared_top_bits", "short_runs", "runs_across_tiles"])
+def test_sort_by_top_bits_and_tie_fix(nw, bits, shape):
+    """dev_sort only runs the passes over the top ~log2(n)+9 bits and lets tie_fix_kernel order the runs that share them;
+    runs longer than it handles (here: every key shares its top bits) must fall back to the full sort; equal keys keep
+    their input order either way"""
+    from katome_amd import device as kd
+    rng = np.random.default_rng(nw * 100 + bits + len(shape))
+    n = 300001
+    low_bits = bits - 32                      # what the tie fix is left with (n < 2^19: 4 top passes)
+    a = np.zeros((n, nw), np.uint64)
+    if shape == "shared_top_bits":            # one run of n records
+        top = np.full(n, 0x2AAAAAA, np.uint64)
+    elif shape == "short_runs":               # runs of ~3 with duplicates inside
+        top = rng.integers(0, n // 3, n).astype(np.uint64)
+    else:                                     # runs of ~40: many cross the 2048-position tiles
+        top = rng.integers(0, n // 40, n).astype(np.uint64)
+    low = rng.integers(0, 50, n).astype(np.uint64) if shape != "shared_top_bits" else rng.integers(0, 1 << 20, n).astype(np.uint64)
+    if nw == 1:
+        a[:, 0] = (top << np.uint64(low_bits)) | low
+    else:
+        hi_bits = bits - 64
+        full_top = [int(t) << low_bits for t in top.tolist()]
+        a[:, 0] = np.array([(v >> 64) & ((1 << hi_bits) - 1) for v in full_top], np.uint64)
+        a[:, 1] = np.array([v & (2**64 - 1) for v in full_top], np.uint64) | low
+    vals = torch.arange(n, dtype=torch.int32, device="cuda")
+    keys = _to_dev(a).view(-1)
+    kd.sort_keys(keys, bits, nw, vals)
+    torch.cuda.synchronize()
+    got, gv = _from_dev(keys, nw), vals.cpu().numpy()
+    order = _lexsort(a)                       # numpy's lexsort is stable: the expected permutation exactly
+    assert np.array_equal(gv, order.astype(np.int32))
+    assert np.array_equal(got, a[order])
