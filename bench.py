@@ -160,6 +160,16 @@ def next_stages(wl, sample_reads):
     return out
 
 
+def _sort_passes(key_bits, n):
+    """(radix passes, tie-fix passes) dev_sort runs for n keys of key_bits bits (radix.hip sort_t)"""
+    all_passes = (key_bits + 7) // 8
+    need = 9 + max(int(n), 1).bit_length()
+    top = (need + 7) // 8
+    if top + 4 <= all_passes and n >= (1 << 16):
+        return top, 1
+    return all_passes, 0
+
+
 def cpu_baseline(wl, sample_reads):
     """the oracle (C restatement of katome's PtGraph::create) on 1 host core, on a bounded sample"""
     from oracle import oracle as o
@@ -270,6 +280,7 @@ def main():
         # an insertion moves a record (8*NW B) and touches a slot (16*NW B)
         cnt = timer.counts or {}
         steps = args.steps
+        sort_passes = [((2 * wl.k + 7) // 8, 0)]
         per_read_extract = (wl.stride + 8 * nwt * tiles + ((wl.stride + 8 * nw * rest) if rest else 0)) if span > 1 else (wl.stride + 8 * nw * W)
         alg = {"extract": lambda launches, reads: reads * per_read_extract,
                "insert": lambda launches, reads: reads * (rest if span > 1 else W) * (8 * nw + 16 * nw),
@@ -286,7 +297,10 @@ def main():
                     cnt["mid_tile_slots"] * 16 * nwm + cnt["distinct_mid_tiles"] * ms2 * 16 * nw)
             else:
                 alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
-            alg["sort_edges"] = lambda launches, reads: steps * n_edges * ((2 * wl.k + 7) // 8) * 2 * (8 * nw + 4)
+            # dev_sort: passes over the top log2(n)+9 bits (all of them if that saves fewer than four), each reading and writing
+            # every (key, weight) pair once, then one more read + write by the tie fix
+            sort_passes[0] = _sort_passes(2 * wl.k, n_edges)
+            alg["sort_edges"] = lambda launches, reads: steps * n_edges * sum(sort_passes[0]) * 2 * (8 * nw + 4)
             alg["emit_edges"] = lambda launches, reads: steps * (cnt["kmer_slots"] * 16 * nw + n_edges * (8 * nw + 4))
         kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",
                         "insert_tiles": "insert_kernel", "expand_tiles": "expand_tiles_kernel",
@@ -320,7 +334,7 @@ def main():
         def roof(name):
             # phases made of several launches of one kernel (the 8 scatter passes of the edge sort, the slot
             # ranges of the expansion) are priced per phase: bytes of the phase / time of the phase
-            passes = (2 * wl.k + 7) // 8
+            passes = sort_passes[0][0]
             parts = {"sort_edges": [(exact["sort_edges"], passes, True),
                                     ("void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw), passes, True),
                                     ("radix_chunk_kernel", passes, True)]}.get(name, [(exact[name], 1, name == "extract")])

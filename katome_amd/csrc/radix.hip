@@ -351,12 +351,14 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
         return KATOME_OK;
     };
     // Enough top bits to tell (nearly) all of n keys apart -- log2(n) + 9, in whole digits -- then the short runs that
-    // share them are put right by tie_fix_kernel.  Long keys save most: 2k = 62 bits: 5 passes instead of 8; 126: 5 of 16.
+    // share them are put right by tie_fix_kernel.  Long keys save most: 2k = 80 bits (k = 40): 5 passes instead of 10; 126: 5 of 16.
     u32 need = 9;
     while (need < 64 && (n >> (need - 9))) ++need;
     const u32 top_passes = (need + RADIX_BITS - 1) / RADIX_BITS, all_passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
     u32 low = 0;                                            // bits below `low` are left to the tie fix
-    if (top_passes + 1 < all_passes && n >= (1u << 16) && !getenv("KATOME_FULL_SORT")) low = (all_passes - top_passes) * RADIX_BITS;
+    // (the tie fix costs about three passes' time on edge lists, where a quarter of the records head a run of 3-5:
+    // worth it from four saved passes on, i.e. for keys of more than ~70 bits -- k > 35)
+    if (top_passes + 4 <= all_passes && n >= (1u << 16) && !getenv("KATOME_FULL_SORT")) low = (all_passes - top_passes) * RADIX_BITS;
     for (u32 shift = low; shift < key_bits; shift += RADIX_BITS) KCHECK(pass(shift));
     if (low) {
         DevBuf overflow(stream);

@@ -230,7 +230,7 @@ def test_synth_reads_match_cpu_definition(oracle, L, npct):
         assert 0 < has_n.sum() < n
 
 
-@pytest.mark.parametrize("nw,bits", [(1, 62), (2, 126), (2, 80)])
+@pytest.mark.parametrize("nw,bits", [(1, 62), (2, 126), (2, 80), (2, 100)])
 @pytest.mark.parametrize("shape", ["shared_top_bits", "short_runs", "runs_across_tiles"])
 def test_sort_by_top_bits_and_tie_fix(nw, bits, shape):
     """dev_sort only runs the passes over the top ~log2(n)+9 bits and lets tie_fix_kernel order the runs that share them;
