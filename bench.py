@@ -268,13 +268,9 @@ def main():
         # insertion = 8*NW B record + 16*NW B slot per insertion
         from katome_amd._lib import lib as _katome_lib
         import ctypes as _C
-        if use_dist:          # the multi-GPU route only tiles reads whose windows are a whole number of tiles
-            span = _katome_lib().katome_tile_span(wl.k, wl.read_len)
-            tiles, rest = (W // span, 0) if span > 1 else (0, W)
-        else:
-            _sp, _t, _r = _C.c_uint32(), _C.c_uint32(), _C.c_uint32()
-            _katome_lib().katome_tile_plan(wl.k, wl.read_len, _C.byref(_sp), _C.byref(_t), _C.byref(_r))
-            span, tiles, rest = _sp.value, _t.value, _r.value
+        _sp, _t, _r = _C.c_uint32(), _C.c_uint32(), _C.c_uint32()          # both routes follow the library's plan
+        _katome_lib().katome_tile_plan(wl.k, wl.read_len, _C.byref(_sp), _C.byref(_t), _C.byref(_r))
+        span, tiles, rest = _sp.value, _t.value, _r.value
         nwt = _katome_lib().katome_tile_words(wl.k, span)
         # extraction writes one record per tile of `span` windows (span = 1: one per window);
         # an insertion moves a record (8*NW B) and touches a slot (16*NW B)

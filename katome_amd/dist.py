@@ -43,7 +43,26 @@ class HipOps:
         return self.b.extract_fixed(packed, n_reads, read_len, skip, out=out, first_read=first_read)
 
     def partition(self, records, n_parts, key_words=None, values=None, core=None):
+        if (key_words or self.nw) == 3:
+            return self._partition_three_words(records, n_parts)
         return self.b.partition(records, n_parts, key_words=key_words, values=values, core=core)
+
+    def _partition_three_words(self, records, n_parts):
+        """Tiles of 64..95 bases: the partition kernels take one- and two-word records, so the records are ordered through
+        an 8-bit radix pass over (owner, position) pairs and then moved.  Any function of the tile will do as its owner --
+        identical tiles only have to meet on one rank."""
+        rec = records.view(-1, 3)
+        n = rec.shape[0]
+        if n == 0:
+            return records, [0] * n_parts
+        mixed = rec[:, 0] * -7046029254386353131 + (rec[:, 1] ^ (rec[:, 1] >> 29)) * -4658895280553007687 + (rec[:, 2] ^ (rec[:, 2] >> 31))
+        owner = ((mixed >> 17) & 0x7FFFFFFF) % n_parts
+        owner = torch.where(rec[:, 0] == -1, torch.full_like(owner, n_parts), owner)          # windows of skipped reads go last
+        pos = torch.arange(n, dtype=torch.int32, device=rec.device)
+        keys = owner.contiguous()
+        self.kd.sort_keys(keys, 8, 1, pos, device=self.dev)                                     # stable: one 8-bit pass
+        counts = [int(c) for c in torch.bincount(keys, minlength=n_parts + 1)[:n_parts].tolist()]
+        return rec[pos[:sum(counts)].to(torch.int64)].reshape(-1), counts
 
     def insert(self, records, weights=None):
         self.b.insert(records, weights)
@@ -56,7 +75,7 @@ class HipOps:
         return self.b.tile_words(span)
 
     def tile_plan(self, read_len):
-        return self.b.tile_plan(read_len, max_tile_words=2)      # the partition passes take one- and two-word records
+        return self.b.tile_plan(read_len)
 
     def extract_remainder(self, packed, n_reads, read_len, span, skip, first_read):
         return self.b.extract_remainder(packed, n_reads, read_len, span, skip, first_read=first_read)

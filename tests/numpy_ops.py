@@ -94,13 +94,14 @@ class NumpyOps:
         return _lib.lib().katome_tile_span(self.k, read_len)          # pure host function of the library
 
     def tile_words(self, span):
-        return 1 if 2 * (self.k + span - 1) <= 62 else 2
+        bits = 2 * (self.k + span - 1)
+        return 1 if bits <= 62 else 2 if bits <= 126 else 3
 
     def tile_plan(self, read_len):
         import ctypes as C_
         from katome_amd import _lib
         sp, t, r = C_.c_uint32(), C_.c_uint32(), C_.c_uint32()
-        _lib.lib().katome_tile_plan_limited(self.k, read_len, 2, C_.byref(sp), C_.byref(t), C_.byref(r))     # pure host function
+        _lib.lib().katome_tile_plan(self.k, read_len, C_.byref(sp), C_.byref(t), C_.byref(r))     # pure host function
         return sp.value, t.value, r.value
 
     def extract_remainder(self, packed, n_reads, read_len, span, skip, first_read):

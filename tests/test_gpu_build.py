@@ -292,7 +292,7 @@ def test_dist_path_on_one_gpu(oracle):
     dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
                             device_id=torch.device("cuda", 0))
     try:
-        for k, rc in ((31, True), (40, True)):
+        for k, rc in ((31, True), (40, True), (63, True)):          # k = 63: three-word tiles through the record route
             n, L = 5000, 150
             ascii_reads = oracle.synth_reads(0, n, L, 100000, 1e-3, 1)
             has_n = (ascii_reads == ord("N")).any(axis=1)
@@ -580,7 +580,8 @@ def _two_rank_worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, o
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,k,rc,L", [(2, 31, True, 150), (3, 31, False, 100), (2, 40, True, 103), (2, 33, True, 92)])
+@pytest.mark.parametrize("world,k,rc,L", [(2, 31, True, 150), (3, 31, False, 100), (2, 40, True, 103), (2, 33, True, 92),
+                                          (2, 63, True, 150)])
 def test_multi_rank_on_one_gpu(oracle, tmp_path, world, k, rc, L):
     """katome_amd/dist.py end to end with the HIP kernels on several ranks (all on this box's one GPU; the exchange
     goes through gloo because RCCL refuses two ranks on one device): merged result == the oracle's build"""
