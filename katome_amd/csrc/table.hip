@@ -172,6 +172,20 @@ struct SeenParams {
     u32 mode;              // 0 every window, 1 whole tiles of `span` windows, 2 the windows after the last whole tile
 };
 
+// seen[slot] = min(seen[slot], {a, b}).  The numbers only ever go down, so a plain look first is safe: a pair that is
+// already no greater stays as it is and costs no atomic (device-scope atomics run at the memory side, ~2.5e10/s; most
+// insertions of a k-mer that is seen many times are not its earliest).  The thread that has just put the key in skips
+// the look -- the pair is still all-ones.
+__device__ __forceinline__ void lower_seen(u64* seen, u64 slot, u64 a, u64 b, bool both, u32 was_fresh) {
+    u64 cur_a = ~0ull, cur_b = ~0ull;
+    if (!was_fresh) {
+        const ulonglong2 cur = *reinterpret_cast<const ulonglong2*>(seen + 2 * slot);
+        cur_a = cur.x; cur_b = cur.y;
+    }
+    if (a < cur_a) atomicMin((unsigned long long*)&seen[2 * slot], (unsigned long long)a);
+    if (both && b < cur_b) atomicMin((unsigned long long*)&seen[2 * slot + 1], (unsigned long long)b);
+}
+
 template <int NW, bool SEEN>
 __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type* slots, u64 cap,
                                                         const u64* __restrict__ rec, const u32* __restrict__ wts, u64 n,
@@ -186,7 +200,8 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
             const bool flipped = (key.w[0] & RC_MARK) != 0;
             key.w[0] &= ~RC_MARK;
             u64 slot;
-            fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err, &slot);
+            const u32 was_fresh = upsert(slots, cap, key, wts ? wts[i] : 1u, err, &slot);
+            fresh += was_fresh;
             const u64 g = sp.rec0 + i;
             u64 P, Q;
             if (sp.win_prefix) {        // a read's forward windows take 2*prefix + [0, W), its reverse complement's the next W
@@ -200,12 +215,7 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
                 const u64 r = sp.read0 + g / sp.per_read, i0 = sp.win0 + (g % sp.per_read) * sp.span;
                 P = r * 2 * sp.windows + i0; Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
             }
-            if (sp.rc) {
-                atomicMin((unsigned long long*)&sp.seen[2 * slot + 0], (unsigned long long)(flipped ? Q : P));
-                atomicMin((unsigned long long*)&sp.seen[2 * slot + 1], (unsigned long long)(flipped ? P : Q));
-            } else {
-                atomicMin((unsigned long long*)&sp.seen[2 * slot + 0], (unsigned long long)P);
-            }
+            lower_seen(sp.seen, slot, flipped ? Q : P, flipped ? P : Q, sp.rc != 0, was_fresh);
         } else {
             fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err);
         }
@@ -296,10 +306,10 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
                     // the o-th sub-window of the tile was first put in at base + o*stride; the reverse complement of
                     // the tile holds its reverse complement as sub-window span-1-o
                     u64 slot;
-                    fresh += upsert(kmers, kmer_cap, x, lcnt[t], err, &slot);
+                    const u32 was_fresh = upsert(kmers, kmer_cap, x, lcnt[t], err, &slot);
+                    fresh += was_fresh;
                     const u64 fwd = lseen[2 * t] + (u64)o * stride, rev = lseen[2 * t + 1] + (u64)(span - 1 - o) * stride;
-                    atomicMin((unsigned long long*)&kmer_seen[2 * slot], (unsigned long long)(flipped ? rev : fwd));
-                    if (RC) atomicMin((unsigned long long*)&kmer_seen[2 * slot + 1], (unsigned long long)(flipped ? fwd : rev));
+                    lower_seen(kmer_seen, slot, flipped ? rev : fwd, flipped ? fwd : rev, RC, was_fresh);
                 } else {
                     fresh += upsert(kmers, kmer_cap, x, lcnt[t], err);
                 }
