@@ -384,6 +384,14 @@ int katome_dev_release_cache(int device);
  * values.  d_keys/d_vals are sorted in place (a temporary of equal size is allocated).     */
 int katome_dev_sort(int device, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, uint32_t key_words,
                     uint32_t key_bits, void *stream);
+/* remove_paths' edge removals (pruner.rs:199-217: the collected indices sorted descending, Graph::remove_edge =
+ * swap_remove, an index listed twice removes what was moved in) as katome_dev_remove_dead_paths runs them: d_pos[u]
+ * ascending marked positions, d_mult[u] how often each is listed, of n_edges edges.  -> d_victims (identity of every
+ * removed edge, in removal order; room for sum(d_mult)), the moves d_move_to[i] <- d_move_from[i] that fill the marked
+ * positions below the new count (room for u), counts = {removed, moves, edges left, removals owed to repeats}      */
+int katome_dev_replay_edge_removals(int device, const uint32_t *d_pos, const uint32_t *d_mult, uint64_t u, uint64_t n_edges,
+                                    uint32_t *d_victims, uint32_t *d_move_to, uint32_t *d_move_from, uint64_t *counts,
+                                    void *stream);
 /* in-place unique of sorted keys; returns the new count (synchronises)                     */
 int katome_dev_unique(int device, uint64_t *d_keys, uint64_t n, uint32_t key_words, uint64_t *n_out,
                       void *stream);

@@ -798,6 +798,25 @@ int katome_dev_sort(int device, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, 
     KCHECK(use_device(device));
     return dev_sort(d_keys, d_vals, n, key_words, key_bits, (hipStream_t)stream);
 }
+int katome_dev_replay_edge_removals(int device, const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t n_edges,
+                                    uint32_t* d_victims, uint32_t* d_move_to, uint32_t* d_move_from, uint64_t* counts, void* stream_) {
+    KCHECK(use_device(device));
+    if (!counts || (u && (!d_pos || !d_mult || !d_victims || !d_move_to || !d_move_from))) { set_error("null argument"); return KATOME_E_ARG; }
+    if (n_edges >= 0xFFFFFFFFull) { set_error("more than 2^32 edges"); return KATOME_E_UNSUPPORTED; }
+    hipStream_t stream = (hipStream_t)stream_;
+    ReplayScratch sc(stream);
+    DevBuf victims(stream), to(stream), from(stream);
+    uint64_t m = 0, left = n_edges, moves = 0, dups = 0;
+    KCHECK(dev_replay_edges(d_pos, d_mult, u, n_edges, sc, victims, to, from, &m, &left, &moves, &dups, stream));
+    if (m) KCHECK_HIP(hipMemcpyAsync(d_victims, victims.p, m * 4, hipMemcpyDeviceToDevice, stream));
+    if (moves) {
+        KCHECK_HIP(hipMemcpyAsync(d_move_to, to.p, moves * 4, hipMemcpyDeviceToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(d_move_from, from.p, moves * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    counts[0] = m; counts[1] = moves; counts[2] = left; counts[3] = dups;
+    return KATOME_OK;
+}
 int katome_dev_unique(int device, uint64_t* d_keys, uint64_t n, uint32_t key_words, uint64_t* n_out, void* stream) {
     KCHECK(use_device(device));
     if (key_words != 1 && key_words != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }

@@ -135,6 +135,14 @@ struct PruneGraph {
     uint64_t n_edges, n_nodes;
     uint32_t nw;
 };
+// scratch of dev_replay_edges, kept across the passes of remove_dead_paths
+struct ReplayScratch {
+    DevBuf agg, carry, size_before, jump, totals;
+    explicit ReplayScratch(hipStream_t stream) : agg(stream), carry(stream), size_before(stream), jump(stream), totals(stream) {}
+};
+int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t n_edges, ReplayScratch& scratch, DevBuf& victims,
+                     DevBuf& move_to, DevBuf& move_from, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups,
+                     hipStream_t stream);
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream);
 // Clean::remove_weak_edges with petgraph's retain_edges / retain_nodes numbering, same graph, in place
 int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t stream);

@@ -28,7 +28,6 @@ namespace {
 
 typedef uint32_t u32;
 constexpr u32 NONE32 = REPLAY_NONE;
-constexpr int WALK_TILE = 2048;        // nodes per workgroup in the walk kernel
 constexpr int MARK_ITEMS = 8;          // edges per thread in the mark compaction
 constexpr u64 REDO_FIRST_OUT = 1ull << 63;   // in node_deg: the node lost its first out-edge, first_out is being rebuilt
 
@@ -66,42 +65,66 @@ __device__ __forceinline__ u32 walk(u32 v, u32 two_k, const u64* __restrict__ fi
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void walk_kernel(u64 N, u32 two_k, const u64* __restrict__ first_out, const u64* __restrict__ dst,
-                                                     u64* __restrict__ node_deg, u32* __restrict__ mult,
-                                                     u64* __restrict__ totals /* [0] marks, [1] dead walks, [2] walks */) {
-    __shared__ u32 inputs[WALK_TILE];
-    __shared__ u32 n_inputs;
-    __shared__ u32 blk_marks, blk_dead;
-    for (u64 tile = blockIdx.x; tile * WALK_TILE < N; tile += gridDim.x) {
-        if (threadIdx.x == 0) { n_inputs = 0; blk_marks = 0; blk_dead = 0; }
-        __syncthreads();
-        const u64 base = tile * WALK_TILE;
-        for (u32 j = threadIdx.x; j < WALK_TILE; j += BLOCK) {
-            const u64 v = base + j;
-            // Externals (pruner.rs:165-195): Input = no incoming edge.  (A vertex with no edge at all cannot exist here.)
-            if (v < N) {
-                const u64 deg = node_deg[v];
-                if (deg & REDO_FIRST_OUT) node_deg[v] = deg & ~REDO_FIRST_OUT;      // (walks only read the low half)
-                if ((u32)deg == 0) inputs[atomicAdd(&n_inputs, 1u)] = (u32)v;
-            }
+__device__ __forceinline__ u32 wave_sum(u32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// Externals (pruner.rs:165-195): Input = no incoming edge.  (A vertex with no edge at all cannot exist here.)  The
+// Input vertices are gathered into a list first -- they are a few per cent of the vertices, and a walk is up to 2k
+// dependent look-ups long: walking from inside the scan leaves most lanes of a workgroup idle for that long.
+constexpr u32 INPUT_BUF = 2048;        // Input vertices a workgroup collects in LDS before it claims room in the list
+__global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restrict__ node_deg, u32* __restrict__ list,
+                                                           u64* __restrict__ totals /* [2] walks */) {
+    __shared__ u32 buf[INPUT_BUF];
+    __shared__ u32 cnt;
+    __shared__ u64 base;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const u32 lane = threadIdx.x & 63;
+    const u64 step = (u64)gridDim.x * BLOCK;
+    for (u64 v0 = (u64)blockIdx.x * BLOCK; v0 < N; v0 += step) {          // the whole workgroup stays in the loop together
+        const u64 v = v0 + threadIdx.x;
+        bool input = false;
+        if (v < N) {
+            const u64 deg = node_deg[v];
+            if (deg & REDO_FIRST_OUT) node_deg[v] = deg & ~REDO_FIRST_OUT;      // (walks only read the low half)
+            input = (u32)deg == 0;
+        }
+        const u64 m = __ballot(input);
+        if (m) {
+            u32 at = 0;
+            if (lane == 0) at = atomicAdd(&cnt, (u32)__popcll(m));
+            at = __shfl(at, 0, 64);
+            if (input) buf[at + __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull))] = (u32)v;
         }
         __syncthreads();
-        const u32 cnt = n_inputs;
-        u32 marks = 0, dead = 0;
-        for (u32 j = threadIdx.x; j < cnt; j += BLOCK) {
-            const u32 v = inputs[j];
-            const u32 len = walk<false>(v, two_k, first_out, dst, node_deg, nullptr, 0);
-            if (len) { walk<true>(v, two_k, first_out, dst, node_deg, mult, len); marks += len; dead += 1; }
-        }
-        if (marks) atomicAdd(&blk_marks, marks);
-        if (dead) atomicAdd(&blk_dead, dead);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (blk_marks) atomicAdd((unsigned long long*)&totals[0], (unsigned long long)blk_marks);
-            if (blk_dead) atomicAdd((unsigned long long*)&totals[1], (unsigned long long)blk_dead);
-            if (cnt) atomicAdd((unsigned long long*)&totals[2], (unsigned long long)cnt);
+        const u32 have = cnt;
+        const bool last = v0 + step >= N;
+        if (have > INPUT_BUF - BLOCK || (last && have)) {                  // one claim on the shared counter per ~2000 vertices
+            if (threadIdx.x == 0) { base = atomicAdd((unsigned long long*)&totals[2], (unsigned long long)have); cnt = 0; }
+            __syncthreads();
+            for (u32 j = threadIdx.x; j < have; j += BLOCK) list[base + j] = buf[j];
         }
         __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void walk_kernel(const u32* __restrict__ list, u32 two_k, const u64* __restrict__ first_out,
+                                                     const u64* __restrict__ dst, const u64* __restrict__ node_deg, u32* __restrict__ mult,
+                                                     u64* __restrict__ totals /* [0] marks, [1] dead walks, [2] walks (input) */) {
+    const u64 n = totals[2];
+    u32 marks = 0, dead = 0;
+    for (u64 j = (u64)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (u64)gridDim.x * BLOCK) {
+        const u32 v = list[j];
+        const u32 len = walk<false>(v, two_k, first_out, dst, node_deg, nullptr, 0);
+        if (len) { walk<true>(v, two_k, first_out, dst, node_deg, mult, len); marks += len; dead += 1; }
+    }
+    marks = wave_sum(marks); dead = wave_sum(dead);
+    if ((threadIdx.x & 63) == 0) {
+        if (marks) atomicAdd((unsigned long long*)&totals[0], (unsigned long long)marks);
+        if (dead) atomicAdd((unsigned long long*)&totals[1], (unsigned long long)dead);
     }
 }
 
@@ -246,6 +269,123 @@ struct PinnedU32 {
     }
 };
 
+// ---- remove_edge replay on the device ---------------------------------------------------------------------------------
+// The marked positions are consumed from the top (prune_replay.h, replay_edges, is the sequential statement).  With n the
+// number of edges left, an entry (position d, listed c times) takes min(c, n - d) edges away -- the one at d, then
+// whatever was moved into d -- and leaves n' = max(n - c, d): a function n -> max(n - a, b), and such functions compose
+// to functions of the same shape, (a1, b1) then (a2, b2) = (a1 + a2, max(b1 - a2, b2)).  A scan over the entries, top
+// first, therefore gives every entry the count it starts from, and with it the ordinal of its first removal and the
+// positions its movers come from (n - 1, n - 2, ...).  What sits at such a position is the edge that started there, or,
+// if the position is itself a marked one, whatever that entry left in it: chains that only run upwards, followed by
+// pointer jumping over the tail that disappears (as retain_on_device does).
+struct Clamp { long long a, b; };
+__device__ __forceinline__ Clamp clamp_then(const Clamp& f, const Clamp& g) {      // f first, then g
+    Clamp r; r.a = f.a + g.a; r.b = (f.b - g.a) > g.b ? (f.b - g.a) : g.b; return r;
+}
+__device__ __forceinline__ long long clamp_apply(const Clamp& f, long long n) { return (n - f.a) > f.b ? (n - f.a) : f.b; }
+constexpr int REPLAY_ITEMS = 8;
+constexpr long long CLAMP_NONE = -(1ll << 60);
+
+// entries are numbered r = 0.. from the top: r <-> ascending index u - 1 - r.  MODE 0: the workgroup's composed function
+// -> agg[block].  MODE 1: carry[block] is what precedes the workgroup; size_before[i] for every entry of it, and the
+// count left after the very last entry -> totals[3].
+template <int MODE>
+__global__ __launch_bounds__(BLOCK) void replay_scan_kernel(const u32* __restrict__ pos, const u32* __restrict__ mult, u64 u, u64 n_edges,
+                                                            Clamp* __restrict__ agg, const Clamp* __restrict__ carry,
+                                                            u32* __restrict__ size_before, u64* __restrict__ totals) {
+    __shared__ Clamp part[BLOCK];
+    const u32 tid = threadIdx.x;
+    const u64 r0 = ((u64)blockIdx.x * BLOCK + tid) * REPLAY_ITEMS;
+    Clamp f; f.a = 0; f.b = CLAMP_NONE;
+#pragma unroll
+    for (int j = 0; j < REPLAY_ITEMS; ++j) {
+        const u64 r = r0 + j;
+        if (r < u) { Clamp g; g.a = mult[u - 1 - r]; g.b = pos[u - 1 - r]; f = clamp_then(f, g); }
+    }
+    part[tid] = f;
+    __syncthreads();
+    for (u32 o = 1; o < BLOCK; o <<= 1) {                    // inclusive scan of the threads' functions (order matters)
+        Clamp mine = part[tid], left;
+        const bool take = tid >= o;
+        if (take) left = part[tid - o];
+        __syncthreads();
+        if (take) part[tid] = clamp_then(left, mine);
+        __syncthreads();
+    }
+    if (MODE == 0) {
+        if (tid == BLOCK - 1) agg[blockIdx.x] = part[tid];
+        return;
+    }
+    Clamp before = carry[blockIdx.x];
+    if (tid) before = clamp_then(before, part[tid - 1]);
+    long long n = clamp_apply(before, (long long)n_edges);
+#pragma unroll
+    for (int j = 0; j < REPLAY_ITEMS; ++j) {
+        const u64 r = r0 + j;
+        if (r < u) {
+            const u64 i = u - 1 - r;
+            size_before[i] = (u32)n;
+            const long long left = n - (long long)mult[i], d = pos[i];
+            n = left > d ? left : d;
+            if (i == 0) totals[3] = (u64)n;
+        }
+    }
+}
+// one workgroup: carry[b] = the functions of the workgroups before b, composed
+__global__ __launch_bounds__(BLOCK) void replay_spine_kernel(const Clamp* __restrict__ agg, u64 nb, Clamp* __restrict__ carry) {
+    __shared__ Clamp part[BLOCK];
+    const u32 tid = threadIdx.x;
+    const u64 per = (nb + BLOCK - 1) / BLOCK, b0 = (u64)tid * per, b1 = b0 + per < nb ? b0 + per : nb;
+    Clamp f; f.a = 0; f.b = CLAMP_NONE;
+    for (u64 b = b0; b < b1; ++b) f = clamp_then(f, agg[b]);
+    part[tid] = f;
+    __syncthreads();
+    for (u32 o = 1; o < BLOCK; o <<= 1) {
+        Clamp mine = part[tid], left;
+        const bool take = tid >= o;
+        if (take) left = part[tid - o];
+        __syncthreads();
+        if (take) part[tid] = clamp_then(left, mine);
+        __syncthreads();
+    }
+    Clamp run; run.a = 0; run.b = CLAMP_NONE;
+    if (tid) run = part[tid - 1];
+    for (u64 b = b0; b < b1; ++b) { carry[b] = run; run = clamp_then(run, agg[b]); }
+}
+__global__ __launch_bounds__(BLOCK) void iota_from_kernel(u32* __restrict__ out, u64 n, u32 first) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) out[i] = first + (u32)i;
+}
+// marked positions inside the tail [M, n): where their last occupant comes from; totals[4] = entries below M
+__global__ __launch_bounds__(BLOCK) void replay_links_kernel(const u32* __restrict__ pos, const u32* __restrict__ mult,
+                                                             const u32* __restrict__ size_before, u64 u, u64 M, u32* __restrict__ jump,
+                                                             u64* __restrict__ totals) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < u; i += (u64)gridDim.x * BLOCK) {
+        const u64 d = pos[i];
+        if (d < M) continue;
+        if (i == 0 || pos[i - 1] < M) totals[4] = i;
+        const long long left = (long long)size_before[i] - (long long)mult[i];
+        if (left > (long long)d) jump[d - M] = (u32)left;          // (else the entry ends by taking the last edge itself)
+    }
+}
+// victims in removal order, the moves into the marked positions that stay, the removals owed to repeated indices
+__global__ __launch_bounds__(BLOCK) void replay_emit_kernel(const u32* __restrict__ pos, const u32* __restrict__ mult,
+                                                            const u32* __restrict__ size_before, u64 u, u64 n_edges, u64 M,
+                                                            const u32* __restrict__ jump, u32* __restrict__ victims,
+                                                            u32* __restrict__ move_to, u32* __restrict__ move_from, u64* __restrict__ totals) {
+    u32 dups = 0;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < u; i += (u64)gridDim.x * BLOCK) {
+        const u64 d = pos[i], S = size_before[i];
+        const long long left = (long long)S - (long long)mult[i];
+        const u64 after = left > (long long)d ? (u64)left : d, e = S - after, first = n_edges - S;
+        victims[first] = (u32)d;
+        for (u64 j = 1; j < e; ++j) victims[first + j] = jump[S - j - M];
+        dups += (u32)(e - 1);
+        if (d < M) { move_to[i] = (u32)d; move_from[i] = jump[after - M]; }
+    }
+    dups = wave_sum(dups);
+    if ((threadIdx.x & 63) == 0 && dups) atomicAdd((unsigned long long*)&totals[5], (unsigned long long)dups);
+}
+
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -266,6 +406,59 @@ int upload(DevBuf& d, const U32Buf& h, hipStream_t stream) {
 
 }  // namespace
 
+__global__ void retain_jump_kernel(u32* __restrict__ jump, u64 u, u64 M, u32* __restrict__ changed);
+
+// remove_paths' edge removals (pruner.rs:199-217) for marked positions d_pos[u] (ascending) listed d_mult[] times each,
+// of E edges: victims in removal order, the moves (to[i] <- from[i]) that fill the marked positions below the new count
+int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t E, ReplayScratch& sc, DevBuf& d_victims, DevBuf& to_e,
+                     DevBuf& from_e, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups, hipStream_t stream) {
+    *n_removed = 0; *n_left = E; *n_moves = 0; *n_dups = 0;
+    if (u == 0) return KATOME_OK;
+    DevBuf &agg = sc.agg, &carry = sc.carry, &size_before = sc.size_before, &jump = sc.jump, &totals = sc.totals;
+    KCHECK(ensure(totals, 64, stream));
+    KCHECK_HIP(hipMemsetAsync(totals.p, 0, 64, stream));
+    const u64 nb = (u + (u64)BLOCK * REPLAY_ITEMS - 1) / ((u64)BLOCK * REPLAY_ITEMS);
+    KCHECK(ensure(agg, nb * sizeof(Clamp) + 16, stream)); KCHECK(ensure(carry, nb * sizeof(Clamp) + 16, stream));
+    KCHECK(ensure(size_before, u * 4 + 16, stream));
+    hipLaunchKernelGGL(replay_scan_kernel<0>, dim3((unsigned)nb), dim3(BLOCK), 0, stream, d_pos, d_mult, u, E,
+                       agg.as<Clamp>(), (const Clamp*)nullptr, (u32*)nullptr, totals.as<u64>());
+    hipLaunchKernelGGL(replay_spine_kernel, dim3(1), dim3(BLOCK), 0, stream, agg.as<Clamp>(), nb, carry.as<Clamp>());
+    hipLaunchKernelGGL(replay_scan_kernel<1>, dim3((unsigned)nb), dim3(BLOCK), 0, stream, d_pos, d_mult, u, E,
+                       (Clamp*)nullptr, carry.as<Clamp>(), size_before.as<u32>(), totals.as<u64>());
+    KCHECK_HIP(hipGetLastError());
+    u64 left = 0;
+    KCHECK_HIP(hipMemcpyAsync(&left, totals.as<u64>() + 3, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    const u64 E_new = left, m = E - E_new;
+    KCHECK(ensure(jump, m * 4 + 16, stream));
+    KCHECK(ensure(d_victims, m * 4 + 16, stream));
+    KCHECK(ensure(to_e, u * 4 + 16, stream)); KCHECK(ensure(from_e, u * 4 + 16, stream));
+    const u64 all = u;                                           // totals[4]: entries below the new count (default: all)
+    KCHECK_HIP(hipMemcpyAsync(totals.as<u64>() + 4, &all, 8, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(iota_from_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<u32>(), m, (u32)E_new);
+    hipLaunchKernelGGL(replay_links_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos, d_mult,
+                       size_before.as<u32>(), u, E_new, jump.as<u32>(), totals.as<u64>());
+    for (int round = 0; round < 64; ++round) {
+        KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 6, 0, 8, stream));
+        for (int rep = 0; rep < 2; ++rep)
+            hipLaunchKernelGGL(retain_jump_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<u32>(), m, E_new,
+                               reinterpret_cast<u32*>(totals.as<u64>() + 6));
+        u64 changed = 0;
+        KCHECK_HIP(hipMemcpyAsync(&changed, totals.as<u64>() + 6, 8, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        if (!changed) break;
+    }
+    hipLaunchKernelGGL(replay_emit_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos, d_mult,
+                       size_before.as<u32>(), u, E, E_new, jump.as<u32>(), d_victims.as<u32>(), to_e.as<u32>(), from_e.as<u32>(),
+                       totals.as<u64>());
+    KCHECK_HIP(hipGetLastError());
+    u64 h2[2] = {0, 0};
+    KCHECK_HIP(hipMemcpyAsync(h2, totals.as<u64>() + 4, 16, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    *n_removed = m; *n_left = E_new; *n_moves = h2[0]; *n_dups = h2[1];
+    return KATOME_OK;
+}
+
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream) {
     katome_prune_stats local;
     memset(&local, 0, sizeof local);
@@ -284,11 +477,13 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK(dev_iota(orig.as<u32>(), E, stream));
     }
     KCHECK(node_deg.alloc((N + 1) * 8)); KCHECK(first_out.alloc((N + 1) * 8)); KCHECK(mult.alloc((E + 1) * 4));
-    KCHECK(totals.alloc(32));
+    KCHECK(totals.alloc(64));
     PinnedU32 h_pos, h_mult, h_die;
     EdgeReplay er; NodeReplay nr;
     DevBuf counts(stream), offs(stream), d_pos(stream), d_mult(stream), d_victims(stream), last_touch(stream), d_die(stream);
-    DevBuf to_e(stream), from_e(stream), to_n(stream), from_n(stream), tail_map(stream);
+    DevBuf to_e(stream), from_e(stream), to_n(stream), from_n(stream), tail_map(stream), inputs(stream);
+    ReplayScratch replay_scratch(stream);
+    const bool host_edges = getenv("KATOME_PRUNE_HOST_EDGES") != nullptr;      // the sequential replay of prune_replay.h (A/B checks)
     KCHECK(last_touch.alloc((N + 1) * 4));
     const bool trace = getenv("KATOME_TRACE_PRUNE") != nullptr;
     double lap_t = now_ms();
@@ -311,9 +506,12 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         const double pass_t0 = now_ms();
         double pass_host = 0;
         // (1) walks
-        KCHECK_HIP(hipMemsetAsync(totals.p, 0, 32, stream));
-        hipLaunchKernelGGL(walk_kernel, dim3(grid_for(N, WALK_TILE, 256u * 32u)), dim3(BLOCK), 0, stream, N, two_k, first_out.as<u64>(),
-                           dst, node_deg.as<u64>(), mult.as<u32>(), totals.as<u64>());
+        KCHECK_HIP(hipMemsetAsync(totals.p, 0, 64, stream));
+        KCHECK(ensure(inputs, N * 4 + 16, stream));
+        hipLaunchKernelGGL(input_list_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, node_deg.as<u64>(),
+                           inputs.as<u32>(), totals.as<u64>());
+        hipLaunchKernelGGL(walk_kernel, dim3(256u * 16u), dim3(BLOCK), 0, stream, inputs.as<u32>(), two_k, first_out.as<u64>(), dst,
+                           node_deg.as<u64>(), mult.as<u32>(), totals.as<u64>());
         KCHECK_HIP(hipGetLastError());
         u64 h_tot[3] = {0, 0, 0};
         KCHECK_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, stream));
@@ -337,22 +535,30 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
                            d_pos.as<u32>(), d_mult.as<u32>());
         if (u) hipLaunchKernelGGL(mark_clear_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos.as<u32>(), u, mult.as<u32>());
         KCHECK_HIP(hipGetLastError());
-        KCHECK(h_pos.need(u)); KCHECK(h_mult.need(u));
-        KCHECK_HIP(hipMemcpyAsync(h_pos.p, d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
-        KCHECK_HIP(hipMemcpyAsync(h_mult.p, d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
-        KCHECK_HIP(hipStreamSynchronize(stream));
-        lap("marks to host");
-        // (3) replay of remove_edge
-        double t0 = now_ms();
-        replay_edges(h_pos.p, h_mult.p, u, E, h_tot[0], er);
-        const double t_edges = now_ms() - t0;
-        local.host_ms += t_edges; pass_host += t_edges;
-        const u64 m = er.victims.size();
+        u64 m = 0, E_new = E, n_edge_moves = 0, dups = 0;
+        double t_edges = 0;
+        if (host_edges) {
+            KCHECK(h_pos.need(u)); KCHECK(h_mult.need(u));
+            KCHECK_HIP(hipMemcpyAsync(h_pos.p, d_pos.p, u * 4, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipMemcpyAsync(h_mult.p, d_mult.p, u * 4, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipStreamSynchronize(stream));
+            lap("marks to host");
+            // (3) replay of remove_edge
+            const double t0 = now_ms();
+            replay_edges(h_pos.p, h_mult.p, u, E, h_tot[0], er);
+            t_edges = now_ms() - t0;
+            local.host_ms += t_edges; pass_host += t_edges;
+            m = er.victims.size(); E_new = er.n_new; dups = er.from_duplicates; n_edge_moves = er.move_to.size();
+            KCHECK(upload(d_victims, er.victims, stream));
+            KCHECK(upload(to_e, er.move_to, stream)); KCHECK(upload(from_e, er.move_from, stream));
+        } else {
+            // (3) the same replay as a scan + pointer jumping, without leaving the device
+            KCHECK(dev_replay_edges(d_pos.as<u32>(), d_mult.as<u32>(), u, E, replay_scratch, d_victims, to_e, from_e, &m, &E_new, &n_edge_moves, &dups, stream));
+        }
         local.removed_edges += m;
-        local.removed_by_duplicates += er.from_duplicates;
+        local.removed_by_duplicates += dups;
         lap("replay edges");
         // (4) the nodes each removal isolates
-        KCHECK(upload(d_victims, er.victims, stream));
         KCHECK(ensure(d_die, 2 * m * 4 + 16, stream));
         KCHECK_HIP(hipMemsetAsync(last_touch.p, 0, N * 4, stream));
         hipLaunchKernelGGL(death_count_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
@@ -365,7 +571,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK_HIP(hipStreamSynchronize(stream));
         lap("deaths to host");
         // (5) replay of remove_node
-        t0 = now_ms();
+        const double t0 = now_ms();
         replay_nodes(h_die.p, m, N, nr);
         const double t_nodes = now_ms() - t0;
         local.host_ms += t_nodes; pass_host += t_nodes;
@@ -373,11 +579,10 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         lap("replay nodes");
         // (6) apply the moves, re-label the endpoints of the surviving edges
         {
-            KCHECK(upload(to_e, er.move_to, stream)); KCHECK(upload(from_e, er.move_from, stream));
-            const u64 ne = er.move_to.size();
+            const u64 ne = n_edge_moves;
             if (ne) hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(ne, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_e.as<u32>(),
                                        from_e.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>());
-            E = er.n_new;
+            E = E_new;
             KCHECK(upload(to_n, nr.move_to, stream)); KCHECK(upload(from_n, nr.move_from, stream));
             const u64 nn = nr.move_to.size();
             KCHECK(ensure(tail_map, (N - nr.n_new + 1) * 4, stream));
@@ -396,7 +601,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             fprintf(stderr, "[prune] pass %llu: E %llu N %llu walks %llu dead %llu marked %llu removed %llu (dup %llu) nodes %llu | %.2f ms, host %.2f (edges %.2f nodes %.2f)\n",
                     (unsigned long long)local.passes, (unsigned long long)E, (unsigned long long)N, (unsigned long long)h_tot[2],
                     (unsigned long long)h_tot[1], (unsigned long long)h_tot[0], (unsigned long long)m,
-                    (unsigned long long)er.from_duplicates, (unsigned long long)nr.move_to.size(), now_ms() - pass_t0, pass_host, t_edges, t_nodes);
+                    (unsigned long long)dups, (unsigned long long)nr.move_to.size(), now_ms() - pass_t0, pass_host, t_edges, t_nodes);
     }
     g.n_edges = E; g.n_nodes = N;
     if (st) *st = local;

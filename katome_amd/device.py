@@ -307,6 +307,21 @@ def unique_sorted(keys, key_words, device=0):
     return keys.view(-1)[:out.value * key_words]
 
 
+def replay_edge_removals(pos, mult, n_edges, device=0):
+    """remove_paths' swap_removes (pruner.rs:199-217) for marked positions `pos` (ascending, int32/uint32 on the device)
+    listed `mult` times each -> (victims in removal order, move_to, move_from, edges left, removals owed to repeats)"""
+    u = pos.numel()
+    marks = int(mult.to(torch.int64).sum().item()) if u else 0
+    victims = torch.empty(max(marks, 1), dtype=torch.int32, device=pos.device)
+    to = torch.empty(max(u, 1), dtype=torch.int32, device=pos.device)
+    frm = torch.empty(max(u, 1), dtype=torch.int32, device=pos.device)
+    counts = (C.c_uint64 * 4)()
+    _check(_lib.lib().katome_dev_replay_edge_removals(device, _ptr(pos), _ptr(mult), u, n_edges, _ptr(victims), _ptr(to), _ptr(frm),
+                                                      C.cast(counts, C.c_void_p), _stream()))
+    m, moves, left, dups = (int(x) for x in counts)
+    return victims[:m], to[:moves], frm[:moves], left, dups
+
+
 def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
     ns, nq = sorted_keys.numel() // key_words, queries.numel() // key_words
     out = torch.empty(max(nq, 1), dtype=torch.int64, device=queries.device)

@@ -380,3 +380,48 @@ def test_host_entry_with_stages(oracle, golden_dir, name, k, rc, thr, glen, stag
     _same(g, ref, k)
     with pytest.raises(KatomePanic):          # the stages walk petgraph's numbering
         GpuGraph.create([path], InputFileType.Fastq, rc, thr, stages=stages, original_genome_length=glen)
+
+
+def _naive_edge_removals(pos, mult, n_edges):
+    """remove_paths (pruner.rs:199-217): indices sorted descending, Graph::remove_edge = Vec::swap_remove"""
+    arr = list(range(n_edges))
+    victims, dups = [], 0
+    for d, c in sorted(zip(pos, mult), reverse=True):
+        for r in range(c):
+            if d < len(arr):
+                victims.append(arr[d])
+                dups += r != 0
+                arr[d] = arr[-1]
+                arr.pop()
+    return victims, {p: v for p, v in enumerate(arr) if v != p}, len(arr), dups
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_edge_removal_replay_on_the_device(seed):
+    """katome_dev_replay_edge_removals (scan of n -> max(n - c, d) + pointer jumping) against a literal swap_remove loop:
+    repeated indices, runs that eat the whole tail, entries that end by removing the last edge itself, chains of
+    marked positions feeding marked positions; sizes across several workgroups of the scan"""
+    from katome_amd import device as kd
+    rng = np.random.default_rng(1000 + seed)
+    n_edges = int(rng.integers(1, 60)) if seed % 4 == 0 else int(rng.integers(1000, 30000))
+    style = seed % 5
+    if style == 0:      # a dense block of marks at the very top: pointer chains, pops
+        u = int(rng.integers(1, n_edges + 1))
+        pos = np.arange(n_edges - u, n_edges)
+        pos = pos[rng.random(u) < 0.8] if u > 1 else pos
+    elif style == 1:    # every position marked
+        pos = np.arange(n_edges)
+    else:
+        u = int(rng.integers(0, n_edges + 1)) if style == 2 else int(rng.integers(0, max(2, n_edges // 10)))
+        pos = np.sort(rng.choice(n_edges, u, replace=False))
+    hi = (2, 6, 40, 3, 2)[style]
+    mult = rng.integers(1, hi + 1, len(pos))
+    if len(pos) and seed % 7 == 0:
+        mult[rng.integers(0, len(pos))] = n_edges + 5          # one index listed more often than there are edges
+    want_v, want_moves, want_left, want_dups = _naive_edge_removals(pos.tolist(), mult.tolist(), n_edges)
+    d_pos = torch.from_numpy(pos.astype(np.int64)).to(torch.int32).cuda()
+    d_mult = torch.from_numpy(mult.astype(np.int64)).to(torch.int32).cuda()
+    v, to, frm, left, dups = kd.replay_edge_removals(d_pos, d_mult, n_edges)
+    assert left == want_left and dups == want_dups
+    assert v.cpu().tolist() == want_v
+    assert dict(zip(to.cpu().tolist(), frm.cpu().tolist())) == want_moves and to.numel() == len(want_moves)
