@@ -392,6 +392,13 @@ int katome_dev_sort(int device, uint64_t *d_keys, uint32_t *d_vals, uint64_t n, 
 int katome_dev_replay_edge_removals(int device, const uint32_t *d_pos, const uint32_t *d_mult, uint64_t u, uint64_t n_edges,
                                     uint32_t *d_victims, uint32_t *d_move_to, uint32_t *d_move_from, uint64_t *counts,
                                     void *stream);
+/* remove_single_node after every removed edge (pruner.rs:206-225; Graph::remove_node = swap_remove): d_die[2t],
+ * d_die[2t+1] = the source / target that edge removal t leaves without edges (0xFFFFFFFF: stays); when both go, the
+ * one at the larger current index goes first.  -> the moves d_move_to[i] <- d_move_from[i] of the nodes that end up
+ * re-numbered (room for as many as die), counts = {moves, nodes left, 1 if the device form gave up (chains of moves
+ * longer than it follows: katome_dev_remove_dead_paths then runs the sequential replay on the host; nothing is written)} */
+int katome_dev_replay_node_removals(int device, const uint32_t *d_die, uint64_t m, uint64_t n_nodes, uint32_t *d_move_to,
+                                    uint32_t *d_move_from, uint64_t *counts, void *stream);
 /* in-place unique of sorted keys; returns the new count (synchronises)                     */
 int katome_dev_unique(int device, uint64_t *d_keys, uint64_t n, uint32_t key_words, uint64_t *n_out,
                       void *stream);

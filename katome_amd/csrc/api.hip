@@ -817,6 +817,25 @@ int katome_dev_replay_edge_removals(int device, const uint32_t* d_pos, const uin
     counts[0] = m; counts[1] = moves; counts[2] = left; counts[3] = dups;
     return KATOME_OK;
 }
+int katome_dev_replay_node_removals(int device, const uint32_t* d_die, uint64_t m, uint64_t n_nodes, uint32_t* d_move_to, uint32_t* d_move_from,
+                                    uint64_t* counts, void* stream_) {
+    KCHECK(use_device(device));
+    if (!counts || (m && (!d_die || !d_move_to || !d_move_from))) { set_error("null argument"); return KATOME_E_ARG; }
+    if (n_nodes >= 0xFFFFFFFFull || m >= 0x7FFFFFFFull) { set_error("more than 2^32 nodes"); return KATOME_E_UNSUPPORTED; }
+    hipStream_t stream = (hipStream_t)stream_;
+    NodeReplayScratch sc(stream);
+    DevBuf to(stream), from(stream);
+    uint64_t moves = 0, left = n_nodes;
+    int fell_back = 0;
+    KCHECK(dev_replay_nodes(d_die, m, n_nodes, sc, to, from, &moves, &left, &fell_back, stream));
+    if (moves) {
+        KCHECK_HIP(hipMemcpyAsync(d_move_to, to.p, moves * 4, hipMemcpyDeviceToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(d_move_from, from.p, moves * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    counts[0] = moves; counts[1] = left; counts[2] = (uint64_t)fell_back;
+    return KATOME_OK;
+}
 int katome_dev_unique(int device, uint64_t* d_keys, uint64_t n, uint32_t key_words, uint64_t* n_out, void* stream) {
     KCHECK(use_device(device));
     if (key_words != 1 && key_words != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }

@@ -143,6 +143,12 @@ struct ReplayScratch {
 int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t n_edges, ReplayScratch& scratch, DevBuf& victims,
                      DevBuf& move_to, DevBuf& move_from, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups,
                      hipStream_t stream);
+struct NodeReplayScratch {
+    DevBuf counts, offs, first, hole, dead, flags;
+    explicit NodeReplayScratch(hipStream_t stream) : counts(stream), offs(stream), first(stream), hole(stream), dead(stream), flags(stream) {}
+};
+int dev_replay_nodes(const uint32_t* d_die, uint64_t m, uint64_t n_nodes, NodeReplayScratch& scratch, DevBuf& move_to, DevBuf& move_from,
+                     uint64_t* n_moves, uint64_t* n_left, int* fell_back, hipStream_t stream);
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream);
 // Clean::remove_weak_edges with petgraph's retain_edges / retain_nodes numbering, same graph, in place
 int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t stream);

@@ -386,6 +386,136 @@ __global__ __launch_bounds__(BLOCK) void replay_emit_kernel(const u32* __restric
     if ((threadIdx.x & 63) == 0 && dups) atomicAdd((unsigned long long*)&totals[5], (unsigned long long)dups);
 }
 
+// ---- remove_node replay on the device ---------------------------------------------------------------------------------
+// replay_nodes (prune_replay.h) is the sequential statement.  The M nodes that die leave one at a time; with removal
+// number s the last position L(s) = N - 1 - s is given up and whoever sits there moves into the position p(s) of the
+// node being removed.  Only positions of the tail [N - M, N) are ever given up, each exactly once and in descending
+// order, so "where does the occupant of tail position q go" is one number per tail position: hole[q] = p(N - 1 - q).
+// A node that started at x is, at removal s, at the end of the chain x -> hole[x] -> hole[hole[x]] ... cut where the
+// next position has not been given up yet (N - 1 - q >= s) or lies below the tail.  p(s) itself is such a chain end (for
+// the node removed at s, over positions given up before s): the holes depend on holes of higher positions only.  Most
+// chains have one or two links, so the holes are found in a few rounds: every removal whose chain runs over known
+// holes settles, the rest wait for the next round.  When an edge removal takes both endpoints, the endpoint at the
+// larger current position goes first (pruner.rs:206-225) -- both positions are chain ends at the same removal number.
+constexpr u32 UNRESOLVED = 0xFFFFFFFFu;
+constexpr u32 CHAIN_CAP = 1u << 13;        // links followed per chain before the pass is handed to the host replay
+
+__global__ __launch_bounds__(BLOCK) void die_count_kernel(const u32* __restrict__ die, u64 m, u32* __restrict__ counts) {
+    __shared__ u32 total;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    const u64 base = ((u64)blockIdx.x * BLOCK + threadIdx.x) * MARK_ITEMS;
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j)
+        if (base + j < m) c += (die[2 * (base + j)] != NONE32) + (die[2 * (base + j) + 1] != NONE32);
+    if (c) atomicAdd(&total, c);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+}
+// first[t] = nodes removed before edge removal t; dead[] marks the tail nodes that die
+__global__ __launch_bounds__(BLOCK) void die_first_kernel(const u32* __restrict__ die, u64 m, const u64* __restrict__ block_offs, u64 base_pos,
+                                                          u32* __restrict__ first, unsigned char* __restrict__ dead) {
+    __shared__ u32 wsum[BLOCK / 64];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = ((u64)blockIdx.x * BLOCK + tid) * MARK_ITEMS;
+    u32 cnt[MARK_ITEMS], c = 0;
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j) {
+        cnt[j] = 0;
+        if (base + j < m) {
+            const u32 a = die[2 * (base + j)], b = die[2 * (base + j) + 1];
+            cnt[j] = (a != NONE32) + (b != NONE32);
+            if (a != NONE32 && a >= base_pos) dead[a - base_pos] = 1;
+            if (b != NONE32 && b >= base_pos) dead[b - base_pos] = 1;
+        }
+        c += cnt[j];
+    }
+    u32 incl = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u32 woff = 0;
+    for (u32 w = 0; w < wave; ++w) woff += wsum[w];
+    u64 run = block_offs[blockIdx.x] + woff + incl - c;
+#pragma unroll
+    for (int j = 0; j < MARK_ITEMS; ++j) if (base + j < m) { first[base + j] = (u32)run; run += cnt[j]; }
+}
+// position at removal number s of the node that started at x (alive then); false: a hole on the way is not known yet
+__device__ __forceinline__ bool node_position(u32 x, u64 s, u64 N, u64 base_pos, const u32* hole, u32* flags, u32& out) {
+    u64 q = x;
+    u32 links = 0;
+    while (q >= base_pos && N - 1 - q < s) {
+        const u32 h = hole[q - base_pos];
+        if (h == UNRESOLVED) return false;
+        if (h == q) break;                                   // (the occupant died here; no live node follows this link)
+        q = h;
+        if (++links > CHAIN_CAP) { flags[1] = 1; return false; }
+    }
+    out = (u32)q;
+    return true;
+}
+__global__ __launch_bounds__(BLOCK) void node_holes_kernel(const u32* __restrict__ die, const u32* __restrict__ first, u64 m, u64 N,
+                                                           u64 base_pos, u32* hole, u32* flags /* [0] something waits, [1] chain too long */) {
+    bool waits = false;
+    for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
+        const u32 a = die[2 * t], b = die[2 * t + 1];
+        if (a == NONE32 && b == NONE32) continue;
+        const u64 s = first[t], last = N - 1 - s;
+        if (hole[last - base_pos] != UNRESOLVED) continue;                   // settled in an earlier round
+        if (a != NONE32 && b != NONE32) {
+            u32 pa, pb;
+            if (!node_position(a, s, N, base_pos, hole, flags, pa) || !node_position(b, s, N, base_pos, hole, flags, pb)) { waits = true; continue; }
+            hole[last - 1 - base_pos] = pa < pb ? pa : pb;                      // the second to go (it cannot be the one sitting last)
+            hole[last - base_pos] = pa < pb ? pb : pa;
+        } else {
+            u32 p;
+            if (!node_position(a != NONE32 ? a : b, s, N, base_pos, hole, flags, p)) { waits = true; continue; }
+            hole[last - base_pos] = p;
+        }
+    }
+    if (waits) flags[0] = 1;
+}
+// the tail nodes that stay: where each ends up
+__global__ __launch_bounds__(BLOCK) void node_moves_kernel(const unsigned char* __restrict__ dead, u64 M, u64 base_pos, const u32* __restrict__ hole,
+                                                           u32* __restrict__ move_to, u32* __restrict__ move_from, u64* __restrict__ count,
+                                                           u32* flags) {
+    __shared__ u32 wcnt[BLOCK / 64];
+    __shared__ u64 bbase;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 step = (u64)gridDim.x * BLOCK;
+    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < M; i0 += step) {
+        const u64 i = i0 + tid;
+        bool stays = i < M && !dead[i];
+        u64 q = base_pos + i;
+        if (stays) {
+            u32 links = 0;
+            while (q >= base_pos) {
+                const u32 h = hole[q - base_pos];
+                if (h == UNRESOLVED || h == q || ++links > CHAIN_CAP) { flags[1] = 1; stays = false; break; }
+                q = h;
+            }
+        }
+        const u64 mask = __ballot(stays);
+        if (lane == 0) wcnt[wave] = (u32)__popcll(mask);
+        __syncthreads();
+        if (tid == 0) {
+            u32 tot = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) tot += wcnt[w];
+            bbase = tot ? atomicAdd((unsigned long long*)count, (unsigned long long)tot) : 0;
+        }
+        __syncthreads();
+        if (stays) {
+            u32 woff = 0;
+            for (u32 w = 0; w < wave; ++w) woff += wcnt[w];
+            const u64 at = bbase + woff + __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull));
+            move_to[at] = (u32)q; move_from[at] = (u32)(base_pos + i);
+        }
+        __syncthreads();
+    }
+}
+
 double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
@@ -459,6 +589,52 @@ int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, 
     return KATOME_OK;
 }
 
+// remove_single_node after every removed edge (pruner.rs:206-225) for die[2t], die[2t+1] (the endpoints edge removal t
+// leaves without edges, REPLAY_NONE = stays), of N nodes: the moves to[i] <- from[i] of the tail nodes that stay.
+// *fell_back = 1: a chain was too long for the device form; nothing was produced and the caller runs the host replay.
+int dev_replay_nodes(const uint32_t* d_die, uint64_t m, uint64_t N, NodeReplayScratch& sc, DevBuf& to_n, DevBuf& from_n, uint64_t* n_moves,
+                     uint64_t* n_left, int* fell_back, hipStream_t stream) {
+    *n_moves = 0; *n_left = N; *fell_back = 0;
+    if (m == 0) return KATOME_OK;
+    const u64 nblocks = (m + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
+    KCHECK(ensure(sc.counts, nblocks * 4 + 16, stream)); KCHECK(ensure(sc.offs, (nblocks + 1) * 8 + 16, stream));
+    KCHECK(ensure(sc.flags, 32, stream));
+    hipLaunchKernelGGL(die_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_die, m, sc.counts.as<u32>());
+    KCHECK(dev_scan_counts(sc.counts.as<u32>(), nblocks, sc.offs.as<u64>(), stream));
+    u64 M = 0;
+    KCHECK_HIP(hipMemcpyAsync(&M, sc.offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    if (M == 0) return KATOME_OK;
+    const u64 base_pos = N - M;
+    KCHECK(ensure(sc.first, m * 4 + 16, stream)); KCHECK(ensure(sc.hole, M * 4 + 16, stream)); KCHECK(ensure(sc.dead, M + 16, stream));
+    KCHECK(ensure(to_n, M * 4 + 16, stream)); KCHECK(ensure(from_n, M * 4 + 16, stream));
+    KCHECK_HIP(hipMemsetAsync(sc.hole.p, 0xFF, M * 4, stream));
+    KCHECK_HIP(hipMemsetAsync(sc.dead.p, 0, M, stream));
+    hipLaunchKernelGGL(die_first_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_die, m, sc.offs.as<u64>(), base_pos, sc.first.as<u32>(),
+                       sc.dead.as<unsigned char>());
+    u32 h_flags[2] = {1, 0};
+    for (int round = 0; round < 256 && h_flags[0] && !h_flags[1]; ++round) {
+        KCHECK_HIP(hipMemsetAsync(sc.flags.p, 0, 32, stream));
+        hipLaunchKernelGGL(node_holes_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_die, sc.first.as<u32>(), m, N, base_pos,
+                           sc.hole.as<u32>(), sc.flags.as<u32>());
+        KCHECK_HIP(hipGetLastError());
+        KCHECK_HIP(hipMemcpyAsync(h_flags, sc.flags.p, 8, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+    }
+    if (h_flags[0] || h_flags[1]) { *fell_back = 1; return KATOME_OK; }
+    KCHECK_HIP(hipMemsetAsync(sc.flags.p, 0, 32, stream));
+    hipLaunchKernelGGL(node_moves_kernel, dim3(grid_for(M, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, sc.dead.as<unsigned char>(), M, base_pos,
+                       sc.hole.as<u32>(), to_n.as<u32>(), from_n.as<u32>(), reinterpret_cast<u64*>(sc.flags.as<u32>() + 4), sc.flags.as<u32>());
+    KCHECK_HIP(hipGetLastError());
+    u32 h_end[6] = {0, 0, 0, 0, 0, 0};
+    KCHECK_HIP(hipMemcpyAsync(h_end, sc.flags.p, 24, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    if (h_end[1]) { *fell_back = 1; return KATOME_OK; }
+    *n_moves = (u64)h_end[4] | ((u64)h_end[5] << 32);
+    *n_left = base_pos;
+    return KATOME_OK;
+}
+
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream) {
     katome_prune_stats local;
     memset(&local, 0, sizeof local);
@@ -483,6 +659,8 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     DevBuf counts(stream), offs(stream), d_pos(stream), d_mult(stream), d_victims(stream), last_touch(stream), d_die(stream);
     DevBuf to_e(stream), from_e(stream), to_n(stream), from_n(stream), tail_map(stream), inputs(stream);
     ReplayScratch replay_scratch(stream);
+    NodeReplayScratch node_scratch(stream);
+    const bool host_nodes = getenv("KATOME_PRUNE_HOST_NODES") != nullptr;
     const bool host_edges = getenv("KATOME_PRUNE_HOST_EDGES") != nullptr;      // the sequential replay of prune_replay.h (A/B checks)
     KCHECK(last_touch.alloc((N + 1) * 4));
     const bool trace = getenv("KATOME_TRACE_PRUNE") != nullptr;
@@ -566,16 +744,24 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         hipLaunchKernelGGL(death_emit_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
                            node_deg.as<u64>(), last_touch.as<u32>(), d_die.as<u32>());
         KCHECK_HIP(hipGetLastError());
-        KCHECK(h_die.need(2 * m));
-        KCHECK_HIP(hipMemcpyAsync(h_die.p, d_die.p, 2 * m * 4, hipMemcpyDeviceToHost, stream));
-        KCHECK_HIP(hipStreamSynchronize(stream));
-        lap("deaths to host");
-        // (5) replay of remove_node
-        const double t0 = now_ms();
-        replay_nodes(h_die.p, m, N, nr);
-        const double t_nodes = now_ms() - t0;
-        local.host_ms += t_nodes; pass_host += t_nodes;
-        local.removed_nodes += N - nr.n_new;
+        // (5) replay of remove_node: on the device, or (chains too long for that form, or asked for) on the host
+        u64 n_node_moves = 0, N_new = N;
+        double t_nodes = 0;
+        int on_host = host_nodes ? 1 : 0;
+        if (!on_host) KCHECK(dev_replay_nodes(d_die.as<u32>(), m, N, node_scratch, to_n, from_n, &n_node_moves, &N_new, &on_host, stream));
+        if (on_host) {
+            KCHECK(h_die.need(2 * m));
+            KCHECK_HIP(hipMemcpyAsync(h_die.p, d_die.p, 2 * m * 4, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipStreamSynchronize(stream));
+            lap("deaths to host");
+            const double t0 = now_ms();
+            replay_nodes(h_die.p, m, N, nr);
+            t_nodes = now_ms() - t0;
+            local.host_ms += t_nodes; pass_host += t_nodes;
+            n_node_moves = nr.move_to.size(); N_new = nr.n_new;
+            KCHECK(upload(to_n, nr.move_to, stream)); KCHECK(upload(from_n, nr.move_from, stream));
+        }
+        local.removed_nodes += N - N_new;
         lap("replay nodes");
         // (6) apply the moves, re-label the endpoints of the surviving edges
         {
@@ -583,17 +769,16 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             if (ne) hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(ne, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_e.as<u32>(),
                                        from_e.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>());
             E = E_new;
-            KCHECK(upload(to_n, nr.move_to, stream)); KCHECK(upload(from_n, nr.move_from, stream));
-            const u64 nn = nr.move_to.size();
-            KCHECK(ensure(tail_map, (N - nr.n_new + 1) * 4, stream));
+            const u64 nn = n_node_moves;
+            KCHECK(ensure(tail_map, (N - N_new + 1) * 4, stream));
             if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
-                                       from_n.as<u32>(), nn, nw, nr.n_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
-            if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, nr.n_new,
+                                       from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
+            if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, N_new,
                                             tail_map.as<u32>());
             if (E) hipLaunchKernelGGL(first_out_redo_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, orig.as<u32>(), E,
                                       node_deg.as<u64>(), first_out.as<u64>());
             KCHECK_HIP(hipGetLastError());
-            N = nr.n_new;
+            N = N_new;
             KCHECK_HIP(hipStreamSynchronize(stream));      // the host vectors are reused by the next pass
         }
         lap("apply");
@@ -601,7 +786,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             fprintf(stderr, "[prune] pass %llu: E %llu N %llu walks %llu dead %llu marked %llu removed %llu (dup %llu) nodes %llu | %.2f ms, host %.2f (edges %.2f nodes %.2f)\n",
                     (unsigned long long)local.passes, (unsigned long long)E, (unsigned long long)N, (unsigned long long)h_tot[2],
                     (unsigned long long)h_tot[1], (unsigned long long)h_tot[0], (unsigned long long)m,
-                    (unsigned long long)dups, (unsigned long long)nr.move_to.size(), now_ms() - pass_t0, pass_host, t_edges, t_nodes);
+                    (unsigned long long)dups, (unsigned long long)n_node_moves, now_ms() - pass_t0, pass_host, t_edges, t_nodes);
     }
     g.n_edges = E; g.n_nodes = N;
     if (st) *st = local;

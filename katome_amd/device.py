@@ -322,6 +322,18 @@ def replay_edge_removals(pos, mult, n_edges, device=0):
     return victims[:m], to[:moves], frm[:moves], left, dups
 
 
+def replay_node_removals(die, n_nodes, device=0):
+    """remove_single_node after every removed edge (pruner.rs:206-225) for die[t] = (source, target) left without edges by
+    edge removal t (-1 = stays) -> (move_to, move_from, nodes left, gave_up)"""
+    m = die.numel() // 2
+    to = torch.empty(max(2 * m, 1), dtype=torch.int32, device=die.device)
+    frm = torch.empty(max(2 * m, 1), dtype=torch.int32, device=die.device)
+    counts = (C.c_uint64 * 3)()
+    _check(_lib.lib().katome_dev_replay_node_removals(device, _ptr(die), m, n_nodes, _ptr(to), _ptr(frm), C.cast(counts, C.c_void_p), _stream()))
+    moves, left, gave_up = (int(x) for x in counts)
+    return to[:moves], frm[:moves], left, bool(gave_up)
+
+
 def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
     ns, nq = sorted_keys.numel() // key_words, queries.numel() // key_words
     out = torch.empty(max(nq, 1), dtype=torch.int64, device=queries.device)

@@ -425,3 +425,59 @@ def test_edge_removal_replay_on_the_device(seed):
     assert left == want_left and dups == want_dups
     assert v.cpu().tolist() == want_v
     assert dict(zip(to.cpu().tolist(), frm.cpu().tolist())) == want_moves and to.numel() == len(want_moves)
+
+
+def _naive_node_removals(die, n_nodes):
+    """remove_single_node per endpoint, larger current index first (pruner.rs:206-215); remove_node = swap_remove"""
+    arr = list(range(n_nodes))
+    where = {v: v for v in arr}
+    for a, b in die:
+        gone = sorted((v for v in (a, b) if v >= 0), key=lambda v: where[v], reverse=True)
+        for v in gone:
+            p = where.pop(v)
+            last = arr.pop()
+            if p < len(arr):
+                arr[p] = last
+                where[last] = p
+    return {p: v for p, v in enumerate(arr) if v != p}, len(arr)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_node_removal_replay_on_the_device(seed):
+    """katome_dev_replay_node_removals (holes of the tail positions settled in rounds) against a literal swap_remove loop:
+    pairs and single endpoints, most of the graph dying, removals biased to the tail (nodes that move several times)"""
+    from katome_amd import device as kd
+    rng = np.random.default_rng(5000 + seed)
+    n_nodes = int(rng.integers(2, 80)) if seed % 4 == 0 else int(rng.integers(1000, 40000))
+    style = seed % 5
+    if style == 0:
+        n_die = n_nodes                                                    # everything goes
+    elif style == 1:
+        n_die = int(rng.integers(n_nodes // 2, n_nodes + 1))
+    else:
+        n_die = int(rng.integers(0, n_nodes // 3 + 1))
+    if style == 3:      # the dying nodes sit at the top and leave from the bottom of that block up: long chains of moves
+        dying = list(range(n_nodes - n_die, n_nodes))[::-1]
+    elif style == 4:    # descending from the top: every removal takes the last node itself
+        dying = list(range(n_nodes - n_die, n_nodes))
+    else:
+        dying = rng.permutation(n_nodes)[:n_die].tolist()
+    die = []
+    while dying:
+        kind = rng.integers(0, 4)
+        if kind == 0 and len(dying) >= 2:
+            die.append((dying.pop(), dying.pop()))
+        elif kind == 1:
+            die.append((dying.pop(), -1))
+        elif kind == 2:
+            die.append((-1, dying.pop()))
+        else:
+            die.append((-1, -1))
+    want_moves, want_left = _naive_node_removals(die, n_nodes)
+    d_die = torch.tensor(die, dtype=torch.int32).reshape(-1).cuda() if die else torch.empty(0, dtype=torch.int32, device="cuda")
+    to, frm, left, gave_up = kd.replay_node_removals(d_die, n_nodes)
+    if gave_up:
+        assert style == 3 and n_die > 4000          # only the contrived long chains are handed to the host replay
+        return
+    assert left == want_left
+    assert dict(zip(to.cpu().tolist(), frm.cpu().tolist())) == want_moves and to.numel() == len(want_moves)
