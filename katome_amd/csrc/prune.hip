@@ -29,39 +29,54 @@ namespace {
 typedef uint32_t u32;
 constexpr u32 NONE32 = REPLAY_NONE;
 constexpr int MARK_ITEMS = 8;          // edges per thread in the mark compaction
-constexpr u64 REDO_FIRST_OUT = 1ull << 63;   // in node_deg: the node lost its first out-edge, first_out is being rebuilt
-
-// node_deg[v]: in-degree in the low half, out-degree in the high half.  first_out[v]: (first-seen index + 1) << 32 | position
-// of the out-edge with the largest first-seen index (0 = none).  Both are built once and then kept up to date by the
+// node_deg[v], one word per node so that a step of a walk is one look-up: bits 0-15 in-degree, bits 16-30 out-degree (a
+// (k-1)-mer has at most four edges either way), bit 31 "lost its first out-edge, first_out is being rebuilt", bits 32-63
+// the node its first out-edge leads to (NONE32: no out-edge).  first_out[v]: (first-seen index + 1) << 32 | position of
+// the out-edge with the largest first-seen index (0 = none).  Both are built once and then kept up to date by the
 // kernels below as edges go and as edges and nodes are moved.
+constexpr u64 IN_ONE = 1ull, OUT_ONE = 1ull << 16, IN_MASK = 0xFFFFull, DEG_MASK = 0x7FFFFFFFull;
+constexpr u64 REDO_FIRST_OUT = 1ull << 31;
 __global__ __launch_bounds__(BLOCK) void degree_kernel(const u64* __restrict__ src, const u64* __restrict__ dst,
                                                        const u32* __restrict__ orig, u64 E, u64* __restrict__ node_deg,
                                                        u64* __restrict__ first_out) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
         const u64 a = src[e], b = dst[e];
-        atomicAdd((unsigned long long*)&node_deg[a], 1ull << 32);
-        atomicAdd((unsigned long long*)&node_deg[b], 1ull);
+        atomicAdd((unsigned long long*)&node_deg[a], OUT_ONE);
+        atomicAdd((unsigned long long*)&node_deg[b], IN_ONE);
         atomicMax((unsigned long long*)&first_out[a], ((unsigned long long)(orig[e] + 1u) << 32) | (unsigned long long)e);
     }
+}
+__device__ __forceinline__ u64 with_successor(u64 deg, u64 fo, const u64* __restrict__ dst) {
+    return (deg & DEG_MASK) | ((fo ? dst[(u32)fo] : (u64)NONE32) << 32);
+}
+__global__ __launch_bounds__(BLOCK) void successor_kernel(u64 N, const u64* __restrict__ first_out, const u64* __restrict__ dst,
+                                                          u64* __restrict__ node_deg) {
+    for (u64 v = (u64)blockIdx.x * BLOCK + threadIdx.x; v < N; v += (u64)gridDim.x * BLOCK)
+        node_deg[v] = with_successor(node_deg[v], first_out[v], dst);
 }
 
 // check_dead_path(vertex, Incoming, Outgoing) (pruner.rs:229-257): returns the number of edges of the dead path, 0 if
 // the walk is not dead; with MARK, adds one to mult[] of every edge on the way
-template <bool MARK>
-__device__ __forceinline__ u32 walk(u32 v, u32 two_k, const u64* __restrict__ first_out, const u64* __restrict__ dst,
-                                    const u64* __restrict__ node_deg, u32* __restrict__ mult, u32 len) {
-    u32 cur = v, cnt = 0, n = 0;
+__device__ __forceinline__ u32 walk_length(u32 v, u32 two_k, const u64* __restrict__ node_deg) {
+    u64 w = node_deg[v];
+    u32 cnt = 0, n = 0;
     for (;;) {
         cnt += 1;
-        if (!MARK && cnt >= two_k) return 0;                    // "this path is not dead"
-        if (MARK && n == len) return n;
-        const u64 fo = first_out[cur];
-        if (fo == 0) return n;                                  // no out-edge: the whole path is dead
-        const u32 e = (u32)fo;
-        if (MARK) atomicAdd(&mult[e], 1u);
+        if (cnt >= two_k) return 0;                             // "this path is not dead"
+        const u32 next = (u32)(w >> 32);
+        if (next == NONE32) return n;                           // no out-edge: the whole path is dead
         ++n;
+        w = node_deg[next];
+        if ((w & IN_MASK) >= 3) return n;                       // neighbors_directed(current, Incoming).nth(2).is_some()
+    }
+}
+// the same walk over the edges themselves: one more listing of each of its `len` edges
+__device__ __forceinline__ void walk_mark(u32 v, u32 len, const u64* __restrict__ first_out, const u64* __restrict__ dst, u32* __restrict__ mult) {
+    u32 cur = v;
+    for (u32 n = 0; n < len; ++n) {
+        const u32 e = (u32)first_out[cur];
+        atomicAdd(&mult[e], 1u);
         cur = (u32)dst[e];
-        if ((u32)node_deg[cur] >= 3) return n;                  // neighbors_directed(current, Incoming).nth(2).is_some()
     }
 }
 
@@ -75,8 +90,9 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 // Input vertices are gathered into a list first -- they are a few per cent of the vertices, and a walk is up to 2k
 // dependent look-ups long: walking from inside the scan leaves most lanes of a workgroup idle for that long.
 constexpr u32 INPUT_BUF = 2048;        // Input vertices a workgroup collects in LDS before it claims room in the list
-__global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restrict__ node_deg, u32* __restrict__ list,
-                                                           u64* __restrict__ totals /* [2] walks */) {
+__global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restrict__ node_deg, const u64* __restrict__ first_out,
+                                                           const u64* __restrict__ dst, const u32* __restrict__ tail_map /* of the pass before */,
+                                                           u32* __restrict__ list, u64* __restrict__ totals /* [2] walks */) {
     __shared__ u32 buf[INPUT_BUF];
     __shared__ u32 cnt;
     __shared__ u64 base;
@@ -89,8 +105,10 @@ __global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restric
         bool input = false;
         if (v < N) {
             const u64 deg = node_deg[v];
-            if (deg & REDO_FIRST_OUT) node_deg[v] = deg & ~REDO_FIRST_OUT;      // (walks only read the low half)
-            input = (u32)deg == 0;
+            const u32 next = (u32)(deg >> 32);
+            if (deg & REDO_FIRST_OUT) node_deg[v] = with_successor(deg & ~REDO_FIRST_OUT, first_out[v], dst);   // a new first out-edge
+            else if (tail_map && next != NONE32 && next >= N) node_deg[v] = (deg & DEG_MASK) | ((u64)tail_map[next - N] << 32);   // it was moved
+            input = (deg & IN_MASK) == 0;
         }
         const u64 m = __ballot(input);
         if (m) {
@@ -118,8 +136,8 @@ __global__ __launch_bounds__(BLOCK) void walk_kernel(const u32* __restrict__ lis
     u32 marks = 0, dead = 0;
     for (u64 j = (u64)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (u64)gridDim.x * BLOCK) {
         const u32 v = list[j];
-        const u32 len = walk<false>(v, two_k, first_out, dst, node_deg, nullptr, 0);
-        if (len) { walk<true>(v, two_k, first_out, dst, node_deg, mult, len); marks += len; dead += 1; }
+        const u32 len = walk_length(v, two_k, node_deg);
+        if (len) { walk_mark(v, len, first_out, dst, mult); marks += len; dead += 1; }
     }
     marks = wave_sum(marks); dead = wave_sum(dead);
     if ((threadIdx.x & 63) == 0) {
@@ -178,8 +196,8 @@ __global__ __launch_bounds__(BLOCK) void death_count_kernel(const u32* __restric
             first_out[a] = 0;
             atomicOr((unsigned long long*)&node_deg[a], REDO_FIRST_OUT);
         }
-        atomicAdd((unsigned long long*)&node_deg[a], 0ull - (1ull << 32));
-        atomicAdd((unsigned long long*)&node_deg[b], 0ull - 1ull);
+        atomicAdd((unsigned long long*)&node_deg[a], 0ull - OUT_ONE);
+        atomicAdd((unsigned long long*)&node_deg[b], 0ull - IN_ONE);
         atomicMax(&last_touch[a], (u32)t + 1u);
         atomicMax(&last_touch[b], (u32)t + 1u);
     }
@@ -190,8 +208,8 @@ __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict
     for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
         const u32 e = victims[t];
         const u64 a = src[e], b = dst[e];
-        const bool da = (node_deg[a] & ~REDO_FIRST_OUT) == 0 && last_touch[a] == (u32)t + 1u;
-        const bool db = b != a && (node_deg[b] & ~REDO_FIRST_OUT) == 0 && last_touch[b] == (u32)t + 1u;
+        const bool da = (node_deg[a] & (DEG_MASK & ~REDO_FIRST_OUT)) == 0 && last_touch[a] == (u32)t + 1u;
+        const bool db = b != a && (node_deg[b] & (DEG_MASK & ~REDO_FIRST_OUT)) == 0 && last_touch[b] == (u32)t + 1u;
         die[2 * t] = da ? (u32)a : NONE32;
         die[2 * t + 1] = db ? (u32)b : NONE32;
     }
@@ -678,8 +696,11 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     KCHECK_HIP(hipMemsetAsync(mult.p, 0, E * 4, stream));
     if (E) hipLaunchKernelGGL(degree_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, orig.as<u32>(), E,
                               node_deg.as<u64>(), first_out.as<u64>());
+    if (N) hipLaunchKernelGGL(successor_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, first_out.as<u64>(), dst,
+                              node_deg.as<u64>());
     KCHECK_HIP(hipGetLastError());
     lap("adjacency");
+    bool nodes_moved = false;                 // tail_map holds the moves of the pass before
     while (E) {
         const double pass_t0 = now_ms();
         double pass_host = 0;
@@ -687,7 +708,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK_HIP(hipMemsetAsync(totals.p, 0, 64, stream));
         KCHECK(ensure(inputs, N * 4 + 16, stream));
         hipLaunchKernelGGL(input_list_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, node_deg.as<u64>(),
-                           inputs.as<u32>(), totals.as<u64>());
+                           first_out.as<u64>(), dst, nodes_moved ? tail_map.as<u32>() : (const u32*)nullptr, inputs.as<u32>(), totals.as<u64>());
         hipLaunchKernelGGL(walk_kernel, dim3(256u * 16u), dim3(BLOCK), 0, stream, inputs.as<u32>(), two_k, first_out.as<u64>(), dst,
                            node_deg.as<u64>(), mult.as<u32>(), totals.as<u64>());
         KCHECK_HIP(hipGetLastError());
@@ -770,6 +791,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
                                        from_e.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>());
             E = E_new;
             const u64 nn = n_node_moves;
+            nodes_moved = nn != 0;
             KCHECK(ensure(tail_map, (N - N_new + 1) * 4, stream));
             if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
                                        from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
