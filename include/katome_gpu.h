@@ -305,15 +305,16 @@ int katome_dev_finalize(katome_builder *b, katome_dev_graph *out, void *stream);
 
 /* Prunable::remove_dead_paths for PtGraph (pruner.rs:36-82; Externals 165-195, remove_paths 199-217,
  * check_dead_path 229-257), in place on the finalized graph of a FIRST_SEEN_ORDER builder: call after
- * katome_dev_finalize; `graph` is updated (counts shrink, labels are rewritten).  The walks, the degree
- * bookkeeping and the array moves run on the device; the two sequential swap_remove replays that fix petgraph's
- * re-numbering run on the host between them (see prune.hip).                                          */
+ * katome_dev_finalize; `graph` is updated (counts shrink, labels are rewritten).  Everything runs on the device:
+ * the walks, the degree bookkeeping, the two swap_remove replays that fix petgraph's re-numbering (edges: a scan
+ * + pointer jumping; nodes: the vacated tail positions settled in rounds) and the array moves.  Only a pass whose
+ * node moves chain further than the device form follows is replayed sequentially on the host (see prune.hip).  */
 typedef struct {
     uint64_t passes;                 /* iterations of the reference's outer loop, the last (empty) one included */
     uint64_t walks, dead_walks;      /* walks started from vertices without incoming edges / walks found dead   */
     uint64_t marked;                 /* edge indices collected, duplicates counted                              */
     uint64_t removed_edges, removed_by_duplicates, removed_nodes;
-    double   host_ms;                /* time in the sequential replays                                          */
+    double   host_ms;                /* time in sequential host replays (0 unless a pass fell back to them)     */
     double   total_ms;
 } katome_prune_stats;
 int katome_dev_remove_dead_paths(katome_builder *b, katome_dev_graph *graph, katome_prune_stats *stats, void *stream);

@@ -29,6 +29,7 @@ namespace {
 typedef uint32_t u32;
 constexpr u32 NONE32 = REPLAY_NONE;
 constexpr int MARK_ITEMS = 8;          // edges per thread in the mark compaction
+static_assert(BLOCK * MARK_ITEMS == 2048, "one 'touched' byte per workgroup of the mark compaction (MARK_GROUP_SHIFT)");
 // node_deg[v], one word per node so that a step of a walk is one look-up: bits 0-15 in-degree, bits 16-30 out-degree (a
 // (k-1)-mer has at most four edges either way), bit 31 "lost its first out-edge, first_out is being rebuilt", bits 32-63
 // the node its first out-edge leads to (NONE32: no out-edge).  first_out[v]: (first-seen index + 1) << 32 | position of
@@ -71,11 +72,14 @@ __device__ __forceinline__ u32 walk_length(u32 v, u32 two_k, const u64* __restri
     }
 }
 // the same walk over the edges themselves: one more listing of each of its `len` edges
-__device__ __forceinline__ void walk_mark(u32 v, u32 len, const u64* __restrict__ first_out, const u64* __restrict__ dst, u32* __restrict__ mult) {
+constexpr u32 MARK_GROUP_SHIFT = 11;       // 2048 edges (one workgroup of the mark compaction) share a "something is marked" byte
+__device__ __forceinline__ void walk_mark(u32 v, u32 len, const u64* __restrict__ first_out, const u64* __restrict__ dst, u32* __restrict__ mult,
+                                          unsigned char* __restrict__ touched) {
     u32 cur = v;
     for (u32 n = 0; n < len; ++n) {
         const u32 e = (u32)first_out[cur];
         atomicAdd(&mult[e], 1u);
+        touched[e >> MARK_GROUP_SHIFT] = 1;
         cur = (u32)dst[e];
     }
 }
@@ -131,13 +135,14 @@ __global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restric
 
 __global__ __launch_bounds__(BLOCK) void walk_kernel(const u32* __restrict__ list, u32 two_k, const u64* __restrict__ first_out,
                                                      const u64* __restrict__ dst, const u64* __restrict__ node_deg, u32* __restrict__ mult,
+                                                     unsigned char* __restrict__ touched,
                                                      u64* __restrict__ totals /* [0] marks, [1] dead walks, [2] walks (input) */) {
     const u64 n = totals[2];
     u32 marks = 0, dead = 0;
     for (u64 j = (u64)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (u64)gridDim.x * BLOCK) {
         const u32 v = list[j];
         const u32 len = walk_length(v, two_k, node_deg);
-        if (len) { walk_mark(v, len, first_out, dst, mult); marks += len; dead += 1; }
+        if (len) { walk_mark(v, len, first_out, dst, mult, touched); marks += len; dead += 1; }
     }
     marks = wave_sum(marks); dead = wave_sum(dead);
     if ((threadIdx.x & 63) == 0) {
@@ -147,8 +152,13 @@ __global__ __launch_bounds__(BLOCK) void walk_kernel(const u32* __restrict__ lis
 }
 
 // marked edge indices, ascending, with their multiplicity: count / scan / write
-__global__ __launch_bounds__(BLOCK) void mark_count_kernel(const u32* __restrict__ mult, u64 E, u32* __restrict__ counts) {
+__global__ __launch_bounds__(BLOCK) void mark_count_kernel(const u32* __restrict__ mult, u64 E, u32* __restrict__ counts,
+                                                           const unsigned char* __restrict__ touched = nullptr) {
     __shared__ u32 total;
+    if (touched && !touched[blockIdx.x]) {                 // nothing marked among this workgroup's edges: mult is not read
+        if (threadIdx.x == 0) counts[blockIdx.x] = 0;
+        return;
+    }
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     const u64 base = ((u64)blockIdx.x * BLOCK + threadIdx.x) * MARK_ITEMS;
@@ -160,8 +170,10 @@ __global__ __launch_bounds__(BLOCK) void mark_count_kernel(const u32* __restrict
     if (threadIdx.x == 0) counts[blockIdx.x] = total;
 }
 __global__ __launch_bounds__(BLOCK) void mark_write_kernel(const u32* __restrict__ mult, u64 E, const u64* __restrict__ block_offs,
-                                                           u32* __restrict__ out_pos, u32* __restrict__ out_mult) {
+                                                           u32* __restrict__ out_pos, u32* __restrict__ out_mult,
+                                                           const unsigned char* __restrict__ touched) {
     __shared__ u32 wsum[BLOCK / 64];
+    if (!touched[blockIdx.x]) return;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 base = ((u64)blockIdx.x * BLOCK + tid) * MARK_ITEMS;
     u32 m[MARK_ITEMS], c = 0;
@@ -179,8 +191,9 @@ __global__ __launch_bounds__(BLOCK) void mark_write_kernel(const u32* __restrict
     for (int j = 0; j < MARK_ITEMS; ++j) if (m[j]) { out_pos[pos] = (u32)(base + j); out_mult[pos] = m[j]; ++pos; }
 }
 
-__global__ __launch_bounds__(BLOCK) void mark_clear_kernel(const u32* __restrict__ pos, u64 n, u32* __restrict__ mult) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) mult[pos[i]] = 0;
+__global__ __launch_bounds__(BLOCK) void mark_clear_kernel(const u32* __restrict__ pos, u64 n, u32* __restrict__ mult,
+                                                           unsigned char* __restrict__ touched) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) { mult[pos[i]] = 0; touched[pos[i] >> MARK_GROUP_SHIFT] = 0; }
 }
 
 // which endpoints lose their last edge with removal t: take the removed edges out of the degree words, remember the
@@ -262,11 +275,19 @@ __global__ __launch_bounds__(BLOCK) void fill_u32_kernel(u32* __restrict__ p, u6
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) p[i] = v;
 }
 
-// nodes that lost their first out-edge: the largest first-seen index among the out-edges that are left
-__global__ __launch_bounds__(BLOCK) void first_out_redo_kernel(const u64* __restrict__ src, const u32* __restrict__ orig, u64 E,
+// one pass over the edges that are left: endpoints that were moved get their new ids (REMAP), and nodes that lost
+// their first out-edge find the largest first-seen index among the out-edges they still have
+template <bool REMAP>
+__global__ __launch_bounds__(BLOCK) void first_out_redo_kernel(u64* __restrict__ src, u64* __restrict__ dst, const u32* __restrict__ orig, u64 E,
+                                                               u64 n_new, const u32* __restrict__ tail_map,
                                                                const u64* __restrict__ node_deg, u64* __restrict__ first_out) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
-        const u64 a = src[e];
+        u64 a = src[e];
+        if (REMAP) {
+            if (a >= n_new) { a = tail_map[a - n_new]; src[e] = a; }
+            const u64 b = dst[e];
+            if (b >= n_new) dst[e] = tail_map[b - n_new];
+        }
         if (node_deg[a] & REDO_FIRST_OUT)
             atomicMax((unsigned long long*)&first_out[a], ((unsigned long long)(orig[e] + 1u) << 32) | (unsigned long long)e);
     }
@@ -664,7 +685,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     u64 E = g.n_edges, N = g.n_nodes;
     u64* src = g.edge_src->as<u64>(); u64* dst = g.edge_dst->as<u64>();
     u32* weight = g.edge_weight->as<u32>(); u64* key = g.edge_key->as<u64>(); u64* node_key = g.node_key->as<u64>();
-    DevBuf node_deg(stream), first_out(stream), mult(stream), totals(stream);
+    DevBuf node_deg(stream), first_out(stream), mult(stream), totals(stream), touched(stream);
     DevBuf& orig = *g.edge_age;
     if (orig.bytes < (E + 1) * 4) {
         KCHECK(orig.alloc((E + 1) * 4, stream));
@@ -694,6 +715,8 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     KCHECK_HIP(hipMemsetAsync(node_deg.p, 0, N * 8, stream));
     KCHECK_HIP(hipMemsetAsync(first_out.p, 0, N * 8, stream));
     KCHECK_HIP(hipMemsetAsync(mult.p, 0, E * 4, stream));
+    KCHECK(touched.alloc((E >> MARK_GROUP_SHIFT) + 16));
+    KCHECK_HIP(hipMemsetAsync(touched.p, 0, (E >> MARK_GROUP_SHIFT) + 16, stream));
     if (E) hipLaunchKernelGGL(degree_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, orig.as<u32>(), E,
                               node_deg.as<u64>(), first_out.as<u64>());
     if (N) hipLaunchKernelGGL(successor_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, first_out.as<u64>(), dst,
@@ -710,7 +733,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         hipLaunchKernelGGL(input_list_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, node_deg.as<u64>(),
                            first_out.as<u64>(), dst, nodes_moved ? tail_map.as<u32>() : (const u32*)nullptr, inputs.as<u32>(), totals.as<u64>());
         hipLaunchKernelGGL(walk_kernel, dim3(256u * 16u), dim3(BLOCK), 0, stream, inputs.as<u32>(), two_k, first_out.as<u64>(), dst,
-                           node_deg.as<u64>(), mult.as<u32>(), totals.as<u64>());
+                           node_deg.as<u64>(), mult.as<u32>(), touched.as<unsigned char>(), totals.as<u64>());
         KCHECK_HIP(hipGetLastError());
         u64 h_tot[3] = {0, 0, 0};
         KCHECK_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, stream));
@@ -724,15 +747,17 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         // (2) the marked indices, ascending (the reference sorts them descending; they are consumed from the top)
         const u64 nblocks = (E + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
         KCHECK(ensure(counts, nblocks * 4 + 16, stream)); KCHECK(ensure(offs, (nblocks + 1) * 8 + 16, stream));
-        hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, counts.as<u32>());
+        hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, counts.as<u32>(),
+                           (const unsigned char*)touched.as<unsigned char>());
         KCHECK(dev_scan_counts(counts.as<u32>(), nblocks, offs.as<u64>(), stream));
         u64 u = 0;
         KCHECK_HIP(hipMemcpyAsync(&u, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
         KCHECK(ensure(d_pos, u * 4 + 16, stream)); KCHECK(ensure(d_mult, u * 4 + 16, stream));
         hipLaunchKernelGGL(mark_write_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, mult.as<u32>(), E, offs.as<u64>(),
-                           d_pos.as<u32>(), d_mult.as<u32>());
-        if (u) hipLaunchKernelGGL(mark_clear_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos.as<u32>(), u, mult.as<u32>());
+                           d_pos.as<u32>(), d_mult.as<u32>(), (const unsigned char*)touched.as<unsigned char>());
+        if (u) hipLaunchKernelGGL(mark_clear_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos.as<u32>(), u, mult.as<u32>(),
+                                  touched.as<unsigned char>());
         KCHECK_HIP(hipGetLastError());
         u64 m = 0, E_new = E, n_edge_moves = 0, dups = 0;
         double t_edges = 0;
@@ -795,10 +820,10 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             KCHECK(ensure(tail_map, (N - N_new + 1) * 4, stream));
             if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
                                        from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
-            if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, N_new,
-                                            tail_map.as<u32>());
-            if (E) hipLaunchKernelGGL(first_out_redo_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, orig.as<u32>(), E,
-                                      node_deg.as<u64>(), first_out.as<u64>());
+            if (E && nn) hipLaunchKernelGGL(first_out_redo_kernel<true>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst,
+                                            orig.as<u32>(), E, N_new, tail_map.as<u32>(), node_deg.as<u64>(), first_out.as<u64>());
+            else if (E) hipLaunchKernelGGL(first_out_redo_kernel<false>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst,
+                                           orig.as<u32>(), E, N_new, (const u32*)nullptr, node_deg.as<u64>(), first_out.as<u64>());
             KCHECK_HIP(hipGetLastError());
             N = N_new;
             KCHECK_HIP(hipStreamSynchronize(stream));      // the host vectors are reused by the next pass
@@ -873,7 +898,7 @@ static int retain_on_device(const u32* d_flag, u64 n, DevBuf& to, DevBuf& from, 
     const u64 nblocks = (n + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
     DevBuf counts(stream), offs(stream), jump(stream), changed(stream);
     KCHECK(counts.alloc(nblocks * 4 + 16)); KCHECK(offs.alloc((nblocks + 1) * 8 + 16)); KCHECK(changed.alloc(16));
-    hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_flag, n, counts.as<u32>());
+    hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_flag, n, counts.as<u32>(), (const unsigned char*)nullptr);
     KCHECK(dev_scan_counts(counts.as<u32>(), nblocks, offs.as<u64>(), stream));
     u64 u = 0;
     KCHECK_HIP(hipMemcpyAsync(&u, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
@@ -895,7 +920,7 @@ static int retain_on_device(const u32* d_flag, u64 n, DevBuf& to, DevBuf& from, 
         DevBuf tcounts(stream), toffs(stream);
         const u64 tblocks = (u + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
         KCHECK(tcounts.alloc(tblocks * 4 + 16)); KCHECK(toffs.alloc((tblocks + 1) * 8 + 16));
-        hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)tblocks), dim3(BLOCK), 0, stream, d_flag + M, u, tcounts.as<u32>());
+        hipLaunchKernelGGL(mark_count_kernel, dim3((unsigned)tblocks), dim3(BLOCK), 0, stream, d_flag + M, u, tcounts.as<u32>(), (const unsigned char*)nullptr);
         KCHECK(dev_scan_counts(tcounts.as<u32>(), tblocks, toffs.as<u64>(), stream));
         u64 in_tail = 0;
         KCHECK_HIP(hipMemcpyAsync(&in_tail, toffs.as<u64>() + tblocks, 8, hipMemcpyDeviceToHost, stream));
