@@ -400,6 +400,8 @@ int katome_dev_replay_edge_removals(int device, const uint32_t *d_pos, const uin
  * longer than it follows: katome_dev_remove_dead_paths then runs the sequential replay on the host; nothing is written)} */
 int katome_dev_replay_node_removals(int device, const uint32_t *d_die, uint64_t m, uint64_t n_nodes, uint32_t *d_move_to,
                                     uint32_t *d_move_from, uint64_t *counts, void *stream);
+/* exclusive prefix sums of m u32 counts as u64: d_offs[i] = counts[0] + .. + counts[i-1], d_offs[m] = the total   */
+int katome_dev_scan_counts(int device, const uint32_t *d_counts, uint64_t m, uint64_t *d_offs, void *stream);
 /* in-place unique of sorted keys; returns the new count (synchronises)                     */
 int katome_dev_unique(int device, uint64_t *d_keys, uint64_t n, uint32_t key_words, uint64_t *n_out,
                       void *stream);

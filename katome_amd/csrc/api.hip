@@ -836,6 +836,11 @@ int katome_dev_replay_node_removals(int device, const uint32_t* d_die, uint64_t 
     counts[0] = moves; counts[1] = left; counts[2] = (uint64_t)fell_back;
     return KATOME_OK;
 }
+int katome_dev_scan_counts(int device, const uint32_t* d_counts, uint64_t m, uint64_t* d_offs, void* stream) {
+    KCHECK(use_device(device));
+    if (!d_offs || (m && !d_counts)) { set_error("null argument"); return KATOME_E_ARG; }
+    return dev_scan_counts(d_counts, m, d_offs, (hipStream_t)stream);
+}
 int katome_dev_unique(int device, uint64_t* d_keys, uint64_t n, uint32_t key_words, uint64_t* n_out, void* stream) {
     KCHECK(use_device(device));
     if (key_words != 1 && key_words != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }

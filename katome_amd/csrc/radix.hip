@@ -475,7 +475,8 @@ __global__ __launch_bounds__(BLOCK) void uniq_count_kernel(const u64* __restrict
 }
 
 // exclusive scan of m u32 counts into u64 offsets, one workgroup; offs[m] = grand total
-__global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict__ counts, u64 m, u64* __restrict__ offs) {
+template <class T>
+__global__ __launch_bounds__(1024) void scan_counts_kernel(const T* __restrict__ counts, u64 m, u64* __restrict__ offs) {
     __shared__ u64 wsum[16];
     __shared__ u64 carry_s;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict
     __syncthreads();
     for (u64 b0 = 0; b0 < m; b0 += 1024) {
         u64 i = b0 + tid;
-        u64 v = i < m ? counts[i] : 0;
+        u64 v = i < m ? (u64)counts[i] : 0;
         u64 incl = v;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { u64 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
@@ -498,6 +499,40 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const u32* __restrict
         __syncthreads();
     }
     if (tid == 0) offs[m] = carry_s;
+}
+// long arrays: every workgroup sums SCAN_CHUNK counts, one workgroup scans those sums, every workgroup scans its chunk
+// again from its sum's offset (one workgroup walking 600 k counts alone took 2 ms, as long as a pass over 10 GB)
+constexpr u32 SCAN_CHUNK = 4096;
+__global__ __launch_bounds__(1024) void scan_chunk_sums_kernel(const u32* __restrict__ counts, u64 m, u64* __restrict__ sums) {
+    __shared__ u64 wsum[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = (u64)blockIdx.x * SCAN_CHUNK;
+    u64 v = 0;
+    for (u32 j = tid; j < SCAN_CHUNK; j += 1024) if (base + j < m) v += counts[base + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    if (tid == 0) { u64 t = 0; for (int w = 0; w < 16; ++w) t += wsum[w]; sums[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void scan_chunks_kernel(const u32* __restrict__ counts, u64 m, const u64* __restrict__ chunk_offs,
+                                                           u64* __restrict__ offs) {
+    __shared__ u64 wsum[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 base = (u64)blockIdx.x * SCAN_CHUNK + (u64)tid * (SCAN_CHUNK / 1024);       // 4 consecutive counts per thread
+    u64 c[SCAN_CHUNK / 1024], mine = 0;
+#pragma unroll
+    for (u32 j = 0; j < SCAN_CHUNK / 1024; ++j) { c[j] = base + j < m ? (u64)counts[base + j] : 0; mine += c[j]; }
+    u64 incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { u64 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    u64 run = chunk_offs[blockIdx.x] + incl - mine;
+    for (int w = 0; w < 16; ++w) if (w < (int)wave) run += wsum[w];
+#pragma unroll
+    for (u32 j = 0; j < SCAN_CHUNK / 1024; ++j) { if (base + j < m) offs[base + j] = run; run += c[j]; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 1023) offs[m] = chunk_offs[gridDim.x];
 }
 
 template <int NW>
@@ -515,7 +550,16 @@ __global__ __launch_bounds__(BLOCK) void uniq_write_kernel(const u64* __restrict
 }
 
 int dev_scan_counts(const uint32_t* d_counts, uint64_t m, uint64_t* d_offs, hipStream_t stream) {
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, d_counts, m, d_offs);
+    if (m <= 16 * SCAN_CHUNK) {
+        hipLaunchKernelGGL(scan_counts_kernel<u32>, dim3(1), dim3(1024), 0, stream, d_counts, m, d_offs);
+    } else {
+        const u64 chunks = (m + SCAN_CHUNK - 1) / SCAN_CHUNK;
+        DevBuf sums(stream), chunk_offs(stream);
+        KCHECK(sums.alloc(chunks * 8 + 16)); KCHECK(chunk_offs.alloc((chunks + 1) * 8 + 16));
+        hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3((unsigned)chunks), dim3(1024), 0, stream, d_counts, m, sums.as<u64>());
+        hipLaunchKernelGGL(scan_counts_kernel<u64>, dim3(1), dim3(1024), 0, stream, sums.as<u64>(), chunks, chunk_offs.as<u64>());
+        hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)chunks), dim3(1024), 0, stream, d_counts, m, chunk_offs.as<u64>(), d_offs);
+    }
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }

@@ -334,6 +334,14 @@ def replay_node_removals(die, n_nodes, device=0):
     return to[:moves], frm[:moves], left, bool(gave_up)
 
 
+def scan_counts(counts, device=0):
+    """exclusive prefix sums (int64, one more entry than counts: the total) of int32/uint32 counts on the device"""
+    m = counts.numel()
+    offs = torch.empty(m + 1, dtype=torch.int64, device=counts.device)
+    _check(_lib.lib().katome_dev_scan_counts(device, _ptr(counts), m, _ptr(offs), _stream()))
+    return offs
+
+
 def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
     ns, nq = sorted_keys.numel() // key_words, queries.numel() // key_words
     out = torch.empty(max(nq, 1), dtype=torch.int64, device=queries.device)

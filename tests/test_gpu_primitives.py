@@ -263,3 +263,21 @@ def test_sort_by_top_bits_and_tie_fix(nw, bits, shape):
     order = _lexsort(a)                       # numpy's lexsort is stable: the expected permutation exactly
     assert np.array_equal(gv, order.astype(np.int32))
     assert np.array_equal(got, a[order])
+
+
+@pytest.mark.parametrize("m", [0, 1, 1000, 1024, 65536, 65537, 300001, (1 << 20) + 17])
+def test_scan_counts(m):
+    """dev_scan_counts: one workgroup for short arrays, chunk sums + chunk scans for long ones"""
+    from katome_amd import device as kd
+    rng = np.random.default_rng(m)
+    counts = rng.integers(0, 5000, m).astype(np.int64)
+    if m > 10:
+        counts[rng.integers(0, m, 5)] = 0xFFFFFFF0            # sums pass 2^32
+    d = torch.from_numpy(counts).to(torch.int32 if m == 0 else torch.int64).cuda()
+    d = (d & 0xFFFFFFFF).to(torch.int64)
+    d32 = torch.empty(m, dtype=torch.int32, device="cuda")
+    if m:
+        d32.copy_(torch.where(d >= (1 << 31), d - (1 << 32), d).to(torch.int32))
+    offs = kd.scan_counts(d32).cpu().numpy()
+    want = np.concatenate([[0], np.cumsum(counts.astype(np.uint64))]).astype(np.uint64)
+    assert (offs.view(np.uint64) == want).all()
