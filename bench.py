@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument("--first-seen-order", action="store_true",
                     help="number edges and nodes in the reference's first-seen (petgraph) order (single GPU)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
+    ap.add_argument("--min-weight", type=int, default=0,
+                    help="Clean::remove_weak_edges(threshold) as the edges are read out (pruner.rs:84-93; not the BASELINE metric's configuration)")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--next-stages-reads", type=int, default=20_000_000,
                     help="also time first-seen-order build + remove_dead_paths + shrink on this many reads (0 = skip; N = 1 only)")
@@ -85,13 +87,15 @@ class PhaseTimer:
         return out
 
 
-def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=False):
+def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=False, min_weight=0):
     """one step on one GPU; returns (n_edges, n_nodes)"""
     from katome_amd import device as kd
     hint = int(wl.expected_distinct_canonical() * 2.2)
     b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint,
                    first_seen_order=first_seen)
     b.profile(True)
+    if min_weight:
+        b.remove_weak_edges(min_weight)
     span, tiles, rest = b.tile_plan(wl.read_len)
     try:
         for r0 in range(0, wl.reads, batch_reads):
@@ -228,10 +232,10 @@ def main():
                              device=packed.device)
 
         def step():
-            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer, args.first_seen_order)
+            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer, args.first_seen_order, args.min_weight)
     else:
         from katome_amd import dist as kdist
-        job = kdist.DistBuild(wl, batch_reads=batch_reads, timer=timer)
+        job = kdist.DistBuild(wl, batch_reads=batch_reads, timer=timer, min_weight=args.min_weight)
         accepted = job.accepted_total
 
         def step():
@@ -352,6 +356,7 @@ def main():
                                       wl.err_rate),
                        "reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads,
                        "tile_span": span, "order": "first-seen (petgraph)" if args.first_seen_order else "by packed key",
+                       "min_weight": args.min_weight,
                        "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),

@@ -30,13 +30,18 @@ import torch.distributed as dist
 class HipOps:
     """device primitives of libkatome_gpu.so (katome_amd/device.py)"""
 
-    def __init__(self, k, rc, device, table_slots_hint=0):
+    def __init__(self, k, rc, device, table_slots_hint=0, min_weight=0):
+        """min_weight: Clean::remove_weak_edges (pruner.rs:84-93) when the edges are read out -- every k-mer's weight is
+        complete at its owner by then; nodes left without edges never get an id (finalize_distributed numbers the
+        endpoints of the edges that stay)"""
         from . import device as kd
         self.kd = kd
         self.k, self.rc = k, rc
         self.nw = kd.record_words(k)
         self.dev = device
         self.b = kd.Builder(k, rc, device=device, table_slots_hint=table_slots_hint)
+        if min_weight:
+            self.b.remove_weak_edges(min_weight)
         self.tdev = self.b.tdev
 
     def extract_fixed(self, packed, n_reads, read_len, skip, out, first_read):
@@ -445,8 +450,9 @@ def shard_range(total_reads, world, rank):
 class DistBuild:
     """bench.py's N>1 job: the synthetic workload sharded over the ranks, resident in HBM"""
 
-    def __init__(self, wl, batch_reads, timer=None, group=None):
+    def __init__(self, wl, batch_reads, timer=None, group=None, min_weight=0):
         from . import device as kd
+        self.min_weight = min_weight
         # tile records are small (8-16 tiles of 16 B per read): larger batches mean fewer exchange rounds
         self.wl, self.batch_reads, self.timer, self.group = wl, max(batch_reads, 16 * 1024 * 1024), timer, group
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
@@ -464,7 +470,7 @@ class DistBuild:
     def build(self):
         wl = self.wl
         hint = int(wl.expected_distinct_canonical() * 2.2 / self.world * 1.1)
-        ops = HipOps(wl.k, wl.reverse_complement, self.dev, table_slots_hint=hint)
+        ops = HipOps(wl.k, wl.reverse_complement, self.dev, table_slots_hint=hint, min_weight=self.min_weight)
         ops.b.profile(self.timer is not None)
         phases = _Phases(self.timer is not None)
         try:

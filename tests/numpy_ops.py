@@ -19,8 +19,8 @@ def _rc(v, k):
 
 
 class NumpyOps:
-    def __init__(self, k, rc):
-        self.k, self.rc = k, rc
+    def __init__(self, k, rc, min_weight=0):
+        self.k, self.rc, self.min_weight = k, rc, min_weight
         self.nw = 1 if 2 * k <= 62 else 2
         self.table = {}
         self.tiles = {}
@@ -169,7 +169,7 @@ class NumpyOps:
                     out[r] = c
             else:
                 out[v] = c
-        keys = sorted(out)
+        keys = sorted(v for v in out if out[v] >= self.min_weight)      # Clean::remove_weak_edges (pruner.rs:84-93)
         return (self._to_tensor(keys).reshape(-1, self.nw),
                 torch.tensor([out[v] for v in keys], dtype=torch.int64).to(torch.int32))
 

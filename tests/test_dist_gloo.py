@@ -24,7 +24,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
+def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir, min_weight=0):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, HERE)
     from helpers import pack_reads_ascii, words_to_int
@@ -41,7 +41,7 @@ def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
         # every rank packs only its own shard
         packed = torch.from_numpy(pack_reads_ascii(clean[r0:r1]).reshape(-1).copy()) if r1 > r0 else torch.zeros(0, dtype=torch.uint8)
         skip = torch.from_numpy(has_n[r0:r1].astype(np.uint8))
-        ops = NumpyOps(k, rc)
+        ops = NumpyOps(k, rc, min_weight)
         kdist.build_shard(ops, packed, skip, r1 - r0, read_len, batch_reads)
         g = kdist.finalize_distributed(ops)
         nw = ops.nw
@@ -92,6 +92,31 @@ def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads
     assert (total_nodes, total_edges) == (ref.n_nodes, ref.n_edges)
     assert sorted(node_of_id) == list(range(ref.n_nodes))       # dense global numbering
     assert len(set(node_of_id.values())) == ref.n_nodes
+
+
+@pytest.mark.parametrize("world,k,rc,threshold", [(2, 11, True, 2), (3, 12, False, 3)])
+def test_distributed_build_with_weak_edges_removed(oracle, tmp_path, world, k, rc, threshold):
+    """Clean::remove_weak_edges (pruner.rs:84-93) on the sharded build: the weights are complete at the k-mers' owners, the
+    edges under the threshold are never read out and the nodes they leave alone never get an id -- same edge multiset and
+    node count as the oracle's build + remove_weak_edges"""
+    n_reads, read_len = 220, 50
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, k, rc, n_reads, read_len, 64, str(tmp_path), threshold), nprocs=world, join=True)
+    ref = oracle.build_ascii(oracle.synth_reads(0, n_reads, read_len, 3000, 2e-2, 4), k, rc, remove_weak_edges=threshold)
+    from helpers import int_to_kmer
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r), allow_pickle=True) for r in range(world)]
+    merged, nodes = {}, set()
+    mask = (1 << (2 * (k - 1))) - 1
+    for p in parts:
+        node_of = {int(p["node_base"]) + i: int(key) for i, key in enumerate(p["node_key"])}
+        nodes.update(node_of.values())
+        for key, w in zip(p["edge_key"], p["weight"]):
+            assert int(key) not in merged and int(np.uint32(w)) >= threshold
+            merged[int(key)] = int(np.uint32(w))
+        assert (int(p["total_nodes"]), int(p["total_edges"])) == (ref.n_nodes, ref.n_edges)
+    assert sorted((int_to_kmer(v, k), w) for v, w in merged.items()) == ref.multiset()
+    assert nodes == {v >> 2 for v in merged} | {v & mask for v in merged} and len(nodes) == ref.n_nodes
+    assert 0 < ref.n_edges < oracle.build_ascii(oracle.synth_reads(0, n_reads, read_len, 3000, 2e-2, 4), k, rc).n_edges
 
 
 def _exchange_worker(rank, world, port, out_dir):

@@ -305,6 +305,16 @@ def test_dist_path_on_one_gpu(oracle):
             g = kdist.finalize_distributed(ops)
             ref = oracle.build_ascii(ascii_reads, k, rc)
             assert (g.total_nodes, g.total_edges, g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges, ref.n_nodes, ref.n_edges)
+            if k == 31:                                   # the same with Clean::remove_weak_edges(2) at the owners (pruner.rs:84-93)
+                weak = kdist.HipOps(k, rc, 0, min_weight=2)
+                kdist.build_shard(weak, packed, skip, n, L, 1024)
+                gw = kdist.finalize_distributed(weak)
+                refw = oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=2)
+                assert (gw.total_nodes, gw.total_edges) == (refw.n_nodes, refw.n_edges) and 0 < refw.n_edges < ref.n_edges
+                wk = gw.edge_key.cpu().numpy().view(np.uint64).reshape(-1)
+                assert dict(zip((int(x) for x in wk), gw.edge_weight.cpu().numpy().view(np.uint32).tolist())) == \
+                    {kmer_to_int(s): c for s, c in refw.multiset()}
+                weak.close()
             nw = ops.nw
             ek = g.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
             keys = [int(r[0]) if nw == 1 else (int(r[0]) << 64) | int(r[1]) for r in ek]
