@@ -283,6 +283,92 @@ def test_properties_at_scale():
     b.close(); b2.close()
 
 
+def _chunked_all(fn, n, step=1 << 26):
+    return all(bool(fn(i, min(n, i + step))) for i in range(0, n, step))
+
+
+def test_properties_at_full_c3_size():
+    """BASELINE configs[2] in full (200 M reads x 150 bp, k=31, both strands; the configuration `bench.py` times), through
+    the route the bench takes (tiles of 30 windows, two expansion levels): invariants that do not need the oracle --
+    every window counted on both strands, ascending distinct k-mers, endpoints = the k-mer's two (k-1)-mers, dense node
+    ids, strand symmetry of the weights (sampled)"""
+    from katome_amd import device as kd
+    from katome_amd.workloads import WORKLOADS
+    wl = WORKLOADS["c3"]
+    free_b, _total = torch.cuda.mem_get_info()
+    if free_b < 200 * (1 << 30):
+        pytest.skip("needs a whole MI355X (200 GiB free)")
+    packed, _skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, 0)
+    b = kd.Builder(wl.k, True, table_slots_hint=int(wl.expected_distinct_canonical() * 2.2))
+    try:
+        step = 4 << 20
+        for r0 in range(0, wl.reads, step):
+            b.count_reads(packed, min(step, wl.reads - r0), wl.read_len, None, first_read=r0)
+        dg = b.finalize()
+        E, N, k = dg.n_edges, dg.n_nodes, wl.k
+        assert 1_500_000_000 < E < 1_700_000_000 and N < E
+        total = 0
+        for i in range(0, E, 1 << 27):
+            total += int(dg.edge_weight[i:i + (1 << 27)].to(torch.int64).sum().item())
+        assert total == 2 * wl.reads * wl.windows_per_read              # k odd: no k-mer is its own reverse complement
+        keys, nodes = dg.edge_key[:, 0], dg.node_key[:, 0]
+        assert _chunked_all(lambda a, z: (keys[a + 1:z + 1] > keys[a:min(z, E - 1)]).all(), E - 1)
+        mask = (1 << (2 * (k - 1))) - 1
+        assert _chunked_all(lambda a, z: (nodes[dg.edge_src[a:z]] == (keys[a:z] >> 2)).all(), E)
+        assert _chunked_all(lambda a, z: (nodes[dg.edge_dst[a:z]] == (keys[a:z] & mask)).all(), E)
+        n_src = int(dg.edge_src[-1].item()) + 1                           # sources are numbered along the sorted edges
+        assert _chunked_all(lambda a, z: (nodes[a + 1:min(z + 1, n_src)] > nodes[a:min(z, n_src - 1)]).all(), n_src - 1)
+        assert bool((nodes[n_src + 1:] > nodes[n_src:-1]).all())         # then the nodes without out-edges, ascending
+        sample = torch.randint(0, E, (1 << 22,), device=keys.device)
+        x = keys[sample]
+        y = torch.zeros_like(x)
+        for i in range(k):
+            y |= (3 - ((x >> (2 * i)) & 3)) << (2 * (k - 1 - i))
+        r = kd.rank_in_sorted(dg.edge_key.reshape(-1), y.contiguous(), 2 * k, 1)
+        assert bool((r >= 0).all()) and bool((dg.edge_weight[r] == dg.edge_weight[sample]).all())
+    finally:
+        b.close()
+        kd.release_cache()
+
+
+def test_pruning_properties_at_scale():
+    """20 M reads of C3 (161 M edges) in the reference's numbering, then remove_dead_paths: what does not need the oracle --
+    the arrays stay one graph (endpoints = the k-mer's (k-1)-mers, ages distinct), nothing is invented (weights and k-mers
+    come from the build), and the result is a fixpoint (a second call removes nothing, in one pass)"""
+    from katome_amd import device as kd
+    from katome_amd.workloads import WORKLOADS
+    wl = WORKLOADS["c3"].scaled(20_000_000)
+    packed, _skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, 0)
+    b = kd.Builder(wl.k, True, first_seen_order=True, table_slots_hint=int(wl.expected_distinct_canonical() * 2.2))
+    try:
+        step = 4 << 20
+        for r0 in range(0, wl.reads, step):
+            b.count_reads(packed, min(step, wl.reads - r0), wl.read_len, None, first_read=r0)
+        dg = b.finalize()
+        E0, N0 = dg.n_edges, dg.n_nodes
+        built = torch.sort(dg.edge_key[:, 0].clone()).values
+        weight_of = dg.edge_weight.clone()
+        dg, st = b.remove_dead_paths()
+        E, N, k = dg.n_edges, dg.n_nodes, wl.k
+        assert st["removed_edges"] == E0 - E and st["removed_nodes"] == N0 - N and 0 < E < E0 and st["host_ms"] == 0.0
+        keys, nodes = dg.edge_key[:, 0], dg.node_key[:, 0]
+        assert bool((nodes[dg.edge_src] == (keys >> 2)).all()) and bool((nodes[dg.edge_dst] == (keys & ((1 << (2 * (k - 1))) - 1))).all())
+        assert int(torch.unique(nodes).numel()) == N and int(torch.unique(keys).numel()) == E
+        age = dg.edge_age.to(torch.int64)
+        assert int(torch.unique(age).numel()) == E and int(age.max().item()) < E0
+        assert bool((weight_of[age] == dg.edge_weight).all())            # an edge keeps its weight; its age is its old index
+        pos = torch.searchsorted(built, keys)
+        assert bool((built[pos.clamp(max=E0 - 1)] == keys).all())
+        touched = torch.zeros(N, dtype=torch.bool, device=keys.device)
+        touched[dg.edge_src] = True; touched[dg.edge_dst] = True
+        assert bool(touched.all())                                       # no node without an edge is left behind
+        dg2, st2 = b.remove_dead_paths()
+        assert (dg2.n_edges, dg2.n_nodes, st2["passes"], st2["removed_edges"]) == (E, N, 1, 0)
+    finally:
+        b.close()
+        kd.release_cache()
+
+
 def test_dist_path_on_one_gpu(oracle):
     """katome_amd/dist.py with the HIP ops (RCCL backend, world size 1 on this box): same graph as the oracle"""
     import socket
