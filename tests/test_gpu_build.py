@@ -331,6 +331,45 @@ def test_properties_at_full_c3_size():
         kd.release_cache()
 
 
+def test_properties_at_c5_share_size():
+    """100 M reads of BASELINE configs[4] (k=63, 128-bit keys; three-word tiles of 90 bases + left-over windows): the same
+    invariants on two-word keys"""
+    from katome_amd import device as kd
+    from katome_amd.workloads import WORKLOADS
+    wl = WORKLOADS["c5"].scaled(100_000_000)
+    free_b, _total = torch.cuda.mem_get_info()
+    if free_b < 200 * (1 << 30):
+        pytest.skip("needs a whole MI355X (200 GiB free)")
+    packed, _skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, 0)
+    b = kd.Builder(wl.k, True, table_slots_hint=int(wl.expected_distinct_canonical() * 2.2))
+    try:
+        span, tiles, rest = b.tile_plan(wl.read_len)
+        assert (span, tiles, rest) == (28, 3, 4) and b.tile_words(span) == 3
+        step = 4 << 20
+        for r0 in range(0, wl.reads, step):
+            b.count_reads(packed, min(step, wl.reads - r0), wl.read_len, None, first_read=r0)
+        dg = b.finalize()
+        E, N, k = dg.n_edges, dg.n_nodes, wl.k
+        assert E > wl.genome_len and N < E
+        assert int(dg.edge_weight.to(torch.int64).sum().item()) == 2 * wl.reads * wl.windows_per_read
+        SIGN = -(1 << 63)
+
+        def less(ah, al, bh, bl):                       # unsigned 128-bit a < b on (hi, lo) int64 pairs
+            return (ah < bh) | ((ah == bh) & ((al ^ SIGN) < (bl ^ SIGN)))    # (hi < 2^62: signed compare is right)
+        kh, kl = dg.edge_key[:, 0], dg.edge_key[:, 1]
+        nh, nl = dg.node_key[:, 0], dg.node_key[:, 1]
+        assert bool(less(kh[:-1], kl[:-1], kh[1:], kl[1:]).all())
+        src_h, src_l = kh >> 2, ((kl >> 2) & ((1 << 62) - 1)) | (kh << 62)
+        assert bool((nh[dg.edge_src] == src_h).all()) and bool((nl[dg.edge_src] == src_l).all())
+        assert bool((nh[dg.edge_dst] == (kh & ((1 << (2 * (k - 1) - 64)) - 1))).all()) and bool((nl[dg.edge_dst] == kl).all())
+        n_src = int(dg.edge_src[-1].item()) + 1
+        assert bool(less(nh[:n_src - 1], nl[:n_src - 1], nh[1:n_src], nl[1:n_src]).all())
+        assert bool(less(nh[n_src:-1], nl[n_src:-1], nh[n_src + 1:], nl[n_src + 1:]).all())
+    finally:
+        b.close()
+        kd.release_cache()
+
+
 def test_pruning_properties_at_scale():
     """20 M reads of C3 (161 M edges) in the reference's numbering, then remove_dead_paths: what does not need the oracle --
     the arrays stay one graph (endpoints = the k-mer's (k-1)-mers, ages distinct), nothing is invented (weights and k-mers
