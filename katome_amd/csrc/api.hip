@@ -8,7 +8,10 @@
 #include <algorithm>
 #include <chrono>
 #include <new>
+#include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "common.h"
 
@@ -915,8 +918,41 @@ void katome_contigs_free(katome_contigs* c) {
 
 }  // extern "C"
 
+// KATOME_TRACE_BUILD=1: wall time of the host entries' stages on stderr
+static void build_lap(const char* what, bool reset = false) {
+    static const bool on = getenv("KATOME_TRACE_BUILD") != nullptr;
+    static std::chrono::steady_clock::time_point last;
+    if (!on) return;
+    const auto now = std::chrono::steady_clock::now();
+    if (!reset) fprintf(stderr, "[build] %-28s %9.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+    last = now;
+}
+
+// Host memory for a result array.  A device -> host copy into pages the process has never touched runs at the rate one
+// thread takes page faults (~9 GB/s measured on the MI355X box; into touched pages, pinned or not, the same copy runs at
+// ~55 GB/s), so large arrays are taken 2 MiB-aligned, offered to the kernel as huge pages and first touched by several
+// threads at once.  Released with free().
+static void* host_result_alloc(size_t bytes) {
+    const size_t big = (size_t)64 << 20, huge = (size_t)2 << 20;
+    if (bytes < big) return malloc(std::max<size_t>(bytes, 1));
+    void* p = nullptr;
+    if (posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) != 0) return nullptr;
+    (void)madvise(p, bytes, MADV_HUGEPAGE);
+    unsigned T = std::thread::hardware_concurrency();
+    T = std::max(1u, std::min(T ? T : 4u, 16u));
+    const size_t pages = (bytes + 4095) / 4096, per = (pages + T - 1) / T;
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; ++t)
+        th.emplace_back([=]() {
+            volatile char* c = static_cast<volatile char*>(p);
+            for (size_t pg = t * per; pg < std::min(pages, (t + 1) * per); ++pg) c[pg * 4096] = 0;
+        });
+    for (auto& x : th) x.join();
+    return p;
+}
+
 template <class T, class Owner> static int d2h(Owner* o, const T** dst, const void* d_src, size_t count) {
-    T* h = (T*)malloc(std::max<size_t>(count, 1) * sizeof(T));
+    T* h = (T*)host_result_alloc(std::max<size_t>(count, 1) * sizeof(T));
     if (!h) { set_error("out of host memory"); return KATOME_E_OOM; }
     o->mem.push_back(h);
     if (count) KCHECK_HIP(hipMemcpy(h, d_src, count * sizeof(T), hipMemcpyDeviceToHost));
@@ -943,10 +979,13 @@ static int run_stages(katome_builder* b, const char* stages, uint64_t genome_len
 static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** out, const char* stages = nullptr, uint64_t genome_len = 0) {
     katome_dev_graph dg;
     if (stages && *stages && !b->first_seen) { set_error("stages after the build need KATOME_FLAG_FIRST_SEEN_ORDER"); return KATOME_E_ARG; }
+    build_lap("counting (H2D, kernels)");
     KCHECK(katome_dev_finalize(b, &dg, nullptr));
+    build_lap("finalize");
     if (b->s.flags & KATOME_FLAG_REMOVE_DEAD_PATHS) KCHECK(katome_dev_remove_dead_paths(b, &dg, nullptr, nullptr));
     KCHECK(run_stages(b, stages, genome_len));
     KCHECK(katome_dev_current_graph(b, &dg));
+    build_lap("stages after the build");
     GraphOwner* o = new (std::nothrow) GraphOwner();
     if (!o) { set_error("out of host memory"); return KATOME_E_OOM; }
     memset(&o->g, 0, sizeof o->g);
@@ -963,6 +1002,7 @@ static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** 
         katome_graph_free(g);
         return rc;
     }
+    build_lap("graph to host arrays");
     *out = g;
     return KATOME_OK;
 }
@@ -1118,7 +1158,9 @@ void katome_reads_free(katome_reads* r) {
 static int build_files_impl(const katome_settings* s, const char* const* paths, size_t n_paths, const Finish& finish) {
     if (!s || (!paths && n_paths)) { set_error("null argument"); return KATOME_E_ARG; }
     HostReads hr;
+    build_lap("", true);
     KCHECK(ingest_files(s, paths, n_paths, hr));           // path / parse / short-read errors surface before any GPU work
+    build_lap("ingest (host)");
     if (s->file_type == 2) {
         // BFCounter (create_bfc, builder.rs:79-115; add_read_bfc, pt_graph.rs:317-330): every kept line is a k-mer
         // with a weight -> one record per line (read length == k), added with its weight.  Lines naming the same
