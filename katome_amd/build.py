@@ -133,13 +133,26 @@ def _paths(paths):
 class GpuGraph:
     """The collection the GPU build produces: what `Convert<GpuGIR> for PtGraph` consumes.
 
-    Arrays (numpy, copied out of the C result): edge_src/edge_dst (dense node ids), edge_weight (u32),
-    edge_label ([n_edges, 1+ceil(k/4)] compress_edge format), edge_key / node_key (packed k-mers /
+    Arrays (numpy views of the C result, which lives as long as any of them does): edge_src/edge_dst (dense node ids),
+    edge_weight (u32), edge_label ([n_edges, 1+ceil(k/4)] compress_edge format), edge_key / node_key (packed k-mers /
     (k-1)-mers, [n, key_words] u64, most significant word first).
     """
 
+    class _Owner:
+        """frees the katome_graph when the last array that views it is gone"""
+
+        def __init__(self, gptr):
+            self.gptr = gptr
+
+        def __del__(self):
+            try:
+                _lib.lib().katome_graph_free(self.gptr)
+            except Exception:       # interpreter shutdown
+                pass
+
     def __init__(self, gptr):
         g = gptr.contents
+        owner = GpuGraph._Owner(gptr)
         ne, nn, nw = g.n_edges, g.n_nodes, g.key_words
         self.k = g.k
         self.n_nodes, self.n_edges, self.read_bytes = nn, ne, g.read_bytes
@@ -149,7 +162,9 @@ class GpuGraph:
             n = int(np.prod(shape))
             if n == 0:
                 return np.zeros(shape, dtype)
-            return np.ctypeslib.as_array(ptr, (n,)).reshape(shape).copy()
+            buf = (C.c_char * (n * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents))
+            buf._owner = owner                      # numpy keeps `buf` as the arrays' base, `buf` keeps the C result
+            return np.frombuffer(buf, dtype=dtype).reshape(shape)
 
         self.edge_src = arr(g.edge_src, (ne,), np.uint64)
         self.edge_dst = arr(g.edge_dst, (ne,), np.uint64)
@@ -186,10 +201,7 @@ class GpuGraph:
                                                         original_genome_length, C.byref(gp)))
         else:
             _check(_lib.lib().katome_build_files(C.byref(s), _paths(input_files), len(input_files), C.byref(gp)))
-        try:
-            g = cls(gp)
-        finally:
-            _lib.lib().katome_graph_free(gp)
+        g = cls(gp)                                   # the arrays view the C result and free it with their last reference
         return g, g.read_bytes
 
     @classmethod
@@ -205,10 +217,7 @@ class GpuGraph:
             skip_p = skip.ctypes.data
         gp = C.POINTER(_lib.Graph)()
         _check(_lib.lib().katome_build_packed(C.byref(s), packed.ctypes.data, n_reads, read_len, skip_p, C.byref(gp)))
-        try:
-            g = cls(gp)
-        finally:
-            _lib.lib().katome_graph_free(gp)
+        g = cls(gp)
         return g, g.read_bytes
 
     # ---- Stats<CollectionStats> (stats/collections.rs:137-168) ---------------------------------
