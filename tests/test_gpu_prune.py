@@ -66,10 +66,16 @@ def _random_reads(seed, n_reads, read_len, genome_len, err):
     return reads
 
 
+@pytest.mark.parametrize("host_replays", [False, True])
 @pytest.mark.parametrize("seed", range(24))
-def test_random_graphs_against_oracle(oracle, seed):
-    """small k and noisy reads: branching, cycles, self-loops, merging tips (duplicate indices), several passes"""
+def test_random_graphs_against_oracle(oracle, monkeypatch, seed, host_replays):
+    """small k and noisy reads: branching, cycles, self-loops, merging tips (duplicate indices), several passes.
+    host_replays: the sequential statement of the two index replays (prune_replay.h) instead of their device forms --
+    the route a pass takes when its node moves chain further than the device form follows"""
     from katome_amd import device as kd
+    if host_replays:
+        monkeypatch.setenv("KATOME_PRUNE_HOST_EDGES", "1")
+        monkeypatch.setenv("KATOME_PRUNE_HOST_NODES", "1")
     k = [4, 5, 6, 8, 11, 17][seed % 6]
     L = k + 3 + seed % 7
     reads = _random_reads(seed, 30 + 40 * seed, L, 60 + 50 * seed, 0.04)
@@ -93,6 +99,7 @@ def test_random_graphs_against_oracle(oracle, seed):
         assert np.array_equal(dg.edge_dst.cpu().numpy().view(np.uint64), ref.edge_dst)
         assert st["removed_edges"] == ref0.n_edges - ref.n_edges and st["removed_nodes"] == ref0.n_nodes - ref.n_nodes
         assert st["passes"] >= 1 and st["marked"] >= st["removed_edges"] - st["removed_by_duplicates"]
+        assert (st["host_ms"] > 0) == (host_replays and st["removed_edges"] > 0)
         b.close()
 
 
