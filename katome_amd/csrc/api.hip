@@ -198,7 +198,7 @@ static int extract_var_common(katome_builder* b, const uint8_t* d_packed, uint64
                               const uint32_t* d_len, const uint64_t* d_rec_prefix, const uint64_t* d_win_prefix, uint64_t n_reads,
                               uint64_t n_records, uint64_t total_windows, uint32_t span, uint32_t mode, uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
-    if (mode == 1 && (span < 2 || b->s.k + span - 1 > 63)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    if (mode == 1 && (span < 2 || b->s.k + span - 1 > 95)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
     if (b->first_seen) {
         if (b->reads_inserted) { set_error("first-seen order: fixed- and variable-length batches cannot be mixed in one build"); return KATOME_E_UNSUPPORTED; }
         // the insert that follows reads these
@@ -437,7 +437,7 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
     if (span < 2 || b->s.k + span - 1 > 95 || (b->tiles_ready && span != b->span)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
-    if (b->first_seen && b->var_prefix && b->s.k + span - 1 > 63) { set_error("variable-length reads: tiles of at most 63 bases"); return KATOME_E_ARG; }
+    if (b->first_seen && b->var_prefix && b->s.k + span - 1 > 95) { set_error("variable-length reads: tiles of at most 95 bases"); return KATOME_E_ARG; }
     if (n_records == 0) return KATOME_OK;
     b->span = span;
     const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
@@ -1208,14 +1208,14 @@ static int build_files_impl(const katome_settings* s, const char* const* paths, 
                 hist[W] += 1;
             }
             uint64_t best = hr.total_windows;
-            for (uint32_t sp = 2; sp <= 33 && s->k + sp - 1 <= 63; ++sp) {
+            for (uint32_t sp = 2; sp <= 33 && s->k + sp - 1 <= 95; ++sp) {      // (the same charges as katome_tile_plan)
                 bool breakable = sp <= 16;
                 for (uint32_t d = 3; d <= 8 && !breakable; ++d) breakable = sp % d == 0;
                 uint64_t cost = 0;
-                for (size_t W = 1; W < hist.size(); ++W) cost += hist[W] * (W / sp + W % sp + (breakable ? 0 : 2));
+                for (size_t W = 1; W < hist.size(); ++W) cost += hist[W] * (W / sp + W % sp + (breakable ? 0 : 4));
                 if (cost < best || (cost == best && span > 1)) { best = cost; span = sp; }
             }
-            if (const char* e = getenv("KATOME_TILE_SPAN")) { const uint32_t sp = (uint32_t)atoi(e); if (sp >= 1 && s->k + sp - 1 <= 63) span = sp; }
+            if (const char* e = getenv("KATOME_TILE_SPAN")) { const uint32_t sp = (uint32_t)atoi(e); if (sp >= 1 && s->k + sp - 1 <= 95) span = sp; }
         }
         DevBuf d_tpref, d_rpref;
         std::vector<uint64_t> pref, tpref, rpref;

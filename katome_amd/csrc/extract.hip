@@ -237,9 +237,12 @@ int launch_extract_var(uint32_t k0, bool rc, const uint8_t* d_packed, uint64_t p
     if (nw == 1) {
         if (rc) hipLaunchKernelGGL((extract_general_kernel<1, true, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
         else    hipLaunchKernelGGL((extract_general_kernel<1, false, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
-    } else {
+    } else if (nw == 2) {
         if (rc) hipLaunchKernelGGL((extract_general_kernel<2, true, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
         else    hipLaunchKernelGGL((extract_general_kernel<2, false, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
+    } else {                      // tiles of 64..95 bases
+        if (rc) hipLaunchKernelGGL((extract_general_kernel<3, true, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
+        else    hipLaunchKernelGGL((extract_general_kernel<3, false, ArrayAddr>), grid, block, 0, stream, d_packed, packed_bytes, a, total_windows, k, d_records);
     }
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;

@@ -181,7 +181,8 @@ def _variable_length_fastq(path, seed, n_reads, k, genome_len=3000, err=0.01):
 
 
 @pytest.mark.parametrize("tiles", [True, False])
-@pytest.mark.parametrize("k,rc,n_reads", [(11, True, 900), (12, False, 700), (31, True, 1500), (40, True, 800), (5, True, 200)])
+@pytest.mark.parametrize("k,rc,n_reads", [(11, True, 900), (12, False, 700), (31, True, 1500), (40, True, 800), (5, True, 200),
+                                          (63, True, 400), (47, False, 500)])        # tiles of 64..95 bases (three words)
 def test_variable_length_reads_in_reference_order(oracle, tmp_path, monkeypatch, k, rc, n_reads, tiles):
     """first-seen numbering and remove_dead_paths for reads of unequal length (the general file route: one record
     per window, sequence numbers from the per-read window prefix), in one batch and in many"""
