@@ -64,7 +64,9 @@ def _worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir, m
                                                                 (2, 11, True, 130, 64, 53), (3, 11, False, 150, 40, 57),
                                                                 (2, 60, True, 60, 64, 75),
                                                                 (3, 11, True, 100, 40, 53),      # the third rank gets no reads at all
-                                                                (3, 12, False, 60, 64, 50)])     # two ranks without reads
+                                                                (3, 12, False, 60, 64, 50),      # two ranks without reads
+                                                                (8, 11, True, 700, 64, 50),      # the node's eight ranks
+                                                                (8, 33, False, 200, 1000, 50)])  # ... some of them idle
 def test_distributed_build_equals_oracle(oracle, tmp_path, world, k, rc, n_reads, batch, read_len):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, k, rc, n_reads, read_len, batch, str(tmp_path)), nprocs=world, join=True)
