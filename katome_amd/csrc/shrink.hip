@@ -39,31 +39,37 @@ __device__ __forceinline__ bool is_inner(u64 v, const u64* node_deg, const u32* 
     return node_deg[v] == ((1ull << 32) | 1ull) && in_edge[v] != out_edge[v];
 }
 
+// One word per node so that a step of a walk is one look-up: for an inner vertex (the vertex its out-edge leads to) << 32 |
+// that out-edge, NOT_INNER for every other vertex.
+constexpr u64 NOT_INNER = ~0ull;
+__global__ __launch_bounds__(BLOCK) void node_word_kernel(u64 N, const u64* __restrict__ node_deg, const u32* __restrict__ in_edge,
+                                                          const u32* __restrict__ out_edge, const u64* __restrict__ dst, u64* __restrict__ word) {
+    for (u64 v = (u64)blockIdx.x * BLOCK + threadIdx.x; v < N; v += (u64)gridDim.x * BLOCK) {
+        u64 w = NOT_INNER;
+        if (is_inner(v, node_deg, in_edge, out_edge)) { const u32 oe = out_edge[v]; w = (dst[oe] << 32) | oe; }
+        word[v] = w;
+    }
+}
+
 // flag[e] = 1 for head edges; every edge a head's walk passes gets covered[e] = 1
 __global__ __launch_bounds__(BLOCK) void head_walk_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, u64 E,
-                                                          const u64* __restrict__ node_deg, const u32* __restrict__ in_edge,
-                                                          const u32* __restrict__ out_edge, u32* __restrict__ flag, u32* __restrict__ covered) {
+                                                          const u64* __restrict__ word, u32* __restrict__ flag, u32* __restrict__ covered) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
-        const bool head = !is_inner(src[e], node_deg, in_edge, out_edge);
+        const bool head = word[src[e]] == NOT_INNER;
         flag[e] = head ? 1u : 0u;
         if (!head) continue;
         covered[e] = 1;
-        u64 cur = dst[e];
-        while (is_inner(cur, node_deg, in_edge, out_edge)) {
-            const u32 nx = out_edge[cur];
-            covered[nx] = 1;
-            cur = dst[nx];
-        }
+        for (u64 w = word[dst[e]]; w != NOT_INNER; w = word[w >> 32]) covered[(u32)w] = 1;
     }
 }
 // cycles of inner vertices: the edge leaving the cycle's smallest vertex becomes its head
 __global__ __launch_bounds__(BLOCK) void cycle_head_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, u64 E,
-                                                           const u32* __restrict__ out_edge, const u32* __restrict__ covered, u32* __restrict__ flag) {
+                                                           const u64* __restrict__ word, const u32* __restrict__ covered, u32* __restrict__ flag) {
     for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
         if (covered[e]) continue;
         const u64 start = src[e];
         bool smallest = true;
-        for (u64 cur = dst[e]; cur != start; cur = dst[out_edge[cur]]) if (cur < start) { smallest = false; break; }
+        for (u64 cur = dst[e]; cur != start; cur = word[cur] >> 32) if (cur < start) { smallest = false; break; }   // (all inner)
         if (smallest) flag[e] = 1;
     }
 }
@@ -107,8 +113,7 @@ __global__ __launch_bounds__(BLOCK) void flag_write_kernel(const u32* __restrict
 
 // per merged edge: number of k-mers on its path, its last vertex, the bytes its label takes
 __global__ __launch_bounds__(BLOCK) void path_measure_kernel(const u32* __restrict__ heads, u64 n_heads, const u64* __restrict__ src,
-                                                             const u64* __restrict__ dst, const u64* __restrict__ node_deg,
-                                                             const u32* __restrict__ in_edge, const u32* __restrict__ out_edge, u32 k,
+                                                             const u64* __restrict__ dst, const u64* __restrict__ word, u32 k,
                                                              u32* __restrict__ path_len, u32* __restrict__ label_bytes, u64* __restrict__ end_node,
                                                              u32* __restrict__ keep_node) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n_heads; i += (u64)gridDim.x * BLOCK) {
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(BLOCK) void path_measure_kernel(const u32* __restri
         const u64 start = src[h];
         u64 cur = dst[h];
         u32 m = 1;
-        while (cur != start && is_inner(cur, node_deg, in_edge, out_edge)) { cur = dst[out_edge[cur]]; ++m; }
+        while (cur != start) { const u64 w = word[cur]; if (w == NOT_INNER) break; cur = w >> 32; ++m; }
         path_len[i] = m;
         label_bytes[i] = 1 + (k + m - 1 + 3) / 4;
         end_node[i] = cur;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void path_measure_kernel(const u32* __restri
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void path_write_kernel(const u32* __restrict__ heads, u64 n_heads, const u64* __restrict__ src,
                                                            const u64* __restrict__ dst, const u32* __restrict__ weight, const u64* __restrict__ key,
-                                                           const u32* __restrict__ out_edge, const u32* __restrict__ path_len,
+                                                           const u64* __restrict__ word, const u32* __restrict__ path_len,
                                                            const u64* __restrict__ label_off, const u64* __restrict__ end_node,
                                                            const u32* __restrict__ new_id, u32 k, u64* __restrict__ o_src, u64* __restrict__ o_dst,
                                                            u32* __restrict__ o_weight, uint8_t* __restrict__ o_label) {
@@ -147,10 +152,10 @@ __global__ __launch_bounds__(BLOCK) void path_write_kernel(const u32* __restrict
         }
         u64 cur = dst[h];
         for (u32 s = 1; s < m; ++s) {                             // then the last base of every further edge
-            const u32 e = out_edge[cur];
-            acc = (acc << 2) | (u32)(key[(u64)e * NW + NW - 1] & 3);
+            const u64 w = word[cur];
+            acc = (acc << 2) | (u32)(key[(u64)(u32)w * NW + NW - 1] & 3);
             if (++have == 4) { *out++ = (uint8_t)acc; acc = 0; have = 0; }
-            cur = dst[e];
+            cur = w >> 32;
         }
         if (have) *out = (uint8_t)(acc << (2 * (4 - have)));     // left-aligned, zero padding in the low bits
     }
@@ -191,9 +196,13 @@ int dev_shrink(const ShrinkInput& g, ShrinkOutput& out, hipStream_t stream) {
     KCHECK_HIP(hipMemsetAsync(covered.p, 0, E * 4, stream));
     const dim3 ge(grid_for(E, BLOCK, 256u * 32u)), blk(BLOCK);
     hipLaunchKernelGGL(adjacency_kernel, ge, blk, 0, stream, g.edge_src, g.edge_dst, E, node_deg.as<u64>(), in_edge.as<u32>(), out_edge.as<u32>());
-    hipLaunchKernelGGL(head_walk_kernel, ge, blk, 0, stream, g.edge_src, g.edge_dst, E, node_deg.as<u64>(), in_edge.as<u32>(), out_edge.as<u32>(),
-                       flag.as<u32>(), covered.as<u32>());
-    hipLaunchKernelGGL(cycle_head_kernel, ge, blk, 0, stream, g.edge_src, g.edge_dst, E, out_edge.as<u32>(), covered.as<u32>(), flag.as<u32>());
+    DevBuf word(stream);
+    KCHECK(word.alloc((N + 1) * 8));
+    hipLaunchKernelGGL(node_word_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), blk, 0, stream, N, node_deg.as<u64>(), in_edge.as<u32>(),
+                       out_edge.as<u32>(), g.edge_dst, word.as<u64>());
+    node_deg.release(); in_edge.release(); out_edge.release();
+    hipLaunchKernelGGL(head_walk_kernel, ge, blk, 0, stream, g.edge_src, g.edge_dst, E, word.as<u64>(), flag.as<u32>(), covered.as<u32>());
+    hipLaunchKernelGGL(cycle_head_kernel, ge, blk, 0, stream, g.edge_src, g.edge_dst, E, word.as<u64>(), covered.as<u32>(), flag.as<u32>());
     KCHECK_HIP(hipGetLastError());
     u64 H = 0;
     KCHECK(compact(flag.as<u32>(), E, heads, nullptr, &H, stream));
@@ -204,7 +213,7 @@ int dev_shrink(const ShrinkInput& g, ShrinkOutput& out, hipStream_t stream) {
     KCHECK(keep.alloc((N + 1) * 4)); KCHECK(label_off.alloc((H + 2) * 8)); KCHECK(new_id.alloc((N + 1) * 4));
     KCHECK_HIP(hipMemsetAsync(keep.p, 0, N * 4, stream));
     hipLaunchKernelGGL(path_measure_kernel, dim3(grid_for(H, BLOCK, 256u * 32u)), blk, 0, stream, heads.as<u32>(), H, g.edge_src, g.edge_dst,
-                       node_deg.as<u64>(), in_edge.as<u32>(), out_edge.as<u32>(), k, path_len.as<u32>(), label_bytes.as<u32>(),
+                       word.as<u64>(), k, path_len.as<u32>(), label_bytes.as<u32>(),
                        end_node.as<u64>(), keep.as<u32>());
     KCHECK_HIP(hipGetLastError());
     KCHECK(dev_scan_counts(label_bytes.as<u32>(), H, label_off.as<u64>(), stream));
@@ -217,11 +226,11 @@ int dev_shrink(const ShrinkInput& g, ShrinkOutput& out, hipStream_t stream) {
     KCHECK(out.node_key.alloc((NK + 1) * 8 * nw, stream));
     if (nw == 1)
         hipLaunchKernelGGL(path_write_kernel<1>, dim3(grid_for(H, BLOCK, 256u * 32u)), blk, 0, stream, heads.as<u32>(), H, g.edge_src, g.edge_dst,
-                           g.edge_weight, g.edge_key, out_edge.as<u32>(), path_len.as<u32>(), label_off.as<u64>(), end_node.as<u64>(),
+                           g.edge_weight, g.edge_key, word.as<u64>(), path_len.as<u32>(), label_off.as<u64>(), end_node.as<u64>(),
                            new_id.as<u32>(), k, out.edge_src.as<u64>(), out.edge_dst.as<u64>(), out.edge_weight.as<u32>(), out.edge_label.as<uint8_t>());
     else
         hipLaunchKernelGGL(path_write_kernel<2>, dim3(grid_for(H, BLOCK, 256u * 32u)), blk, 0, stream, heads.as<u32>(), H, g.edge_src, g.edge_dst,
-                           g.edge_weight, g.edge_key, out_edge.as<u32>(), path_len.as<u32>(), label_off.as<u64>(), end_node.as<u64>(),
+                           g.edge_weight, g.edge_key, word.as<u64>(), path_len.as<u32>(), label_off.as<u64>(), end_node.as<u64>(),
                            new_id.as<u32>(), k, out.edge_src.as<u64>(), out.edge_dst.as<u64>(), out.edge_weight.as<u32>(), out.edge_label.as<uint8_t>());
     if (NK) hipLaunchKernelGGL(gather_nodes_kernel, dim3(grid_for(NK, BLOCK, 256u * 32u)), blk, 0, stream, kept.as<u32>(), NK, g.node_key, nw,
                                out.node_key.as<u64>());
