@@ -81,7 +81,7 @@ inline int use_device(int device) {
 
 inline int check_k(uint32_t k) {
     if (k <= 1) { set_error("assertion failed: k_size > 1"); return KATOME_E_ARG; }   // prelude.rs:35
-    if (k < 3 || k > 63) { set_error("k = %u unsupported (3..63)", k); return KATOME_E_ARG; }
+    if (k < 3 || k > 63) { set_error("k = %u unsupported (3..63)", k); return KATOME_E_UNSUPPORTED; }   // valid for the reference, not here
     return KATOME_OK;
 }
 

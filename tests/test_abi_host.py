@@ -87,7 +87,7 @@ def test_error_statuses_mirror_reference_panics(golden_dir, tmp_path):
     trunc.write_text("@a\nACGT\n+\n")
     assert status([str(trunc)], k=3)[0] == "E_PARSE"
     assert status([os.path.join(golden_dir, "data1.txt")], k=1)[0] == "E_ARG"       # prelude.rs:35
-    assert status([os.path.join(golden_dir, "data1.txt")], k=64)[0] == "E_ARG"
+    assert status([os.path.join(golden_dir, "data1.txt")], k=64)[0] == "E_UNSUPPORTED"   # fine for the reference, two-word keys end at k = 63
     # errors are found in input order: the bad path wins over the good one before it (builder.rs:46)
     assert status([os.path.join(golden_dir, "data1.txt"), os.path.join(golden_dir, "nope")])[0] == "E_PATH"
 
