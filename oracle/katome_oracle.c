@@ -627,6 +627,7 @@ static int add_read_fastaq(builder_t *b, const uint8_t *read, size_t len, int re
     uint8_t kbuf[64];
     if (reverse_complement) {
         uint8_t *reversed = (uint8_t *)xrealloc(NULL, n_win * slot);
+        reversed[(n_win - 1) * slot] = 0;   /* (n_win >= 1: tells the compiler the last slot is written before it is read) */
         for (size_t cnt = 0; cnt < n_win; ++cnt) {
             ko_compress_kmer_with_rev_compl(read + cnt, K_SIZE, kbuf, reversed + cnt * slot);
             add_single_edge_fastaq(b, cnt == 0, kbuf, &s, &t);
@@ -741,6 +742,7 @@ static int gir_add_read_fastaq(gir_t *g, const uint8_t *read, size_t len, int re
     uint8_t kbuf[64];
     if (reverse_complement) {
         uint8_t *reversed = (uint8_t *)xrealloc(NULL, n_win * slot);
+        reversed[(n_win - 1) * slot] = 0;   /* (n_win >= 1: tells the compiler the last slot is written before it is read) */
         for (size_t cnt = 0; cnt < n_win; ++cnt) {
             ko_compress_kmer_with_rev_compl(read + cnt, K_SIZE, kbuf, reversed + cnt * slot);
             gir_add_single_edge(g, cnt == 0, kbuf, &s, &t, read[cnt + K_SIZE - 1]);
