@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     ap.add_argument("--min-weight", type=int, default=0,
                     help="Clean::remove_weak_edges(threshold) as the edges are read out (pruner.rs:84-93; not the BASELINE metric's configuration)")
+    ap.add_argument("--table-factor", type=float, default=2.2, help="k-mer table slots per expected distinct canonical k-mer")
     ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
     ap.add_argument("--next-stages-reads", type=int, default=20_000_000,
                     help="also time first-seen-order build + remove_dead_paths + shrink on this many reads (0 = skip; N = 1 only)")
@@ -87,10 +88,10 @@ class PhaseTimer:
         return out
 
 
-def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=False, min_weight=0):
+def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=False, min_weight=0, table_factor=2.2):
     """one step on one GPU; returns (n_edges, n_nodes)"""
     from katome_amd import device as kd
-    hint = int(wl.expected_distinct_canonical() * 2.2)
+    hint = int(wl.expected_distinct_canonical() * table_factor)
     b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint,
                    first_seen_order=first_seen)
     b.profile(True)
@@ -232,7 +233,7 @@ def main():
                              device=packed.device)
 
         def step():
-            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer, args.first_seen_order, args.min_weight)
+            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer, args.first_seen_order, args.min_weight, args.table_factor)
     else:
         from katome_amd import dist as kdist
         job = kdist.DistBuild(wl, batch_reads=batch_reads, timer=timer, min_weight=args.min_weight)
