@@ -30,26 +30,32 @@ __device__ __forceinline__ bool ambiguous(u64 deg) {
     const u32 in = (u32)deg, out = (u32)(deg >> 32);
     return in > 1 || out > 1 || (in == 0 && out >= 1);
 }
-__global__ __launch_bounds__(BLOCK) void contig_mean_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, u64 E,
-                                                            const u64* __restrict__ node_deg, const u32* __restrict__ out_edge,
-                                                            u32* __restrict__ weight) {
-    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
-        if (!ambiguous(node_deg[src[e]])) continue;           // contigs start at the out-edges of ambiguous vertices
-        u64 sum = weight[e], len = 1, cur = dst[e];
-        for (;;) {
-            const u64 deg = node_deg[cur];
-            if ((u32)(deg >> 32) != 1 || ambiguous(deg)) break;
-            const u32 nx = out_edge[cur];
-            sum += weight[nx]; ++len;
-            cur = dst[nx];
-        }
-        const u32 w = (u32)round((double)sum / (double)len);  // (sum as f64 / contig.len() as f64).round() as EdgeWeight
-        weight[e] = w;
-        cur = dst[e];
-        for (u64 i = 1; i < len; ++i) { const u32 nx = out_edge[cur]; weight[nx] = w; cur = dst[nx]; }
+// One word per vertex so that a step of a contig walk is one look-up: a vertex a contig runs through (exactly one out-edge,
+// not ambiguous) holds (the vertex that edge leads to) << 32 | that edge; an ambiguous vertex AMBIGUOUS; any other END.
+constexpr u64 AMBIGUOUS = ~0ull, END = ~0ull - 1;
+__global__ __launch_bounds__(BLOCK) void node_word_kernel(u64 N, const u64* __restrict__ node_deg, const u32* __restrict__ out_edge,
+                                                          const u64* __restrict__ dst, u64* __restrict__ word) {
+    for (u64 v = (u64)blockIdx.x * BLOCK + threadIdx.x; v < N; v += (u64)gridDim.x * BLOCK) {
+        const u64 deg = node_deg[v];
+        u64 w = END;
+        if (ambiguous(deg)) w = AMBIGUOUS;
+        else if ((u32)(deg >> 32) == 1) { const u32 oe = out_edge[v]; w = (dst[oe] << 32) | oe; }
+        word[v] = w;
     }
 }
-
+__global__ __launch_bounds__(BLOCK) void contig_mean_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, u64 E,
+                                                            const u64* __restrict__ word, u32* __restrict__ weight) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
+        if (word[src[e]] != AMBIGUOUS) continue;              // contigs start at the out-edges of ambiguous vertices
+        u64 sum = weight[e], len = 1;
+        const u64 first = word[dst[e]];
+        for (u64 w = first; w < END; w = word[w >> 32]) { sum += weight[(u32)w]; ++len; }
+        const u32 mean = (u32)round((double)sum / (double)len);  // (sum as f64 / contig.len() as f64).round() as EdgeWeight
+        weight[e] = mean;
+        u64 w = first;
+        for (u64 i = 1; i < len; ++i) { weight[(u32)w] = mean; w = word[w >> 32]; }
+    }
+}
 __global__ __launch_bounds__(BLOCK) void weight_sums_kernel(const u32* __restrict__ weight, u64 E, u32 threshold, u64* __restrict__ sums) {
     __shared__ u64 s_all, s_low;
     if (threadIdx.x == 0) { s_all = 0; s_low = 0; }
@@ -87,7 +93,11 @@ int dev_standardize_contigs(const uint64_t* src, const uint64_t* dst, uint32_t* 
     KCHECK_HIP(hipMemsetAsync(node_deg.p, 0, N * 8, stream));
     const dim3 grid(grid_for(E, BLOCK, 256u * 32u)), blk(BLOCK);
     hipLaunchKernelGGL(adjacency_kernel, grid, blk, 0, stream, src, dst, E, node_deg.as<u64>(), out_edge.as<u32>());
-    hipLaunchKernelGGL(contig_mean_kernel, grid, blk, 0, stream, src, dst, E, node_deg.as<u64>(), out_edge.as<u32>(), weight);
+    DevBuf word(stream);
+    KCHECK(word.alloc((N + 1) * 8));
+    hipLaunchKernelGGL(node_word_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), blk, 0, stream, N, node_deg.as<u64>(), out_edge.as<u32>(), dst,
+                       word.as<u64>());
+    hipLaunchKernelGGL(contig_mean_kernel, grid, blk, 0, stream, src, dst, E, word.as<u64>(), weight);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
