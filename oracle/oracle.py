@@ -365,8 +365,8 @@ def scan_files(paths, file_type=1):
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     r = rp.contents
-    off = np.ctypeslib.as_array(r.off, (r.n_accepted + 1,)).copy()
-    seq = np.ctypeslib.as_array(r.seq, (max(r.read_bytes, 1),)).copy()[:r.read_bytes]
+    off = np.ctypeslib.as_array(r.off, (r.n_accepted + 1,)).copy() if bool(r.off) else np.zeros(1, np.uint64)
+    seq = np.ctypeslib.as_array(r.seq, (max(r.read_bytes, 1),)).copy()[:r.read_bytes] if bool(r.seq) else np.zeros(0, np.uint8)
     out = dict(n_records=r.n_records, n_accepted=r.n_accepted, read_bytes=r.read_bytes, seq=seq, off=off)
     lib().ko_reads_free(rp)
     return out

@@ -181,3 +181,87 @@ def test_parallel_ingest_equals_sequential(tmp_path, monkeypatch, oracle):
         with pytest.raises(KatomePanic) as e:
             ingest_files([str(path)], ft, k)
         assert e.value.name == "E_SHORT_READ", threads
+
+
+def _mutated_text(rng, fastq):
+    """a small FASTQ / FASTA text with the irregularities real files have (and a few no file should have)"""
+    lines = []
+    n_rec = int(rng.integers(0, 14))
+    for i in range(n_rec):
+        n = int(rng.integers(0, 40)) if rng.random() < 0.15 else int(rng.integers(6, 60))
+        s = "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+        r = rng.random()
+        if r < 0.10 and n:
+            p = int(rng.integers(0, n)); s = s[:p] + "N" + s[p + 1:]
+        elif r < 0.15 and n:
+            s = s.lower()
+        elif r < 0.20:
+            s = s + "  "
+        if fastq:
+            q = "".join(chr(int(c)) for c in rng.integers(33, 74, len(s)))
+            if rng.random() < 0.2 and q:
+                q = "@" + q[1:]
+            rec = ["@r%d extra words" % i, s, "+" if rng.random() < 0.8 else "+r%d" % i, q]
+        else:
+            w = int(rng.integers(5, 30))
+            rec = [">r%d" % i] + ([s[j:j + w] for j in range(0, len(s), w)] or ([""] if rng.random() < 0.5 else []))
+        lines += rec
+    # damage
+    for _ in range(int(rng.integers(0, 3))):
+        if not lines:
+            break
+        kind = rng.integers(0, 6)
+        p = int(rng.integers(0, len(lines)))
+        if kind == 0:
+            del lines[p]                                   # a line goes missing
+        elif kind == 1:
+            lines.insert(p, "")                            # a blank line
+        elif kind == 2:
+            lines[p] = "x" + lines[p][1:] if lines[p] else "x"   # a first character that is not @ + >
+        elif kind == 3:
+            lines = lines[:p]                              # the file ends early
+        elif kind == 4:
+            lines[p] = lines[p] + "\r"                     # one CRLF line
+        else:
+            lines.insert(p, lines[p])                      # a line twice
+    sep = "\r\n" if rng.random() < 0.1 else "\n"
+    text = sep.join(lines)
+    if lines and rng.random() < 0.8:
+        text += sep
+    return text
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_ingest_fuzz_against_oracle(tmp_path, monkeypatch, oracle, seed):
+    """irregular and damaged FASTQ / FASTA text: the product's scan -- on one thread and cut into many pieces -- and the
+    oracle's parser (both restate bio 0.10's readers) accept the same reads or stop with the same status"""
+    rng = np.random.default_rng(9000 + seed)
+    k = 5
+    for case in range(40):
+        fastq = bool(rng.integers(0, 2))
+        ft = InputFileType.Fastq if fastq else InputFileType.Fasta
+        path = tmp_path / ("f%d.%s" % (case, "fq" if fastq else "fa"))
+        path.write_bytes(_mutated_text(rng, fastq).encode())
+        try:
+            want = ("ok", oracle.build_files([str(path)], k, False, file_type=int(ft)).read_bytes)
+            reads = oracle.scan_files([str(path)], file_type=int(ft))
+        except oracle.OracleError as e:
+            want, reads = ("error", e.name), None
+        for threads, chunk in (("1", None), ("4", "8"), ("7", "1")):
+            monkeypatch.setenv("KATOME_INGEST_THREADS", threads)
+            if chunk:
+                monkeypatch.setenv("KATOME_INGEST_MIN_CHUNK", chunk)
+            else:
+                monkeypatch.delenv("KATOME_INGEST_MIN_CHUNK", raising=False)
+            try:
+                r = ingest_files([str(path)], ft, k)
+                got = ("ok", r["read_bytes"])
+            except KatomePanic as e:
+                r, got = None, ("error", e.name)
+            assert got == want, (seed, case, threads, path.read_bytes())
+            if r is not None:
+                assert (r["n_records"], r["n_reads"]) == (reads["n_records"], reads["n_accepted"])
+                oracle.set_k(k)
+                for i in range(r["n_reads"]):
+                    seq = bytes(reads["seq"][reads["off"][i]:reads["off"][i + 1]])
+                    assert bytes(r["packed"][r["byte_off"][i]:r["byte_off"][i + 1]]) == oracle.compress_node(seq) and r["len"][i] == len(seq)
