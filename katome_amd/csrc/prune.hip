@@ -58,6 +58,61 @@ __global__ __launch_bounds__(BLOCK) void successor_kernel(u64 N, const u64* __re
 
 // check_dead_path(vertex, Incoming, Outgoing) (pruner.rs:229-257): returns the number of edges of the dead path, 0 if
 // the walk is not dead; with MARK, adds one to mult[] of every edge on the way
+// Per vertex, the positions of its out-edges by the edge's LAST base and of its in-edges by the edge's FIRST base: a
+// (k-1)-mer has at most four of each and they differ in exactly that base, so a slot is found without searching and kept
+// current in O(1) when an edge moves.  With them a pass touches only what it changes: the first out-edge of a vertex that
+// lost it is the youngest of its (at most three) remaining out-edges, and the edges whose endpoint was
+// re-numbered are the (at most eight) edges in the moved vertex's slots -- no pass over all edges.
+struct Slots { u32* out; u32* in; u32 nw, k; };
+__device__ __forceinline__ u32 last_base(const u64* __restrict__ key, u64 e, u32 nw) { return (u32)(key[e * nw + nw - 1] & 3); }
+__device__ __forceinline__ u32 first_base(const u64* __restrict__ key, u64 e, u32 nw, u32 k) {
+    const u32 bit = 2 * (k - 1);                                       // of the right-aligned k-mer, w[0] the high word
+    return (u32)(key[e * nw + (nw - 1 - bit / 64)] >> (bit % 64)) & 3;
+}
+__global__ __launch_bounds__(BLOCK) void slots_init_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, const u64* __restrict__ key,
+                                                           u64 E, Slots sl) {
+    for (u64 e = (u64)blockIdx.x * BLOCK + threadIdx.x; e < E; e += (u64)gridDim.x * BLOCK) {
+        sl.out[src[e] * 4 + last_base(key, e, sl.nw)] = (u32)e;
+        sl.in[dst[e] * 4 + first_base(key, e, sl.nw, sl.k)] = (u32)e;
+    }
+}
+// vertices that lost their first out-edge in this pass (listed by death_count_kernel): the youngest out-edge left
+__global__ __launch_bounds__(BLOCK) void redo_slots_kernel(const u32* __restrict__ list, u64 n, Slots sl, const u32* __restrict__ orig,
+                                                           const u64* __restrict__ dst, u64* __restrict__ node_deg, u64* __restrict__ first_out) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u64 a = list[i];
+        u64 best = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const u32 e = sl.out[a * 4 + b];
+            if (e != NONE32) { const u64 c = ((u64)(orig[e] + 1u) << 32) | e; best = c > best ? c : best; }
+        }
+        first_out[a] = best;
+        node_deg[a] = with_successor(node_deg[a], best, dst);
+    }
+}
+// vertices that were moved (to[i] <- from[i]): their edges name them by the new id; a vertex whose first out-edge leads to
+// a moved vertex gets the new successor
+__global__ __launch_bounds__(BLOCK) void remap_slots_kernel(const u32* __restrict__ to, u64 n, u64 n_new, const u32* __restrict__ tail_map, Slots sl,
+                                                            u64* __restrict__ src, u64* __restrict__ dst, const u64* __restrict__ first_out,
+                                                            u64* __restrict__ node_deg) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u64 d = to[i];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const u32 eo = sl.out[d * 4 + b];
+            if (eo != NONE32) src[eo] = d;
+            const u32 ei = sl.in[d * 4 + b];
+            if (ei != NONE32) {
+                dst[ei] = d;
+                u64 p = src[ei];                                      // (its own move may or may not have been written yet)
+                if (p >= n_new) p = tail_map[p - n_new];
+                if ((u32)first_out[p] == ei && first_out[p] != 0) node_deg[p] = (node_deg[p] & 0xFFFFFFFFull) | (d << 32);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ u32 walk_length(u32 v, u32 two_k, const u64* __restrict__ node_deg) {
     u64 w = node_deg[v];
     u32 cnt = 0, n = 0;
@@ -200,19 +255,41 @@ __global__ __launch_bounds__(BLOCK) void mark_clear_kernel(const u32* __restrict
 // last removal that touched each node, then ask per removal
 __global__ __launch_bounds__(BLOCK) void death_count_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
                                                             const u64* __restrict__ dst, u64* __restrict__ node_deg,
-                                                            u64* __restrict__ first_out, u32* __restrict__ last_touch) {
-    for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
-        const u32 e = victims[t];
-        const u64 a = src[e], b = dst[e];
-        const u64 fo = first_out[a];
-        if (fo != 0 && (u32)fo == e) {              // the list head goes: the next live out-edge is found by first_out_redo_kernel
-            first_out[a] = 0;
-            atomicOr((unsigned long long*)&node_deg[a], REDO_FIRST_OUT);
+                                                            u64* __restrict__ first_out, u32* __restrict__ last_touch,
+                                                            Slots sl, const u64* __restrict__ key, u32* __restrict__ redo_list,
+                                                            u64* __restrict__ redo_count) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 step = (u64)gridDim.x * BLOCK;
+    for (u64 t0 = (u64)blockIdx.x * BLOCK; t0 < m; t0 += step) {            // whole waves stay in the loop together
+        const u64 t = t0 + threadIdx.x;
+        bool head = false;
+        u64 a = 0;
+        if (t < m) {
+            const u32 e = victims[t];
+            a = src[e];
+            const u64 b = dst[e];
+            const u64 fo = first_out[a];
+            head = fo != 0 && (u32)fo == e;                                  // the list head goes
+            if (head) {
+                first_out[a] = 0;
+                if (!sl.out) atomicOr((unsigned long long*)&node_deg[a], REDO_FIRST_OUT);   // found again by first_out_redo_kernel
+            }
+            if (sl.out) { sl.out[a * 4 + last_base(key, e, sl.nw)] = NONE32; sl.in[b * 4 + first_base(key, e, sl.nw, sl.k)] = NONE32; }
+            atomicAdd((unsigned long long*)&node_deg[a], 0ull - OUT_ONE);
+            atomicAdd((unsigned long long*)&node_deg[b], 0ull - IN_ONE);
+            atomicMax(&last_touch[a], (u32)t + 1u);
+            atomicMax(&last_touch[b], (u32)t + 1u);
         }
-        atomicAdd((unsigned long long*)&node_deg[a], 0ull - OUT_ONE);
-        atomicAdd((unsigned long long*)&node_deg[b], 0ull - IN_ONE);
-        atomicMax(&last_touch[a], (u32)t + 1u);
-        atomicMax(&last_touch[b], (u32)t + 1u);
+        if (sl.out) {                                                        // ... or listed for redo_slots_kernel
+            const u64 mask = __ballot(head);
+            if (mask) {
+                u64 base = 0;
+                const int leader = __ffsll((unsigned long long)mask) - 1;
+                if ((int)lane == leader) base = atomicAdd((unsigned long long*)redo_count, (unsigned long long)__popcll(mask));
+                base = __shfl(base, leader, 64);
+                if (head) redo_list[base + __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull))] = (u32)a;
+            }
+        }
     }
 }
 __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
@@ -232,10 +309,12 @@ __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict
 // targets below it, so the copies never overlap
 __global__ __launch_bounds__(BLOCK) void move_edges_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
                                                            u64* __restrict__ src, u64* __restrict__ dst, u32* __restrict__ weight,
-                                                           u32* __restrict__ orig, u64* __restrict__ key, u64* __restrict__ first_out) {
+                                                           u32* __restrict__ orig, u64* __restrict__ key, u64* __restrict__ first_out,
+                                                           Slots sl) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         const u64 d = to[i], s = from[i];
         const u64 a = src[s];
+        if (sl.out) { sl.out[a * 4 + last_base(key, s, sl.nw)] = (u32)d; sl.in[dst[s] * 4 + first_base(key, s, sl.nw, sl.k)] = (u32)d; }
         if (first_out) {
             const u64 fo = first_out[a];
             if (fo != 0 && (u32)fo == (u32)s) first_out[a] = (fo & 0xFFFFFFFF00000000ull) | d;  // the head follows its edge
@@ -246,11 +325,16 @@ __global__ __launch_bounds__(BLOCK) void move_edges_kernel(const u32* __restrict
 }
 __global__ __launch_bounds__(BLOCK) void move_nodes_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
                                                            u64 n_new, u64* __restrict__ node_key, u64* __restrict__ node_deg,
-                                                           u64* __restrict__ first_out, u32* __restrict__ tail_map) {
+                                                           u64* __restrict__ first_out, u32* __restrict__ tail_map,
+                                                           Slots sl) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         const u64 d = to[i], s = from[i];
         for (u32 w = 0; w < nw; ++w) node_key[d * nw + w] = node_key[s * nw + w];
         if (node_deg) { node_deg[d] = node_deg[s]; first_out[d] = first_out[s]; }
+        if (sl.out) {
+            reinterpret_cast<uint4*>(sl.out)[d] = reinterpret_cast<const uint4*>(sl.out)[s];
+            reinterpret_cast<uint4*>(sl.in)[d] = reinterpret_cast<const uint4*>(sl.in)[s];
+        }
         tail_map[s - n_new] = (u32)d;
     }
 }
@@ -702,6 +786,14 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     const bool host_nodes = getenv("KATOME_PRUNE_HOST_NODES") != nullptr;
     const bool host_edges = getenv("KATOME_PRUNE_HOST_EDGES") != nullptr;      // the sequential replay of prune_replay.h (A/B checks)
     KCHECK(last_touch.alloc((N + 1) * 4));
+    // adjacency slots (32 B per vertex): without them -- not enough memory, or KATOME_PRUNE_NO_SLOTS -- every pass streams all edges
+    DevBuf out_slots(stream), in_slots(stream), redo_list(stream);
+    Slots slots{nullptr, nullptr, nw, k};
+    if (!getenv("KATOME_PRUNE_NO_SLOTS") && out_slots.alloc((N + 1) * 16) == KATOME_OK && in_slots.alloc((N + 1) * 16) == KATOME_OK) {
+        slots.out = out_slots.as<u32>(); slots.in = in_slots.as<u32>();
+    } else {
+        out_slots.release(); in_slots.release();
+    }
     const bool trace = getenv("KATOME_TRACE_PRUNE") != nullptr;
     double lap_t = now_ms();
     auto lap = [&](const char* what) {
@@ -721,6 +813,11 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
                               node_deg.as<u64>(), first_out.as<u64>());
     if (N) hipLaunchKernelGGL(successor_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, first_out.as<u64>(), dst,
                               node_deg.as<u64>());
+    if (slots.out && E) {
+        KCHECK_HIP(hipMemsetAsync(out_slots.p, 0xFF, N * 16, stream));
+        KCHECK_HIP(hipMemsetAsync(in_slots.p, 0xFF, N * 16, stream));
+        hipLaunchKernelGGL(slots_init_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, key, E, slots);
+    }
     KCHECK_HIP(hipGetLastError());
     lap("adjacency");
     bool nodes_moved = false;                 // tail_map holds the moves of the pass before
@@ -731,7 +828,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK_HIP(hipMemsetAsync(totals.p, 0, 64, stream));
         KCHECK(ensure(inputs, N * 4 + 16, stream));
         hipLaunchKernelGGL(input_list_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, node_deg.as<u64>(),
-                           first_out.as<u64>(), dst, nodes_moved ? tail_map.as<u32>() : (const u32*)nullptr, inputs.as<u32>(), totals.as<u64>());
+                           first_out.as<u64>(), dst, (nodes_moved && !slots.out) ? tail_map.as<u32>() : (const u32*)nullptr, inputs.as<u32>(), totals.as<u64>());
         hipLaunchKernelGGL(walk_kernel, dim3(256u * 16u), dim3(BLOCK), 0, stream, inputs.as<u32>(), two_k, first_out.as<u64>(), dst,
                            node_deg.as<u64>(), mult.as<u32>(), touched.as<unsigned char>(), totals.as<u64>());
         KCHECK_HIP(hipGetLastError());
@@ -785,8 +882,12 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         // (4) the nodes each removal isolates
         KCHECK(ensure(d_die, 2 * m * 4 + 16, stream));
         KCHECK_HIP(hipMemsetAsync(last_touch.p, 0, N * 4, stream));
+        if (slots.out) {
+            KCHECK(ensure(redo_list, m * 4 + 16, stream));
+            KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 7, 0, 8, stream));
+        }
         hipLaunchKernelGGL(death_count_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
-                           node_deg.as<u64>(), first_out.as<u64>(), last_touch.as<u32>());
+                           node_deg.as<u64>(), first_out.as<u64>(), last_touch.as<u32>(), slots, key, redo_list.as<u32>(), totals.as<u64>() + 7);
         hipLaunchKernelGGL(death_emit_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
                            node_deg.as<u64>(), last_touch.as<u32>(), d_die.as<u32>());
         KCHECK_HIP(hipGetLastError());
@@ -813,17 +914,32 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         {
             const u64 ne = n_edge_moves;
             if (ne) hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(ne, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_e.as<u32>(),
-                                       from_e.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>());
+                                       from_e.as<u32>(), ne, nw, src, dst, weight, orig.as<u32>(), key, first_out.as<u64>(), slots);
             E = E_new;
             const u64 nn = n_node_moves;
             nodes_moved = nn != 0;
             KCHECK(ensure(tail_map, (N - N_new + 1) * 4, stream));
-            if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
-                                       from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>());
-            if (E && nn) hipLaunchKernelGGL(first_out_redo_kernel<true>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst,
-                                            orig.as<u32>(), E, N_new, tail_map.as<u32>(), node_deg.as<u64>(), first_out.as<u64>());
-            else if (E) hipLaunchKernelGGL(first_out_redo_kernel<false>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst,
-                                           orig.as<u32>(), E, N_new, (const u32*)nullptr, node_deg.as<u64>(), first_out.as<u64>());
+            if (slots.out) {
+                // what changed, and nothing else: new first out-edges (edge positions are final, node ids still the old ones),
+                // then the vertices move, then the edges in a moved vertex's slots learn its new id
+                u64 n_redo = 0;
+                KCHECK_HIP(hipMemcpyAsync(&n_redo, totals.as<u64>() + 7, 8, hipMemcpyDeviceToHost, stream));
+                KCHECK_HIP(hipStreamSynchronize(stream));
+                if (n_redo) hipLaunchKernelGGL(redo_slots_kernel, dim3(grid_for(n_redo, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, redo_list.as<u32>(),
+                                               n_redo, slots, orig.as<u32>(), dst, node_deg.as<u64>(), first_out.as<u64>());
+                if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
+                                           from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>(), slots);
+                if (nn) hipLaunchKernelGGL(remap_slots_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(), nn, N_new,
+                                           tail_map.as<u32>(), slots, src, dst, first_out.as<u64>(), node_deg.as<u64>());
+            } else {
+                if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
+                                           from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>(),
+                                           Slots{nullptr, nullptr, 0, 0});
+                if (E && nn) hipLaunchKernelGGL(first_out_redo_kernel<true>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst,
+                                                orig.as<u32>(), E, N_new, tail_map.as<u32>(), node_deg.as<u64>(), first_out.as<u64>());
+                else if (E) hipLaunchKernelGGL(first_out_redo_kernel<false>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst,
+                                               orig.as<u32>(), E, N_new, (const u32*)nullptr, node_deg.as<u64>(), first_out.as<u64>());
+            }
             KCHECK_HIP(hipGetLastError());
             N = N_new;
             KCHECK_HIP(hipStreamSynchronize(stream));      // the host vectors are reused by the next pass
@@ -969,7 +1085,7 @@ int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t
     KCHECK(retain_on_device(flag.as<u32>(), E, to, from, &n_moves, &E_new, stream));
     if (n_moves)
         hipLaunchKernelGGL(move_edges_kernel, dim3(grid_for(n_moves, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(),
-                           from.as<u32>(), n_moves, nw, src, dst, weight, orig.as<u32>(), key, (u64*)nullptr);
+                           from.as<u32>(), n_moves, nw, src, dst, weight, orig.as<u32>(), key, (u64*)nullptr, Slots{nullptr, nullptr, 0, 0});
     E = E_new;
     // retain_nodes(|n| has a neighbour)
     hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, flag.as<u32>(), N, 1u);
@@ -980,7 +1096,7 @@ int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t
     DevBuf tail_map(stream);
     KCHECK(tail_map.alloc((N - N_new + 1) * 4));
     if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to.as<u32>(), from.as<u32>(),
-                               nn, nw, N_new, node_key, (u64*)nullptr, (u64*)nullptr, tail_map.as<u32>());
+                               nn, nw, N_new, node_key, (u64*)nullptr, (u64*)nullptr, tail_map.as<u32>(), Slots{nullptr, nullptr, 0, 0});
     if (E && nn) hipLaunchKernelGGL(remap_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, E, N_new, tail_map.as<u32>());
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipStreamSynchronize(stream));

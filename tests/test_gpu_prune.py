@@ -66,14 +66,17 @@ def _random_reads(seed, n_reads, read_len, genome_len, err):
     return reads
 
 
-@pytest.mark.parametrize("host_replays", [False, True])
+@pytest.mark.parametrize("host_replays", [False, True, "no slots"])
 @pytest.mark.parametrize("seed", range(24))
 def test_random_graphs_against_oracle(oracle, monkeypatch, seed, host_replays):
     """small k and noisy reads: branching, cycles, self-loops, merging tips (duplicate indices), several passes.
     host_replays: the sequential statement of the two index replays (prune_replay.h) instead of their device forms --
     the route a pass takes when its node moves chain further than the device form follows"""
     from katome_amd import device as kd
-    if host_replays:
+    if host_replays == "no slots":       # without the per-vertex edge slots every pass streams all edges (the low-memory route)
+        monkeypatch.setenv("KATOME_PRUNE_NO_SLOTS", "1")
+        host_replays = False
+    elif host_replays:
         monkeypatch.setenv("KATOME_PRUNE_HOST_EDGES", "1")
         monkeypatch.setenv("KATOME_PRUNE_HOST_NODES", "1")
     k = [4, 5, 6, 8, 11, 17][seed % 6]
