@@ -30,13 +30,16 @@ typedef uint32_t u32;
 constexpr u32 NONE32 = REPLAY_NONE;
 constexpr int MARK_ITEMS = 8;          // edges per thread in the mark compaction
 static_assert(BLOCK * MARK_ITEMS == 2048, "one 'touched' byte per workgroup of the mark compaction (MARK_GROUP_SHIFT)");
-// node_deg[v], one word per node so that a step of a walk is one look-up: bits 0-15 in-degree, bits 16-30 out-degree (a
-// (k-1)-mer has at most four edges either way), bit 31 "lost its first out-edge, first_out is being rebuilt", bits 32-63
+// node_deg[v], one word per node so that a step of a walk is one look-up: bits 0-15 in-degree, bits 16-29 out-degree (a
+// (k-1)-mer has at most four edges either way), bit 30 "listed as an Input vertex", bit 31 "lost its first out-edge, first_out is being rebuilt", bits 32-63
 // the node its first out-edge leads to (NONE32: no out-edge).  first_out[v]: (first-seen index + 1) << 32 | position of
 // the out-edge with the largest first-seen index (0 = none).  Both are built once and then kept up to date by the
 // kernels below as edges go and as edges and nodes are moved.
 constexpr u64 IN_ONE = 1ull, OUT_ONE = 1ull << 16, IN_MASK = 0xFFFFull, DEG_MASK = 0x7FFFFFFFull;
 constexpr u64 REDO_FIRST_OUT = 1ull << 31;
+constexpr u64 LISTED = 1ull << 30;          // the vertex is in the list of Input vertices that is carried from pass to pass
+constexpr u64 DEGREES = 0x3FFFFFFFull;      // in- and out-degree
+constexpr u32 DIED = 0xFFFFFFFFu;           // in last_touch: the vertex is removed in this pass
 __global__ __launch_bounds__(BLOCK) void degree_kernel(const u64* __restrict__ src, const u64* __restrict__ dst,
                                                        const u32* __restrict__ orig, u64 E, u64* __restrict__ node_deg,
                                                        u64* __restrict__ first_out) {
@@ -151,7 +154,7 @@ __device__ __forceinline__ u32 wave_sum(u32 v) {
 constexpr u32 INPUT_BUF = 2048;        // Input vertices a workgroup collects in LDS before it claims room in the list
 __global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restrict__ node_deg, const u64* __restrict__ first_out,
                                                            const u64* __restrict__ dst, const u32* __restrict__ tail_map /* of the pass before */,
-                                                           u32* __restrict__ list, u64* __restrict__ totals /* [2] walks */) {
+                                                           u32* __restrict__ list, u64* __restrict__ totals /* [2] walks */, bool keep_list) {
     __shared__ u32 buf[INPUT_BUF];
     __shared__ u32 cnt;
     __shared__ u64 base;
@@ -168,6 +171,7 @@ __global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restric
             if (deg & REDO_FIRST_OUT) node_deg[v] = with_successor(deg & ~REDO_FIRST_OUT, first_out[v], dst);   // a new first out-edge
             else if (tail_map && next != NONE32 && next >= N) node_deg[v] = (deg & DEG_MASK) | ((u64)tail_map[next - N] << 32);   // it was moved
             input = (deg & IN_MASK) == 0;
+            if (input && keep_list && !(deg & LISTED)) node_deg[v] = (deg & ~REDO_FIRST_OUT) | LISTED;   // (no first out-edge is lost before the first pass)
         }
         const u64 m = __ballot(input);
         if (m) {
@@ -292,19 +296,84 @@ __global__ __launch_bounds__(BLOCK) void death_count_kernel(const u32* __restric
         }
     }
 }
-__global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
-                                                           const u64* __restrict__ dst, const u64* __restrict__ node_deg,
-                                                           const u32* __restrict__ last_touch, u32* __restrict__ die) {
-    for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
-        const u32 e = victims[t];
-        const u64 a = src[e], b = dst[e];
-        const bool da = (node_deg[a] & (DEG_MASK & ~REDO_FIRST_OUT)) == 0 && last_touch[a] == (u32)t + 1u;
-        const bool db = b != a && (node_deg[b] & (DEG_MASK & ~REDO_FIRST_OUT)) == 0 && last_touch[b] == (u32)t + 1u;
-        die[2 * t] = da ? (u32)a : NONE32;
-        die[2 * t + 1] = db ? (u32)b : NONE32;
+// The Input vertices of the next pass without looking at every vertex: those of this pass that are still there (a vertex
+// with no in-edge cannot gain one) plus the vertices whose last in-edge this pass removed, minus the ones that died, under
+// their new ids where they were moved.
+__global__ __launch_bounds__(BLOCK) void inputs_update_kernel(const u32* __restrict__ old_list, u64 n_old, const u32* __restrict__ fresh, u64 n_fresh,
+                                                              const u32* __restrict__ last_touch, u64 n_new, const u32* __restrict__ tail_map,
+                                                              u64* __restrict__ node_deg, u32* __restrict__ out, u64* __restrict__ count) {
+    __shared__ u32 wcnt[BLOCK / 64];
+    __shared__ u64 bbase;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 total = n_old + n_fresh, step = (u64)gridDim.x * BLOCK;
+    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < total; i0 += step) {
+        const u64 i = i0 + tid;
+        bool keep = false;
+        u32 v = 0;
+        if (i < total) {
+            v = i < n_old ? old_list[i] : fresh[i - n_old];
+            keep = last_touch[v] != DIED;                                  // (ids of the pass that just ended)
+            if (keep && v >= n_new) v = tail_map[v - n_new];
+            if (keep && i >= n_old) node_deg[v] |= LISTED;                 // (one entry per vertex: no other writer)
+        }
+        const u64 mask = __ballot(keep);
+        if (lane == 0) wcnt[wave] = (u32)__popcll(mask);
+        __syncthreads();
+        if (tid == 0) {
+            u32 tot = 0;
+            for (int w = 0; w < BLOCK / 64; ++w) tot += wcnt[w];
+            bbase = tot ? atomicAdd((unsigned long long*)count, (unsigned long long)tot) : 0;
+        }
+        __syncthreads();
+        if (keep) {
+            u32 woff = 0;
+            for (u32 w = 0; w < wave; ++w) woff += wcnt[w];
+            out[bbase + woff + __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull))] = v;
+        }
+        __syncthreads();
     }
 }
 
+__global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
+                                                           const u64* __restrict__ dst, const u64* __restrict__ node_deg,
+                                                           u32* last_touch, u32* __restrict__ die,
+                                                           u32* __restrict__ fresh /* nullptr: no list of Input vertices is kept */, u64* __restrict__ fresh_count) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 step = (u64)gridDim.x * BLOCK;
+    for (u64 t0 = (u64)blockIdx.x * BLOCK; t0 < m; t0 += step) {            // whole waves stay in the loop together
+        const u64 t = t0 + threadIdx.x;
+        u32 f0 = NONE32, f1 = NONE32;                                        // endpoints that have just become Input vertices
+        if (t < m) {
+            const u32 e = victims[t];
+            const u64 a = src[e], b = dst[e];
+            const u64 wa = node_deg[a], wb = node_deg[b];
+            // the removal that touched a vertex last speaks for it (exactly one does)
+            const bool mine_a = last_touch[a] == (u32)t + 1u, mine_b = b != a && last_touch[b] == (u32)t + 1u;
+            const bool da = mine_a && (wa & DEGREES) == 0, db = mine_b && (wb & DEGREES) == 0;
+            die[2 * t] = da ? (u32)a : NONE32;
+            die[2 * t + 1] = db ? (u32)b : NONE32;
+            if (fresh) {
+                // (the other removals that touched a dying vertex compare its last_touch with their own number: neither the
+                // old value nor DIED matches, so this store may land while they look)
+                if (da) last_touch[a] = DIED;
+                if (db) last_touch[b] = DIED;
+                if (mine_a && !da && (wa & IN_MASK) == 0 && !(wa & LISTED)) f0 = (u32)a;
+                if (mine_b && !db && (wb & IN_MASK) == 0 && !(wb & LISTED)) f1 = (u32)b;
+            }
+        }
+        if (fresh) {
+            const u64 m0 = __ballot(f0 != NONE32), m1 = __ballot(f1 != NONE32);
+            if (m0 | m1) {
+                u64 base = 0;
+                if (lane == 0) base = atomicAdd((unsigned long long*)fresh_count, (unsigned long long)(__popcll(m0) + __popcll(m1)));
+                base = __shfl(base, 0, 64);
+                const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
+                if (f0 != NONE32) fresh[base + __popcll(m0 & below)] = f0;
+                if (f1 != NONE32) fresh[base + __popcll(m0) + __popcll(m1 & below)] = f1;
+            }
+        }
+    }
+}
 // moves: every array entry of the edge (node) at `from` goes to `to`; sources lie at or above the new count and
 // targets below it, so the copies never overlap
 __global__ __launch_bounds__(BLOCK) void move_edges_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
@@ -821,14 +890,21 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     KCHECK_HIP(hipGetLastError());
     lap("adjacency");
     bool nodes_moved = false;                 // tail_map holds the moves of the pass before
+    bool have_inputs = false;                 // `inputs` already holds this pass's Input vertices
+    u64 n_inputs = 0;
+    DevBuf inputs_next(stream), fresh_inputs(stream);
     while (E) {
         const double pass_t0 = now_ms();
         double pass_host = 0;
         // (1) walks
         KCHECK_HIP(hipMemsetAsync(totals.p, 0, 64, stream));
-        KCHECK(ensure(inputs, N * 4 + 16, stream));
-        hipLaunchKernelGGL(input_list_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, node_deg.as<u64>(),
-                           first_out.as<u64>(), dst, (nodes_moved && !slots.out) ? tail_map.as<u32>() : (const u32*)nullptr, inputs.as<u32>(), totals.as<u64>());
+        if (have_inputs) {                                   // carried over from the pass before (inputs_update_kernel)
+            KCHECK_HIP(hipMemcpyAsync(totals.as<u64>() + 2, &n_inputs, 8, hipMemcpyHostToDevice, stream));
+        } else {
+            KCHECK(ensure(inputs, N * 4 + 16, stream));
+            hipLaunchKernelGGL(input_list_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, node_deg.as<u64>(),
+                               first_out.as<u64>(), dst, (nodes_moved && !slots.out) ? tail_map.as<u32>() : (const u32*)nullptr, inputs.as<u32>(), totals.as<u64>(), slots.out != nullptr);
+        }
         hipLaunchKernelGGL(walk_kernel, dim3(256u * 16u), dim3(BLOCK), 0, stream, inputs.as<u32>(), two_k, first_out.as<u64>(), dst,
                            node_deg.as<u64>(), mult.as<u32>(), touched.as<unsigned char>(), totals.as<u64>());
         KCHECK_HIP(hipGetLastError());
@@ -883,13 +959,14 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK(ensure(d_die, 2 * m * 4 + 16, stream));
         KCHECK_HIP(hipMemsetAsync(last_touch.p, 0, N * 4, stream));
         if (slots.out) {
-            KCHECK(ensure(redo_list, m * 4 + 16, stream));
-            KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 7, 0, 8, stream));
+            KCHECK(ensure(redo_list, m * 4 + 16, stream)); KCHECK(ensure(fresh_inputs, 2 * m * 4 + 16, stream));
+            KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 5, 0, 16, stream));       // [5] vertices that lost their first out-edge, [6] new Inputs
         }
         hipLaunchKernelGGL(death_count_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
-                           node_deg.as<u64>(), first_out.as<u64>(), last_touch.as<u32>(), slots, key, redo_list.as<u32>(), totals.as<u64>() + 7);
+                           node_deg.as<u64>(), first_out.as<u64>(), last_touch.as<u32>(), slots, key, redo_list.as<u32>(), totals.as<u64>() + 5);
         hipLaunchKernelGGL(death_emit_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
-                           node_deg.as<u64>(), last_touch.as<u32>(), d_die.as<u32>());
+                           node_deg.as<u64>(), last_touch.as<u32>(), d_die.as<u32>(), slots.out ? fresh_inputs.as<u32>() : (u32*)nullptr,
+                           totals.as<u64>() + 6);
         KCHECK_HIP(hipGetLastError());
         // (5) replay of remove_node: on the device, or (chains too long for that form, or asked for) on the host
         u64 n_node_moves = 0, N_new = N;
@@ -922,15 +999,28 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             if (slots.out) {
                 // what changed, and nothing else: new first out-edges (edge positions are final, node ids still the old ones),
                 // then the vertices move, then the edges in a moved vertex's slots learn its new id
-                u64 n_redo = 0;
-                KCHECK_HIP(hipMemcpyAsync(&n_redo, totals.as<u64>() + 7, 8, hipMemcpyDeviceToHost, stream));
+                u64 h_cnt[2] = {0, 0};
+                KCHECK_HIP(hipMemcpyAsync(h_cnt, totals.as<u64>() + 5, 16, hipMemcpyDeviceToHost, stream));
                 KCHECK_HIP(hipStreamSynchronize(stream));
+                const u64 n_redo = h_cnt[0], n_fresh = h_cnt[1];
                 if (n_redo) hipLaunchKernelGGL(redo_slots_kernel, dim3(grid_for(n_redo, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, redo_list.as<u32>(),
                                                n_redo, slots, orig.as<u32>(), dst, node_deg.as<u64>(), first_out.as<u64>());
                 if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
                                            from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>(), slots);
                 if (nn) hipLaunchKernelGGL(remap_slots_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(), nn, N_new,
                                            tail_map.as<u32>(), slots, src, dst, first_out.as<u64>(), node_deg.as<u64>());
+                // next pass's Input vertices from this pass's, without a look at every vertex
+                const u64 n_old = h_tot[2], cand = n_old + n_fresh;
+                KCHECK(ensure(inputs_next, cand * 4 + 16, stream));
+                KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 7, 0, 8, stream));
+                if (cand) hipLaunchKernelGGL(inputs_update_kernel, dim3(grid_for(cand, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, inputs.as<u32>(), n_old,
+                                             fresh_inputs.as<u32>(), n_fresh, last_touch.as<u32>(), N_new, tail_map.as<u32>(), node_deg.as<u64>(),
+                                             inputs_next.as<u32>(), totals.as<u64>() + 7);
+                KCHECK_HIP(hipGetLastError());
+                KCHECK_HIP(hipMemcpyAsync(&n_inputs, totals.as<u64>() + 7, 8, hipMemcpyDeviceToHost, stream));
+                KCHECK_HIP(hipStreamSynchronize(stream));
+                std::swap(inputs.p, inputs_next.p); std::swap(inputs.bytes, inputs_next.bytes);
+                have_inputs = true;
             } else {
                 if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
                                            from_n.as<u32>(), nn, nw, N_new, node_key, node_deg.as<u64>(), first_out.as<u64>(), tail_map.as<u32>(),
