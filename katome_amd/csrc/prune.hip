@@ -195,18 +195,27 @@ __global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restric
 __global__ __launch_bounds__(BLOCK) void walk_kernel(const u32* __restrict__ list, u32 two_k, const u64* __restrict__ first_out,
                                                      const u64* __restrict__ dst, const u64* __restrict__ node_deg, u32* __restrict__ mult,
                                                      unsigned char* __restrict__ touched,
-                                                     u64* __restrict__ totals /* [0] marks, [1] dead walks, [2] walks (input) */) {
+                                                     const u32* __restrict__ stamp, u32 walk_from /* 0: every listed vertex */, bool check,
+                                                     u64* __restrict__ totals /* [0] marks, [1] dead walks, [2] listed (input), [3] walked,
+                                                                                 [4] (check) dead walks that would have been skipped */) {
     const u64 n = totals[2];
-    u32 marks = 0, dead = 0;
+    u32 marks = 0, dead = 0, walked = 0;
     for (u64 j = (u64)blockIdx.x * BLOCK + threadIdx.x; j < n; j += (u64)gridDim.x * BLOCK) {
         const u32 v = list[j];
+        const bool skip = walk_from && stamp[v] < walk_from;   // nothing within reach of its walk has changed: still not dead
+        if (skip && !check) continue;
+        walked += 1;
         const u32 len = walk_length(v, two_k, node_deg);
-        if (len) { walk_mark(v, len, first_out, dst, mult, touched); marks += len; dead += 1; }
+        if (len) {
+            walk_mark(v, len, first_out, dst, mult, touched); marks += len; dead += 1;
+            if (skip) atomicAdd((unsigned long long*)&totals[4], 1ull);          // KATOME_PRUNE_CHECK_WALKS: must never happen
+        }
     }
-    marks = wave_sum(marks); dead = wave_sum(dead);
+    marks = wave_sum(marks); dead = wave_sum(dead); walked = wave_sum(walked);
     if ((threadIdx.x & 63) == 0) {
         if (marks) atomicAdd((unsigned long long*)&totals[0], (unsigned long long)marks);
         if (dead) atomicAdd((unsigned long long*)&totals[1], (unsigned long long)dead);
+        if (walked) atomicAdd((unsigned long long*)&totals[3], (unsigned long long)walked);
     }
 }
 
@@ -301,7 +310,8 @@ __global__ __launch_bounds__(BLOCK) void death_count_kernel(const u32* __restric
 // their new ids where they were moved.
 __global__ __launch_bounds__(BLOCK) void inputs_update_kernel(const u32* __restrict__ old_list, u64 n_old, const u32* __restrict__ fresh, u64 n_fresh,
                                                               const u32* __restrict__ last_touch, u64 n_new, const u32* __restrict__ tail_map,
-                                                              u64* __restrict__ node_deg, u32* __restrict__ out, u64* __restrict__ count) {
+                                                              u64* __restrict__ node_deg, u32* __restrict__ out, u64* __restrict__ count,
+                                                              u32* __restrict__ stamp, u32 walk_code) {
     __shared__ u32 wcnt[BLOCK / 64];
     __shared__ u64 bbase;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(BLOCK) void inputs_update_kernel(const u32* __restr
             v = i < n_old ? old_list[i] : fresh[i - n_old];
             keep = last_touch[v] != DIED;                                  // (ids of the pass that just ended)
             if (keep && v >= n_new) v = tail_map[v - n_new];
-            if (keep && i >= n_old) node_deg[v] |= LISTED;                 // (one entry per vertex: no other writer)
+            if (keep && i >= n_old) { node_deg[v] |= LISTED; if (stamp) atomicMax(&stamp[v], walk_code); }   // (one entry per vertex: no other writer)
         }
         const u64 mask = __ballot(keep);
         if (lane == 0) wcnt[wave] = (u32)__popcll(mask);
@@ -337,12 +347,14 @@ __global__ __launch_bounds__(BLOCK) void inputs_update_kernel(const u32* __restr
 __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict__ victims, u64 m, const u64* __restrict__ src,
                                                            const u64* __restrict__ dst, const u64* __restrict__ node_deg,
                                                            u32* last_touch, u32* __restrict__ die,
-                                                           u32* __restrict__ fresh /* nullptr: no list of Input vertices is kept */, u64* __restrict__ fresh_count) {
+                                                           u32* __restrict__ fresh /* nullptr: no list of Input vertices is kept */, u64* __restrict__ fresh_count,
+                                                           u32* __restrict__ changed /* nullptr: not wanted */, u64* __restrict__ changed_count) {
     const u32 lane = threadIdx.x & 63;
     const u64 step = (u64)gridDim.x * BLOCK;
     for (u64 t0 = (u64)blockIdx.x * BLOCK; t0 < m; t0 += step) {            // whole waves stay in the loop together
         const u64 t = t0 + threadIdx.x;
         u32 f0 = NONE32, f1 = NONE32;                                        // endpoints that have just become Input vertices
+        u32 c0 = NONE32, c1 = NONE32;                                        // endpoints that stay, with a degree or a successor changed
         if (t < m) {
             const u32 e = victims[t];
             const u64 a = src[e], b = dst[e];
@@ -359,6 +371,18 @@ __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict
                 if (db) last_touch[b] = DIED;
                 if (mine_a && !da && (wa & IN_MASK) == 0 && !(wa & LISTED)) f0 = (u32)a;
                 if (mine_b && !db && (wb & IN_MASK) == 0 && !(wb & LISTED)) f1 = (u32)b;
+                if (changed) { if (mine_a && !da) c0 = (u32)a; if (mine_b && !db) c1 = (u32)b; }
+            }
+        }
+        if (changed) {
+            const u64 m0 = __ballot(c0 != NONE32), m1 = __ballot(c1 != NONE32);
+            if (m0 | m1) {
+                u64 base = 0;
+                if (lane == 0) base = atomicAdd((unsigned long long*)changed_count, (unsigned long long)(__popcll(m0) + __popcll(m1)));
+                base = __shfl(base, 0, 64);
+                const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
+                if (c0 != NONE32) changed[base + __popcll(m0 & below)] = c0;
+                if (c1 != NONE32) changed[base + __popcll(m0) + __popcll(m1 & below)] = c1;
             }
         }
         if (fresh) {
@@ -374,6 +398,43 @@ __global__ __launch_bounds__(BLOCK) void death_emit_kernel(const u32* __restrict
         }
     }
 }
+// Which listed Input vertices must be walked again: a walk reads, for up to 2k vertices along first out-edges, each
+// vertex's successor and in-degree -- so its outcome can only differ from the pass before if one of the vertices whose
+// degree or successor this pass changed lies within 2k steps of it.  From every such vertex the vertices that reach it
+// along their first out-edges are visited backwards (in-edge slots, kept only where the source's first out-edge is that
+// edge), depth first with the smallest depth seen per vertex stamped (pass number and depth in one word, atomicMax), and
+// every vertex visited is stamped "walk in this pass"; the walks then skip the listed vertices without the stamp.
+// stamp = pass number * STAMP_STEP + (STAMP_STEP - 1 - depth): a later pass, or the same pass nearer to a change, is larger
+constexpr u32 STAMP_STEP = 256;            // depths go to 2k <= 126
+constexpr int WALK_STACK = 3 * 126 + 8;
+__global__ __launch_bounds__(BLOCK) void affected_kernel(const u32* __restrict__ changed, u64 n, u64 n_new, const u32* __restrict__ tail_map,
+                                                         Slots sl, const u64* __restrict__ src, const u64* __restrict__ node_deg,
+                                                         u32* __restrict__ stamp, u32 code0 /* this pass, depth 0 */, u32 max_depth) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        u32 x = changed[i];
+        if (x >= n_new) x = tail_map[x - n_new];
+        u32 sv[WALK_STACK]; unsigned char sd[WALK_STACK];
+        int top = 0;
+        sv[0] = x; sd[0] = 0; top = 1;
+        while (top) {
+            --top;
+            const u32 v = sv[top]; const u32 d = sd[top];
+            const u32 code = code0 - d;                               // shallower = larger
+            if (atomicMax(&stamp[v], code) >= code) continue;          // seen in this pass at this depth or nearer
+            if (d == max_depth) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const u32 e = sl.in[(u64)v * 4 + b];
+                if (e == NONE32) continue;
+                const u32 p = (u32)src[e];
+                if ((u32)(node_deg[p] >> 32) != v) continue;          // p's walk does not come this way
+                if (top == WALK_STACK) continue;                      // (cannot happen: 3 * depth + 4 entries at most)
+                sv[top] = p; sd[top] = (unsigned char)(d + 1); ++top;
+            }
+        }
+    }
+}
+
 // moves: every array entry of the edge (node) at `from` goes to `to`; sources lie at or above the new count and
 // targets below it, so the copies never overlap
 __global__ __launch_bounds__(BLOCK) void move_edges_kernel(const u32* __restrict__ to, const u32* __restrict__ from, u64 n, u32 nw,
@@ -856,7 +917,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     const bool host_edges = getenv("KATOME_PRUNE_HOST_EDGES") != nullptr;      // the sequential replay of prune_replay.h (A/B checks)
     KCHECK(last_touch.alloc((N + 1) * 4));
     // adjacency slots (32 B per vertex): without them -- not enough memory, or KATOME_PRUNE_NO_SLOTS -- every pass streams all edges
-    DevBuf out_slots(stream), in_slots(stream), redo_list(stream);
+    DevBuf out_slots(stream), in_slots(stream), redo_list(stream), stamp(stream);
     Slots slots{nullptr, nullptr, nw, k};
     if (!getenv("KATOME_PRUNE_NO_SLOTS") && out_slots.alloc((N + 1) * 16) == KATOME_OK && in_slots.alloc((N + 1) * 16) == KATOME_OK) {
         slots.out = out_slots.as<u32>(); slots.in = in_slots.as<u32>();
@@ -882,6 +943,8 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
                               node_deg.as<u64>(), first_out.as<u64>());
     if (N) hipLaunchKernelGGL(successor_kernel, dim3(grid_for(N, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, N, first_out.as<u64>(), dst,
                               node_deg.as<u64>());
+    KCHECK(stamp.alloc((slots.out ? N + 1 : 1) * 4));
+    if (slots.out) KCHECK_HIP(hipMemsetAsync(stamp.p, 0, (N + 1) * 4, stream));
     if (slots.out && E) {
         KCHECK_HIP(hipMemsetAsync(out_slots.p, 0xFF, N * 16, stream));
         KCHECK_HIP(hipMemsetAsync(in_slots.p, 0xFF, N * 16, stream));
@@ -892,7 +955,10 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     bool nodes_moved = false;                 // tail_map holds the moves of the pass before
     bool have_inputs = false;                 // `inputs` already holds this pass's Input vertices
     u64 n_inputs = 0;
-    DevBuf inputs_next(stream), fresh_inputs(stream);
+    DevBuf inputs_next(stream), fresh_inputs(stream), changed(stream);
+    const bool check_walks = getenv("KATOME_PRUNE_CHECK_WALKS") != nullptr;   // walk everything and verify that the skipped walks are not dead
+    u32 walk_from = 0;                        // 0: walk every listed vertex; else only those stamped at or above this (affected_kernel)
+    const u64 track_max = getenv("KATOME_PRUNE_WALK_ALL") ? 0 : (1ull << 20);   // passes that remove more edges than this re-walk everything
     while (E) {
         const double pass_t0 = now_ms();
         double pass_host = 0;
@@ -906,14 +972,15 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
                                first_out.as<u64>(), dst, (nodes_moved && !slots.out) ? tail_map.as<u32>() : (const u32*)nullptr, inputs.as<u32>(), totals.as<u64>(), slots.out != nullptr);
         }
         hipLaunchKernelGGL(walk_kernel, dim3(256u * 16u), dim3(BLOCK), 0, stream, inputs.as<u32>(), two_k, first_out.as<u64>(), dst,
-                           node_deg.as<u64>(), mult.as<u32>(), touched.as<unsigned char>(), totals.as<u64>());
+                           node_deg.as<u64>(), mult.as<u32>(), touched.as<unsigned char>(), stamp.as<u32>(), walk_from, check_walks, totals.as<u64>());
         KCHECK_HIP(hipGetLastError());
-        u64 h_tot[3] = {0, 0, 0};
-        KCHECK_HIP(hipMemcpyAsync(h_tot, totals.p, 24, hipMemcpyDeviceToHost, stream));
+        u64 h_tot[5] = {0, 0, 0, 0, 0};
+        KCHECK_HIP(hipMemcpyAsync(h_tot, totals.p, 40, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
         lap("walks");
+        if (h_tot[4]) { set_error("remove_dead_paths: %llu dead walks started at vertices the change tracking would have skipped (pass %llu)", (unsigned long long)h_tot[4], (unsigned long long)local.passes + 1); return KATOME_E_DEVICE; }
         local.passes += 1;
-        local.walks += h_tot[2];
+        local.walks += h_tot[3];
         if (h_tot[0] == 0) break;                         // to_remove.is_empty() (pruner.rs:76)
         local.dead_walks += h_tot[1];
         local.marked += h_tot[0];
@@ -960,13 +1027,15 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
         KCHECK_HIP(hipMemsetAsync(last_touch.p, 0, N * 4, stream));
         if (slots.out) {
             KCHECK(ensure(redo_list, m * 4 + 16, stream)); KCHECK(ensure(fresh_inputs, 2 * m * 4 + 16, stream));
-            KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 5, 0, 16, stream));       // [5] vertices that lost their first out-edge, [6] new Inputs
+            KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 4, 0, 24, stream));       // [4] changed vertices, [5] lost their first out-edge, [6] new Inputs
         }
+        const bool track = slots.out && m <= track_max;
+        if (track) KCHECK(ensure(changed, 2 * m * 4 + 16, stream));
         hipLaunchKernelGGL(death_count_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
                            node_deg.as<u64>(), first_out.as<u64>(), last_touch.as<u32>(), slots, key, redo_list.as<u32>(), totals.as<u64>() + 5);
         hipLaunchKernelGGL(death_emit_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_victims.as<u32>(), m, src, dst,
                            node_deg.as<u64>(), last_touch.as<u32>(), d_die.as<u32>(), slots.out ? fresh_inputs.as<u32>() : (u32*)nullptr,
-                           totals.as<u64>() + 6);
+                           totals.as<u64>() + 6, track ? changed.as<u32>() : (u32*)nullptr, totals.as<u64>() + 4);
         KCHECK_HIP(hipGetLastError());
         // (5) replay of remove_node: on the device, or (chains too long for that form, or asked for) on the host
         u64 n_node_moves = 0, N_new = N;
@@ -999,10 +1068,10 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
             if (slots.out) {
                 // what changed, and nothing else: new first out-edges (edge positions are final, node ids still the old ones),
                 // then the vertices move, then the edges in a moved vertex's slots learn its new id
-                u64 h_cnt[2] = {0, 0};
-                KCHECK_HIP(hipMemcpyAsync(h_cnt, totals.as<u64>() + 5, 16, hipMemcpyDeviceToHost, stream));
+                u64 h_cnt[3] = {0, 0, 0};
+                KCHECK_HIP(hipMemcpyAsync(h_cnt, totals.as<u64>() + 4, 24, hipMemcpyDeviceToHost, stream));
                 KCHECK_HIP(hipStreamSynchronize(stream));
-                const u64 n_redo = h_cnt[0], n_fresh = h_cnt[1];
+                const u64 n_changed = h_cnt[0], n_redo = h_cnt[1], n_fresh = h_cnt[2];
                 if (n_redo) hipLaunchKernelGGL(redo_slots_kernel, dim3(grid_for(n_redo, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, redo_list.as<u32>(),
                                                n_redo, slots, orig.as<u32>(), dst, node_deg.as<u64>(), first_out.as<u64>());
                 if (nn) hipLaunchKernelGGL(move_nodes_kernel, dim3(grid_for(nn, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, to_n.as<u32>(),
@@ -1015,7 +1084,15 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
                 KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 7, 0, 8, stream));
                 if (cand) hipLaunchKernelGGL(inputs_update_kernel, dim3(grid_for(cand, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, inputs.as<u32>(), n_old,
                                              fresh_inputs.as<u32>(), n_fresh, last_touch.as<u32>(), N_new, tail_map.as<u32>(), node_deg.as<u64>(),
-                                             inputs_next.as<u32>(), totals.as<u64>() + 7);
+                                             inputs_next.as<u32>(), totals.as<u64>() + 7, stamp.as<u32>(), (u32)(local.passes + 1) * STAMP_STEP + (STAMP_STEP - 1));
+                // which of them the next pass has to walk: everything, or what lies within reach of a change
+                walk_from = 0;
+                if (track) {
+                    if (n_changed) hipLaunchKernelGGL(affected_kernel, dim3(grid_for(n_changed, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, changed.as<u32>(),
+                                                      n_changed, N_new, tail_map.as<u32>(), slots, src, node_deg.as<u64>(), stamp.as<u32>(),
+                                                      (u32)(local.passes + 1) * STAMP_STEP + (STAMP_STEP - 1), two_k);
+                    walk_from = (u32)(local.passes + 1) * STAMP_STEP;
+                }
                 KCHECK_HIP(hipGetLastError());
                 KCHECK_HIP(hipMemcpyAsync(&n_inputs, totals.as<u64>() + 7, 8, hipMemcpyDeviceToHost, stream));
                 KCHECK_HIP(hipStreamSynchronize(stream));
