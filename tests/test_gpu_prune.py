@@ -66,7 +66,7 @@ def _random_reads(seed, n_reads, read_len, genome_len, err):
     return reads
 
 
-@pytest.mark.parametrize("host_replays", [False, True, "no slots"])
+@pytest.mark.parametrize("host_replays", [False, True, "no slots", "walk all", "check walks"])
 @pytest.mark.parametrize("seed", range(24))
 def test_random_graphs_against_oracle(oracle, monkeypatch, seed, host_replays):
     """small k and noisy reads: branching, cycles, self-loops, merging tips (duplicate indices), several passes.
@@ -75,6 +75,12 @@ def test_random_graphs_against_oracle(oracle, monkeypatch, seed, host_replays):
     from katome_amd import device as kd
     if host_replays == "no slots":       # without the per-vertex edge slots every pass streams all edges (the low-memory route)
         monkeypatch.setenv("KATOME_PRUNE_NO_SLOTS", "1")
+        host_replays = False
+    elif host_replays == "walk all":     # every listed Input vertex is walked in every pass, as the reference does
+        monkeypatch.setenv("KATOME_PRUNE_WALK_ALL", "1")
+        host_replays = False
+    elif host_replays == "check walks":  # ... and the call fails if a walk the change tracking would skip is dead
+        monkeypatch.setenv("KATOME_PRUNE_CHECK_WALKS", "1")
         host_replays = False
     elif host_replays:
         monkeypatch.setenv("KATOME_PRUNE_HOST_EDGES", "1")
