@@ -10,10 +10,15 @@
 // swap_remove, so every removal re-labels the last edge / node, and an index that two walks both collected removes
 // whatever edge was swapped in.  That bookkeeping decides the final numbering (and, through the duplicates, the
 // surviving set), so it is reproduced exactly:
-//   * device: degrees and first_edge(Outgoing) of every node (petgraph's list head = the live out-edge added last =
-//     largest first-seen index; swap_remove re-labels edges but never reorders the lists), the walks, the marks per
-//     edge index, which endpoints die with which removal, and applying the resulting moves to the arrays;
-//   * host: the two sequential swap_remove replays (edges: two descending streams; nodes: arrays over the dying tail).
+// everything on the device --
+//   * degrees and first_edge(Outgoing) of every vertex (petgraph's list head = the live out-edge added last = largest
+//     first-seen index; swap_remove re-labels edges but never reorders the lists), per-vertex edge slots, the list of
+//     Input vertices, the walks (after small passes only those within reach of a change), the marks per edge index;
+//   * the two swap_remove replays in parallel form (edges: a scan of n -> max(n - c, d) functions + pointer jumping;
+//     vertices: where the occupant of each vacated tail position goes, settled in rounds), which endpoints die with
+//     which removal, and the resulting moves applied to the arrays;
+//   * prune_replay.h keeps the sequential statement of the two replays for a pass whose vertex moves chain further than
+//     the device form follows (and for A/B runs).
 #include <stdlib.h>
 
 #include <algorithm>
