@@ -551,8 +551,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 KCHECK(dev_sort(b->edge_key.as<u64>(), idx.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
                 KCHECK(b->edge_weight.alloc((b->n_edges + 1) * 4, stream));
                 KCHECK(b->edge_seq.alloc((b->n_edges + 1) * 8, stream));
-                KCHECK(dev_gather_u32(raw_w.as<u32>(), idx.as<u32>(), b->n_edges, b->edge_weight.as<u32>(), stream));
-                KCHECK(dev_gather_u64(raw_seq.as<u64>(), idx.as<u32>(), b->n_edges, b->edge_seq.as<u64>(), stream));
+                KCHECK(dev_gather_seq_weight(raw_seq.as<u64>(), idx.as<u32>(), b->n_edges, b->edge_seq.as<u64>(), b->edge_weight.as<u32>(), stream));
             } else {
                 KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
             }

@@ -114,6 +114,7 @@ int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t 
 int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src,
                  uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream);
 int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream);
+int dev_gather_seq_weight(const uint64_t* pairs, const uint32_t* idx, uint64_t n, uint64_t* seq, uint32_t* weight, hipStream_t stream);
 int dev_gather_u32(const uint32_t* src, const uint32_t* idx, uint64_t n, uint32_t* dst, hipStream_t stream);
 int dev_gather_u64(const uint64_t* src, const uint32_t* idx, uint64_t n, uint64_t* dst, hipStream_t stream);
 int dev_gather_keys(const uint64_t* src, const uint32_t* idx, uint64_t n, uint32_t nw, uint64_t* dst, hipStream_t stream);

@@ -928,6 +928,20 @@ int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream) {
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
+// {sequence number, weight} pairs (table.hip emit, first-seen order) brought into the order of idx[] and split
+__global__ __launch_bounds__(BLOCK) void gather_seq_weight_kernel(const ulonglong2* __restrict__ pairs, const u32* __restrict__ idx, u64 n,
+                                                                  u64* __restrict__ seq, u32* __restrict__ weight) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const ulonglong2 p = pairs[idx[i]];
+        seq[i] = p.x; weight[i] = (u32)p.y;
+    }
+}
+int dev_gather_seq_weight(const uint64_t* pairs, const uint32_t* idx, uint64_t n, uint64_t* seq, uint32_t* weight, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(gather_seq_weight_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream,
+                              reinterpret_cast<const ulonglong2*>(pairs), idx, n, seq, weight);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
 int dev_gather_u32(const uint32_t* src, const uint32_t* idx, uint64_t n, uint32_t* dst, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(gather_kernel<u32>, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, idx, n, dst);
     KCHECK_HIP(hipGetLastError());

@@ -386,14 +386,14 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
             }
 #pragma unroll
             for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = key[j].w[q];
-            out_w[pos] = w;
-            if (seen) out_seq[pos] = s0;
+            if (seen) { out_seq[2 * pos] = s0; out_seq[2 * pos + 1] = w; }   // first-seen order: {sequence number, weight} side by side
+            else out_w[pos] = w;
             ++pos;
             if (nemit[j] == 2) {
 #pragma unroll
                 for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rc.w[q];
-                out_w[pos] = w;
-                if (seen) out_seq[pos] = s1;
+                if (seen) { out_seq[2 * pos] = s1; out_seq[2 * pos + 1] = w; }
+                else out_w[pos] = w;
                 ++pos;
             }
         }
@@ -530,9 +530,10 @@ int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf&
     KCHECK(table_occupied(t, &occ, stream));
     const uint64_t upper = occ * (rc ? 2 : 1);
     KCHECK(keys.alloc((upper + 1) * 8 * t.nw, stream));
-    KCHECK(weights.alloc((upper + 1) * 4, stream));
     const u64* seen = nullptr; u64* out_seq = nullptr;
-    if (seqs && t.track_seen) { KCHECK(seqs->alloc((upper + 1) * 8, stream)); seen = t.seen.as<u64>(); out_seq = seqs->as<u64>(); }
+    // first-seen order: the weights travel with the sequence numbers ([upper][2] u64 in `seqs`, one gather later); `weights` stays empty
+    if (seqs && t.track_seen) { KCHECK(seqs->alloc((upper + 1) * 16, stream)); seen = t.seen.as<u64>(); out_seq = seqs->as<u64>(); }
+    else KCHECK(weights.alloc((upper + 1) * 4, stream));
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
