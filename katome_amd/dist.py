@@ -380,25 +380,28 @@ def finalize_distributed(ops, group=None, phases=_NO_PHASES):
     keys, weights = ops.edges()                       # [E, nw] ascending, [E]
     E = weights.numel()
     dev = weights.device
-    # this rank's nodes that have out-edges are the sources of its own edges: read off the sorted list, no sort
+    # every edge asks the owner of its target for the id, remembering which edge asked; while the questions travel, this
+    # rank's own nodes with out-edges are read off its sorted edges (they are the sources of its own edges: no sort)
+    with phases("route_targets"):
+        if E:
+            T = ops.target_keys(keys)
+            P, counts, origin = ops.partition(T, world, key_words=nw, values=torch.arange(E, dtype=torch.int32, device=dev),
+                                              core=node_core)
+            del T
+        else:
+            P, counts, origin = ops.empty(0), [0] * world, torch.empty(0, dtype=torch.int32, device=dev)
+    with phases("exchange_targets"):
+        questions = _AsyncExchange([(P, nw)], counts, group)
     if E:
         with phases("local_source_ids"):
             S, lsrc = ops.source_ids(keys)
-            T = ops.target_keys(keys)
     else:
-        S, lsrc, T = ops.empty(0), ops.empty(0), ops.empty(0)
+        S, lsrc = ops.empty(0), ops.empty(0)
     n_src = S.numel() // nw
-    # every edge asks the owner of its target for the id, remembering which edge asked
-    with phases("route_targets"):
-        if E:
-            P, counts, origin = ops.partition(T, world, key_words=nw, values=torch.arange(E, dtype=torch.int32, device=dev),
-                                              core=node_core)
-        else:
-            P, counts, origin = T, [0] * world, torch.empty(0, dtype=torch.int32, device=dev)
-        del T
     with phases("exchange_targets"):
-        R, recv_counts = _exchange(P, counts, nw, group)
-    del P
+        R = questions.wait()[0]
+        recv_counts = questions.recv_counts
+    del P, questions
     # answer: position among the sources, or -- for a node without out-edges -- among the (few) other nodes owned here
     with phases("answer_ids"):
         nR = R.numel() // nw
