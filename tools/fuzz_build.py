@@ -20,6 +20,8 @@ for c in range(cases):
     glen = max(L + 1, int(rng.choice([L + 5, 300, 3000, 40000])))
     rc, first_seen = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     prune = first_seen and rng.random() < 0.5
+    stages = str(rng.choice(["d", "w", "dw", "wd", "dc", "cd", "wcd", "dcwc", "dcwce", "dcwced"])) if (first_seen and L > k and rng.random() < 0.6) else None
+    thr = int(rng.choice([1, 2, 3, 5]))
     npct = int(rng.choice([0, 0, 3]))
     reads = o.synth_reads(int(rng.integers(0, 1000)), n, L, glen, float(rng.choice([0.0, 1e-3, 2e-2])), npct)
     has_n = (reads == ord("N")).any(axis=1)
@@ -32,9 +34,23 @@ for c in range(cases):
         for r0 in range(0, n, step):
             b.count_reads(packed, min(step, n - r0), L, skip, first_read=r0)
         dg = b.finalize()
-        if prune:
-            dg, _ = b.remove_dead_paths()
-        ref = o.build_ascii(reads, k, rc, remove_dead_paths=prune)
+        if stages:                                        # the stages of assemble_with_graph, in a random order
+            o.set_genome_length(glen)
+            for st in stages:
+                if st == "d":
+                    b.remove_dead_paths()
+                elif st == "c":
+                    b.standardize_contigs()
+                elif st == "w":
+                    b.remove_weak_edges(thr)
+                else:
+                    b.standardize_edges(glen, thr)
+            dg = b.graph()
+            ref = o.build_ascii(reads, k, rc, remove_weak_edges=thr, stages=stages)
+        else:
+            if prune:
+                dg, _ = b.remove_dead_paths()
+            ref = o.build_ascii(reads, k, rc, remove_dead_paths=prune)
         ok = (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
         if ok and first_seen:
             ok = (np.array_equal(dg.edge_label.cpu().numpy(), ref.edge_label) and
@@ -50,6 +66,6 @@ for c in range(cases):
         b.close()
     if not ok:
         bad += 1
-        print("MISMATCH case %d: k=%d L=%d n=%d glen=%d rc=%s first_seen=%s prune=%s step=%d" % (c, k, L, n, glen, rc, first_seen, prune, step), flush=True)
+        print("MISMATCH case %d: k=%d L=%d n=%d glen=%d rc=%s first_seen=%s prune=%s stages=%s thr=%d step=%d" % (c, k, L, n, glen, rc, first_seen, prune, stages, thr, step), flush=True)
 print("%d cases, %d mismatches" % (cases, bad))
 sys.exit(1 if bad else 0)
