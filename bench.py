@@ -366,7 +366,11 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
         if world == 1 and not use_dist and args.next_stages_reads > 0:
-            line["next_stages"] = next_stages(wl, args.next_stages_reads)
+            try:                       # not part of the metric: whatever goes wrong here must not cost the line above
+                kd.release_cache()
+                line["next_stages"] = next_stages(wl, args.next_stages_reads)
+            except Exception as e:     # noqa: BLE001
+                line["next_stages"] = {"error": "%s: %s" % (type(e).__name__, e)}
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
