@@ -22,7 +22,7 @@ def short(name):
 lines = ["# rocprofv3 summary %s" % tag, ""]
 stats = find("trace/**/*kernel_stats.csv")
 if stats:
-    lines += ["## kernel stats (rocprofv3 --kernel-trace --stats; whole bench.py run incl. warmup)", "",
+    lines += ["## kernel stats (rocprofv3 --kernel-trace --stats; whole bench.py run incl. its set-up and warm-up builds)", "",
               "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
     for row in csv.DictReader(open(stats)):
         lines.append("| %s | %s | %.2f | %.1f | %s |" % (short(row["Name"]), row["Calls"], float(row["TotalDurationNs"]) / 1e6,
