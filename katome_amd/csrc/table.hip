@@ -49,12 +49,21 @@ __device__ __forceinline__ u32 upsert(Slot1* slots, u64 cap, Key<1> key, u32 add
     return 0;
 }
 
+// First-seen-order mode, keys of two and three words: the thread that puts a key in also writes the key's first two sequence
+// numbers, with plain stores inside the claim (nobody can reach seen[slot] before the key is published), instead of two
+// atomicMin afterwards.  (One-word keys are published by a single CAS; giving them a claim window for this was measured and
+// costs more than the two atomics it saves: C3's last expansion level 162 -> 174 ms.)
+struct SeenInit { u64* seen; u64 a, b; bool both; };
+__device__ __forceinline__ void seen_store(const SeenInit& si, u64 s) {
+    st_agent(&si.seen[2 * s], si.a);
+    if (si.both) st_agent(&si.seen[2 * s + 1], si.b);
+}
 // 128-bit keys: there is no 128-bit CAS, so the high word is claimed with LOCK set, the low word
 // is stored, drained (s_waitcnt) and then the high word is re-published with OCC.  A lane never
 // waits while it holds a claim (claim and publication are one straight-line block), so lanes of
 // one wave cannot deadlock each other; a lane that meets a LOCKed slot with ITS high word simply
 // re-reads the slot on its next loop trip.
-__device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add, u32* err, u64* slot_out = nullptr) {
+__device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add, u32* err, u64* slot_out = nullptr, const SeenInit* si = nullptr) {
     u64 s = hash_to_range(hash_key(key), cap);
     u64 spins = 0;
     for (u64 probes = 0; probes < cap;) {
@@ -68,6 +77,7 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
             cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
             if (cur == 0) {
                 st_agent(&slots[s].lo, key.w[1]);
+                if (si) seen_store(*si, s);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&slots[s].hi, key.w[0] | OCC);
                 atomicAdd(&slots[s].count, add);
@@ -96,7 +106,7 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
 }
 
 // three-word keys: the same claim / publish protocol with two payload words
-__device__ __forceinline__ u32 upsert(Slot3* slots, u64 cap, Key<3> key, u32 add, u32* err, u64* slot_out = nullptr) {
+__device__ __forceinline__ u32 upsert(Slot3* slots, u64 cap, Key<3> key, u32 add, u32* err, u64* slot_out = nullptr, const SeenInit* si = nullptr) {
     u64 s = hash_to_range(hash_key(key), cap);
     u64 spins = 0;
     for (u64 probes = 0; probes < cap;) {
@@ -108,6 +118,7 @@ __device__ __forceinline__ u32 upsert(Slot3* slots, u64 cap, Key<3> key, u32 add
             if (cur == 0) {
                 st_agent(&slots[s].mid, key.w[1]);
                 st_agent(&slots[s].lo, key.w[2]);
+                if (si) seen_store(*si, s);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 st_agent(&slots[s].hi, key.w[0] | OCC);
                 atomicAdd(&slots[s].count, add);
@@ -135,6 +146,17 @@ __device__ __forceinline__ u32 upsert(Slot3* slots, u64 cap, Key<3> key, u32 add
     *err = 1;
     return 0;
 }
+
+__device__ __forceinline__ u32 upsert_seen(Slot1* slots, u64 cap, Key<1> key, u32 add, u32* err, u64* slot_out, const SeenInit& si) {
+    const u32 fresh = upsert(slots, cap, key, add, err, slot_out);
+    if (fresh) {                                   // (others may already be lowering the pair: atomics)
+        atomicMin((unsigned long long*)&si.seen[2 * *slot_out], (unsigned long long)si.a);
+        if (si.both) atomicMin((unsigned long long*)&si.seen[2 * *slot_out + 1], (unsigned long long)si.b);
+    }
+    return fresh;
+}
+__device__ __forceinline__ u32 upsert_seen(Slot2* slots, u64 cap, Key<2> key, u32 add, u32* err, u64* slot_out, const SeenInit& si) { return upsert(slots, cap, key, add, err, slot_out, &si); }
+__device__ __forceinline__ u32 upsert_seen(Slot3* slots, u64 cap, Key<3> key, u32 add, u32* err, u64* slot_out, const SeenInit& si) { return upsert(slots, cap, key, add, err, slot_out, &si); }
 
 struct TableAux { u64 occupied; u32 err; u32 pad; };
 
@@ -199,9 +221,6 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
         if (SEEN) {
             const bool flipped = (key.w[0] & RC_MARK) != 0;
             key.w[0] &= ~RC_MARK;
-            u64 slot;
-            const u32 was_fresh = upsert(slots, cap, key, wts ? wts[i] : 1u, err, &slot);
-            fresh += was_fresh;
             const u64 g = sp.rec0 + i;
             u64 P, Q;
             if (sp.win_prefix) {        // a read's forward windows take 2*prefix + [0, W), its reverse complement's the next W
@@ -215,7 +234,11 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
                 const u64 r = sp.read0 + g / sp.per_read, i0 = sp.win0 + (g % sp.per_read) * sp.span;
                 P = r * 2 * sp.windows + i0; Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
             }
-            lower_seen(sp.seen, slot, flipped ? Q : P, flipped ? P : Q, sp.rc != 0, was_fresh);
+            const SeenInit si{sp.seen, flipped ? Q : P, flipped ? P : Q, sp.rc != 0};
+            u64 slot = 0;
+            const u32 was_fresh = upsert_seen(slots, cap, key, wts ? wts[i] : 1u, err, &slot, si);   // (a new key gets the pair inside the claim)
+            fresh += was_fresh;
+            if (!was_fresh) lower_seen(sp.seen, slot, si.a, si.b, si.both, 0);
         } else {
             fresh += upsert(slots, cap, key, wts ? wts[i] : 1u, err);
         }
@@ -305,11 +328,12 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
                 if (kmer_seen) {
                     // the o-th sub-window of the tile was first put in at base + o*stride; the reverse complement of
                     // the tile holds its reverse complement as sub-window span-1-o
-                    u64 slot;
-                    const u32 was_fresh = upsert(kmers, kmer_cap, x, lcnt[t], err, &slot);
-                    fresh += was_fresh;
                     const u64 fwd = lseen[2 * t] + (u64)o * stride, rev = lseen[2 * t + 1] + (u64)(span - 1 - o) * stride;
-                    lower_seen(kmer_seen, slot, flipped ? rev : fwd, flipped ? fwd : rev, RC, was_fresh);
+                    const SeenInit si{kmer_seen, flipped ? rev : fwd, flipped ? fwd : rev, RC};
+                    u64 slot = 0;
+                    const u32 was_fresh = upsert_seen(kmers, kmer_cap, x, lcnt[t], err, &slot, si);
+                    fresh += was_fresh;
+                    if (!was_fresh) lower_seen(kmer_seen, slot, si.a, si.b, si.both, 0);
                 } else {
                     fresh += upsert(kmers, kmer_cap, x, lcnt[t], err);
                 }

@@ -15,7 +15,7 @@ out = ["# %s — every stage before collapse on one MI355X (tools/bench_pipeline
        "remove_dead_paths — `assemble_with_graph` (asm/basic_assembler.rs:58-72) up to `collapse`, each stage index for index the reference's graph "
        "(tests/test_gpu_prune.py::test_every_stage_up_to_collapse, tools/soak_pipeline.py).\n",
        "One process per run, so `build` includes the first allocations, whose cost is the driver's: near zero on a fresh box, 10-35 GB/s when "
-       "another process has just used the memory (DESIGN.md section 3). The warm build is 1.03 s (`bench.py --first-seen-order`).\n"]
+       "another process has just used the memory (DESIGN.md section 3). The warm build is 1.02 s (`bench.py --first-seen-order`).\n"]
 for f, cmd in (("pipeline100.json", "--workload c3 --reads 100000000"), ("pipeline_c3.json", "--workload c3")):
     d = json.load(open(G(f)))
     out += ["## `python tools/bench_pipeline.py %s`\n" % cmd, "| stage | ms | nodes after | edges after |\n|---|---|---|---|"]
@@ -42,7 +42,7 @@ out = ["# %s — remove_dead_paths with both swap_remove replays on the device, 
        "`stats` is unchanged; `host_ms` is 0 because no pass fell back to the sequential replay.\n",
        "## C3 in full (200 M reads, 1.61 G edges): `python tools/bench_prune.py --workload c3`\n",
        "```json\n" + json.dumps(keep(dc3)) + "\n```\n",
-       "`build_ms` is the first build of the process, allocations included (see the pipeline note); the warm build is 1.03 s.\n",
+       "`build_ms` is the first build of the process, allocations included (see the pipeline note); the warm build is 1.02 s.\n",
        "Per-stage times (`KATOME_TRACE_PRUNE=1`), pass 1 and a closing pass:\n",
        "```\n" + "\n".join(block(1)) + "\n...\n" + "\n".join(block(30)) + "\n```\n",
        "All passes:\n\n```\n" + "\n".join(l for l in lines if l.startswith("[prune] pass")) + "\n```\n",
