@@ -1,0 +1,45 @@
+"""Random small builds through shrink (unitig compaction) against the oracle's literal shrink, on the graphs where the
+reference's result does not depend on its traversal order (every vertex reachable from a vertex without incoming edges;
+DESIGN.md section 10).  usage: python tools/fuzz_shrink.py [cases=200] [seed=0]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+from test_gpu_shrink import _contigs, _reaches_everything_from_inputs
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+bad = compared = 0
+for c in range(cases):
+    k = int(rng.choice([5, 9, 15, 16, 21, 31, 32, 33, 40, 55, 63]))
+    L = k + int(rng.integers(1, 100))
+    n = int(rng.integers(1, 2500))
+    glen = int(rng.choice([L + 30, 2000, 30000]))
+    rc = bool(rng.integers(0, 2))
+    err = float(rng.choice([0.0, 0.0, 5e-3, 2e-2]))
+    reads = o.synth_reads(int(rng.integers(0, 1000)), n, L, glen, err, 0)
+    full = o.build_ascii(reads, k, rc)
+    if not _reaches_everything_from_inputs(full):
+        continue
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc, first_seen_order=bool(rng.integers(0, 2)))
+    try:
+        b.count_reads(packed, n, L)
+        b.finalize()
+        dc = b.shrink()
+        want = o.build_ascii(reads, k, rc, stages="s")
+        ok = (dc.n_nodes, dc.n_edges) == (want.n_nodes, want.n_edges) and _contigs(dc, k) == want.contigs()
+    except AssertionError:
+        ok = False
+    finally:
+        b.close()
+    compared += 1
+    if not ok:
+        bad += 1
+        print("MISMATCH case %d: k=%d L=%d n=%d glen=%d rc=%s err=%g" % (c, k, L, n, glen, rc, err), flush=True)
+print("%d cases, %d compared, %d mismatches" % (cases, compared, bad))
+sys.exit(1 if bad else 0)
