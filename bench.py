@@ -8,7 +8,9 @@ k-mer extraction -> k-mer table -> sorted distinct edges -> node numbering, endp
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5] [--reads R]
 
-N>1 is launched by torch.distributed.run, one rank per GPU; reads shard by index and k-mers are
+N>1: one rank per GPU.  Started by a launcher (torch.distributed.run: WORLD_SIZE set) or, without one, by this very
+script (katome_amd/launch.py: the parent starts the N ranks before anything touches the GPU and relays rank 0's line).
+Reads shard by index and k-mers are
 redistributed by hash with an RCCL all-to-all before insertion (katome_amd/dist.py).
 """
 import argparse
@@ -191,8 +193,30 @@ def cpu_baseline(wl, sample_reads):
             "distinct_edges_per_s": g.n_edges / dt}
 
 
+def run_as_parent(args):
+    """`--gpus N` (N > 1) without a launcher: this process starts the N ranks itself -- BEFORE anything touches the GPU
+    (no torch import here), so no process that has initialised HIP is ever re-executed -- relays rank 0's one JSON line
+    and fails if a rank fails or if the line is not an N-GPU line."""
+    from katome_amd.launch import launch_ranks, relay_one_json_line
+    argv = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    rc, out = launch_ranks(args.gpus, argv)
+    if rc != 0:
+        raise SystemExit("bench.py --gpus %d: a rank failed (exit code %d); no result" % (args.gpus, rc))
+    line = relay_one_json_line(out)
+    if line is None:
+        raise SystemExit("bench.py --gpus %d: rank 0 printed no JSON line" % args.gpus)
+    if json.loads(line).get("n_gpus") != args.gpus:
+        raise SystemExit("bench.py --gpus %d: the ranks report n_gpus=%r" % (args.gpus, json.loads(line).get("n_gpus")))
+    sys.stdout.write(line + "\n")
+    sys.stdout.flush()
+
+
 def main():
     args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return run_as_parent(args)
     # libraries (RCCL) print banners on fd 1; the contract is ONE JSON line on stdout, so the real stdout is
     # set aside for that line and fd 1 points at stderr for everything else
     sys.stdout.flush()
@@ -205,8 +229,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launcher must start exactly --gpus ranks" % (args.gpus, world))
+    n_visible = torch.cuda.device_count()            # (counting devices does not initialise HIP)
+    if n_visible < int(os.environ.get("LOCAL_WORLD_SIZE", world)):
+        raise SystemExit("rank %d: --gpus %d but only %d GPU(s) visible on this node" % (rank, args.gpus, n_visible))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the build has no CPU fallback")
     torch.cuda.set_device(local_rank)
