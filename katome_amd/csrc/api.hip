@@ -70,6 +70,7 @@ struct katome_builder {
     uint64_t var_records = 0;                  // how many of them: the insert that follows must take exactly these
     uint32_t var_mode = 0, var_span = 1;       // 0 every window, 1 whole tiles, 2 the windows after the last whole tile
     DevBuf edge_seq;                   // sequence number of each edge's first insertion, aligned with edge_key
+    uint64_t direct_edges = 0;         // BFCounter input: the edges were listed one per line and strand (no table); their count
     uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
     uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
     // sorted distinct oriented edges
@@ -248,6 +249,10 @@ uint32_t katome_key_owner(const uint64_t* key, uint32_t key_words, uint32_t core
         Key<1> a; a.w[0] = key[0];
         return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
     }
+    if (key_words == 3) {
+        Key<3> a; a.w[0] = key[0]; a.w[1] = key[1]; a.w[2] = key[2];
+        return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
+    }
     Key<2> a; a.w[0] = key[0]; a.w[1] = key[1];
     return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
 }
@@ -365,6 +370,35 @@ static int region_passes(uint64_t table_bytes) {
     (void)table_bytes;
     if (const char* e = getenv("KATOME_REGION_PASSES")) return std::max(0, std::min(2, atoi(e)));
     return 0;
+}
+
+// BFCounter input: one edge per kept line and strand, never merged (add_single_edge_bfc, pt_graph.rs:201-213, calls
+// add_edge unconditionally).  d_fwd: the lines' k-mers as packed keys in line order, d_w their weights.  Leaves the
+// builder with its sorted edge list, as katome_dev_edges would.
+static int bfc_set_edges(katome_builder* b, const uint64_t* d_fwd, const uint32_t* d_w, uint64_t n_lines, hipStream_t stream) {
+    const uint64_t E = n_lines * (b->rc ? 2 : 1);
+    const uint32_t nw = b->nw;
+    if (b->edges_ready || b->table_ready || b->tiles_ready) { set_error("BFCounter input cannot be mixed with counted reads"); return KATOME_E_ARG; }
+    b->n_edges = E; b->direct_edges = E;
+    KCHECK(b->edge_key.alloc((E + 1) * 8 * nw, stream));
+    KCHECK(b->edge_weight.alloc((E + 1) * 4, stream));
+    PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
+    if (b->first_seen) {
+        if (E >= (1ull << 32)) { set_error("first-seen order: more than 2^32 edges on one GPU"); return KATOME_E_UNSUPPORTED; }
+        DevBuf raw_w(stream), raw_seq(stream), idx(stream);
+        KCHECK(raw_w.alloc((E + 1) * 4)); KCHECK(raw_seq.alloc((E + 1) * 8)); KCHECK(idx.alloc((E + 1) * 4));
+        KCHECK(dev_bfc_edges(d_fwd, d_w, n_lines, b->s.k, b->rc, b->edge_key.as<u64>(), raw_w.as<u32>(), raw_seq.as<u64>(), stream));
+        KCHECK(dev_iota(idx.as<u32>(), E, stream));
+        KCHECK(dev_sort(b->edge_key.as<u64>(), idx.as<u32>(), E, nw, 2 * b->s.k, stream));
+        KCHECK(b->edge_seq.alloc((E + 1) * 8, stream));
+        KCHECK(dev_gather_u64(raw_seq.as<u64>(), idx.as<u32>(), E, b->edge_seq.as<u64>(), stream));
+        KCHECK(dev_gather_u32(raw_w.as<u32>(), idx.as<u32>(), E, b->edge_weight.as<u32>(), stream));
+    } else {
+        KCHECK(dev_bfc_edges(d_fwd, d_w, n_lines, b->s.k, b->rc, b->edge_key.as<u64>(), b->edge_weight.as<u32>(), nullptr, stream));
+        KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), E, nw, 2 * b->s.k, stream));   // stable: a k-mer's lines stay in file order
+    }
+    b->edges_ready = true;
+    return KATOME_OK;
 }
 
 extern "C" {
@@ -596,8 +630,9 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         };
         const uint64_t N = b->n_nodes;
         if (N >= (1ull << 32)) { set_error("first-seen order: more than 2^32 nodes on one GPU"); return KATOME_E_UNSUPPORTED; }
-        const uint64_t max_seq = b->var_seq_base ? 2 * b->var_seq_base + 2
-                                                 : 2 * (b->reads_inserted + 1) * 2 * (uint64_t)(b->seen_read_len - k + 1) + 2;
+        const uint64_t max_seq = b->direct_edges ? 2 * b->direct_edges + 2
+                                 : b->var_seq_base ? 2 * b->var_seq_base + 2
+                                                   : 2 * (b->reads_inserted + 1) * 2 * (uint64_t)(b->seen_read_len - k + 1) + 2;
         uint32_t bits = 1;
         while (bits < 64 && (max_seq >> bits)) ++bits;
         // (buffers are taken and given back one at a time: at C3 every one of them is 6-13 GB)
@@ -688,6 +723,7 @@ int katome_dev_remove_dead_paths(katome_builder* b, katome_dev_graph* out, katom
     if (!b->finalized) { set_error("remove_dead_paths: call katome_dev_finalize first"); return KATOME_E_ARG; }
     const auto t0 = std::chrono::steady_clock::now();
     PruneGraph g{&b->edge_src, &b->edge_dst, &b->edge_weight, &b->edge_key, &b->node_key, &b->edge_age, b->n_edges, b->n_nodes, b->nw};
+    g.parallel_edges = b->direct_edges != 0;
     katome_prune_stats st;
     {
         PhaseScope ps(b->prof, PH_DEAD_PATHS, stream);
@@ -1165,9 +1201,8 @@ static int build_files_impl(const katome_settings* s, const char* const* paths, 
     build_lap("ingest (host)");
     if (s->file_type == 2) {
         // BFCounter (create_bfc, builder.rs:79-115; add_read_bfc, pt_graph.rs:317-330): every kept line is a k-mer
-        // with a weight -> one record per line (read length == k), added with its weight.  Lines naming the same
-        // k-mer (or, with reverse_complement, a k-mer and its reverse complement) add up here, where the reference
-        // keeps parallel edges: BFCounter output lists each k-mer once, so the two agree on such input.
+        // with a weight -> one edge per line and strand, exactly as add_single_edge_bfc (pt_graph.rs:201-213) adds them:
+        // lines naming the same k-mer, and a k-mer that is its own reverse complement, stay parallel edges.
         katome_builder* b = nullptr;
         KCHECK(katome_builder_create(s, &b));
         int rc = KATOME_OK;
@@ -1177,8 +1212,9 @@ static int build_files_impl(const katome_settings* s, const char* const* paths, 
                 if ((rc = d_packed.alloc(hr.packed_bytes + 32)) || (rc = d_w.alloc(hr.n_reads * 4)) || (rc = d_rec.alloc(hr.n_reads * 8 * b->nw + 16))) break;
                 if (hipMemcpy(d_packed.p, hr.packed, hr.packed_bytes, hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(d_w.p, hr.weight, hr.n_reads * 4, hipMemcpyHostToDevice) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
-                if ((rc = katome_dev_extract_fixed(b, d_packed.as<uint8_t>(), hr.n_reads, s->k, nullptr, d_rec.as<u64>(), nullptr))) break;
-                if ((rc = katome_dev_insert_weighted(b, d_rec.as<u64>(), d_w.as<u32>(), hr.n_reads, nullptr))) break;
+                // the lines' k-mers as they are written (no canonical form: both strands become edges of their own)
+                if ((rc = launch_extract_fixed(s->k, false, d_packed.as<uint8_t>(), hr.n_reads, s->k, nullptr, d_rec.as<u64>(), nullptr))) break;
+                if ((rc = bfc_set_edges(b, d_rec.as<u64>(), d_w.as<u32>(), hr.n_reads, nullptr))) break;
                 if (hipStreamSynchronize(nullptr) != hipSuccess) { set_error("device failure during build"); rc = KATOME_E_DEVICE; break; }
             }
             rc = finish(b, hr.read_bytes);

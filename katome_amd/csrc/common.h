@@ -125,6 +125,9 @@ int dev_permute_edges(uint64_t* key, uint32_t* weight, uint64_t* src, uint64_t* 
 int dev_node_first(const uint64_t* src, const uint64_t* dst, const uint64_t* seq, uint64_t n, uint64_t* node_first, hipStream_t stream);
 int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream);
 int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream);
+// BFCounter lines -> one edge per line (and per strand), unmerged (pt_graph.rs:201-213); seq (nullable) = petgraph index
+int dev_bfc_edges(const uint64_t* d_fwd, const uint32_t* d_w, uint64_t n, uint32_t k, bool rc, uint64_t* d_edge_key,
+                  uint32_t* d_edge_weight, uint64_t* d_edge_seq, hipStream_t stream);
 // exclusive scan of m u32 counts into u64 offsets (offs[m] = total), one workgroup
 int dev_scan_counts(const uint32_t* d_counts, uint64_t m, uint64_t* d_offs, hipStream_t stream);
 
@@ -135,6 +138,7 @@ struct PruneGraph {
                            // edges but never reorders the lists); empty = the edges still sit at their first-seen positions
     uint64_t n_edges, n_nodes;
     uint32_t nw;
+    bool parallel_edges = false;   // BFCounter graphs may hold the same k-mer on several edges: no per-base adjacency slots then
 };
 // scratch of dev_replay_edges, kept across the passes of remove_dead_paths
 struct ReplayScratch {

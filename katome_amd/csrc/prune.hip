@@ -924,7 +924,7 @@ int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hip
     // adjacency slots (32 B per vertex): without them -- not enough memory, or KATOME_PRUNE_NO_SLOTS -- every pass streams all edges
     DevBuf out_slots(stream), in_slots(stream), redo_list(stream), stamp(stream);
     Slots slots{nullptr, nullptr, nw, k};
-    if (!getenv("KATOME_PRUNE_NO_SLOTS") && out_slots.alloc((N + 1) * 16) == KATOME_OK && in_slots.alloc((N + 1) * 16) == KATOME_OK) {
+    if (!g.parallel_edges && !getenv("KATOME_PRUNE_NO_SLOTS") && out_slots.alloc((N + 1) * 16) == KATOME_OK && in_slots.alloc((N + 1) * 16) == KATOME_OK) {
         slots.out = out_slots.as<u32>(); slots.in = in_slots.as<u32>();
     } else {
         out_slots.release(); in_slots.release();

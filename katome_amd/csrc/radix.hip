@@ -30,9 +30,21 @@ template <int NW> struct RadixDigit {
 template <int NW> struct OwnerDigit {
     u64 n_parts;
     u32 core_shift, core_bases;          // core_bases == 0: owner by the whole key; else kmer_bits.h core_owner
-    __device__ __forceinline__ u32 operator()(const Key<NW>& k) const {
-        if (!key_valid(k)) return (u32)n_parts;
+    __device__ __forceinline__ u32 operator()(const Key<NW>& k0) const {
+        if (!key_valid(k0)) return (u32)n_parts;
+        Key<NW> k = k0;
+        k.w[0] &= ~RC_MARK;              // first-seen-order records carry the orientation they dropped: not part of the key
         return core_bases ? (u32)core_owner(k, core_shift, core_bases, n_parts) : (u32)hash_to_range(hash_key(k), n_parts);
+    }
+};
+// owner = the part of an ascending list of u64 values a value falls into: bounds[p] = first value of part p + 1
+// (n_parts - 1 of them); used to spread sequence numbers over the ranks for a global ranking
+struct RangeDigit {
+    const u64* bounds; u32 n_parts;
+    __device__ __forceinline__ u32 operator()(const Key<1>& k) const {
+        u32 p = 0;
+        for (u32 i = 0; i + 1 < n_parts; ++i) p += k.w[0] >= bounds[i];
+        return p;
     }
 };
 
@@ -46,12 +58,14 @@ template <int NW> struct HashDigit {
 template <int NW> __device__ __forceinline__ Key<NW> load_key(const u64* p, u64 i) {
     Key<NW> k;
     if (NW == 1) { k.w[0] = p[i]; }
-    else { ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + 2 * i); k.w[0] = v.x; k.w[NW - 1] = v.y; }
+    else if (NW == 2) { ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p + 2 * i); k.w[0] = v.x; k.w[NW - 1] = v.y; }
+    else { k.w[0] = p[3 * i]; k.w[NW > 2 ? 1 : 0] = p[3 * i + 1]; k.w[NW - 1] = p[3 * i + 2]; }      // three-word tiles (64..95 bases)
     return k;
 }
 template <int NW> __device__ __forceinline__ void store_key(u64* p, u64 i, const Key<NW>& k) {
     if (NW == 1) p[i] = k.w[0];
-    else *reinterpret_cast<ulonglong2*>(p + 2 * i) = make_ulonglong2(k.w[0], k.w[NW - 1]);
+    else if (NW == 2) *reinterpret_cast<ulonglong2*>(p + 2 * i) = make_ulonglong2(k.w[0], k.w[NW - 1]);
+    else { p[3 * i] = k.w[0]; p[3 * i + 1] = k.w[NW > 2 ? 1 : 0]; p[3 * i + 2] = k.w[NW - 1]; }
 }
 
 // ---- pass 1: per-workgroup digit histogram -> counts[block][digit] ----------------------------
@@ -240,6 +254,9 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
     hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>());
     hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
     const size_t lds = (size_t)SORT_TILE * NW * 8;
+    if (lds > (64u << 10)) {          // three-word records: 96 KiB of the CU's 160 KiB
+        KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
                        pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout);
     KCHECK_HIP(hipGetLastError());
@@ -391,9 +408,9 @@ int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32
 // Optional u32 values travel with their records.
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
                   uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift, uint32_t core_bases) {
-    if (core_bases && (core_shift + 2 * core_bases > 64u * nw || 2 * core_bases > 126)) { set_error("partition: core outside the key"); return KATOME_E_ARG; }
+    if (core_bases && (core_shift + 2 * core_bases > 64u * nw || 2 * core_bases > 190)) { set_error("partition: core outside the key"); return KATOME_E_ARG; }
     if (n_parts == 0 || n_parts >= (u32)RADIX) { set_error("n_parts must be 1..255"); return KATOME_E_ARG; }
-    if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
+    if (nw < 1 || nw > 3) { set_error("key_words must be 1..3"); return KATOME_E_ARG; }
     if ((v_in == nullptr) != (v_out == nullptr)) { set_error("partition: values in and out must both be given"); return KATOME_E_ARG; }
     for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
     if (n == 0) return KATOME_OK;
@@ -403,10 +420,14 @@ int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32
         OwnerDigit<1> dg{n_parts, core_shift, core_bases};
         if (v_in) KCHECK((radix_pass<1, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
         else      KCHECK((radix_pass<1, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
-    } else {
+    } else if (nw == 2) {
         OwnerDigit<2> dg{n_parts, core_shift, core_bases};
         if (v_in) KCHECK((radix_pass<2, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
         else      KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
+    } else {                          // three-word tiles (k > 32 with a useful span: C5's 90-mers)
+        OwnerDigit<3> dg{n_parts, core_shift, core_bases};
+        if (v_in) KCHECK((radix_pass<3, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
+        else      KCHECK((radix_pass<3, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
     }
     u64 totals[RADIX];
     KCHECK_HIP(hipMemcpyAsync(totals, pb.totals.p, sizeof totals, hipMemcpyDeviceToHost, stream));
@@ -990,6 +1011,38 @@ int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* 
     dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
     if (key_words_for_k(k) == 1) hipLaunchKernelGGL(endpoints_kernel<1>, grid, block, 0, stream, d_edge_key, n, k, d_src, d_dst);
     else                         hipLaunchKernelGGL(endpoints_kernel<2>, grid, block, 0, stream, d_edge_key, n, k, d_src, d_dst);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+// BFCounter input (create_bfc builder.rs:79-115 -> add_read_bfc pt_graph.rs:317-330 -> add_single_edge_bfc 201-213): every
+// kept line is ONE edge -- and with reverse_complement a second one for its reverse complement, right after it -- added
+// with `add_edge` unconditionally: a k-mer listed twice, or a k-mer that is its own reverse complement, stays as parallel
+// edges.  So there is no table here: line i becomes edge i (2i and 2i+1 with both strands), whose sequence number is its
+// petgraph index.
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void bfc_edges_kernel(const u64* __restrict__ fwd, const u32* __restrict__ w, u64 n, u32 k, bool rc,
+                                                           u64* __restrict__ ek, u32* __restrict__ ew, u64* __restrict__ seq) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        Key<NW> key = load_key<NW>(fwd, i);
+        const u32 wi = w[i];
+        if (rc) {
+            store_key<NW>(ek, 2 * i, key); store_key<NW>(ek, 2 * i + 1, revcomp(key, k));
+            ew[2 * i] = wi; ew[2 * i + 1] = wi;
+            if (seq) { seq[2 * i] = 2 * i; seq[2 * i + 1] = 2 * i + 1; }
+        } else {
+            store_key<NW>(ek, i, key);
+            ew[i] = wi;
+            if (seq) seq[i] = i;
+        }
+    }
+}
+int dev_bfc_edges(const uint64_t* d_fwd, const uint32_t* d_w, uint64_t n, uint32_t k, bool rc, uint64_t* d_edge_key,
+                  uint32_t* d_edge_weight, uint64_t* d_edge_seq, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
+    if (key_words_for_k(k) == 1) hipLaunchKernelGGL(bfc_edges_kernel<1>, grid, block, 0, stream, d_fwd, d_w, n, k, rc, d_edge_key, d_edge_weight, d_edge_seq);
+    else                         hipLaunchKernelGGL(bfc_edges_kernel<2>, grid, block, 0, stream, d_fwd, d_w, n, k, rc, d_edge_key, d_edge_weight, d_edge_seq);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }

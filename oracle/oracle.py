@@ -288,9 +288,11 @@ def build_files(paths, k, reverse_complement=False, file_type=1, with_gir=False,
         lib().ko_graph_free(gp)
 
 
-def build_bfc(paths, k, reverse_complement=False, threshold=0):
+def build_bfc(paths, k, reverse_complement=False, threshold=0, remove_dead_paths=False, stages=None):
     gp = C.POINTER(KoGraph)()
+    _stages(None, remove_dead_paths, stages)
     rc = lib().ko_build_bfc(_paths(paths), len(paths), int(reverse_complement), threshold, k, C.byref(gp))
+    lib().ko_set_post_build(b"", 0)
     if rc:
         raise OracleError(rc, lib().ko_last_error().decode())
     try:

@@ -19,12 +19,13 @@ def _build_files(paths, k, rc, ft=None):
     return GpuGraph.create(paths, ft if ft is not None else InputFileType.Fastq, rc, 0)
 
 
-def _check_graph_consistency(g, k):
-    """structure every build must have, whatever the input"""
+def _check_graph_consistency(g, k, distinct=True):
+    """structure every build must have, whatever the input (distinct=False: BFCounter input may list a k-mer on several lines,
+    which stay parallel edges as in the reference)"""
     nw = g.key_words
     ek = g.key_ints("edge")
     nk = g.key_ints("node")
-    assert ek == sorted(ek) and len(set(ek)) == len(ek)              # ascending distinct k-mers
+    assert ek == sorted(ek) and (not distinct or len(set(ek)) == len(ek))   # ascending (distinct) k-mers
     assert len(set(nk)) == len(nk)                                   # distinct (k-1)-mers
     n_src = len(set(g.edge_src.tolist()))                            # nodes with out-edges come first, ascending,
     assert nk[:n_src] == sorted(nk[:n_src]) and nk[n_src:] == sorted(nk[n_src:])   # then the out-edge-less ones, ascending
@@ -99,11 +100,14 @@ def test_multifile_and_graph_topology_vs_oracle(oracle, golden_dir):
     assert ours == theirs and len(node_name) == g.n_nodes
 
 
-def test_variable_length_reads_and_fasta(oracle, tmp_path):
+@pytest.mark.parametrize("k,rc", [(11, True), (12, False), (33, True), (33, False), (63, True)])
+def test_variable_length_reads_and_fasta(oracle, tmp_path, k, rc):
+    """the file route with reads of unequal length (FASTQ, and the same reads as multi-line FASTA) against the oracle;
+    k = 33 and 63: 128-bit keys (an accepted read shorter than k is fatal in the reference, so lengths start at k)"""
     rng = np.random.default_rng(5)
     lines, fa = [], []
     for i in range(300):
-        n = int(rng.integers(12, 400))
+        n = int(rng.integers(max(12, k), 400))
         s = "".join("ACGT"[c] for c in rng.integers(0, 4, n))
         if i % 17 == 0:
             s = s[:5] + "N" + s[6:]
@@ -114,16 +118,14 @@ def test_variable_length_reads_and_fasta(oracle, tmp_path):
     faf = tmp_path / "var.fa"
     faf.write_text("\n".join(fa) + "\n")
     from katome_amd.build import InputFileType
-    for k, rc in ((11, True), (12, False), (33, True)):
-        ref = oracle.build_files([str(fq)], k, rc) if k <= 12 else None
-        if ref is None:
-            continue
-        g, rb = _build_files([str(fq)], k, rc)
-        assert rb == ref.read_bytes and g.multiset() == ref.multiset()
-        g2, rb2 = _build_files([str(faf)], k, rc, InputFileType.Fasta)
-        ref2 = oracle.build_files([str(faf)], k, rc, file_type=0)
-        assert rb2 == ref2.read_bytes == rb and g2.multiset() == ref2.multiset() == g.multiset()
-        _check_graph_consistency(g, k)
+    ref = oracle.build_files([str(fq)], k, rc)
+    g, rb = _build_files([str(fq)], k, rc)
+    assert rb == ref.read_bytes and g.multiset() == ref.multiset()
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    g2, rb2 = _build_files([str(faf)], k, rc, InputFileType.Fasta)
+    ref2 = oracle.build_files([str(faf)], k, rc, file_type=0)
+    assert rb2 == ref2.read_bytes == rb and g2.multiset() == ref2.multiset() == g.multiset()
+    _check_graph_consistency(g, k)
 
 
 def test_error_paths_on_gpu_box(golden_dir):
@@ -203,6 +205,40 @@ def test_synthetic_build_equals_oracle(oracle, k, rc, n, L):
     assert g.key_ints("edge") == list(ref_keys)
     assert g.multiset() == ref.multiset()
     _check_graph_consistency(g, k)
+
+
+def test_c2_in_full_equals_oracle(oracle):
+    """BASELINE configs[1] in full -- 1 M synthetic 150 bp reads, k=31, both strands, 1 % of the reads hold an N -- through
+    the host ABI (katome_build_packed) against the oracle's sequential build: the whole edge multiset (labels in
+    compress_edge format + weights), node and edge counts, read bytes and the CollectionStats the reference's tests
+    compare (stats/collections.rs:137-168).  The oracle needs a couple of minutes for its 2.4e8 insertions."""
+    from katome_amd.build import GpuGraph
+    from katome_amd.workloads import WORKLOADS
+    wl = WORKLOADS["c2"]
+    ascii_reads = oracle.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, wl.n_inject_percent)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("C")
+    g, rb = GpuGraph.create_from_packed(pack_reads_ascii(clean).reshape(-1), wl.reads, wl.read_len,
+                                        skip=has_n.astype(np.uint8), reverse_complement=True, k=wl.k)
+    del clean
+    ref = oracle.build_ascii(ascii_reads, wl.k, True)
+    assert rb == ref.read_bytes == int((~has_n).sum()) * wl.read_len and 0 < int(has_n.sum()) < wl.reads // 50
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges) and g.n_edges > 9_000_000
+
+    def ordered(labels, weights):           # rows sorted as byte strings; the weights follow their labels
+        v = np.ascontiguousarray(labels).view("V%d" % labels.shape[1]).reshape(-1)
+        o = np.argsort(v, kind="stable")
+        return np.ascontiguousarray(labels)[o], np.asarray(weights)[o]
+    gl, gw = ordered(g.edge_label, g.edge_weight)
+    rl, rw = ordered(ref.edge_label, ref.edge_weight)
+    assert np.array_equal(gl, rl) and np.array_equal(gw.astype(np.uint32), rw.astype(np.uint32))
+    st = g.stats()
+    for f in ("node_count", "edge_count", "max_edge_weight", "max_in_degree", "max_out_degree", "incoming_vert_count",
+              "outgoing_vert_count"):
+        assert getattr(st, f) == ref.stats[f], f
+    assert round(st.avg_edge_weight, 2) == round(ref.stats["avg_edge_weight"], 2)          # stats/collections.rs:71-89
+    assert round(st.avg_out_degree, 2) == round(ref.stats["avg_out_degree"], 2)
 
 
 def test_high_multiplicity_and_table_growth(oracle):
@@ -522,6 +558,12 @@ def test_bfcounter_input(oracle, golden_dir, tmp_path, k, rc):
             continue
         seen.add(min(km, r))
         lines.append("%s\t%d" % (km if rng.random() < 0.5 else r, w + rng.randrange(3)))
+    # the reference adds every line with add_edge, unconditionally (pt_graph.rs:200-213): a k-mer listed twice -- in the
+    # same orientation or as its reverse complement -- stays as parallel edges, and so it must here
+    lines += [lines[0], lines[3], "%s\t%d" % (lines[5].split("\t")[0].translate(comp)[::-1], 7)]
+    if k % 2 == 0:
+        pal = ("ACGT" * k)[:k // 2]
+        lines.append("%s\t5" % (pal + pal.translate(comp)[::-1]))      # its own reverse complement: two parallel edges with rc
     bfc = tmp_path / "kmers.bfc"
     bfc.write_text("\n".join(lines) + "\n")
     for thr in (0, 2):
@@ -532,16 +574,10 @@ def test_bfcounter_input(oracle, golden_dir, tmp_path, k, rc):
             g, rb = GpuGraph.create([str(bfc)], InputFileType.BFCounter, rc, thr)
         ref = oracle.build_bfc([str(bfc)], k, rc, thr)
         assert rb == ref.read_bytes
-        if rc and k % 2 == 0:
-            # a self-complementary k-mer is two parallel edges in the reference, one edge of twice the weight here
-            merged = {}
-            for km, w in ref.multiset():
-                merged[km] = merged.get(km, 0) + w
-            assert g.multiset() == sorted(merged.items())
-        else:
-            assert g.multiset() == ref.multiset()
-            assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
-        _check_graph_consistency(g, k)
+        assert g.multiset() == ref.multiset()
+        assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+        assert len(g.multiset()) > len(set(km for km, _ in g.multiset()))       # parallel edges really are there
+        _check_graph_consistency(g, k, distinct=False)
 
 
 def _fixture_on_device(golden_dir, name, k):
@@ -675,11 +711,17 @@ def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
     from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
     base = oracle.build_files([os.path.join(golden_dir, "data1.txt")], 31, False)
     bfc = tmp_path / "k.bfc"
-    bfc.write_text("".join("%s\t%d\n" % (km, w) for km, w in reversed(base.multiset())))
+    ms = list(reversed(base.multiset()))
+    comp = str.maketrans("ACGT", "TGCA")
+    ms += [ms[2], (ms[4][0].translate(comp)[::-1], 9), ms[2]]         # repeated lines: parallel edges (pt_graph.rs:200-213)
+    bfc.write_text("".join("%s\t%d\n" % (km, w) for km, w in ms))
     set_global_k_sizes(31)
     for rc in (False, True):
         g, _ = GpuGraph.create([str(bfc)], InputFileType.BFCounter, rc, 0, first_seen_order=True)
         _assert_same_as_reference_order(g, oracle.build_bfc([str(bfc)], 31, rc, 0))
+        # ... and the reference's first pruning on such a graph (no per-base adjacency slots with parallel edges)
+        g, _ = GpuGraph.create([str(bfc)], InputFileType.BFCounter, rc, 0, first_seen_order=True, remove_dead_paths=True)
+        _assert_same_as_reference_order(g, oracle.build_bfc([str(bfc)], 31, rc, 0, remove_dead_paths=True))
 
 
 def _two_rank_worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
