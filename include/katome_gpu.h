@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define KATOME_ABI_VERSION 1
+#define KATOME_ABI_VERSION 2
 
 /* settings.flags.  FIRST_SEEN_ORDER: number edges and nodes exactly as the reference's sequential loop does --
  * petgraph edge indices in the order `add_edge` is first called for them, node indices in the order `add_node`
@@ -38,6 +38,10 @@ extern "C" {
  * walks and swap-removes depend on petgraph's numbering, so this needs FIRST_SEEN_ORDER as well (KATOME_E_ARG
  * otherwise); the result then equals the reference's pruned PtGraph index for index.                      */
 #define KATOME_FLAG_REMOVE_DEAD_PATHS 2u
+/* n_devices > 1 only: all ranks of the sharded build run on settings.device (peer copies instead of RCCL, which refuses two
+ * ranks on one GPU).  Exercises the whole multi-GPU route -- sharding, routing, exchanges, global numbering -- on a
+ * one-GPU box; no performance meaning.                                                                       */
+#define KATOME_FLAG_RANKS_SHARE_DEVICE 4u
 
 /* status codes: the reference's panics, one code each */
 enum {
@@ -61,8 +65,15 @@ typedef struct {
     uint8_t  reverse_complement; /* Config::reverse_complement                                     */
     uint16_t flags;              /* KATOME_FLAG_*                                                   */
     uint32_t min_weight;         /* minimal_weight_threshold (BFCounter ingest only, builder.rs:106)*/
-    int32_t  device;             /* HIP device ordinal of the MI355X to build on                     */
-    uint64_t table_slots_hint;   /* 0 = size the (k-1)-mer/edge table automatically                 */
+    int32_t  device;             /* HIP device ordinal of the (first) MI355X to build on             */
+    uint64_t table_slots_hint;   /* 0 = size the (k-1)-mer/edge table automatically (whole build)   */
+    /* GPUs of this node to build on: 0 or 1 = settings.device alone; n > 1 = devices device .. device+n-1,
+     * one host thread and one rank per GPU INSIDE this call, reads sharded by index, records routed to their owners over
+     * RCCL (katome_build_files / katome_build_packed; fixed-length reads -- other inputs are built on `device` alone).
+     * The result does not depend on n in FIRST_SEEN_ORDER (the reference's numbering); by packed key, edges and nodes
+     * come rank by rank (every rank's in ascending order).                                                   */
+    int32_t  n_devices;
+    uint32_t _reserved;
 } katome_settings;
 
 /* Result of a build, host memory, owned by the library until katome_graph_free().
@@ -212,7 +223,7 @@ int katome_dev_extract_var_remainder(katome_builder *b, const uint8_t *d_packed,
                                      const uint64_t *d_win_prefix, uint64_t n_reads, uint64_t total_rest,
                                      uint64_t total_windows, uint32_t span, uint64_t *d_records, void *stream);
 
-/* group records of `key_words` u64 words by owner rank = mulhi(mix(key), n_parts) (stable; invalid records are
+/* group records of `key_words` (1..3) u64 words by owner rank = mulhi(mix(key), n_parts) (stable; invalid records are
  * dropped); optional u32 values travel with their records (both d_values and d_values_out, or neither).
  * d_out: same size as d_records; h_counts[n_parts] receives the records per part (synchronises)       */
 int katome_dev_partition(int device, const uint64_t *d_records, const uint32_t *d_values, uint64_t n_records,
@@ -378,6 +389,81 @@ int katome_dev_edges(katome_builder *b, uint64_t **d_edge_key, uint32_t **d_edge
 /* The library keeps freed device blocks for reuse (hipMalloc/hipFree of multi-GiB buffers are slow);
  * this hands them back to the driver.                                                         */
 int katome_dev_release_cache(int device);
+
+/* ---- multi-GPU: the sharded build, one rank per GPU -------------------------------------------------------
+ * The reference is one sequential loop (builder.rs:152-160); what shards is the read set.  Reads are split contiguously by
+ * index over the ranks; every rank extracts its own records and routes each to its owner rank; owners count; the graph
+ * is numbered across ranks.  Inside katome_build_* (settings.n_devices) the ranks are host threads of the calling process;
+ * a job that runs one PROCESS per GPU (bench.py under a launcher) creates a communicator per process and drives
+ * katome_dist_* itself.                                                                                       */
+typedef struct katome_comm katome_comm;
+#define KATOME_COMM_ID_BYTES 128
+/* rank 0 makes the id (ncclGetUniqueId), every rank gets it out of band and joins (ncclCommInitRank) */
+int katome_comm_unique_id(uint8_t *id /* [KATOME_COMM_ID_BYTES] */);
+int katome_comm_create_rccl(const uint8_t *id, int rank, int world, int device, katome_comm **out);
+/* the caller moves the bytes (tests: torch.distributed/gloo): element counts and offsets per peer, host or device
+ * buffers (on_device); op: 0 sum, 1 max, 2 min.  Non-zero return = failure.                                 */
+typedef struct {
+    void *user;
+    int (*alltoallv)(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_cnt, void *recv,
+                     const uint64_t *recv_off, const uint64_t *recv_cnt, uint64_t elem_bytes, int on_device);
+    int (*allreduce_u64)(void *user, uint64_t *vals, uint64_t n, int op);
+} katome_comm_callbacks;
+int katome_comm_create_callbacks(const katome_comm_callbacks *cb, int rank, int world, int device, katome_comm **out);
+void katome_comm_destroy(katome_comm *c);
+int katome_comm_rank(const katome_comm *c);
+int katome_comm_world(const katome_comm *c);
+const char *katome_comm_kind(const katome_comm *c);               /* "rccl", "local", "callbacks" */
+/* a single message above this many bytes travels in rounds (default 1 GiB) */
+int katome_comm_set_max_message_bytes(katome_comm *c, uint64_t bytes);
+int katome_comm_allreduce_u64(katome_comm *c, uint64_t *vals, uint64_t n, int op);
+/* variable all-to-all: `send` holds send_cnt[p] elements for each peer p, in peer order; recv_cnt[p] is filled in and
+ * `recv` (room for recv_capacity elements) receives them grouped by source.  Collective.                   */
+int katome_comm_exchange(katome_comm *c, const void *send, const uint64_t *send_cnt, void *recv, uint64_t recv_capacity,
+                         uint64_t *recv_cnt, uint64_t elem_bytes, int on_device, void *stream);
+
+typedef struct katome_dist_builder katome_dist_builder;
+/* one rank's share of the graph, device arrays owned by the builder */
+typedef struct {
+    uint64_t n_edges, n_nodes;            /* on this rank: its edges are the out-edges of the nodes it owns ...      */
+    uint64_t total_edges, total_nodes;    /* ... of the whole graph                                                  */
+    uint64_t node_base;                   /* by packed key: global id of this rank's node i = node_base + i           */
+    uint32_t key_words, label_stride;
+    uint64_t *d_edge_key;                 /* [n_edges][key_words] ascending                                          */
+    uint32_t *d_edge_weight;
+    uint64_t *d_edge_src, *d_edge_dst;    /* GLOBAL node ids                                                         */
+    uint8_t  *d_edge_label;
+    uint64_t *d_node_key;                 /* [n_nodes][key_words]                                                    */
+    uint64_t *d_edge_id, *d_node_id;      /* FIRST_SEEN_ORDER: the reference's (petgraph) index of every edge / node of
+                                             this rank; NULL by packed key                                           */
+} katome_dist_graph;
+/* settings as for katome_builder_create (settings.device = this rank's GPU; table_slots_hint for the WHOLE build);
+ * the communicator stays the caller's.  Every call below is collective: all ranks make it, in the same order.        */
+int  katome_dist_create(const katome_settings *s, katome_comm *comm, katome_dist_builder **out);
+void katome_dist_destroy(katome_dist_builder *d);
+/* this rank's reads, device pointers: reads [first_read, first_read + n_reads) of the whole input in input order (the
+ * reference's numbering needs the global index), fixed length, in batches of batch_reads (0 = default).  May be called
+ * again with the reads that follow.                                                                           */
+int  katome_dist_add_reads(katome_dist_builder *d, const uint8_t *d_packed, uint64_t first_read, uint64_t n_reads,
+                           uint32_t read_len, const uint8_t *d_skip, uint64_t batch_reads, void *stream);
+/* Clean::remove_weak_edges(threshold) when the edges are read out (by packed key only; see katome_dev_remove_weak_edges) */
+int  katome_dist_remove_weak_edges(katome_dist_builder *d, uint32_t threshold);
+int  katome_dist_finalize(katome_dist_builder *d, katome_dist_graph *out, void *stream);
+/* FIRST_SEEN_ORDER: bring the whole graph to rank `root` in the reference's index order and hand it to a single-GPU
+ * builder there (*root_builder; NULL on the other ranks; owned by `d`), on which katome_dev_remove_dead_paths,
+ * katome_dev_remove_weak_edges, katome_dev_standardize_*, katome_dev_shrink and katome_dev_current_graph work as after
+ * katome_dev_finalize.  The pruning of BASELINE config 5 runs this way: its walks and swap-removes depend on the global
+ * numbering; the whole graph has to fit the root's HBM (< 2^32 edges).                           */
+int  katome_dist_gather(katome_dist_builder *d, int root, katome_builder **root_builder, void *stream);
+/* the rank's single-GPU builder underneath (per-phase kernel timing: katome_builder_profile*) */
+katome_builder *katome_dist_inner(katome_dist_builder *d);
+/* exchange accounting since the last read: katome_dist_exchange_count() phases named by katome_dist_exchange_name(),
+ * out[4*i..] = {calls, bytes that left this rank, largest single (rank -> peer) message, microseconds inside the exchange} */
+uint32_t katome_dist_exchange_count(void);
+const char *katome_dist_exchange_name(uint32_t phase);
+int  katome_dist_exchange_read(katome_dist_builder *d, uint64_t *out);
+/* contiguous shard of `total_reads` for `rank` (starts are multiples of 64 reads: 16-byte aligned packed rows) */
+void katome_shard_range(uint64_t total_reads, uint32_t world, uint32_t rank, uint64_t *first, uint64_t *count);
 
 /* ---- device primitives the finalize is built from (exported for the multi-GPU driver and
  * for unit tests; each is a hand-written HIP kernel set) -------------------------------- */

@@ -15,7 +15,8 @@ STATUS = {0: "OK", -1: "E_PATH", -2: "E_IS_DIR", -3: "E_NOT_EXIST", -4: "E_OPEN"
 
 class Settings(C.Structure):
     _fields_ = [("k", C.c_uint32), ("file_type", C.c_uint8), ("reverse_complement", C.c_uint8), ("flags", C.c_uint16),
-                ("min_weight", C.c_uint32), ("device", C.c_int32), ("table_slots_hint", C.c_uint64)]
+                ("min_weight", C.c_uint32), ("device", C.c_int32), ("table_slots_hint", C.c_uint64),
+                ("n_devices", C.c_int32), ("_reserved", C.c_uint32)]
 
 
 class Graph(C.Structure):
@@ -62,6 +63,23 @@ class DevGraph(C.Structure):
                 ("label_stride", C.c_uint32), ("d_edge_key", C.c_void_p), ("d_edge_weight", C.c_void_p),
                 ("d_edge_src", C.c_void_p), ("d_edge_dst", C.c_void_p), ("d_edge_label", C.c_void_p),
                 ("d_node_key", C.c_void_p), ("d_edge_age", C.c_void_p)]
+
+
+class DistGraph(C.Structure):
+    _fields_ = [("n_edges", C.c_uint64), ("n_nodes", C.c_uint64), ("total_edges", C.c_uint64), ("total_nodes", C.c_uint64),
+                ("node_base", C.c_uint64), ("key_words", C.c_uint32), ("label_stride", C.c_uint32),
+                ("d_edge_key", C.c_void_p), ("d_edge_weight", C.c_void_p), ("d_edge_src", C.c_void_p),
+                ("d_edge_dst", C.c_void_p), ("d_edge_label", C.c_void_p), ("d_node_key", C.c_void_p),
+                ("d_edge_id", C.c_void_p), ("d_node_id", C.c_void_p)]
+
+
+# the caller's transport (katome_comm_callbacks)
+A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, u64p, u64p, C.c_void_p, u64p, u64p, C.c_uint64, C.c_int)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, u64p, C.c_uint64, C.c_int)
+
+
+class CommCallbacks(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("alltoallv", A2A_FN), ("allreduce_u64", ALLREDUCE_FN)]
 
 
 # every symbol include/katome_gpu.h declares: name -> (restype, argtypes)
@@ -126,6 +144,28 @@ SYMBOLS = {
     "katome_dev_endpoints": (_i, [_i, _vp, _u64, _u32, _vp, _vp, _vp]),
     "katome_dev_labels": (_i, [_i, _vp, _u64, _u32, _vp, _vp]),
     "katome_dev_synth_reads": (_i, [_i, _u64, _u64, _u32, _u64, _dbl, _u32, _vp, _vp, _vp]),
+    # multi-GPU: communicators and the sharded build
+    "katome_comm_unique_id": (_i, [_vp]),
+    "katome_comm_create_rccl": (_i, [_vp, _i, _i, _i, C.POINTER(_vp)]),
+    "katome_comm_create_callbacks": (_i, [C.POINTER(CommCallbacks), _i, _i, _i, C.POINTER(_vp)]),
+    "katome_comm_destroy": (None, [_vp]),
+    "katome_comm_rank": (_i, [_vp]),
+    "katome_comm_world": (_i, [_vp]),
+    "katome_comm_kind": (C.c_char_p, [_vp]),
+    "katome_comm_set_max_message_bytes": (_i, [_vp, _u64]),
+    "katome_comm_allreduce_u64": (_i, [_vp, u64p, _u64, _i]),
+    "katome_comm_exchange": (_i, [_vp, _vp, u64p, _vp, _u64, u64p, _u64, _i, _vp]),
+    "katome_dist_create": (_i, [C.POINTER(Settings), _vp, C.POINTER(_vp)]),
+    "katome_dist_destroy": (None, [_vp]),
+    "katome_dist_add_reads": (_i, [_vp, _vp, _u64, _u64, _u32, _vp, _u64, _vp]),
+    "katome_dist_remove_weak_edges": (_i, [_vp, _u32]),
+    "katome_dist_finalize": (_i, [_vp, C.POINTER(DistGraph), _vp]),
+    "katome_dist_gather": (_i, [_vp, _i, C.POINTER(_vp), _vp]),
+    "katome_dist_inner": (_vp, [_vp]),
+    "katome_dist_exchange_count": (_u32, []),
+    "katome_dist_exchange_name": (C.c_char_p, [_u32]),
+    "katome_dist_exchange_read": (_i, [_vp, u64p]),
+    "katome_shard_range": (None, [_u64, _u32, _u32, u64p, u64p]),
 }
 
 

@@ -111,18 +111,24 @@ class CollectionStats:
 
 FLAG_FIRST_SEEN_ORDER = 1
 FLAG_REMOVE_DEAD_PATHS = 2
+FLAG_RANKS_SHARE_DEVICE = 4
 
 
 def make_settings(k, file_type=InputFileType.Fastq, reverse_complement=False, min_weight=0, device=0,
-                  table_slots_hint=0, first_seen_order=False, remove_dead_paths=False):
+                  table_slots_hint=0, first_seen_order=False, remove_dead_paths=False, n_devices=1,
+                  ranks_share_device=False):
+    """n_devices: GPUs of this node to build on (device .. device+n-1; one rank per GPU inside the call);
+    ranks_share_device: all those ranks on `device` -- the rehearsal of the sharded route on a one-GPU box"""
     s = _lib.Settings()
     s.k = k
     s.file_type = int(file_type)
     s.reverse_complement = 1 if reverse_complement else 0
-    s.flags = (FLAG_FIRST_SEEN_ORDER if first_seen_order else 0) | (FLAG_REMOVE_DEAD_PATHS if remove_dead_paths else 0)
+    s.flags = ((FLAG_FIRST_SEEN_ORDER if first_seen_order else 0) | (FLAG_REMOVE_DEAD_PATHS if remove_dead_paths else 0) |
+               (FLAG_RANKS_SHARE_DEVICE if ranks_share_device else 0))
     s.min_weight = min_weight
     s.device = device
     s.table_slots_hint = table_slots_hint
+    s.n_devices = n_devices
     return s
 
 
@@ -185,7 +191,7 @@ class GpuGraph:
     # ---- Build::create (builder.rs:42-54) ----------------------------------------------------
     @classmethod
     def create(cls, input_files, ft, reverse_complement, minimal_weight_threshold=0, device=0, first_seen_order=False,
-               remove_dead_paths=False, stages=None, original_genome_length=0):
+               remove_dead_paths=False, stages=None, original_genome_length=0, n_devices=1, ranks_share_device=False):
         """-> (GpuGraph, number_of_read_bytes); uses the global k set by set_global_k_sizes.
         stages: stages of assemble_with_graph to run on the device after the build, e.g. "dcwced" = everything before
         collapse (d remove_dead_paths, c standardize_contigs, w remove_weak_edges(minimal_weight_threshold),
@@ -194,7 +200,8 @@ class GpuGraph:
         remove_dead_paths: also run Prunable::remove_dead_paths (pruner.rs:36-82) as assemble() does next
         (asm/basic_assembler.rs:58-62); needs first_seen_order."""
         s = make_settings(K_SIZE, ft, reverse_complement, minimal_weight_threshold, device,
-                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths)
+                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths, n_devices=n_devices,
+                          ranks_share_device=ranks_share_device)
         gp = C.POINTER(_lib.Graph)()
         if stages:
             _check(_lib.lib().katome_build_files_staged(C.byref(s), _paths(input_files), len(input_files), stages.encode(),
@@ -206,10 +213,12 @@ class GpuGraph:
 
     @classmethod
     def create_from_packed(cls, packed, n_reads, read_len, skip=None, reverse_complement=False, device=0, k=None,
-                           first_seen_order=False, remove_dead_paths=False):
+                           first_seen_order=False, remove_dead_paths=False, n_devices=1, ranks_share_device=False,
+                           table_slots_hint=0):
         """Same build from 2-bit packed reads (numpy uint8), the synthetic-workload entry."""
         s = make_settings(K_SIZE if k is None else k, InputFileType.Fastq, reverse_complement, 0, device,
-                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths)
+                          table_slots_hint=table_slots_hint, first_seen_order=first_seen_order,
+                          remove_dead_paths=remove_dead_paths, n_devices=n_devices, ranks_share_device=ranks_share_device)
         packed = np.ascontiguousarray(packed, dtype=np.uint8)
         skip_p = None
         if skip is not None:

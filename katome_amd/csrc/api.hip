@@ -8,84 +8,14 @@
 #include <algorithm>
 #include <chrono>
 #include <new>
+#include <string>
 #include <thread>
 #include <vector>
 
 #include <sys/mman.h>
 
-#include "common.h"
-
-using namespace katome;
-
-// optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
-enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
-             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_SHRINK, PH_COUNT };
-static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
-                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles", "first_seen_order", "remove_dead_paths", "shrink"};
-struct Profiler {
-    bool on = false;
-    struct Ev { int phase; hipEvent_t a, b; };
-    std::vector<Ev> evs;
-    ~Profiler() { clear(); }
-    void clear() { for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } evs.clear(); }
-};
-struct PhaseScope {
-    Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase;
-    PhaseScope(Profiler& prof, int ph, hipStream_t st) : p(prof.on ? &prof : nullptr), s(st), phase(ph) {
-        if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
-    }
-    ~PhaseScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b}); } }
-};
-
-struct katome_builder {
-    katome_settings s;
-    Profiler prof;
-    uint32_t nw = 1;
-    bool rc = false;
-    Table table;
-    bool table_ready = false;
-    // tiled counting: (k+span-1)-mers counted first, expanded into `table` before the edges are read out
-    Table tiles;
-    bool tiles_ready = false;
-    uint32_t span = 1;
-    // big tiles (span > 16) are first broken into mid tiles of span2 windows (a second tile table), those into k-mers
-    Table tiles2;
-    bool tiles2_ready = false;
-    uint32_t span2 = 0;
-    uint64_t stat_tiles2 = 0, stat_tile2_slots = 0;
-    // bookkeeping for katome_builder_counts: distinct tiles, tile-table slots, distinct stored k-mers, k-mer-table slots
-    // first-seen-order mode (KATOME_FLAG_FIRST_SEEN_ORDER)
-    bool first_seen = false;
-    uint64_t reads_inserted = 0;       // reads whose records have been handed to an insert so far
-    uint32_t seen_read_len = 0;        // read length of the last extraction (records per read follow from it)
-    // reads whose windows are not a whole number of tiles: the trailing windows come as plain k-mer records right after
-    // the batch's tiles (katome_dev_extract_remainder); first-seen order needs to know where they sit in their reads
-    bool rem_pending = false;
-    uint32_t rem_win0 = 0, rem_per_read = 0;
-    uint64_t last_batch_read0 = 0, last_batch_reads = 0;
-    const uint64_t* var_prefix = nullptr;   // variable-length reads: window prefix of the last extraction (device), its reads
-    uint64_t var_reads = 0, var_windows = 0;   // and windows; var_seq_base: sequence numbers handed out by earlier batches
-    uint64_t var_seq_base = 0;
-    const uint64_t* var_rec_prefix = nullptr;  // records before each read for the records just extracted (tiles / left-over windows)
-    uint64_t var_records = 0;                  // how many of them: the insert that follows must take exactly these
-    uint32_t var_mode = 0, var_span = 1;       // 0 every window, 1 whole tiles, 2 the windows after the last whole tile
-    DevBuf edge_seq;                   // sequence number of each edge's first insertion, aligned with edge_key
-    uint64_t direct_edges = 0;         // BFCounter input: the edges were listed one per line and strand (no table); their count
-    uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
-    uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
-    // sorted distinct oriented edges
-    bool edges_ready = false;
-    DevBuf edge_key, edge_weight;
-    uint64_t n_edges = 0;
-    // scratch for ordering a batch by table region before it is inserted
-    DevBuf scratch_k[2], scratch_w[2];
-    // finalized graph
-    DevBuf edge_src, edge_dst, edge_label, node_key;
-    ShrinkOutput shrunk;               // result of katome_dev_shrink
-    DevBuf edge_age;                   // first-seen-order graphs once remove_* has moved edges (PruneGraph::edge_age)
-    uint64_t n_nodes = 0;
-    bool finalized = false;
-};
+#include "builder.h"
+#include "comm.h"
 
 extern "C" {
 
@@ -308,6 +238,20 @@ static int ensure_table(katome_builder* b, uint64_t incoming, uint64_t* room, hi
     return ensure_table(b, b->table, b->table_ready, b->nw, b->s.table_slots_hint, incoming, room, stream);
 }
 
+int builder_insert(katome_builder* b, Table& table, bool& ready, uint32_t nw, uint64_t hint, const uint64_t* d_records,
+                   const uint32_t* d_weights, uint64_t n, SeenOrigin* origin, int phase, hipStream_t stream) {
+    for (uint64_t done = 0; done < n;) {
+        uint64_t room = 0;
+        KCHECK(ensure_table(b, table, ready, nw, hint, n - done, &room, stream));
+        const uint64_t m = std::min(n - done, room);
+        PhaseScope ps(b->prof, phase, stream);
+        if (origin) origin->rec0 = done;               // (idx / pairs of an explicit origin are indexed from the batch's start)
+        KCHECK(table_insert(table, d_records + done * nw, d_weights ? d_weights + done : nullptr, m, stream, table.track_seen ? origin : nullptr));
+        done += m;
+    }
+    return KATOME_OK;
+}
+
 // span of the mid tiles a big tile is broken into: the divisor of `span` in 2..8 closest to 6; 0 = expand directly
 static uint32_t mid_span(uint32_t span) {
     if (span <= 16 || getenv("KATOME_ONE_LEVEL_TILES")) return 0;
@@ -332,7 +276,7 @@ static int expand_level(katome_builder* b, Table& from, Table& to, bool& to_read
 }
 
 // big tiles -> mid tiles (when the span is large); leaves the tiles that hold k-mers directly in `*last`
-static int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, hipStream_t stream) {
+int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, hipStream_t stream) {
     uint64_t n_tiles = 0;
     KCHECK(table_occupied(b->tiles, &n_tiles, stream));
     b->stat_tiles = n_tiles; b->stat_tile_slots = b->tiles.cap;
@@ -602,6 +546,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
 
 int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (b && b->finalized) return out ? katome_dev_current_graph(b, out) : KATOME_OK;      // (also: a graph installed by katome_dist_gather)
     KCHECK(katome_dev_edges(b, nullptr, nullptr, nullptr, stream_));
     const uint64_t E = b->n_edges;
     const uint32_t nw = b->nw, k = b->s.k;
@@ -1094,10 +1039,152 @@ extern "C" {
 
 }  // extern "C"
 
+// settings.n_devices > 1: the sharded build (dist.hip) with the ranks as host threads of this call, one per GPU.  Reads are
+// split contiguously by index; every rank copies its own share to its GPU.  By packed key the host arrays are the ranks'
+// shares one after the other (every rank copies its slice out itself); in the reference's numbering the graph is
+// gathered to the first GPU in index order, where the stages the flags ask for run and the result is copied out.
+static int build_packed_multi(const katome_settings* s, const uint8_t* packed, uint64_t n_reads, uint32_t read_len,
+                              const uint8_t* skip, const Finish& finish, uint64_t read_bytes) {
+    const int n = s->n_devices;
+    const bool share = (s->flags & KATOME_FLAG_RANKS_SHARE_DEVICE) != 0, first_seen = (s->flags & KATOME_FLAG_FIRST_SEEN_ORDER) != 0;
+    if (n > KATOME_MAX_RANKS) { set_error("n_devices = %d: at most %d", n, KATOME_MAX_RANKS); return KATOME_E_UNSUPPORTED; }
+    KCHECK(use_device(s->device));
+    int n_visible = 0;
+    KCHECK_HIP(hipGetDeviceCount(&n_visible));
+    if (!share && s->device + n > n_visible) { set_error("n_devices = %d from device %d, but %d GPU(s) are visible", n, s->device, n_visible); return KATOME_E_DEVICE; }
+    if ((finish.contigs || (finish.stages && *finish.stages) || (s->flags & KATOME_FLAG_REMOVE_DEAD_PATHS)) && !first_seen) {
+        set_error("n_devices > 1: shrink and the stages after the build need KATOME_FLAG_FIRST_SEEN_ORDER (they run on the graph gathered in the reference's numbering)");
+        return KATOME_E_ARG;
+    }
+    std::vector<int> devices(n);
+    for (int r = 0; r < n; ++r) devices[r] = share ? s->device : s->device + r;
+    std::vector<katome_comm*> comms(n, nullptr);
+    const char* transport = getenv("KATOME_COMM");
+    auto sync = std::make_shared<LocalGroup>(n);                 // host rendezvous of the rank threads, whatever moves the data
+    if (share || (transport && !strcmp(transport, "local"))) {
+        auto group = std::make_shared<LocalGroup>(n);
+        for (int r = 0; r < n; ++r) KCHECK(make_local_comm(group, r, devices[r], &comms[r]));
+    } else {
+        KCHECK(make_rccl_comms_all(devices.data(), n, comms.data()));
+    }
+    struct Shared {
+        std::vector<int> rc; std::vector<std::string> err;
+        std::vector<uint64_t> n_edges, node_base, n_nodes;
+        GraphOwner* owner = nullptr; int alloc_rc = KATOME_OK;
+        uint64_t total_edges = 0, total_nodes = 0;
+    } sh;
+    sh.rc.assign(n, KATOME_OK); sh.err.resize(n); sh.n_edges.assign(n, 0); sh.node_base.assign(n, 0); sh.n_nodes.assign(n, 0);
+    const uint32_t stride = (read_len + 3) / 4;
+    auto body = [&](int r) -> int {
+        KCHECK(use_device(devices[r]));
+        hipStream_t stream = nullptr;
+        KCHECK_HIP(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        katome_settings mine = *s;
+        mine.device = devices[r];
+        katome_dist_builder* d = nullptr;
+        int rc = katome_dist_create(&mine, comms[r], &d);
+        do {
+            if (rc) break;
+            uint64_t first = 0, cnt = 0;
+            katome_shard_range(n_reads, (uint32_t)n, (uint32_t)r, &first, &cnt);
+            DevBuf d_packed(stream), d_skip(stream);
+            if ((rc = d_packed.alloc(cnt * stride + 32))) break;
+            if (cnt && hipMemcpyAsync(d_packed.p, packed + first * stride, cnt * stride, hipMemcpyHostToDevice, stream) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+            if (skip) {
+                if ((rc = d_skip.alloc(cnt + 16))) break;
+                if (cnt && hipMemcpyAsync(d_skip.p, skip + first, cnt, hipMemcpyHostToDevice, stream) != hipSuccess) { set_error("H2D copy failed"); rc = KATOME_E_DEVICE; break; }
+            }
+            if ((rc = katome_dist_add_reads(d, d_packed.as<uint8_t>(), first, cnt, read_len, skip ? d_skip.as<uint8_t>() : nullptr, 0, stream))) break;
+            d_packed.release(); d_skip.release();
+            katome_dist_graph g;
+            if ((rc = katome_dist_finalize(d, &g, stream))) break;
+            if (first_seen) {
+                katome_builder* root = nullptr;
+                if ((rc = katome_dist_gather(d, 0, &root, stream))) break;
+                if (r == 0) {
+                    root->s.flags = s->flags; root->s.min_weight = s->min_weight;       // the stages the caller asked for run here
+                    rc = finish(root, read_bytes);
+                }
+                break;
+            }
+            // by packed key: rank by rank
+            sh.n_edges[r] = g.n_edges; sh.node_base[r] = g.node_base; sh.n_nodes[r] = g.n_nodes;
+            if (!sync->barrier()) { set_error("another rank of this build failed"); rc = KATOME_E_DEVICE; break; }
+            if (r == 0) {
+                GraphOwner* o = new (std::nothrow) GraphOwner();
+                if (!o) { set_error("out of host memory"); sh.alloc_rc = KATOME_E_OOM; }
+                else {
+                    memset(&o->g, 0, sizeof o->g);
+                    katome_graph* hg = &o->g;
+                    hg->n_nodes = g.total_nodes; hg->n_edges = g.total_edges; hg->read_bytes = read_bytes;
+                    hg->k = s->k; hg->key_words = g.key_words; hg->label_stride = g.label_stride;
+                    auto take = [&](size_t bytes) -> void* { void* q = host_result_alloc(bytes); if (q) o->mem.push_back(q); else sh.alloc_rc = KATOME_E_OOM; return q; };
+                    hg->edge_src = (uint64_t*)take(std::max<uint64_t>(g.total_edges, 1) * 8);
+                    hg->edge_dst = (uint64_t*)take(std::max<uint64_t>(g.total_edges, 1) * 8);
+                    hg->edge_weight = (uint32_t*)take(std::max<uint64_t>(g.total_edges, 1) * 4);
+                    hg->edge_label = (uint8_t*)take(std::max<uint64_t>(g.total_edges, 1) * (size_t)g.label_stride);
+                    hg->edge_key = (uint64_t*)take(std::max<uint64_t>(g.total_edges, 1) * 8 * g.key_words);
+                    hg->node_key = (uint64_t*)take(std::max<uint64_t>(g.total_nodes, 1) * 8 * g.key_words);
+                    if (sh.alloc_rc) { set_error("out of host memory"); katome_graph_free(hg); o = nullptr; }
+                }
+                sh.owner = o;
+            }
+            if (!sync->barrier()) { set_error("another rank of this build failed"); rc = KATOME_E_DEVICE; break; }
+            if (!sh.owner) { rc = sh.alloc_rc ? sh.alloc_rc : KATOME_E_OOM; break; }
+            {
+                uint64_t e0 = 0;
+                for (int p = 0; p < r; ++p) e0 += sh.n_edges[p];
+                katome_graph* hg = &sh.owner->g;
+                const uint64_t E = g.n_edges, N = g.n_nodes;
+                const uint32_t nwk = g.key_words, ls = g.label_stride;
+                hipError_t e = hipSuccess;
+                if (E) {
+                    if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint64_t*>(hg->edge_src) + e0, g.d_edge_src, E * 8, hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint64_t*>(hg->edge_dst) + e0, g.d_edge_dst, E * 8, hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint32_t*>(hg->edge_weight) + e0, g.d_edge_weight, E * 4, hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint8_t*>(hg->edge_label) + e0 * ls, g.d_edge_label, E * (size_t)ls, hipMemcpyDeviceToHost, stream);
+                    if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint64_t*>(hg->edge_key) + e0 * nwk, g.d_edge_key, E * 8 * nwk, hipMemcpyDeviceToHost, stream);
+                }
+                if (N && e == hipSuccess) e = hipMemcpyAsync(const_cast<uint64_t*>(hg->node_key) + g.node_base * nwk, g.d_node_key, N * 8 * nwk, hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) { set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = KATOME_E_DEVICE; }
+            }
+        } while (0);
+        if (d) katome_dist_destroy(d);
+        dev_retire_stream(stream);
+        (void)hipStreamDestroy(stream);
+        return rc;
+    };
+    std::vector<std::thread> threads;
+    for (int r = 0; r < n; ++r)
+        threads.emplace_back([&, r]() {
+            const int rc = body(r);
+            sh.rc[r] = rc;
+            if (rc) { sh.err[r] = get_error(); sync->poison(); }     // (ranks waiting at a host rendezvous give up)
+        });
+    for (auto& t : threads) t.join();
+    for (int r = 0; r < n; ++r) katome_comm_destroy(comms[r]);
+    int rc = KATOME_OK;
+    for (int r = 0; r < n && !rc; ++r)
+        if (sh.rc[r] && sh.err[r] != "another rank of this build failed") { rc = sh.rc[r]; set_error("rank %d of %d: %s", r, n, sh.err[r].c_str()); }
+    for (int r = 0; r < n && !rc; ++r) if (sh.rc[r]) { rc = sh.rc[r]; set_error("rank %d of %d: %s", r, n, sh.err[r].c_str()); }
+    if (!first_seen) {
+        if (rc == KATOME_OK && sh.owner && finish.graph) *finish.graph = &sh.owner->g;
+        else if (sh.owner) katome_graph_free(&sh.owner->g);
+    }
+    return rc;
+}
+
 static int build_packed_impl(const katome_settings* s, const uint8_t* packed, uint64_t n_reads, uint32_t read_len,
                              const uint8_t* skip, const Finish& finish, const uint64_t* read_bytes_override = nullptr) {
     if (!s || (!packed && n_reads)) { set_error("null argument"); return KATOME_E_ARG; }
     KCHECK(check_k(s->k));
+    if (s->n_devices > 1 && n_reads && read_len >= s->k) {
+        uint64_t read_bytes = 0;
+        if (read_bytes_override) read_bytes = *read_bytes_override;
+        else for (uint64_t r = 0; r < n_reads; ++r) if (!skip || !skip[r]) read_bytes += read_len;
+        return build_packed_multi(s, packed, n_reads, read_len, skip, finish, read_bytes);
+    }
     if (n_reads && read_len < s->k) {
         // only an ACCEPTED read can be too short (builder.rs:155-158 filters first)
         bool any = !skip;

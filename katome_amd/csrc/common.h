@@ -35,6 +35,8 @@ const char* get_error();
 int dev_malloc(void** out, size_t bytes, hipStream_t stream);
 void dev_free(void* p, hipStream_t stream);
 size_t dev_cached_bytes();
+// call before hipStreamDestroy: cached blocks remember the stream they were last used on
+void dev_retire_stream(hipStream_t stream);
 void dev_release_cache(int device);
 
 // device buffer with RAII; `stream` is the stream the buffer's users are ordered on
@@ -104,6 +106,8 @@ int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t pa
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
                   uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift = 0, uint32_t core_bases = 0);
+int dev_partition_range(const uint64_t* d_vals, const uint32_t* idx_in, uint64_t n, const uint64_t* d_bounds, uint32_t n_parts,
+                        uint64_t* d_out, uint32_t* idx_out, uint64_t* h_counts, hipStream_t stream);
 int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src, uint64_t* n_src,
                    hipStream_t stream);
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
@@ -173,6 +177,8 @@ struct ShrinkOutput {
 };
 int dev_shrink(const ShrinkInput& g, ShrinkOutput& out, hipStream_t stream);
 
+constexpr int KATOME_MAX_RANKS = 16;      // ranks of a sharded build (an MI355X node has 8 GPUs)
+
 // table.hip
 struct Table {
     DevBuf slots;          // NW=1: {u64 key|OCC, u32 count, u32 pad}; NW=2: {u64 hi|flags, u64 lo, u32 count, u32 pad[3]}
@@ -193,6 +199,13 @@ struct SeenOrigin {
     const uint64_t* win_prefix = nullptr; uint64_t n_reads = 0, seq_base = 0;
     // ... whose records may be whole tiles (mode 1) or the windows after them (mode 2): rec_prefix = records before each read
     const uint64_t* rec_prefix = nullptr; uint32_t mode = 0;
+    // sharded build: the records arrive grouped by the rank that extracted them (n_seg segments, segment p = records
+    // [seg_off[p], seg_off[p+1]) of the batch, cut from reads seg_read0[p]...), each with its index in THAT rank's batch ...
+    const uint32_t* idx = nullptr; uint32_t n_seg = 0;
+    uint64_t seg_off[KATOME_MAX_RANKS + 1] = {0}, seg_read0[KATOME_MAX_RANKS] = {0};
+    // ... or with both sequence numbers spelled out ([n][2]: stored orientation, its reverse complement): k-mer records made
+    // out of another rank's tiles
+    const uint64_t* pairs = nullptr;
 };
 int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream);
 int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n, hipStream_t stream,
@@ -203,8 +216,9 @@ int table_grow(Table& t, uint64_t new_cap, hipStream_t stream);
 int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmers, uint32_t k, uint32_t span, uint32_t stride,
                        bool rc, hipStream_t stream);
 // same, but the (k-mer, weight) records are written out instead (multi-GPU: they travel to their owners)
+// (seen: when the tile table tracks first-seen order, the records' two sequence numbers, [n][2])
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
-                                  uint64_t* n_records, hipStream_t stream);
+                                  uint64_t* n_records, hipStream_t stream, DevBuf* seen = nullptr);
 // distinct oriented edges (unsorted): allocates d_keys/d_weights
 int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf& keys, DevBuf& weights, uint64_t* n_edges,
                      hipStream_t stream, DevBuf* seqs = nullptr);

@@ -1,0 +1,673 @@
+// dist.hip -- the sharded (multi-GPU) build: one rank per GPU, one exchange step per phase.
+//
+// The reference's Build::create (builder.rs:42-54) is one sequential loop over the reads (builder.rs:152-160); reads are
+// independent until their k-mers meet in the graph, so what shards is the read set:
+//   1. every rank cuts its own reads (a contiguous run of the input) into records -- TILES, the (k+span-1)-mers covering
+//      `span` consecutive windows, plus the windows left over (table.hip) -- and routes each record to its owner rank,
+//      owner = mulhi(mix(record), world) (radix.hip partition; three-word tiles included);
+//   2. one all-to-all per batch brings the records to their owners (comm.h), which count them in their tile table;
+//   3. every rank turns its distinct tiles into (k-mer, count) records and a second, much smaller all-to-all brings those
+//      to the K-MER's owner = mulhi(mix(canonical middle (k-2)-mer), world): shared by a k-mer and its reverse complement
+//      and by all out-edges of a node, so a node and its <= 4 out-edges live on one rank (the HmGIR shape, hm_gir.rs:91-153);
+//   4. the graph is numbered across ranks.  By packed key: a rank's nodes with out-edges are the run heads of its own sorted
+//      edges; every edge asks the owner of its target for the target's id (one key out, one id back), which also registers
+//      the nodes without out-edges (they count in node_count, stats/collections.rs:196).  In the reference's own numbering
+//      (KATOME_FLAG_FIRST_SEEN_ORDER; petgraph indices, pt_graph.rs:149,194): every record carries where it sits in the
+//      input, owners keep the earliest sequence number per k-mer and strand, and edges and nodes get their GLOBAL rank
+//      among all ranks' sequence numbers (global_rank: range partition by splitters from a merged histogram, local sort,
+//      ranks back over the mirrored exchange) -- the same indices whatever the number of ranks.
+// The stages of assemble_with_graph that walk petgraph's adjacency and swap_remove by index (pruner.rs:36-82) need the whole
+// graph in index order: katome_dist_gather brings it to one rank, where prune.hip runs unchanged.
+#include <algorithm>
+#include <chrono>
+#include <string>
+#include <vector>
+
+#include "builder.h"
+#include "comm.h"
+
+namespace {
+
+enum XPhase { X_RECORDS, X_KMERS, X_TARGETS, X_IDS, X_RANK_NODES, X_RANK_EDGES, X_GATHER, X_COUNT };
+const char* const XPHASE_NAMES[X_COUNT] = {"exchange_records", "exchange_kmers", "exchange_targets", "exchange_ids",
+                                           "rank_nodes", "rank_edges", "gather"};
+
+// ---- small kernels ---------------------------------------------------------------------------------------------------
+#define KLAUNCH(kernel, n, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid_for((n), BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, __VA_ARGS__)
+#define KLOOP(i, n) for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < (n); i += (u64)gridDim.x * BLOCK)
+
+// every record whose key was not found among the sources (rank == UINT64_MAX): its key and where it stands
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void compact_missing_kernel(const u64* __restrict__ rank, const u64* __restrict__ keys, u64 n,
+                                                                 u64* __restrict__ mk, u32* __restrict__ mpos, u64* cursor) {
+    KLOOP(j, n) {
+        if (rank[j] != ~0ull) continue;
+        const u64 m = atomicAdd((unsigned long long*)cursor, 1ull);
+#pragma unroll
+        for (int q = 0; q < NW; ++q) mk[m * NW + q] = keys[j * NW + q];
+        mpos[m] = (u32)j;
+    }
+}
+__global__ __launch_bounds__(BLOCK) void fill_missing_kernel(u64* __restrict__ rank, const u32* __restrict__ mpos, const u64* __restrict__ mrank,
+                                                              u64 m, u64 offset) {
+    KLOOP(i, m) rank[mpos[i]] = offset + mrank[i];
+}
+// out[j] = map ? map[in[j]] : in[j] + base
+__global__ __launch_bounds__(BLOCK) void map_ids_kernel(const u64* __restrict__ in, u64 n, const u64* __restrict__ map, u64 base, u64* __restrict__ out) {
+    KLOOP(j, n) out[j] = map ? map[in[j]] : in[j] + base;
+}
+__global__ __launch_bounds__(BLOCK) void scatter_u64_kernel(const u64* __restrict__ vals, const u32* __restrict__ pos, u64 n, u64* __restrict__ out) {
+    KLOOP(j, n) out[pos[j]] = vals[j];
+}
+// first-seen order: node_first[node] = earliest (2 * sequence number + role) over the edges that touch it
+__global__ __launch_bounds__(BLOCK) void src_first_kernel(const u64* __restrict__ lsrc, const u64* __restrict__ seq, u64 n, u64* node_first) {
+    KLOOP(e, n) atomicMin((unsigned long long*)&node_first[lsrc[e]], (unsigned long long)(2 * seq[e]));
+}
+__global__ __launch_bounds__(BLOCK) void dst_first_kernel(const u64* __restrict__ local, const u64* __restrict__ val, u64 n, u64* node_first) {
+    KLOOP(j, n) atomicMin((unsigned long long*)&node_first[local[j]], (unsigned long long)val[j]);
+}
+__global__ __launch_bounds__(BLOCK) void target_value_kernel(const u64* __restrict__ seq, const u32* __restrict__ origin, u64 n, u64* __restrict__ out) {
+    KLOOP(j, n) out[j] = 2 * seq[origin[j]] + 1;
+}
+__global__ __launch_bounds__(BLOCK) void value_hist_kernel(const u64* __restrict__ v, u64 n, u64 width, unsigned long long* hist) {
+    KLOOP(i, n) atomicAdd(&hist[v[i] / width], 1ull);
+}
+__global__ __launch_bounds__(BLOCK) void assign_rank_kernel(const u32* __restrict__ pos, u64 n, u64 base, u64* __restrict__ out) {
+    KLOOP(i, n) out[pos[i]] = base + i;
+}
+// gather-to-root: records land at their global index
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void place_keys_kernel(const u64* __restrict__ gid, const u64* __restrict__ in, u64 n, u64* __restrict__ out) {
+    KLOOP(j, n) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) out[gid[j] * NW + q] = in[j * NW + q];
+    }
+}
+template <class T>
+__global__ __launch_bounds__(BLOCK) void place_kernel(const u64* __restrict__ gid, const T* __restrict__ in, u64 n, T* __restrict__ out) {
+    KLOOP(j, n) out[gid[j]] = in[j];
+}
+
+uint64_t sum(const std::vector<uint64_t>& v) { uint64_t t = 0; for (uint64_t x : v) t += x; return t; }
+
+// KATOME_DIST_TRACE=1: order-free checksum of a device array of u64 words at the checkpoints of a sharded build (stderr)
+void trace_words(const char* what, int rank, const void* d_ptr, uint64_t n_words, hipStream_t stream) {
+    static const bool on = getenv("KATOME_DIST_TRACE") != nullptr;
+    if (!on) return;
+    std::vector<uint64_t> h(n_words);
+    (void)hipStreamSynchronize(stream);
+    if (n_words) (void)hipMemcpy(h.data(), d_ptr, n_words * 8, hipMemcpyDeviceToHost);
+    if (const char* dir = getenv("KATOME_DIST_DUMP")) {
+        std::string name = std::string(dir) + "/" + what + "." + std::to_string(rank) + ".bin";
+        for (char& c : name) if (c == ' ' || c == ':') c = '_';
+        if (FILE* f = fopen(name.c_str(), "wb")) {
+            if (strstr(what, "slots")) { for (uint64_t i = 0; i + 3 < n_words; i += 4) if (h[i] >> 63) fwrite(&h[i], 8, 4, f); }   // occupied 32-byte slots only
+            else fwrite(h.data(), 8, n_words, f);
+            fclose(f);
+        }
+    }
+    uint64_t a = 0, x = 0, mx = 0;
+    for (uint64_t v : h) { a += v * 0x9E3779B97F4A7C15ull; x ^= v; mx = std::max(mx, v); }
+    fprintf(stderr, "[dist %d] %-28s n=%llu sum=%016llx xor=%016llx max=%llu\n", rank, what, (unsigned long long)n_words,
+            (unsigned long long)a, (unsigned long long)x, (unsigned long long)mx);
+}
+
+}  // namespace
+
+struct katome_dist_builder {
+    katome_settings s;
+    katome_comm* comm = nullptr;
+    katome_builder* b = nullptr;             // this rank's single-GPU builder (tables, sorted edges)
+    uint32_t nw = 1;
+    bool rc = false, first_seen = false;
+    // the plan, the same on every rank (a function of k and the read length)
+    bool planned = false;
+    uint32_t read_len = 0, W = 0, span = 1, tiles_per_read = 0, rest = 0, nwt = 1;
+    uint64_t reads_end = 0;                  // one past the last read this rank has added (first-seen: bounds the sequence numbers)
+    bool finalized = false;
+    // this rank's share of the numbered graph
+    DevBuf edge_src, edge_dst, edge_label, node_key, edge_gid, node_gid;
+    uint64_t n_edges = 0, n_nodes = 0, total_edges = 0, total_nodes = 0, node_base = 0;
+    katome::ExchangeStats xstats[X_COUNT];
+
+    int world() const { return comm->world(); }
+    int rank() const { return comm->rank(); }
+    // all-to-all of records grouped by destination, accounted to `phase`
+    int xchg(int phase, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, hipStream_t stream) {
+        const katome::ExchangeStats before = comm->stats;
+        KCHECK(comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream));
+        katome::ExchangeStats& x = xstats[phase];
+        x.calls += comm->stats.calls - before.calls; x.bytes_out += comm->stats.bytes_out - before.bytes_out;
+        x.bytes_in += comm->stats.bytes_in - before.bytes_in; x.ms += comm->stats.ms - before.ms;
+        for (int p = 0; p < world(); ++p) if (p != rank()) x.max_pair_bytes = std::max<uint64_t>(x.max_pair_bytes, send_cnt[p] * elem_bytes);
+        return KATOME_OK;
+    }
+};
+
+namespace {
+
+// One batch's records, already grouped by owner (`part`, counts per owner; idx: each record's index in this rank's batch,
+// first-seen order only): exchange, then count what arrived in the tile table (tiles) or the k-mer table.
+int route_and_insert(katome_dist_builder* d, const u64* part, const u32* idx, const std::vector<uint64_t>& counts, uint32_t nwr, bool tiles,
+                     uint64_t read0, uint32_t per_read, uint32_t win0, uint32_t span, hipStream_t stream) {
+    katome_builder* b = d->b;
+    const int world = d->world();
+    std::vector<uint64_t> rcnt(world, 0);
+    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+    const uint64_t nR = sum(rcnt);
+    DevBuf recv(stream), ridx(stream);
+    KCHECK(recv.alloc(std::max<uint64_t>(nR, 1) * 8 * nwr));
+    KCHECK(d->xchg(X_RECORDS, part, counts.data(), recv.p, rcnt.data(), 8 * nwr, stream));
+    SeenOrigin origin;
+    if (d->first_seen) {
+        KCHECK(ridx.alloc(std::max<uint64_t>(nR, 1) * 4));
+        KCHECK(d->xchg(X_RECORDS, idx, counts.data(), ridx.p, rcnt.data(), 4, stream));
+        std::vector<uint64_t> read0s(world, 0);
+        KCHECK(d->comm->allgather(read0, read0s.data()));
+        origin.idx = ridx.as<u32>(); origin.n_seg = (uint32_t)world;
+        for (int p = 0; p < world; ++p) { origin.seg_off[p + 1] = origin.seg_off[p] + rcnt[p]; origin.seg_read0[p] = read0s[p]; }
+        origin.per_read = per_read; origin.span = span; origin.windows = d->W; origin.win0 = win0; origin.rc = d->rc;
+    }
+    if (nR == 0) return KATOME_OK;
+    if (tiles) {
+        b->span = span;
+        return builder_insert(b, b->tiles, b->tiles_ready, d->nwt, b->s.table_slots_hint / 4, recv.as<u64>(), nullptr, nR,
+                              d->first_seen ? &origin : nullptr, PH_INSERT_TILES, stream);
+    }
+    return builder_insert(b, b->table, b->table_ready, d->nw, b->s.table_slots_hint, recv.as<u64>(), nullptr, nR,
+                          d->first_seen ? &origin : nullptr, PH_INSERT, stream);
+}
+
+// every rank's distinct tiles -> (k-mer, count[, sequence numbers]) records -> the k-mers' owners
+int expand_and_route_kmers(katome_dist_builder* d, hipStream_t stream) {
+    katome_builder* b = d->b;
+    const int world = d->world();
+    const uint32_t nw = d->nw, k = d->s.k;
+    DevBuf keys(stream), weights(stream), seen(stream);
+    uint64_t n_rec = 0;
+    if (b->tiles_ready) {
+        Table* last = nullptr; uint32_t last_span = 1;
+        trace_words("tiles: slots", d->rank(), b->tiles.slots.p, b->tiles.cap * b->tiles.slot_bytes() / 8, stream);
+        KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+        trace_words("last level: slots", d->rank(), last->slots.p, last->cap * last->slot_bytes() / 8, stream);
+        {
+            PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+            KCHECK(table_expand_tiles_to_records(*last, k, last_span, d->rc, keys, weights, &n_rec, stream, d->first_seen ? &seen : nullptr));
+        }
+        trace_words("last level after: slots", d->rank(), last->slots.p, last->cap * last->slot_bytes() / 8, stream);
+        b->tiles.release(); b->tiles2.release();
+        b->tiles_ready = false; b->tiles2_ready = false;
+    }
+    trace_words("expand: record keys", d->rank(), keys.p, n_rec * nw, stream);
+    trace_words("expand: record weights", d->rank(), weights.p, n_rec / 2, stream);
+    // slices of at most one message's size, the same number of rounds on every rank
+    const uint64_t per_slice = std::max<uint64_t>(1, d->comm->max_message_bytes / (8 * nw));
+    uint64_t ns = (n_rec + per_slice - 1) / per_slice;
+    KCHECK(d->comm->allreduce(&ns, 1, OP_MAX));
+    DevBuf pk(stream), pw(stream), pidx(stream), idx(stream), ppairs(stream);
+    for (uint64_t j = 0; j < ns; ++j) {
+        const uint64_t a = std::min(n_rec, j * per_slice), e = std::min(n_rec, (j + 1) * per_slice), m = e - a;
+        std::vector<uint64_t> counts(world, 0), rcnt(world, 0);
+        if (m) {
+            KCHECK(pk.alloc(m * 8 * nw)); KCHECK(pw.alloc(m * 4));
+            if (d->first_seen) {
+                KCHECK(idx.alloc(m * 4)); KCHECK(pidx.alloc(m * 4)); KCHECK(ppairs.alloc(m * 16));
+                KCHECK(dev_iota(idx.as<u32>(), m, stream));
+                KCHECK(dev_partition(keys.as<u64>() + a * nw, idx.as<u32>(), m, nw, world, pk.as<u64>(), pidx.as<u32>(), counts.data(), stream, 2, k - 2));
+                KCHECK(dev_gather_u32(weights.as<u32>() + a, pidx.as<u32>(), sum(counts), pw.as<u32>(), stream));
+                KCHECK(dev_gather_keys(seen.as<u64>() + 2 * a, pidx.as<u32>(), sum(counts), 2, ppairs.as<u64>(), stream));
+            } else {
+                KCHECK(dev_partition(keys.as<u64>() + a * nw, weights.as<u32>() + a, m, nw, world, pk.as<u64>(), pw.as<u32>(), counts.data(), stream, 2, k - 2));
+            }
+        }
+        KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+        const uint64_t nR = sum(rcnt);
+        DevBuf rk(stream), rw(stream), rp(stream);
+        KCHECK(rk.alloc(std::max<uint64_t>(nR, 1) * 8 * nw)); KCHECK(rw.alloc(std::max<uint64_t>(nR, 1) * 4));
+        KCHECK(d->xchg(X_KMERS, pk.p, counts.data(), rk.p, rcnt.data(), 8 * nw, stream));
+        KCHECK(d->xchg(X_KMERS, pw.p, counts.data(), rw.p, rcnt.data(), 4, stream));
+        trace_words("kmers received: keys", d->rank(), rk.p, nR * nw, stream);
+        trace_words("kmers received: weights", d->rank(), rw.p, nR / 2, stream);
+        SeenOrigin origin;
+        if (d->first_seen) {
+            KCHECK(rp.alloc(std::max<uint64_t>(nR, 1) * 16));
+            KCHECK(d->xchg(X_KMERS, ppairs.p, counts.data(), rp.p, rcnt.data(), 16, stream));
+            origin.pairs = rp.as<u64>(); origin.rc = d->rc;
+        }
+        if (nR) KCHECK(builder_insert(b, b->table, b->table_ready, nw, b->s.table_slots_hint, rk.as<u64>(), rw.as<u32>(), nR,
+                                      d->first_seen ? &origin : nullptr, PH_INSERT, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));           // (the receive buffers go back to the cache at the end of the round)
+    }
+    return KATOME_OK;
+}
+
+// Global rank of every value among the DISTINCT u64 values held by all ranks (sequence numbers): values are spread over the
+// ranks by range -- splitters from the merged 2^16-bucket histogram, so every rank gets about the same number -- sorted
+// there, and each value's rank (ranks before + position) travels back over the mirrored exchange.
+int global_rank(katome_dist_builder* d, int xphase, const u64* vals, uint64_t n, uint64_t vmax, u64* out_rank, hipStream_t stream) {
+    const int world = d->world(), rank = d->rank();
+    constexpr uint64_t NB = 1u << 16;
+    if (n >= (1ull << 32)) { set_error("more than 2^32 values to rank on one GPU"); return KATOME_E_UNSUPPORTED; }
+    const uint64_t width = vmax / NB + 1;
+    DevBuf hist(stream);
+    KCHECK(hist.alloc(NB * 8));
+    KCHECK_HIP(hipMemsetAsync(hist.p, 0, NB * 8, stream));
+    if (n) KLAUNCH(value_hist_kernel, n, stream, vals, n, width, hist.as<unsigned long long>());
+    KCHECK_HIP(hipGetLastError());
+    std::vector<uint64_t> h(NB);
+    KCHECK_HIP(hipMemcpyAsync(h.data(), hist.p, NB * 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    KCHECK(d->comm->allreduce(h.data(), NB, OP_SUM));
+    uint64_t total = 0;
+    for (uint64_t x : h) total += x;
+    // bounds[p] = first value of part p + 1: the bucket where the running count passes (p + 1) / world of the total
+    std::vector<uint64_t> bounds(std::max(world - 1, 1), ~0ull);
+    {
+        uint64_t run = 0; int p = 0;
+        for (uint64_t bkt = 0; bkt < NB && p < world - 1; ++bkt) {
+            while (p < world - 1 && run >= (total * (uint64_t)(p + 1) + world - 1) / world) bounds[p++] = bkt * width;
+            run += h[bkt];
+        }
+    }
+    DevBuf d_bounds(stream), idx(stream), pv(stream), pidx(stream);
+    KCHECK(d_bounds.alloc(bounds.size() * 8));
+    KCHECK_HIP(hipMemcpyAsync(d_bounds.p, bounds.data(), bounds.size() * 8, hipMemcpyHostToDevice, stream));
+    std::vector<uint64_t> counts(world, 0), rcnt(world, 0);
+    KCHECK(idx.alloc((n + 1) * 4)); KCHECK(pv.alloc((n + 1) * 8)); KCHECK(pidx.alloc((n + 1) * 4));
+    KCHECK(dev_iota(idx.as<u32>(), n, stream));
+    KCHECK(dev_partition_range(vals, idx.as<u32>(), n, d_bounds.as<u64>(), (uint32_t)world, pv.as<u64>(), pidx.as<u32>(), counts.data(), stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));               // (bounds was read from a host vector)
+    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+    const uint64_t nR = sum(rcnt);
+    if (nR >= (1ull << 32)) { set_error("more than 2^32 values to rank on one GPU"); return KATOME_E_UNSUPPORTED; }
+    DevBuf rv(stream), pos(stream), ans(stream), back(stream);
+    KCHECK(rv.alloc((nR + 1) * 8)); KCHECK(pos.alloc((nR + 1) * 4)); KCHECK(ans.alloc((nR + 1) * 8)); KCHECK(back.alloc((n + 1) * 8));
+    KCHECK(d->xchg(xphase, pv.p, counts.data(), rv.p, rcnt.data(), 8, stream));
+    uint32_t bits = 1;
+    while (bits < 64 && (vmax >> bits)) ++bits;
+    KCHECK(dev_iota(pos.as<u32>(), nR, stream));
+    KCHECK(dev_sort(rv.as<u64>(), pos.as<u32>(), nR, 1, bits, stream));
+    std::vector<uint64_t> all(world, 0);
+    KCHECK(d->comm->allgather(nR, all.data()));
+    uint64_t base = 0;
+    for (int p = 0; p < rank; ++p) base += all[p];
+    if (nR) KLAUNCH(assign_rank_kernel, nR, stream, pos.as<u32>(), nR, base, ans.as<u64>());
+    KCHECK_HIP(hipGetLastError());
+    KCHECK(d->xchg(xphase, ans.p, rcnt.data(), back.p, counts.data(), 8, stream));       // the mirrored route
+    if (n) KLAUNCH(scatter_u64_kernel, n, stream, back.as<u64>(), pidx.as<u32>(), n, out_rank);
+    KCHECK_HIP(hipGetLastError());
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+int fill_graph(katome_dist_builder* d, katome_dist_graph* out) {
+    if (!out) return KATOME_OK;
+    katome_builder* b = d->b;
+    memset(out, 0, sizeof *out);
+    out->n_edges = d->n_edges; out->n_nodes = d->n_nodes; out->total_edges = d->total_edges; out->total_nodes = d->total_nodes;
+    out->node_base = d->node_base; out->key_words = d->nw; out->label_stride = label_stride_for_k(d->s.k);
+    out->d_edge_key = b->edge_key.as<u64>(); out->d_edge_weight = b->edge_weight.as<u32>();
+    out->d_edge_src = d->edge_src.as<u64>(); out->d_edge_dst = d->edge_dst.as<u64>(); out->d_edge_label = d->edge_label.as<uint8_t>();
+    out->d_node_key = d->node_key.as<u64>();
+    out->d_edge_id = d->first_seen ? d->edge_gid.as<u64>() : nullptr;
+    out->d_node_id = d->first_seen ? d->node_gid.as<u64>() : nullptr;
+    return KATOME_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void katome_shard_range(uint64_t total_reads, uint32_t world, uint32_t rank, uint64_t* first, uint64_t* count) {
+    if (world == 0) world = 1;
+    const uint64_t per = ((total_reads + world - 1) / world + 63) / 64 * 64;
+    const uint64_t r0 = std::min(total_reads, (uint64_t)rank * per), r1 = std::min(total_reads, r0 + per);
+    if (first) *first = r0;
+    if (count) *count = r1 - r0;
+}
+
+uint32_t katome_dist_exchange_count(void) { return X_COUNT; }
+const char* katome_dist_exchange_name(uint32_t phase) { return phase < X_COUNT ? XPHASE_NAMES[phase] : ""; }
+int katome_dist_exchange_read(katome_dist_builder* d, uint64_t* out) {
+    if (!d || !out) { set_error("null argument"); return KATOME_E_ARG; }
+    for (int i = 0; i < X_COUNT; ++i) {
+        out[4 * i] = d->xstats[i].calls; out[4 * i + 1] = d->xstats[i].bytes_out; out[4 * i + 2] = d->xstats[i].max_pair_bytes;
+        out[4 * i + 3] = (uint64_t)(d->xstats[i].ms * 1000.0);
+        d->xstats[i] = katome::ExchangeStats();
+    }
+    return KATOME_OK;
+}
+
+int katome_dist_create(const katome_settings* s, katome_comm* comm, katome_dist_builder** out) {
+    if (!s || !comm || !out) { set_error("null argument"); return KATOME_E_ARG; }
+    *out = nullptr;
+    if (comm->world() > KATOME_MAX_RANKS) { set_error("at most %d ranks", KATOME_MAX_RANKS); return KATOME_E_UNSUPPORTED; }
+    katome_settings mine = *s;
+    mine.n_devices = 1;
+    mine.flags = (uint16_t)(s->flags & KATOME_FLAG_FIRST_SEEN_ORDER);      // (stages run after katome_dist_gather, on the root)
+    // the hint is for the whole build; every rank owns about 1/world of the keys
+    if (mine.table_slots_hint) mine.table_slots_hint = (uint64_t)((double)mine.table_slots_hint / comm->world() * 1.1) + 1024;
+    katome_builder* b = nullptr;
+    KCHECK(katome_builder_create(&mine, &b));
+    katome_dist_builder* d = new (std::nothrow) katome_dist_builder();
+    if (!d) { katome_builder_destroy(b); set_error("out of host memory"); return KATOME_E_OOM; }
+    d->s = *s; d->comm = comm; d->b = b; d->nw = b->nw; d->rc = b->rc; d->first_seen = b->first_seen;
+    *out = d;
+    return KATOME_OK;
+}
+
+void katome_dist_destroy(katome_dist_builder* d) {
+    if (!d) return;
+    (void)hipSetDevice(d->s.device);
+    katome_builder_destroy(d->b);
+    delete d;
+}
+
+katome_builder* katome_dist_inner(katome_dist_builder* d) { return d ? d->b : nullptr; }
+
+int katome_dist_remove_weak_edges(katome_dist_builder* d, uint32_t threshold) {
+    if (!d) { set_error("null argument"); return KATOME_E_ARG; }
+    if (d->first_seen) { set_error("first-seen order: remove_weak_edges runs on the gathered graph (katome_dist_gather), with petgraph's numbering"); return KATOME_E_ARG; }
+    return katome_dev_remove_weak_edges(d->b, threshold);
+}
+
+int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,
+                          const uint8_t* d_skip, uint64_t batch_reads, void* stream_) {
+    if (!d || (!d_packed && n_reads)) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    katome_builder* b = d->b;
+    KCHECK_HIP(hipSetDevice(d->s.device));
+    if (d->finalized) { set_error("builder already finalized"); return KATOME_E_ARG; }
+    const uint32_t k = d->s.k, nw = d->nw;
+    if (read_len < k) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }       // pt_graph.rs:278
+    if (!d->planned) {
+        d->read_len = read_len; d->W = read_len - k + 1;
+        if (!katome_tile_plan_limited(k, read_len, 3, &d->span, &d->tiles_per_read, &d->rest)) { d->span = 1; d->tiles_per_read = 0; d->rest = d->W; }
+        d->nwt = d->span > 1 ? katome_tile_words(k, d->span) : nw;
+        d->planned = true;
+    } else if (read_len != d->read_len) {
+        set_error("the sharded build takes reads of one length (%u, then %u)", d->read_len, read_len);
+        return KATOME_E_UNSUPPORTED;
+    }
+    const int world = d->world();
+    const bool tiled = d->span > 1;
+    const uint32_t per_read = tiled ? d->tiles_per_read : d->W, nwr = tiled ? d->nwt : nw, stride = (read_len + 3) / 4;
+    // tile records are small (a few per read): large batches mean few exchange rounds
+    uint64_t batch = batch_reads ? batch_reads : (tiled ? (16ull << 20) : (4ull << 20));
+    batch = std::max<uint64_t>(64, batch / 64 * 64);
+    uint64_t nb = (n_reads + batch - 1) / batch;
+    KCHECK(d->comm->allreduce(&nb, 1, OP_MAX));                    // every rank takes part in every exchange
+    const uint64_t cap_reads = std::min(batch, std::max<uint64_t>(n_reads, 1));
+    const uint32_t first_rest = tiled ? d->tiles_per_read * d->span : 0;
+    DevBuf recbuf(stream), part(stream), idx(stream), pidx(stream);
+    const uint64_t cap_rec = cap_reads * std::max<uint32_t>(per_read, d->rest);
+    KCHECK(recbuf.alloc(cap_rec * 8 * nwr + 64)); KCHECK(part.alloc(cap_rec * 8 * nwr + 64));
+    if (d->first_seen) { KCHECK(idx.alloc(cap_rec * 4 + 64)); KCHECK(pidx.alloc(cap_rec * 4 + 64)); }
+    for (uint64_t i = 0; i < nb; ++i) {
+        const uint64_t r0 = std::min(n_reads, i * batch), nr = std::min(batch, n_reads - r0);
+        const uint8_t* p = d_packed ? d_packed + r0 * stride : nullptr;
+        const uint8_t* sk = d_skip ? d_skip + r0 : nullptr;
+        std::vector<uint64_t> counts(world, 0);
+        if (nr) {
+            {
+                PhaseScope ps(b->prof, PH_EXTRACT, stream);
+                KCHECK(launch_extract_fixed(k, d->rc, p, nr, read_len, sk, recbuf.as<u64>(), stream, tiled ? d->span : 1, d->first_seen && d->rc));
+            }
+            const uint64_t n_rec = nr * per_read;
+            if (d->first_seen) KCHECK(dev_iota(idx.as<u32>(), n_rec, stream));
+            PhaseScope ps(b->prof, PH_REGION_ORDER, stream);       // ("region_order" doubles as the routing pass here)
+            // a tile's owner may be any function of the tile -- identical tiles only have to meet on one rank; a k-mer's owner
+            // is its canonical middle
+            KCHECK(dev_partition(recbuf.as<u64>(), d->first_seen ? idx.as<u32>() : nullptr, n_rec, nwr, world, part.as<u64>(),
+                                 d->first_seen ? pidx.as<u32>() : nullptr, counts.data(), stream, tiled ? 0 : 2, tiled ? 0 : k - 2));
+        }
+        KCHECK(route_and_insert(d, part.as<u64>(), pidx.as<u32>(), counts, nwr, tiled, first_read + r0, per_read, 0, tiled ? d->span : 1, stream));
+        if (tiled && d->rest) {                                    // the windows after the last whole tile of every read
+            std::vector<uint64_t> rcounts(world, 0);
+            if (nr) {
+                {
+                    PhaseScope ps(b->prof, PH_EXTRACT, stream);
+                    KCHECK(launch_extract_fixed(k, d->rc, p, nr, read_len, sk, recbuf.as<u64>(), stream, 1, d->first_seen && d->rc, first_rest, d->rest));
+                }
+                const uint64_t n_rec = nr * d->rest;
+                if (d->first_seen) KCHECK(dev_iota(idx.as<u32>(), n_rec, stream));
+                PhaseScope ps(b->prof, PH_REGION_ORDER, stream);
+                KCHECK(dev_partition(recbuf.as<u64>(), d->first_seen ? idx.as<u32>() : nullptr, n_rec, nw, world, part.as<u64>(),
+                                     d->first_seen ? pidx.as<u32>() : nullptr, rcounts.data(), stream, 2, k - 2));
+            }
+            KCHECK(route_and_insert(d, part.as<u64>(), pidx.as<u32>(), rcounts, nw, false, first_read + r0, d->rest, first_rest, 1, stream));
+        }
+        KCHECK_HIP(hipStreamSynchronize(stream));
+    }
+    d->reads_end = std::max(d->reads_end, first_read + n_reads);
+    return KATOME_OK;
+}
+
+int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* stream_) {
+    if (!d) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    katome_builder* b = d->b;
+    KCHECK_HIP(hipSetDevice(d->s.device));
+    if (d->finalized) return fill_graph(d, out);
+    const int world = d->world(), rank = d->rank();
+    const uint32_t nw = d->nw, k = d->s.k, node_bits = 2 * (k - 1);
+    // agree on the plan (a rank that was given no reads has none) and on the extent of the input
+    uint64_t plan[2] = {d->planned ? d->span : 0, d->reads_end};
+    KCHECK(d->comm->allreduce(plan, 2, OP_MAX));
+    const bool tiled = plan[0] > 1;
+    const uint64_t total_reads = plan[1];
+    if (tiled) KCHECK(expand_and_route_kmers(d, stream));
+    KCHECK(katome_dev_edges(b, nullptr, nullptr, nullptr, stream));       // this rank's distinct oriented edges, ascending (+ edge_seq)
+    const uint64_t E = b->n_edges;
+    if (E >= (1ull << 32)) { set_error("more than 2^32 edges on one rank"); return KATOME_E_UNSUPPORTED; }
+    const u64* keys = b->edge_key.as<u64>();
+    const u64* seq = d->first_seen ? b->edge_seq.as<u64>() : nullptr;
+    trace_words("edges: keys", rank, keys, E * nw, stream);
+    if (seq) trace_words("edges: seq", rank, seq, E, stream);
+    // every edge asks the owner of its target (k-1)-mer for the target's id, remembering which edge asked
+    DevBuf T(stream), origin(stream), P(stream), porigin(stream), tv(stream);
+    std::vector<uint64_t> counts(world, 0), rcnt(world, 0);
+    KCHECK(T.alloc((E + 1) * 8 * nw)); KCHECK(origin.alloc((E + 1) * 4)); KCHECK(P.alloc((E + 1) * 8 * nw)); KCHECK(porigin.alloc((E + 1) * 4));
+    if (E) {
+        KCHECK(dev_endpoints(keys, E, k, nullptr, T.as<u64>(), stream));
+        KCHECK(dev_iota(origin.as<u32>(), E, stream));
+        KCHECK(dev_partition(T.as<u64>(), origin.as<u32>(), E, nw, world, P.as<u64>(), porigin.as<u32>(), counts.data(), stream, 0, k - 2));
+    }
+    T.release(); origin.release();
+    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+    const uint64_t nR = sum(rcnt);
+    if (nR >= (1ull << 32)) { set_error("more than 2^32 target look-ups on one rank"); return KATOME_E_UNSUPPORTED; }
+    DevBuf R(stream), rv(stream);
+    KCHECK(R.alloc((nR + 1) * 8 * nw));
+    KCHECK(d->xchg(X_TARGETS, P.p, counts.data(), R.p, rcnt.data(), 8 * nw, stream));
+    if (d->first_seen) {                                     // ... and tells it when it first touched the target (2 * seq + 1)
+        KCHECK(tv.alloc((E + 1) * 8)); KCHECK(rv.alloc((nR + 1) * 8));
+        if (E) KLAUNCH(target_value_kernel, E, stream, seq, porigin.as<u32>(), E, tv.as<u64>());
+        KCHECK_HIP(hipGetLastError());
+        KCHECK(d->xchg(X_TARGETS, tv.p, counts.data(), rv.p, rcnt.data(), 8, stream));
+        tv.release();
+    }
+    P.release();
+    // this rank's nodes with out-edges are the sources of its own sorted edges: no sort, no exchange
+    DevBuf S(stream), lsrc(stream);
+    uint64_t n_src = 0;
+    KCHECK(lsrc.alloc((E + 1) * 8));
+    if (E) KCHECK(dev_source_ids(keys, E, k, S, lsrc.as<u64>(), &n_src, stream));
+    // answer: position among the sources or -- for a node without out-edges -- among the other nodes owned here
+    DevBuf local(stream), sinks(stream);
+    uint64_t n_sinks = 0;
+    KCHECK(local.alloc((nR + 1) * 8));
+    if (nR) {
+        if (n_src) KCHECK(dev_rank(S.as<u64>(), n_src, nw, node_bits, R.as<u64>(), nR, local.as<u64>(), stream));
+        else KCHECK_HIP(hipMemsetAsync(local.p, 0xFF, nR * 8, stream));
+        DevBuf mk(stream), mpos(stream), cursor(stream), mrank(stream);
+        KCHECK(cursor.alloc(8));
+        KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+        KCHECK(mk.alloc((nR + 1) * 8 * nw)); KCHECK(mpos.alloc((nR + 1) * 4));
+        if (nw == 1) KLAUNCH(compact_missing_kernel<1>, nR, stream, local.as<u64>(), R.as<u64>(), nR, mk.as<u64>(), mpos.as<u32>(), cursor.as<u64>());
+        else         KLAUNCH(compact_missing_kernel<2>, nR, stream, local.as<u64>(), R.as<u64>(), nR, mk.as<u64>(), mpos.as<u32>(), cursor.as<u64>());
+        KCHECK_HIP(hipGetLastError());
+        uint64_t m = 0;
+        KCHECK_HIP(hipMemcpyAsync(&m, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        if (m) {
+            KCHECK(sinks.alloc(m * 8 * nw)); KCHECK(mrank.alloc(m * 8));
+            KCHECK_HIP(hipMemcpyAsync(sinks.p, mk.p, m * 8 * nw, hipMemcpyDeviceToDevice, stream));
+            KCHECK(dev_sort(sinks.as<u64>(), nullptr, m, nw, node_bits, stream));
+            KCHECK(dev_unique(sinks.as<u64>(), m, nw, &n_sinks, stream));
+            KCHECK(dev_rank(sinks.as<u64>(), n_sinks, nw, node_bits, mk.as<u64>(), m, mrank.as<u64>(), stream));
+            KLAUNCH(fill_missing_kernel, m, stream, local.as<u64>(), mpos.as<u32>(), mrank.as<u64>(), m, n_src);
+            KCHECK_HIP(hipGetLastError());
+        }
+    }
+    R.release();
+    const uint64_t n_owned = n_src + n_sinks;
+    std::vector<uint64_t> all(world, 0);
+    KCHECK(d->comm->allgather(n_owned, all.data()));
+    uint64_t base = 0, total_nodes = 0;
+    for (int p = 0; p < world; ++p) { if (p < rank) base += all[p]; total_nodes += all[p]; }
+    // node keys: the sources ascending, then the others ascending
+    KCHECK(d->node_key.alloc((n_owned + 1) * 8 * nw, stream));
+    if (n_src) KCHECK_HIP(hipMemcpyAsync(d->node_key.p, S.p, n_src * 8 * nw, hipMemcpyDeviceToDevice, stream));
+    if (n_sinks) KCHECK_HIP(hipMemcpyAsync(d->node_key.as<u64>() + n_src * nw, sinks.p, n_sinks * 8 * nw, hipMemcpyDeviceToDevice, stream));
+    S.release(); sinks.release();
+    const u64* id_map = nullptr;
+    if (d->first_seen) {
+        // the reference numbers a node when its first edge is added (add_fasta_node, pt_graph.rs:142-154): source of the
+        // edge's first insertion at 2 * seq, target at 2 * seq + 1; the node's index is the rank of the earliest such number
+        const uint64_t max_seq = 2 * (total_reads + 1) * 2 * (uint64_t)std::max<uint32_t>(d->W, 1) + 2;
+        DevBuf node_first(stream);
+        KCHECK(node_first.alloc((n_owned + 1) * 8));
+        KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, n_owned * 8, stream));
+        if (E) KLAUNCH(src_first_kernel, E, stream, lsrc.as<u64>(), seq, E, node_first.as<u64>());
+        if (nR) KLAUNCH(dst_first_kernel, nR, stream, local.as<u64>(), rv.as<u64>(), nR, node_first.as<u64>());
+        KCHECK_HIP(hipGetLastError());
+        KCHECK(d->node_gid.alloc((n_owned + 1) * 8, stream));
+        KCHECK(global_rank(d, X_RANK_NODES, node_first.as<u64>(), n_owned, 2 * max_seq + 2, d->node_gid.as<u64>(), stream));
+        id_map = d->node_gid.as<u64>();
+        base = 0;
+    }
+    rv.release();
+    // ids travel back over the mirrored exchange and are put where their edges are
+    DevBuf ans(stream), back(stream);
+    KCHECK(ans.alloc((nR + 1) * 8)); KCHECK(back.alloc((E + 1) * 8));
+    if (nR) KLAUNCH(map_ids_kernel, nR, stream, local.as<u64>(), nR, id_map, base, ans.as<u64>());
+    KCHECK_HIP(hipGetLastError());
+    KCHECK(d->xchg(X_IDS, ans.p, rcnt.data(), back.p, counts.data(), 8, stream));
+    KCHECK(d->edge_src.alloc((E + 1) * 8, stream)); KCHECK(d->edge_dst.alloc((E + 1) * 8, stream));
+    if (E) {
+        KLAUNCH(scatter_u64_kernel, E, stream, back.as<u64>(), porigin.as<u32>(), E, d->edge_dst.as<u64>());
+        KLAUNCH(map_ids_kernel, E, stream, lsrc.as<u64>(), E, id_map, base, d->edge_src.as<u64>());
+    }
+    KCHECK_HIP(hipGetLastError());
+    if (d->first_seen) {                                     // petgraph edge index = rank of the edge's first insertion (pt_graph.rs:194)
+        const uint64_t max_seq = 2 * (total_reads + 1) * 2 * (uint64_t)std::max<uint32_t>(d->W, 1) + 2;
+        KCHECK(d->edge_gid.alloc((E + 1) * 8, stream));
+        KCHECK(global_rank(d, X_RANK_EDGES, seq, E, max_seq, d->edge_gid.as<u64>(), stream));
+    }
+    const uint32_t lstride = label_stride_for_k(k);
+    KCHECK(d->edge_label.alloc((E + 1) * (size_t)lstride + 16, stream));
+    {
+        PhaseScope ps(b->prof, PH_LABELS, stream);
+        KCHECK(dev_labels(keys, E, k, d->edge_label.as<uint8_t>(), stream));
+    }
+    trace_words("finalize end: keys", rank, keys, E * nw, stream);
+    trace_words("finalize end: src", rank, d->edge_src.p, E, stream);
+    trace_words("finalize end: dst", rank, d->edge_dst.p, E, stream);
+    if (d->first_seen) { trace_words("finalize end: edge ids", rank, d->edge_gid.p, E, stream); trace_words("finalize end: node ids", rank, d->node_gid.p, n_owned, stream); }
+    uint64_t tot = E;
+    KCHECK(d->comm->allreduce(&tot, 1, OP_SUM));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    d->n_edges = E; d->n_nodes = n_owned; d->total_edges = tot; d->total_nodes = total_nodes; d->node_base = d->first_seen ? 0 : base;
+    d->finalized = true;
+    return fill_graph(d, out);
+}
+
+int katome_dist_gather(katome_dist_builder* d, int root, katome_builder** root_builder, void* stream_) {
+    if (!d) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    katome_builder* b = d->b;
+    KCHECK_HIP(hipSetDevice(d->s.device));
+    if (root_builder) *root_builder = nullptr;
+    if (!d->finalized || !d->first_seen) { set_error("katome_dist_gather: a finalized FIRST_SEEN_ORDER build only (its indices place the edges)"); return KATOME_E_ARG; }
+    const int world = d->world(), rank = d->rank();
+    if (root < 0 || root >= world) { set_error("root out of range"); return KATOME_E_ARG; }
+    const uint32_t nw = d->nw;
+    const uint64_t E = d->n_edges, N = d->n_nodes, TE = d->total_edges, TN = d->total_nodes;
+    if (TE >= 0xFFFFFFFFull || TN >= 0xFFFFFFFFull) { set_error("katome_dist_gather: the whole graph (%llu edges) does not fit one GPU's 2^32 indices", (unsigned long long)TE); return KATOME_E_UNSUPPORTED; }
+    std::vector<uint64_t> ecnt(world, 0), ncnt(world, 0), ercnt(world, 0), nrcnt(world, 0);
+    ecnt[root] = E; ncnt[root] = N;
+    KCHECK(d->comm->exchange_counts(ecnt.data(), ercnt.data()));
+    KCHECK(d->comm->exchange_counts(ncnt.data(), nrcnt.data()));
+    const bool me = rank == root;
+    const uint64_t rE = me ? TE : 0, rN = me ? TN : 0;
+    // this rank's share moves out of its builder; the root's builder then receives the whole graph
+    DevBuf l_key(stream), l_w(stream);
+    { const size_t n = b->edge_key.bytes; l_key.adopt(b->edge_key.take(), n); }
+    { const size_t n = b->edge_weight.bytes; l_w.adopt(b->edge_weight.take(), n); }
+    b->edge_seq.release();
+    DevBuf g_gid(stream), tmp(stream);
+    KCHECK(g_gid.alloc((rE + 1) * 8));
+    KCHECK(d->xchg(X_GATHER, d->edge_gid.p, ecnt.data(), g_gid.p, ercnt.data(), 8, stream));
+    auto bring = [&](const void* mine, size_t elem, void** landed) -> int {
+        KCHECK(tmp.alloc((rE + 1) * elem));
+        KCHECK(d->xchg(X_GATHER, mine, ecnt.data(), tmp.p, ercnt.data(), elem, stream));
+        *landed = tmp.p;
+        return KATOME_OK;
+    };
+    void* in = nullptr;
+    trace_words("gather: my keys", rank, l_key.p, E * nw, stream);
+    trace_words("gather: ids at root", rank, g_gid.p, rE, stream);
+    KCHECK(bring(l_key.p, 8 * nw, &in));
+    trace_words("gather: keys at root", rank, in, rE * nw, stream);
+    if (me) {
+        KCHECK(b->edge_key.alloc((TE + 1) * 8 * nw, stream));
+        if (TE) { if (nw == 1) KLAUNCH(place_keys_kernel<1>, TE, stream, g_gid.as<u64>(), (const u64*)in, TE, b->edge_key.as<u64>());
+                  else         KLAUNCH(place_keys_kernel<2>, TE, stream, g_gid.as<u64>(), (const u64*)in, TE, b->edge_key.as<u64>()); }
+    }
+    l_key.release();
+    KCHECK(bring(l_w.p, 4, &in));
+    if (me) {
+        KCHECK(b->edge_weight.alloc((TE + 1) * 4, stream));
+        if (TE) KLAUNCH(place_kernel<u32>, TE, stream, g_gid.as<u64>(), (const u32*)in, TE, b->edge_weight.as<u32>());
+    }
+    l_w.release();
+    KCHECK(bring(d->edge_src.p, 8, &in));
+    if (me) {
+        KCHECK(b->edge_src.alloc((TE + 1) * 8, stream));
+        if (TE) KLAUNCH(place_kernel<u64>, TE, stream, g_gid.as<u64>(), (const u64*)in, TE, b->edge_src.as<u64>());
+    }
+    KCHECK(bring(d->edge_dst.p, 8, &in));
+    if (me) {
+        KCHECK(b->edge_dst.alloc((TE + 1) * 8, stream));
+        if (TE) KLAUNCH(place_kernel<u64>, TE, stream, g_gid.as<u64>(), (const u64*)in, TE, b->edge_dst.as<u64>());
+    }
+    KCHECK_HIP(hipGetLastError());
+    // nodes
+    DevBuf n_gid(stream), n_key(stream);
+    KCHECK(n_gid.alloc((rN + 1) * 8)); KCHECK(n_key.alloc((rN + 1) * 8 * nw));
+    KCHECK(d->xchg(X_GATHER, d->node_gid.p, ncnt.data(), n_gid.p, nrcnt.data(), 8, stream));
+    KCHECK(d->xchg(X_GATHER, d->node_key.p, ncnt.data(), n_key.p, nrcnt.data(), 8 * nw, stream));
+    if (me) {
+        KCHECK(b->node_key.alloc((TN + 1) * 8 * nw, stream));
+        if (TN) { if (nw == 1) KLAUNCH(place_keys_kernel<1>, TN, stream, n_gid.as<u64>(), n_key.as<u64>(), TN, b->node_key.as<u64>());
+                  else         KLAUNCH(place_keys_kernel<2>, TN, stream, n_gid.as<u64>(), n_key.as<u64>(), TN, b->node_key.as<u64>()); }
+        KCHECK_HIP(hipGetLastError());
+        b->n_edges = TE; b->n_nodes = TN;
+        trace_words("gather: placed keys", rank, b->edge_key.p, TE * nw, stream);
+        trace_words("gather: placed nodes", rank, b->node_key.p, TN * nw, stream);
+        const uint32_t lstride = label_stride_for_k(d->s.k);
+        KCHECK(b->edge_label.alloc((TE + 1) * (size_t)lstride + 16, stream));
+        KCHECK(dev_labels(b->edge_key.as<u64>(), TE, d->s.k, b->edge_label.as<uint8_t>(), stream));
+        b->edge_age.release();
+        b->edges_ready = true; b->finalized = true;
+        if (root_builder) *root_builder = b;
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    // the ranks' shares have been consumed
+    d->edge_src.release(); d->edge_dst.release(); d->edge_label.release(); d->node_key.release(); d->edge_gid.release(); d->node_gid.release();
+    d->n_edges = d->n_nodes = 0;
+    return KATOME_OK;
+}
+
+}  // extern "C"

@@ -42,6 +42,8 @@ int dev_malloc(void** out, size_t bytes, hipStream_t stream) {
     int device = 0;
     (void)hipGetDevice(&device);
     void* p = c.pool.allocate(bytes, device, stream);
+    static const bool log_all = getenv("KATOME_TRACE_BLOCKS") != nullptr;     // every block handed out / taken back (overlap hunting)
+    if (log_all) fprintf(stderr, "[katome block] + %p %zu dev %d stream %p\n", p, SegmentPool<HipBackend>::round_size(bytes), device, (void*)stream);
     if (!p) {
         set_error("hipMalloc(%zu bytes) failed: out of device memory (%zu bytes held in segments, %zu of them free)", bytes,
                   c.pool.segment_bytes(), c.pool.free_bytes());
@@ -56,13 +58,25 @@ void dev_free(void* p, hipStream_t stream) {
     if (!p) return;
     Cache& c = cache();
     std::lock_guard<std::mutex> lk(c.mu);
+    static const bool log_all = getenv("KATOME_TRACE_BLOCKS") != nullptr;
+    if (log_all) fprintf(stderr, "[katome block] - %p stream %p\n", p, (void*)stream);
     if (!c.pool.deallocate(p, stream, stream != nullptr)) (void)hipFree(p);
+}
+
+void dev_retire_stream(hipStream_t stream) {
+    if (!stream) return;
+    (void)hipStreamSynchronize(stream);
+    Cache& c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.pool.retire_stream(stream, nullptr);
 }
 
 size_t dev_cached_bytes() {
     Cache& c = cache();
     std::lock_guard<std::mutex> lk(c.mu);
-    return c.pool.free_bytes();
+    int device = 0;
+    (void)hipGetDevice(&device);
+    return c.pool.free_bytes_on(device);            // what the CURRENT device could get back (ranks of one process own one device each)
 }
 
 void dev_release_cache(int device) {

@@ -84,7 +84,19 @@ public:
         }
     }
 
+    // a stream is about to be destroyed (its work is complete): blocks last used on it no longer need a wait -- and must
+    // not name it any more
+    void retire_stream(Stream s, Stream idle) {
+        for (auto& kv : free_) if (kv.second->stream == s) kv.second->stream = idle;
+        for (auto& kv : live_) if (kv.second->stream == s) kv.second->stream = idle;
+    }
+
     size_t free_bytes() const { return free_bytes_; }                  // cached: free blocks, whole segments or parts
+    size_t free_bytes_on(int device) const {                           // ... of one device
+        size_t t = 0;
+        for (const auto& kv : free_) if (kv.second->device == device) t += kv.second->bytes;
+        return t;
+    }
     size_t segment_bytes() const { return segment_bytes_; }            // everything taken from the backend
     size_t live_blocks() const { return live_.size(); }
     size_t free_blocks() const { return free_.size(); }

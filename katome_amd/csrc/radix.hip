@@ -436,6 +436,24 @@ int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32
     return KATOME_OK;
 }
 
+// group u64 values (with their u32 companions) by the range they fall into: part p = [bounds[p-1], bounds[p]), d_bounds on the
+// device (n_parts - 1 of them, ascending).  Stable.  Used to spread sequence numbers over the ranks (dist.hip global_rank).
+int dev_partition_range(const uint64_t* d_vals, const uint32_t* idx_in, uint64_t n, const uint64_t* d_bounds, uint32_t n_parts,
+                        uint64_t* d_out, uint32_t* idx_out, uint64_t* h_counts, hipStream_t stream) {
+    if (n_parts == 0 || n_parts >= (u32)RADIX) { set_error("n_parts must be 1..255"); return KATOME_E_ARG; }
+    for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
+    if (n == 0) return KATOME_OK;
+    PassBuffers pb;
+    KCHECK(pb.init(n, stream));
+    RangeDigit dg{d_bounds, n_parts};
+    KCHECK((radix_pass<1, true>(d_vals, idx_in, n, dg, d_out, idx_out, pb, stream)));
+    u64 totals[RADIX];
+    KCHECK_HIP(hipMemcpyAsync(totals, pb.totals.p, sizeof totals, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    for (u32 p = 0; p < n_parts; ++p) h_counts[p] = totals[p];
+    return KATOME_OK;
+}
+
 // order records by the table region they hash to (1 or 2 stable 8-bit passes over the top hash bits), so
 // that the insert kernel that follows works through the table one cache-sized region at a time.
 // Result lands in `bufs[passes & 1]` where bufs = {scratch_a, scratch_b}; returns that pointer.

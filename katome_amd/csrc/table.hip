@@ -192,6 +192,10 @@ struct SeenParams {
     u64 n_reads, seq_base;
     const u64* rec_prefix; // records of this launch's kind before each read (== win_prefix for one record per window)
     u32 mode;              // 0 every window, 1 whole tiles of `span` windows, 2 the windows after the last whole tile
+    // sharded build (SeenOrigin): index of every record in its source rank's batch + the segments, or explicit pairs
+    const u32* idx; u32 n_seg;
+    u64 seg_off[KATOME_MAX_RANKS + 1], seg_read0[KATOME_MAX_RANKS];
+    const u64* pairs;
 };
 
 // seen[slot] = min(seen[slot], {a, b}).  The numbers only ever go down, so a plain look first is safe: a pair that is
@@ -223,7 +227,15 @@ __global__ __launch_bounds__(BLOCK) void insert_kernel(typename SlotOf<NW>::type
             key.w[0] &= ~RC_MARK;
             const u64 g = sp.rec0 + i;
             u64 P, Q;
-            if (sp.win_prefix) {        // a read's forward windows take 2*prefix + [0, W), its reverse complement's the next W
+            if (sp.pairs) {             // both numbers came with the record (already relative to the stored orientation)
+                P = sp.pairs[2 * g]; Q = sp.pairs[2 * g + 1];
+            } else if (sp.idx) {        // record idx[g] of the batch its source rank cut from reads seg_read0[source]...
+                u32 seg = 0;
+                while (seg + 1 < sp.n_seg && g >= sp.seg_off[seg + 1]) ++seg;
+                const u64 j = sp.idx[g];
+                const u64 r = sp.seg_read0[seg] + j / sp.per_read, i0 = sp.win0 + (j % sp.per_read) * sp.span;
+                P = r * 2 * sp.windows + i0; Q = r * 2 * sp.windows + 2 * sp.windows - i0 - sp.span;
+            } else if (sp.win_prefix) {        // a read's forward windows take 2*prefix + [0, W), its reverse complement's the next W
                 u64 lo = 0, hi = sp.n_reads;
                 while (hi - lo > 1) { const u64 mid = (lo + hi) >> 1; if (sp.rec_prefix[mid] <= g) lo = mid; else hi = mid; }
                 const u64 w0 = sp.win_prefix[lo], W = sp.win_prefix[lo + 1] - w0, j = g - sp.rec_prefix[lo];
@@ -324,6 +336,8 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
             Key<NWK> x = sub_window<NWT, NWK>(tk, k, span, stride, o);
             bool flipped = false;
             if (RC) x = canonical_flip(x, k, flipped);
+            u64 seq_fwd = 0, seq_rev = 0;          // records with sequence numbers: read now (see below)
+            if (!TO_TABLE && tile_seen) { seq_fwd = lseen[2 * t] + (u64)o * stride; seq_rev = lseen[2 * t + 1] + (u64)(span - 1 - o) * stride; }
             if (TO_TABLE) {
                 if (kmer_seen) {
                     // the o-th sub-window of the tile was first put in at base + o*stride; the reverse complement of
@@ -341,6 +355,14 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
 #pragma unroll
                 for (int q = 0; q < NWK; ++q) out_keys[(bbase + p) * NWK + q] = x.w[q];
                 out_w[bbase + p] = lcnt[t];
+                if (tile_seen) {        // (kmer_seen is the records' [n][2] output here)
+                    // Two 8-byte stores whose values were read from LDS BEFORE the key and weight stores above were issued.
+                    // With the pair read from LDS after those stores (into the registers that had held their addresses) and
+                    // written as one 16-byte store, about one tile in 5000 came out with the buffer's previous contents in
+                    // place of its keys on MI355X (hipcc 7.2; found by comparing with the same expansion without numbers).
+                    __hip_atomic_store(&kmer_seen[2 * (bbase + p)], flipped ? seq_rev : seq_fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&kmer_seen[2 * (bbase + p) + 1], flipped ? seq_fwd : seq_rev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
         }
         __syncthreads();
@@ -462,6 +484,9 @@ int table_insert(Table& t, const uint64_t* d_records, const uint32_t* d_weights,
         sp.span = origin->span; sp.windows = origin->windows; sp.rc = origin->rc; sp.win0 = origin->win0;
         sp.win_prefix = origin->win_prefix; sp.n_reads = origin->n_reads; sp.seq_base = origin->seq_base;
         sp.rec_prefix = origin->rec_prefix ? origin->rec_prefix : origin->win_prefix; sp.mode = origin->mode;
+        sp.idx = origin->idx; sp.n_seg = origin->n_seg; sp.pairs = origin->pairs;
+        for (int i = 0; i <= KATOME_MAX_RANKS; ++i) sp.seg_off[i] = origin->seg_off[i];
+        for (int i = 0; i < KATOME_MAX_RANKS; ++i) sp.seg_read0[i] = origin->seg_read0[i];
         if (t.nw == 1)
             hipLaunchKernelGGL((insert_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, d_records, d_weights, n, &aux->occupied, &aux->err, sp);
         else if (t.nw == 2)
@@ -502,7 +527,7 @@ int table_grow(Table& t, uint64_t new_cap, hipStream_t stream) {
 // tile-table slots [slot0, slot1); every tile holds `span` windows of `k` bases, `stride` bases apart
 template <bool TO_TABLE>
 static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint32_t k, uint32_t span, uint32_t stride, bool rc,
-                         u64* out_keys, u32* out_w, u64* cursor, hipStream_t stream) {
+                         u64* out_keys, u32* out_w, u64* cursor, hipStream_t stream, u64* out_seen = nullptr) {
     const uint32_t nwk = (uint32_t)key_words_for_k(k);
     TableAux* aux = kmers ? kmers->counter.as<TableAux>() : nullptr;
     if (slot1 <= slot0) return KATOME_OK;
@@ -511,8 +536,8 @@ static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint3
     hipLaunchKernelGGL((expand_tiles_kernel<NWT, NWK, RCV, TO_TABLE>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), \
                        slot0, slot1, k, span, stride, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
                        aux ? &aux->occupied : nullptr, aux ? &aux->err : nullptr, out_keys, out_w, cursor,                      \
-                       (kmers && kmers->track_seen) ? tiles.seen.as<u64>() : nullptr,                                          \
-                       (kmers && kmers->track_seen) ? kmers->seen.as<u64>() : nullptr)
+                       ((kmers && kmers->track_seen) || out_seen) ? tiles.seen.as<u64>() : nullptr,                            \
+                       (kmers && kmers->track_seen) ? kmers->seen.as<u64>() : out_seen)
     if (tiles.nw == 1) { if (rc) KATOME_EXPAND(1, 1, true); else KATOME_EXPAND(1, 1, false); }
     else if (tiles.nw == 2) {
         if (nwk == 1) { if (rc) KATOME_EXPAND(2, 1, true); else KATOME_EXPAND(2, 1, false); }
@@ -533,16 +558,18 @@ int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmer
 }
 
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
-                                  uint64_t* n_records, hipStream_t stream) {
+                                  uint64_t* n_records, hipStream_t stream, DevBuf* seen) {
     uint64_t occ = 0;
     KCHECK(table_occupied(tiles, &occ, stream));
     const uint32_t nwk = (uint32_t)key_words_for_k(k);
     KCHECK(keys.alloc((occ * span + 1) * 8 * nwk, stream));
     KCHECK(weights.alloc((occ * span + 1) * 4, stream));
+    u64* out_seen = nullptr;
+    if (seen && tiles.track_seen) { KCHECK(seen->alloc((occ * span + 1) * 16, stream)); out_seen = seen->as<u64>(); }
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
-    KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, 1, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream));
+    KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, 1, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream, out_seen));
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     return KATOME_OK;

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), name
     assert sorted(_lib.SYMBOLS) == names          # the Python binding covers the whole header
-    assert katome_amd.lib().katome_abi_version() == 1
+    assert katome_amd.lib().katome_abi_version() == 2
 
 
 def test_record_words():

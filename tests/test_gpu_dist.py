@@ -1,0 +1,177 @@
+"""The sharded (multi-GPU) build through the C ABI (`settings.n_devices`, katome_amd/csrc/dist.hip): on a one-GPU box the
+ranks share the card (KATOME_FLAG_RANKS_SHARE_DEVICE: peer copies instead of RCCL, same sharding / routing / exchange /
+global-numbering code), and RCCL itself runs at world size 1.  Parity against the oracle's single sequential build:
+by packed key the edge multiset and node set; in the reference's numbering every array index for index, whatever the
+number of ranks -- including BASELINE config 5's shape (k=63, three-word tiles, remove_dead_paths)."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from helpers import int_to_kmer, pack_reads_ascii  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _reads(oracle, n, L, genome=3000, err=2e-2, npct=4):
+    ascii_reads = oracle.synth_reads(0, n, L, genome, err, npct)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("A")
+    return ascii_reads, pack_reads_ascii(clean).reshape(-1).copy(), has_n.astype(np.uint8)
+
+
+def _same_arrays(g, ref):
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    assert np.array_equal(g.edge_label, ref.edge_label)          # same edge at every index
+    assert np.array_equal(g.edge_weight, ref.edge_weight)
+    assert np.array_equal(g.edge_src, ref.edge_src) and np.array_equal(g.edge_dst, ref.edge_dst)
+
+
+# katome_tile_plan: L=50: k=11 -> 2 tiles of 20 windows; k=33 -> 1 tile of 18 (two-word key, one three-word tile of 50 bases
+# = two words ...); L=150, k=63: 3 tiles of 28 windows (90-mers: THREE-word tiles) + 4 windows; L=53, k=11: 43 windows
+# = 2 tiles of 21 + 1 left over; k=60, L=75: 16 windows -> one tile of 16 (75 bases, three words)
+CASES = [(2, 11, True, 260, 50), (3, 12, False, 200, 50), (2, 33, True, 130, 50), (4, 11, True, 300, 53),
+         (2, 63, True, 120, 150), (3, 60, False, 90, 75), (8, 31, True, 700, 150), (3, 11, True, 100, 53),
+         (4, 40, True, 64, 100)]           # the last ones leave ranks without reads (shards are multiples of 64 reads)
+
+
+@pytest.mark.parametrize("world,k,rc,n,L", CASES)
+def test_sharded_build_by_packed_key_equals_oracle(oracle, world, k, rc, n, L):
+    from katome_amd.build import GpuGraph
+    ascii_reads, packed, skip = _reads(oracle, n, L)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world,
+                                        ranks_share_device=True)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert rb == ref.read_bytes
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    assert g.multiset() == ref.multiset()
+    ek, nk = g.key_ints("edge"), g.key_ints("node")
+    assert len(set(ek)) == len(ek) and len(set(nk)) == len(nk)       # every k-mer on exactly one rank, every node owned once
+    mask = (1 << (2 * (k - 1))) - 1
+    for e in range(g.n_edges):
+        assert nk[int(g.edge_src[e])] == ek[e] >> 2 and nk[int(g.edge_dst[e])] == ek[e] & mask
+    assert set(g.edge_src.tolist()) | set(g.edge_dst.tolist()) == set(range(g.n_nodes))
+    oracle.set_k(k)
+    for e in range(0, g.n_edges, max(1, g.n_edges // 200)):
+        assert bytes(g.edge_label[e]) == oracle.compress_edge(int_to_kmer(ek[e], k).encode())
+
+
+@pytest.mark.parametrize("world,k,rc,n,L", CASES)
+def test_sharded_build_in_reference_order_equals_oracle(oracle, world, k, rc, n, L):
+    """KATOME_FLAG_FIRST_SEEN_ORDER on the sharded route: petgraph's own edge and node indices (pt_graph.rs:149,194) from
+    global ranks of the first-insertion sequence numbers -- identical to the sequential build for any number of ranks"""
+    from katome_amd.build import GpuGraph
+    ascii_reads, packed, skip = _reads(oracle, n, L)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world,
+                                        ranks_share_device=True, first_seen_order=True)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert rb == ref.read_bytes
+    _same_arrays(g, ref)
+
+
+@pytest.mark.parametrize("world,k,rc,n,L,genome,err", [(2, 63, True, 400, 150, 4000, 5e-4), (4, 63, True, 900, 150, 9000, 3e-4),
+                                                       (8, 63, False, 600, 150, 4000, 5e-4), (2, 63, True, 400, 150, 4000, 5e-3),
+                                                       (3, 31, True, 1500, 150, 9000, 1e-2), (2, 40, False, 800, 100, 5000, 2e-3)])
+def test_config5_shape_pruned_on_the_sharded_route(oracle, world, k, rc, n, L, genome, err):
+    """BASELINE config 5's shape: k=63 (two-word keys, three-word tiles), reads sharded over the ranks, then the reference's
+    first pruning -- Prunable::remove_dead_paths (pruner.rs:36-82), whose walks follow petgraph's adjacency and whose
+    swap_removes re-number by index -- on the graph gathered to one rank in the reference's numbering.  Index for index
+    against the oracle's literal petgraph."""
+    from katome_amd.build import GpuGraph
+    ascii_reads, packed, skip = _reads(oracle, n, L, genome, err, 1)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world,
+                                        ranks_share_device=True, first_seen_order=True, remove_dead_paths=True)
+    ref = oracle.build_ascii(ascii_reads, k, rc, remove_dead_paths=True)
+    full = oracle.build_ascii(ascii_reads, k, rc)
+    assert ref.n_edges < full.n_edges and (ref.n_edges > 0 or err > 1e-3)   # something was pruned; at the high error rate: everything
+    _same_arrays(g, ref)
+
+
+def test_every_stage_after_a_sharded_build(oracle, tmp_path):
+    """katome_build_files_staged with n_devices: the FASTQ fixture sharded over three ranks, every stage of
+    assemble_with_graph before collapse on the gathered graph; the graph collapse() receives, index for index"""
+    from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data3.txt")
+    set_global_k_sizes(31)
+    oracle.set_genome_length(20000)
+    g, rb = GpuGraph.create([path], InputFileType.Fastq, True, 2, first_seen_order=True, stages="dcwced",
+                            original_genome_length=20000, n_devices=3, ranks_share_device=True)
+    ref = oracle.build_files([path], 31, True, remove_weak_edges=2, stages="dcwced")
+    assert rb == ref.read_bytes
+    _same_arrays(g, ref)
+
+
+def test_inputs_the_sharded_route_does_not_take_are_built_on_one_gpu(oracle, tmp_path):
+    """reads of unequal length and BFCounter input: n_devices is a resource hint, the result is the same graph"""
+    from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
+    rng = np.random.default_rng(3)
+    lines = []
+    for i in range(120):
+        n = int(rng.integers(40, 90))
+        lines += ["@r%d" % i, "".join("ACGT"[c] for c in rng.integers(0, 4, n)), "+", "I" * n]
+    fq = tmp_path / "var.fq"
+    fq.write_text("\n".join(lines) + "\n")
+    set_global_k_sizes(21)
+    g, rb = GpuGraph.create([str(fq)], InputFileType.Fastq, True, 0, n_devices=2, ranks_share_device=True)
+    ref = oracle.build_files([str(fq)], 21, True)
+    assert rb == ref.read_bytes and g.multiset() == ref.multiset()
+
+
+def test_too_many_devices_is_an_error():
+    from katome_amd.build import GpuGraph, KatomePanic
+    packed = np.zeros(64 * 13, np.uint8)
+    with pytest.raises(KatomePanic) as e:
+        GpuGraph.create_from_packed(packed, 64, 50, reverse_complement=True, k=11, n_devices=torch.cuda.device_count() + 1)
+    assert e.value.name == "E_DEVICE" and "visible" in e.value.message
+    with pytest.raises(KatomePanic) as e:      # pruning needs the reference's numbering, on any number of GPUs
+        GpuGraph.create_from_packed(packed, 64, 50, reverse_complement=True, k=11, n_devices=2, ranks_share_device=True,
+                                    remove_dead_paths=True)
+    assert e.value.name == "E_ARG"
+
+
+def _dist_build_one_process(k, rc, packed_t, skip_t, n, L, first_seen, comm, dev=0):
+    """one rank (of a world of 1) driving katome_dist_* itself, as a process-per-GPU job does"""
+    from katome_amd import _lib
+    from katome_amd.build import make_settings
+    L_ = _lib.lib()
+    s = make_settings(k, reverse_complement=rc, device=dev, first_seen_order=first_seen)
+    d = C.c_void_p()
+    assert L_.katome_dist_create(C.byref(s), comm, C.byref(d)) == 0, _lib.last_error()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert L_.katome_dist_add_reads(d, C.c_void_p(packed_t.data_ptr()), 0, n, L, C.c_void_p(skip_t.data_ptr()), 256, stream) == 0, _lib.last_error()
+    g = _lib.DistGraph()
+    assert L_.katome_dist_finalize(d, C.byref(g), stream) == 0, _lib.last_error()
+    return d, g
+
+
+def test_rccl_transport_at_world_size_one(oracle):
+    """RCCL itself (ncclCommInitRank from a unique id, grouped send/recv to self, allreduce): the process-per-GPU route
+    of bench.py with one rank -- same graph as the oracle's, exchange accounting readable"""
+    from katome_amd import _lib
+    L_ = _lib.lib()
+    ident = (C.c_uint8 * 128)()
+    assert L_.katome_comm_unique_id(ident) == 0, _lib.last_error()
+    comm = C.c_void_p()
+    assert L_.katome_comm_create_rccl(ident, 0, 1, 0, C.byref(comm)) == 0, _lib.last_error()
+    assert L_.katome_comm_kind(comm) == b"rccl" and L_.katome_comm_world(comm) == 1
+    k, rc, n, L = 31, True, 1000, 150
+    ascii_reads, packed, skip = _reads(oracle, n, L, 20000, 5e-3, 2)
+    pt, st = torch.from_numpy(np.concatenate([packed, np.zeros(32, np.uint8)])).cuda(), torch.from_numpy(skip).cuda()
+    d, g = _dist_build_one_process(k, rc, pt, st, n, L, False, comm)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert (g.total_nodes, g.total_edges) == (ref.n_nodes, ref.n_edges) == (g.n_nodes, g.n_edges)
+    w = torch.empty(g.n_edges, dtype=torch.int32, device="cuda")
+    C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(w.data_ptr()), C.c_void_p(g.d_edge_weight), C.c_size_t(g.n_edges * 4), 3)
+    assert int(w.to(torch.int64).sum().item()) == int(ref.edge_weight.astype(np.uint64).sum())
+    nx = L_.katome_dist_exchange_count()
+    stats = (C.c_uint64 * (4 * nx))()
+    assert L_.katome_dist_exchange_read(d, stats) == 0
+    names = [L_.katome_dist_exchange_name(i).decode() for i in range(nx)]
+    assert "exchange_records" in names and stats[4 * names.index("exchange_records")] > 0      # calls were counted
+    L_.katome_dist_destroy(d)
+    L_.katome_comm_destroy(comm)
