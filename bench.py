@@ -65,7 +65,14 @@ def parse_args():
     ap.add_argument("--min-weight", type=int, default=0,
                     help="Clean::remove_weak_edges(threshold) as the edges are read out (pruner.rs:84-93; not the BASELINE metric's configuration)")
     ap.add_argument("--table-factor", type=float, default=2.2, help="k-mer table slots per expected distinct canonical k-mer")
-    ap.add_argument("--cpu-sample-reads", type=int, default=150_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=300_000,
+                    help="reads of the workload the oracle builds on one host core (1e6 = all of C2; ~85 s there)")
+    ap.add_argument("--prune", action="store_true",
+                    help="BASELINE config 5: Prunable::remove_dead_paths after the build (reference order; N > 1: on the gathered graph)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline: skip the reference-order build, the unhinted build and the end-to-end region")
+    ap.add_argument("--end-to-end-reads", type=int, default=20_000_000,
+                    help="SURVEY 8(d) region (ii): host packed reads -> host arrays through katome_build_packed, on this many reads")
     ap.add_argument("--next-stages-reads", type=int, default=20_000_000,
                     help="also time first-seen-order build + remove_dead_paths + shrink on this many reads (0 = skip; N = 1 only)")
     return ap.parse_args()
@@ -91,12 +98,13 @@ class PhaseTimer:
         return out
 
 
-def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=False, min_weight=0, table_factor=2.2):
-    """one step on one GPU; returns (n_edges, n_nodes)"""
+def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=False, min_weight=0, table_factor=2.2, prune=False):
+    """one step on one GPU; returns (n_edges, n_nodes).  table_factor 0 = no hint: the tables start small and grow by
+    re-hashing, as for a caller that knows nothing about its input (settings.table_slots_hint = 0)"""
     from katome_amd import device as kd
     hint = int(wl.expected_distinct_canonical() * table_factor)
     b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index, table_slots_hint=hint,
-                   first_seen_order=first_seen)
+                   first_seen_order=first_seen or prune)
     b.profile(True)
     if min_weight:
         b.remove_weak_edges(min_weight)
@@ -113,11 +121,56 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=Fa
                 rec = b.extract_fixed(packed, nr, wl.read_len, skip, out=recbuf, first_read=r0)
                 b.insert(rec)
         dg = b.finalize()
+        n_edges, n_nodes = dg.n_edges, dg.n_nodes
+        if prune:                                   # BASELINE config 5's pruner pass (pruner.rs:36-82)
+            dg, _ = b.remove_dead_paths()
+            n_edges, n_nodes = dg.n_edges, dg.n_nodes
         timer.add(b.profile_read())
         timer.counts = b.counts()
-        return dg.n_edges, dg.n_nodes
+        return n_edges, n_nodes
     finally:
         b.close()
+
+
+def timed(step, steps, torch):
+    """ms per step of `steps` steps, after set-up builds until the library's memory cache has settled"""
+    for _ in range(3):
+        free_before = torch.cuda.mem_get_info()[0]
+        step()
+        if torch.cuda.mem_get_info()[0] + (64 << 20) >= free_before:
+            break
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3 / steps, out
+
+
+def end_to_end(wl, reads):
+    """SURVEY 8(d) region (ii): packed reads in HOST memory -> katome_build_packed (H2D, build, D2H) -> host arrays; the
+    PCIe- and copy-inclusive figure a caller of the host ABI sees -- never `value`"""
+    import numpy as np
+    from katome_amd import device as kd
+    from katome_amd.build import GpuGraph
+    w = wl.scaled(min(reads, wl.reads))
+    packed, skip = kd.synth_reads(0, w.reads, w.read_len, w.genome_len, w.err_rate, w.n_inject_percent, device=0)
+    h_packed = packed[:w.reads * w.stride].cpu().numpy()
+    h_skip = skip[:w.reads].cpu().numpy() if w.n_inject_percent else None
+    del packed, skip
+    hint = int(w.expected_distinct_canonical() * 2.2)
+    best = None
+    for _ in range(2):                              # (the first call also pays for the host pages of the result)
+        t0 = time.perf_counter()
+        g, rb = GpuGraph.create_from_packed(h_packed, w.reads, w.read_len, skip=h_skip, reverse_complement=w.reverse_complement,
+                                            k=w.k, table_slots_hint=hint)
+        dt = time.perf_counter() - t0
+        d2h = g.n_edges * (8 + 8 + 4 + g.label_stride + 8 * g.key_words) + g.n_nodes * 8 * g.key_words
+        best = {"reads": w.reads, "ms": dt * 1e3, "kmers_per_s": (rb // w.read_len) * w.windows_per_read / dt,
+                "h2d_bytes": int(h_packed.nbytes), "d2h_bytes": int(d2h), "distinct_edges": int(g.n_edges),
+                "what": "host packed reads -> katome_build_packed -> host arrays (H2D + build + D2H), second of two calls"}
+        del g
+    return best
 
 
 def next_stages(wl, sample_reads):
@@ -238,9 +291,11 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the build has no CPU fallback")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
-    if use_dist:
+    if world > 1:
         if "MASTER_ADDR" not in os.environ:
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
+        # torch.distributed: rendezvous, the barrier and the MAX over ranks around the timed region; the build's own
+        # exchanges are RCCL calls inside libkatome_gpu.so (katome_amd/csrc/comm.cpp)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     wl = WORKLOADS[args.workload]
@@ -261,10 +316,14 @@ def main():
                              device=packed.device)
 
         def step():
-            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer, args.first_seen_order, args.min_weight, args.table_factor)
+            return one_build_single(wl, packed, skip_arg, recbuf, batch_reads, timer, args.first_seen_order, args.min_weight,
+                                    args.table_factor, args.prune)
     else:
-        from katome_amd import dist as kdist
-        job = kdist.DistBuild(wl, batch_reads=batch_reads, timer=timer, min_weight=args.min_weight)
+        from katome_amd import shard as ks
+        comm = ks.Comm.rccl(rank, world, local_rank)
+        job = ks.DistBuild(wl, comm, batch_reads=0 if args.batch_reads == 4 * 1024 * 1024 else batch_reads, timer=timer,
+                           first_seen_order=args.first_seen_order or args.prune, min_weight=args.min_weight,
+                           table_factor=args.table_factor, prune=args.prune)
         accepted = job.accepted_total
 
         def step():
@@ -278,7 +337,7 @@ def main():
         free_before = torch.cuda.mem_get_info()[0]
         step()
         settled = torch.cuda.mem_get_info()[0] + (64 << 20) >= free_before
-        if use_dist:                      # (every rank takes part in every build: agree)
+        if world > 1:                     # (every rank takes part in every build: agree)
             flag = torch.tensor([1 if settled else 0], dtype=torch.int64, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             settled = bool(flag.item())
@@ -289,7 +348,7 @@ def main():
     timer.collect()
     if os.environ.get("KATOME_TRACE_ALLOC"):
         print("[bench] warm-up done", file=sys.stderr, flush=True)
-    if use_dist:
+    if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -297,17 +356,14 @@ def main():
     for _ in range(args.steps):
         n_edges, n_nodes = step()
     torch.cuda.synchronize()
-    if use_dist:
+    if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     phases = timer.collect()
-    if use_dist:
+    if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        cnt = torch.tensor([n_edges, n_nodes], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cnt)
-        n_edges, n_nodes = int(cnt[0].item()), int(cnt[1].item())
+        dt = float(t.item())             # (the ranks already report whole-graph edge and node counts)
 
     if rank == 0:
         ms_per_step = dt * 1e3 / args.steps
@@ -347,6 +403,10 @@ def main():
             sort_passes[0] = _sort_passes(2 * wl.k, n_edges)
             alg["sort_edges"] = lambda launches, reads: steps * n_edges * sum(sort_passes[0]) * 2 * (8 * nw + 4)
             alg["emit_edges"] = lambda launches, reads: steps * (cnt["kmer_slots"] * 16 * nw + n_edges * (8 * nw + 4))
+            # node numbering off the sorted edges: keys read by the run-head count and write passes and by the target look-up,
+            # one node key probed per target, source and target ids and the node keys written (N ~ E)
+            alg["node_set"] = lambda launches, reads: steps * n_edges * (4 * 8 * nw + 8 + 8 + 8 * nw)
+            alg["labels"] = lambda launches, reads: steps * n_edges * (8 * nw + 1 + (wl.k + 3) // 4)
         kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",
                         "insert_tiles": "insert_kernel", "expand_tiles": "expand_tiles_kernel",
                         "expand_mid_tiles": "expand_tiles_kernel (big tiles -> mid tiles)",
@@ -400,16 +460,54 @@ def main():
                                    % (wl.name, wl.reads, wl.read_len, wl.k, wl.reverse_complement, wl.genome_len,
                                       wl.err_rate),
                        "reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads,
-                       "tile_span": span, "order": "first-seen (petgraph)" if args.first_seen_order else "by packed key",
+                       "tile_span": span, "order": "first-seen (petgraph)" if (args.first_seen_order or args.prune) else "by packed key",
                        "min_weight": args.min_weight,
                        "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
             "roofline": roofline, "roofline_extract": roof("extract"), "kernels": kernels, "counts": cnt,
         }
+        if args.prune:
+            line["config"]["pruner"] = "remove_dead_paths after the build (reference order%s)" % (", on the graph gathered to rank 0" if use_dist else "")
+        if use_dist:
+            # per exchange phase: bytes that left rank 0 per step, time inside the exchange (HIP events on the stream the RCCL
+            # calls are enqueued on), and the per-link rate that implies on the full xGMI mesh (bytes / (N-1) links) against
+            # ~153 GB/s per link and direction
+            ex = {}
+            for name, x in job.exchange.items():
+                per_step_bytes, per_step_ms = x["bytes_out"] / (args.steps + 0.0), x["ms"] / args.steps
+                links = max(world - 1, 1)
+                ex[name] = {"calls_per_step": x["calls"] / args.steps, "bytes_out_per_step": per_step_bytes, "ms_per_step": per_step_ms,
+                            "largest_message_bytes": x["max_message_bytes"],
+                            "per_link_GBs": (per_step_bytes / links / (per_step_ms * 1e-3) / 1e9) if per_step_ms > 0 and world > 1 else None,
+                            "link_peak_GBs": 153.0}
+            line["exchange"] = ex
+            line["config"]["transport"] = comm.kind
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
-        if world == 1 and not use_dist and args.next_stages_reads > 0:
+        if world == 1 and not use_dist and not args.no_extras:
+            # Beside the headline (not `value`): the build in the reference's own numbering -- what INTEGRATION.md's GpuGIR binds
+            # (flags: 1) --, the build of a caller that passes no table hint, and the end-to-end region incl. H2D/D2H
+            try:
+                if not args.first_seen_order and not args.prune:
+                    t2 = PhaseTimer()
+                    ms, _ = timed(lambda: one_build_single(wl, packed, skip_arg, recbuf, batch_reads, t2, True, 0, args.table_factor), 2, torch)
+                    line["reference_order"] = {"ms_per_step": ms, "kmers_per_s": kmers / (ms * 1e-3), "order": "first-seen (petgraph)",
+                                               "steps": 2, "what": "same workload, KATOME_FLAG_FIRST_SEEN_ORDER (INTEGRATION.md's binding)"}
+                t3 = PhaseTimer()
+                ms, _ = timed(lambda: one_build_single(wl, packed, skip_arg, recbuf, batch_reads, t3, args.first_seen_order, 0, 0.0), 2, torch)
+                line["unhinted_table"] = {"ms_per_step": ms, "kmers_per_s": kmers / (ms * 1e-3), "steps": 2,
+                                          "what": "same workload, table_slots_hint = 0 (tables grow by re-hashing)"}
+            except Exception as e:     # noqa: BLE001
+                line["extras_error"] = "%s: %s" % (type(e).__name__, e)
+            try:
+                del packed, recbuf
+                kd.release_cache()
+                if args.end_to_end_reads > 0:
+                    line["end_to_end"] = end_to_end(wl, args.end_to_end_reads)
+            except Exception as e:     # noqa: BLE001
+                line["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if world == 1 and not use_dist and args.next_stages_reads > 0 and not args.no_extras:
             try:                       # not part of the metric: whatever goes wrong here must not cost the line above
                 kd.release_cache()
                 line["next_stages"] = next_stages(wl, args.next_stages_reads)
@@ -418,6 +516,8 @@ def main():
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
+        comm.close()
+    if world > 1:
         dist.destroy_process_group()
 
 

@@ -133,15 +133,25 @@ struct katome_dist_builder {
     int world() const { return comm->world(); }
     int rank() const { return comm->rank(); }
     // all-to-all of records grouped by destination, accounted to `phase`
+    // (RCCL only enqueues: with the builder's profile switched on the exchange is timed with HIP events on its stream)
+    struct XEvent { int phase; hipEvent_t a, b; };
+    std::vector<XEvent> xevents;
     int xchg(int phase, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, hipStream_t stream) {
         const katome::ExchangeStats before = comm->stats;
-        KCHECK(comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream));
+        hipEvent_t ea = nullptr, eb = nullptr;
+        const bool timed = b->prof.on && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
+        if (timed) (void)hipEventRecord(ea, stream);
+        const int rc = comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream);
+        if (timed) { (void)hipEventRecord(eb, stream); xevents.push_back({phase, ea, eb}); }
+        if (rc != KATOME_OK) return rc;
         katome::ExchangeStats& x = xstats[phase];
         x.calls += comm->stats.calls - before.calls; x.bytes_out += comm->stats.bytes_out - before.bytes_out;
-        x.bytes_in += comm->stats.bytes_in - before.bytes_in; x.ms += comm->stats.ms - before.ms;
+        x.bytes_in += comm->stats.bytes_in - before.bytes_in;
+        if (!timed) x.ms += comm->stats.ms - before.ms;
         for (int p = 0; p < world(); ++p) if (p != rank()) x.max_pair_bytes = std::max<uint64_t>(x.max_pair_bytes, send_cnt[p] * elem_bytes);
         return KATOME_OK;
     }
+    ~katome_dist_builder() { for (auto& e : xevents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } }
 };
 
 namespace {
@@ -330,6 +340,16 @@ uint32_t katome_dist_exchange_count(void) { return X_COUNT; }
 const char* katome_dist_exchange_name(uint32_t phase) { return phase < X_COUNT ? XPHASE_NAMES[phase] : ""; }
 int katome_dist_exchange_read(katome_dist_builder* d, uint64_t* out) {
     if (!d || !out) { set_error("null argument"); return KATOME_E_ARG; }
+    if (!d->xevents.empty()) {
+        KCHECK_HIP(hipSetDevice(d->s.device));
+        KCHECK_HIP(hipDeviceSynchronize());
+        for (auto& e : d->xevents) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) d->xstats[e.phase].ms += ms;
+            (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+        }
+        d->xevents.clear();
+    }
     for (int i = 0; i < X_COUNT; ++i) {
         out[4 * i] = d->xstats[i].calls; out[4 * i + 1] = d->xstats[i].bytes_out; out[4 * i + 2] = d->xstats[i].max_pair_bytes;
         out[4 * i + 3] = (uint64_t)(d->xstats[i].ms * 1000.0);

@@ -444,55 +444,6 @@ def test_pruning_properties_at_scale():
         kd.release_cache()
 
 
-def test_dist_path_on_one_gpu(oracle):
-    """katome_amd/dist.py with the HIP ops (RCCL backend, world size 1 on this box): same graph as the oracle"""
-    import socket
-    import torch.distributed as dist
-    from katome_amd import dist as kdist
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
-    try:
-        for k, rc in ((31, True), (40, True), (63, True)):          # k = 63: three-word tiles through the record route
-            n, L = 5000, 150
-            ascii_reads = oracle.synth_reads(0, n, L, 100000, 1e-3, 1)
-            has_n = (ascii_reads == ord("N")).any(axis=1)
-            clean = ascii_reads.copy()
-            clean[clean == ord("N")] = ord("G")
-            packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
-            skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
-            ops = kdist.HipOps(k, rc, 0)
-            kdist.build_shard(ops, packed, skip, n, L, 1024)
-            g = kdist.finalize_distributed(ops)
-            ref = oracle.build_ascii(ascii_reads, k, rc)
-            assert (g.total_nodes, g.total_edges, g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges, ref.n_nodes, ref.n_edges)
-            if k == 31:                                   # the same with Clean::remove_weak_edges(2) at the owners (pruner.rs:84-93)
-                weak = kdist.HipOps(k, rc, 0, min_weight=2)
-                kdist.build_shard(weak, packed, skip, n, L, 1024)
-                gw = kdist.finalize_distributed(weak)
-                refw = oracle.build_ascii(ascii_reads, k, rc, remove_weak_edges=2)
-                assert (gw.total_nodes, gw.total_edges) == (refw.n_nodes, refw.n_edges) and 0 < refw.n_edges < ref.n_edges
-                wk = gw.edge_key.cpu().numpy().view(np.uint64).reshape(-1)
-                assert dict(zip((int(x) for x in wk), gw.edge_weight.cpu().numpy().view(np.uint32).tolist())) == \
-                    {kmer_to_int(s): c for s, c in refw.multiset()}
-                weak.close()
-            nw = ops.nw
-            ek = g.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
-            keys = [int(r[0]) if nw == 1 else (int(r[0]) << 64) | int(r[1]) for r in ek]
-            assert keys == sorted(kmer_to_int(s) for s in ref.kmer_strings())
-            w = dict(zip(keys, g.edge_weight.cpu().numpy().view(np.uint32).tolist()))
-            assert w == {kmer_to_int(s): c for s, c in ref.multiset()}
-            nk = g.node_key.cpu().numpy().view(np.uint64).reshape(-1, nw)
-            nodes = [int(r[0]) if nw == 1 else (int(r[0]) << 64) | int(r[1]) for r in nk]
-            src, dst = g.edge_src.cpu().numpy(), g.edge_dst.cpu().numpy()
-            mask = (1 << (2 * (k - 1))) - 1
-            for e in range(0, len(keys), 97):
-                assert nodes[src[e]] == keys[e] >> 2 and nodes[dst[e]] == keys[e] & mask
-            ops.close()
-    finally:
-        dist.destroy_process_group()
-
-
 @pytest.mark.parametrize("k,L,rc", [(31, 150, True), (31, 150, False), (31, 100, True), (32, 75, True), (12, 51, True),
                                     (40, 103, True), (5, 20, True)])
 def test_tiled_counting_equals_plain_counting(oracle, k, L, rc):
@@ -722,73 +673,6 @@ def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
         # ... and the reference's first pruning on such a graph (no per-base adjacency slots with parallel edges)
         g, _ = GpuGraph.create([str(bfc)], InputFileType.BFCounter, rc, 0, first_seen_order=True, remove_dead_paths=True)
         _assert_same_as_reference_order(g, oracle.build_bfc([str(bfc)], 31, rc, 0, remove_dead_paths=True))
-
-
-def _two_rank_worker(rank, world, port, k, rc, n_reads, read_len, batch_reads, out_dir):
-    """one of several ranks sharing cuda:0: HIP kernels for everything, gloo (host-staged) for the exchanges"""
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    import torch.distributed as dist
-    from katome_amd import dist as kdist
-    from oracle import oracle as o
-    from helpers import pack_reads_ascii as pack
-    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
-    try:
-        torch.cuda.set_device(0)
-        ascii_reads = o.synth_reads(0, n_reads, read_len, 60000, 2e-3, 2)
-        has_n = (ascii_reads == ord("N")).any(axis=1)
-        clean = ascii_reads.copy()
-        clean[clean == ord("N")] = ord("A")
-        r0, r1 = kdist.shard_range(n_reads, world, rank)
-        packed = torch.from_numpy(pack(clean[r0:r1]).reshape(-1).copy()).cuda()
-        skip = torch.from_numpy(has_n[r0:r1].astype(np.uint8)).cuda()
-        ops = kdist.HipOps(k, rc, 0)
-        kdist.build_shard(ops, packed, skip, r1 - r0, read_len, batch_reads)
-        g = kdist.finalize_distributed(ops)
-        nw = ops.nw
-        np.savez(os.path.join(out_dir, "rank%d.npz" % rank),
-                 edge_key=g.edge_key.cpu().numpy().view(np.uint64).reshape(-1, nw), weight=g.edge_weight.cpu().numpy().view(np.uint32),
-                 src=g.edge_src.cpu().numpy(), dst=g.edge_dst.cpu().numpy(), label=g.edge_label.cpu().numpy(),
-                 node_key=g.node_key.cpu().numpy().view(np.uint64).reshape(-1, nw), node_base=g.node_base,
-                 total_nodes=g.total_nodes, total_edges=g.total_edges)
-        ops.close()
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("world,k,rc,L", [(2, 31, True, 150), (3, 31, False, 100), (2, 40, True, 103), (2, 33, True, 92),
-                                          (2, 63, True, 150), (4, 31, True, 150)])       # (the test runner holds the card too: six processes at most)
-def test_multi_rank_on_one_gpu(oracle, tmp_path, world, k, rc, L):
-    """katome_amd/dist.py end to end with the HIP kernels on several ranks (all on this box's one GPU; the exchange
-    goes through gloo because RCCL refuses two ranks on one device): merged result == the oracle's build"""
-    import socket
-    import torch.multiprocessing as mp
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    n_reads = 9000
-    mp.get_context("spawn")
-    mp.spawn(_two_rank_worker, args=(world, port, k, rc, n_reads, L, 2048, str(tmp_path)), nprocs=world, join=True)
-    ref = oracle.build_ascii(oracle.synth_reads(0, n_reads, L, 60000, 2e-3, 2), k, rc)
-    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
-
-    def to_int(row):
-        return int(row[0]) if len(row) == 1 else (int(row[0]) << 64) | int(row[1])
-    node_of = {}
-    for p in parts:
-        for i, row in enumerate(p["node_key"]):
-            node_of[int(p["node_base"]) + i] = to_int(row)
-    merged = {}
-    mask = (1 << (2 * (k - 1))) - 1
-    for p in parts:
-        assert (int(p["total_nodes"]), int(p["total_edges"])) == (ref.n_nodes, ref.n_edges)
-        keys = [to_int(r) for r in p["edge_key"]]
-        for j, (key, w) in enumerate(zip(keys, p["weight"])):
-            assert key not in merged
-            merged[key] = int(w)
-            if j % 53 == 0:
-                assert node_of[int(p["src"][j])] == key >> 2 and node_of[int(p["dst"][j])] == key & mask
-    assert sorted(merged.items()) == sorted((kmer_to_int(s), w) for s, w in ref.multiset())
-    assert sorted(node_of) == list(range(ref.n_nodes)) and len(set(node_of.values())) == ref.n_nodes
 
 
 @pytest.mark.parametrize("k,L,rc,first_seen", [(31, 101, True, False), (31, 101, True, True), (21, 76, False, True), (40, 77, True, False),

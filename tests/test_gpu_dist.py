@@ -175,3 +175,111 @@ def test_rccl_transport_at_world_size_one(oracle):
     assert "exchange_records" in names and stats[4 * names.index("exchange_records")] > 0      # calls were counted
     L_.katome_dist_destroy(d)
     L_.katome_comm_destroy(comm)
+
+
+# ---- one PROCESS per rank (bench.py's shape), several of them sharing this box's one GPU ------------------------------
+def _process_rank(rank, world, port, k, rc, n_reads, read_len, first_seen, prune, out_dir):
+    """HIP kernels for everything; the exchanges travel through torch.distributed/gloo (RCCL refuses two ranks on one GPU)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    from katome_amd import shard as ks
+    from oracle import oracle as o
+    from helpers import pack_reads_ascii as pack
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        ascii_reads = o.synth_reads(0, n_reads, read_len, 60000, 2e-3, 2)
+        has_n = (ascii_reads == ord("N")).any(axis=1)
+        clean = ascii_reads.copy()
+        clean[clean == ord("N")] = ord("A")
+        first, count = ks.shard_range(n_reads, world, rank)
+        packed = torch.from_numpy(np.concatenate([pack(clean[first:first + count]).reshape(-1), np.zeros(32, np.uint8)])).cuda()
+        skip = torch.from_numpy(np.concatenate([has_n[first:first + count].astype(np.uint8), np.zeros(16, np.uint8)])).cuda()
+        comm = ks.Comm.over_torch(device=0)
+        assert comm.kind == "callbacks" and (comm.rank, comm.world) == (rank, world)
+        b = ks.ShardedBuilder(comm, k, rc, 0, first_seen_order=first_seen)
+        b.add_reads(packed, first, count, read_len, skip, batch_reads=2048)
+        g = b.finalize()
+        out = dict(total_nodes=g.total_nodes, total_edges=g.total_edges, node_base=g.node_base,
+                   edge_key=g.edge_key.cpu().numpy().view(np.uint64), weight=g.edge_weight.cpu().numpy().view(np.uint32),
+                   src=g.edge_src.cpu().numpy(), dst=g.edge_dst.cpu().numpy(), node_key=g.node_key.cpu().numpy().view(np.uint64))
+        if first_seen:
+            out.update(edge_id=g.edge_id.cpu().numpy(), node_id=g.node_id.cpu().numpy(), label=g.edge_label.cpu().numpy())
+            root = b.gather(0)
+            assert (root is not None) == (rank == 0)
+            if root is not None:
+                dg = root.remove_dead_paths()[0] if prune else root.graph()
+                out.update(root_src=dg.edge_src.cpu().numpy(), root_dst=dg.edge_dst.cpu().numpy(),
+                           root_weight=dg.edge_weight.cpu().numpy().view(np.uint32), root_label=dg.edge_label.cpu().numpy(),
+                           root_nodes=dg.n_nodes)
+        np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
+        b.close()
+        comm.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(world, *args):
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_process_rank, args=(world, port) + args, nprocs=world, join=True)
+
+
+@pytest.mark.parametrize("world,k,rc,L", [(2, 31, True, 150), (3, 31, False, 100), (2, 63, True, 150), (4, 40, True, 103)])
+def test_process_per_rank_by_packed_key(oracle, tmp_path, world, k, rc, L):      # (the test runner holds the card too: six processes at most)
+    n_reads = 9000
+    _spawn(world, k, rc, n_reads, L, False, False, str(tmp_path))
+    ref = oracle.build_ascii(oracle.synth_reads(0, n_reads, L, 60000, 2e-3, 2), k, rc)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    nw = 1 if 2 * k <= 62 else 2
+
+    def to_int(row):
+        return int(row[0]) if len(row) == 1 else (int(row[0]) << 64) | int(row[1])
+    node_of, merged = {}, {}
+    mask = (1 << (2 * (k - 1))) - 1
+    for p in parts:
+        for i, row in enumerate(p["node_key"].reshape(-1, nw)):
+            node_of[int(p["node_base"]) + i] = to_int(row)
+    for p in parts:
+        assert (int(p["total_nodes"]), int(p["total_edges"])) == (ref.n_nodes, ref.n_edges)
+        keys = [to_int(r) for r in p["edge_key"].reshape(-1, nw)]
+        assert keys == sorted(keys)
+        for j, (key, w) in enumerate(zip(keys, p["weight"])):
+            assert key not in merged
+            merged[key] = int(w)
+            if j % 53 == 0:
+                assert node_of[int(p["src"][j])] == key >> 2 and node_of[int(p["dst"][j])] == key & mask
+    from helpers import kmer_to_int
+    assert sorted(merged.items()) == sorted((kmer_to_int(s), w) for s, w in ref.multiset())
+    assert sorted(node_of) == list(range(ref.n_nodes)) and len(set(node_of.values())) == ref.n_nodes
+
+
+@pytest.mark.parametrize("world,k,rc,L,prune", [(2, 31, True, 150, False), (3, 63, True, 150, True), (2, 40, False, 103, True)])
+def test_process_per_rank_in_reference_order(oracle, tmp_path, world, k, rc, L, prune):
+    """the ranks' shares carry the reference's indices (every index exactly once across ranks, the right edge at each);
+    gathered to rank 0 -- and pruned there -- the arrays equal the oracle's petgraph index for index"""
+    n_reads = 6000
+    _spawn(world, k, rc, n_reads, L, True, prune, str(tmp_path))
+    ascii_reads = oracle.synth_reads(0, n_reads, L, 60000, 2e-3, 2)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    label = np.zeros_like(ref.edge_label)
+    src, dst = np.full(ref.n_edges, -1, np.int64), np.full(ref.n_edges, -1, np.int64)
+    seen_e, seen_n = np.zeros(ref.n_edges, np.int32), np.zeros(ref.n_nodes, np.int32)
+    for p in parts:
+        assert (int(p["total_nodes"]), int(p["total_edges"])) == (ref.n_nodes, ref.n_edges)
+        ids = p["edge_id"]
+        np.add.at(seen_e, ids, 1)
+        np.add.at(seen_n, p["node_id"], 1)
+        label[ids], src[ids], dst[ids] = p["label"], p["src"], p["dst"]
+    assert (seen_e == 1).all() and (seen_n == 1).all()
+    assert np.array_equal(label, ref.edge_label)
+    assert np.array_equal(src.astype(np.uint64), ref.edge_src) and np.array_equal(dst.astype(np.uint64), ref.edge_dst)
+    want = oracle.build_ascii(ascii_reads, k, rc, remove_dead_paths=True) if prune else ref
+    r0 = parts[0]
+    assert int(r0["root_nodes"]) == want.n_nodes
+    assert np.array_equal(r0["root_label"], want.edge_label) and np.array_equal(r0["root_weight"], want.edge_weight)
+    assert np.array_equal(r0["root_src"].astype(np.uint64), want.edge_src) and np.array_equal(r0["root_dst"].astype(np.uint64), want.edge_dst)
