@@ -292,10 +292,10 @@ int katome_dev_expand_tiles(katome_builder *b, uint64_t **d_keys, uint32_t **d_w
  * retain_nodes do (indices visited in descending order, rejected ones swap_removed), so the result keeps the
  * reference's numbering; on such a builder the call is also accepted AFTER katome_dev_finalize (e.g. after
  * katome_dev_remove_dead_paths, the order of asm/basic_assembler.rs:58-66) and then acts at once.       */
-int katome_dev_remove_weak_edges(katome_builder *b, uint32_t threshold);
+int katome_dev_remove_weak_edges(katome_builder *b, uint32_t threshold, void *stream);
 
 /* number of distinct keys in the table so far (synchronises) */
-int katome_dev_table_count(katome_builder *b, uint64_t *out);
+int katome_dev_table_count(katome_builder *b, uint64_t *out, void *stream);
 
 /* device-resident graph; arrays owned by the builder until destroy / next finalize */
 typedef struct {

@@ -113,8 +113,8 @@ SYMBOLS = {
     "katome_dev_source_ids": (_i, [_i, _vp, _u64, _u32, _vp, _vp, u64p, _vp]),
     "katome_dev_insert": (_i, [_vp, _vp, _u64, _vp]),
     "katome_dev_insert_weighted": (_i, [_vp, _vp, _vp, _u64, _vp]),
-    "katome_dev_remove_weak_edges": (_i, [_vp, _u32]),
-    "katome_dev_table_count": (_i, [_vp, u64p]),
+    "katome_dev_remove_weak_edges": (_i, [_vp, _u32, _vp]),
+    "katome_dev_table_count": (_i, [_vp, u64p, _vp]),
     "katome_tile_span": (_u32, [_u32, _u32]),
     "katome_tile_words": (_u32, [_u32, _u32]),
     "katome_tile_plan": (_u32, [_u32, _u32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

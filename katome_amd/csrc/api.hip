@@ -478,14 +478,15 @@ static int weak_edges_ordered(katome_builder* b, uint32_t threshold, hipStream_t
     return KATOME_OK;
 }
 
-int katome_dev_remove_weak_edges(katome_builder* b, uint32_t threshold) {
+int katome_dev_remove_weak_edges(katome_builder* b, uint32_t threshold, void* stream_) {
     if (!b) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
     if (b->finalized && b->first_seen) {
         // on the finished graph, with petgraph's numbering (retain_edges / retain_nodes: descending swap_removes)
         KCHECK_HIP(hipSetDevice(b->s.device));
-        KCHECK(weak_edges_ordered(b, threshold, nullptr));
-        KCHECK(dev_labels(b->edge_key.as<u64>(), b->n_edges, b->s.k, b->edge_label.as<uint8_t>(), nullptr));
-        KCHECK_HIP(hipStreamSynchronize(nullptr));
+        KCHECK(weak_edges_ordered(b, threshold, stream));
+        KCHECK(dev_labels(b->edge_key.as<u64>(), b->n_edges, b->s.k, b->edge_label.as<uint8_t>(), stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
         return KATOME_OK;
     }
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
@@ -493,11 +494,11 @@ int katome_dev_remove_weak_edges(katome_builder* b, uint32_t threshold) {
     return KATOME_OK;
 }
 
-int katome_dev_table_count(katome_builder* b, uint64_t* out) {
+int katome_dev_table_count(katome_builder* b, uint64_t* out, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
     *out = 0;
     if (!b->table_ready) return KATOME_OK;
-    return table_occupied(b->table, out, nullptr);
+    return table_occupied(b->table, out, (hipStream_t)stream);
 }
 
 int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge_weight, uint64_t* n_edges, void* stream_) {
@@ -951,7 +952,7 @@ static int run_stages(katome_builder* b, const char* stages, uint64_t genome_len
         switch (*st) {
             case 'd': KCHECK(katome_dev_remove_dead_paths(b, nullptr, nullptr, nullptr)); break;
             case 'c': KCHECK(katome_dev_standardize_contigs(b, nullptr)); break;
-            case 'w': KCHECK(katome_dev_remove_weak_edges(b, b->s.min_weight)); break;
+            case 'w': KCHECK(katome_dev_remove_weak_edges(b, b->s.min_weight, nullptr)); break;
             case 'e': KCHECK(katome_dev_standardize_edges(b, genome_len, b->s.min_weight, nullptr)); break;
             default: set_error("unknown stage '%c' (d, c, w, e)", *st); return KATOME_E_ARG;
         }

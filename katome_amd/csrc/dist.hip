@@ -388,7 +388,7 @@ katome_builder* katome_dist_inner(katome_dist_builder* d) { return d ? d->b : nu
 int katome_dist_remove_weak_edges(katome_dist_builder* d, uint32_t threshold) {
     if (!d) { set_error("null argument"); return KATOME_E_ARG; }
     if (d->first_seen) { set_error("first-seen order: remove_weak_edges runs on the gathered graph (katome_dist_gather), with petgraph's numbering"); return KATOME_E_ARG; }
-    return katome_dev_remove_weak_edges(d->b, threshold);
+    return katome_dev_remove_weak_edges(d->b, threshold, nullptr);   // (before the edges are read out: only records the threshold)
 }
 
 int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint64_t first_read, uint64_t n_reads, uint32_t read_len,

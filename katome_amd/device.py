@@ -1,8 +1,7 @@
 """Device-resident driver over the C ABI: PyTorch supplies device memory, streams and
 torch.distributed (plumbing); every kernel is in katome_amd/lib/libkatome_gpu.so.
 
-Used by bench.py (inputs resident in HBM before the timed region) and by katome_amd/dist.py
-(one process per GPU).  Mirrors the steps of `Build::create` (reference builder.rs:142-165 ->
+Used by bench.py (inputs resident in HBM before the timed region); the multi-GPU bindings are in katome_amd/shard.py.  Mirrors the steps of `Build::create` (reference builder.rs:142-165 ->
 pt_graph.rs:277-315,172-198,333-345): extract -> insert -> finalize.
 """
 import ctypes as C
@@ -245,7 +244,7 @@ class Builder:
         """Clean::remove_weak_edges (pruner.rs:84-93).  Before finalize(): applied when the edges are read out (first-seen
         order: after the numbering, with petgraph's retain_edges / retain_nodes re-numbering).  On a finalized
         first-seen-order builder: applied now, same re-numbering; fetch the arrays again with graph()."""
-        _check(_lib.lib().katome_dev_remove_weak_edges(self._h, threshold))
+        _check(_lib.lib().katome_dev_remove_weak_edges(self._h, threshold, _stream()))
 
     def standardize_contigs(self):
         """Standardizable::standardize_contigs (standardizer.rs:72-122) on the finalized graph, in place"""
@@ -269,7 +268,7 @@ class Builder:
 
     def table_count(self):
         out = C.c_uint64()
-        _check(_lib.lib().katome_dev_table_count(self._h, C.byref(out)))
+        _check(_lib.lib().katome_dev_table_count(self._h, C.byref(out), _stream()))
         return out.value
 
     # ---- PtGraph::create post-pass -----------------------------------------------------------------

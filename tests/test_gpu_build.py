@@ -722,3 +722,34 @@ def test_read_lengths_that_are_not_whole_tiles(oracle, k, L, rc, first_seen):
     g, _ = GpuGraph.create_from_packed(pack_reads_ascii(clean).reshape(-1), n, L, skip=has_n.astype(np.uint8),
                                        reverse_complement=rc, k=k, first_seen_order=first_seen)
     assert g.multiset() == ref.multiset()
+
+
+def test_build_and_stages_on_a_side_stream(oracle):
+    """every entry takes the caller's stream (torch's current one): a whole build in the reference's numbering and the stages
+    after it under a non-default stream, against the oracle index for index"""
+    from katome_amd import device as kd
+    n, L, k = 3000, 150, 31
+    ascii_reads = oracle.synth_reads(0, n, L, 30000, 3e-3, 1)
+    has_n = (ascii_reads == ord("N")).any(axis=1)
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("A")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+        skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+        b = kd.Builder(k, True, first_seen_order=True, table_slots_hint=1 << 16)
+        for r0 in range(0, n, 1024):
+            b.count_reads(packed, min(1024, n - r0), L, skip, first_read=r0)
+        assert b.table_count() >= 0
+        b.finalize()
+        b.remove_dead_paths()
+        b.remove_weak_edges(2)
+        dg = b.graph()
+        ref = oracle.build_ascii(ascii_reads, k, True, stages="dw", remove_weak_edges=2)
+        assert (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges) and ref.n_edges > 0
+        assert np.array_equal(dg.edge_label.cpu().numpy(), ref.edge_label)
+        assert np.array_equal(dg.edge_weight.cpu().numpy().view(np.uint32), ref.edge_weight)
+        assert np.array_equal(dg.edge_src.cpu().numpy().view(np.uint64), ref.edge_src)
+        assert np.array_equal(dg.edge_dst.cpu().numpy().view(np.uint64), ref.edge_dst)
+        b.close()
+    side.synchronize()
