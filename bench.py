@@ -222,11 +222,12 @@ def next_stages(wl, sample_reads):
 
 
 def _sort_passes(key_bits, n):
-    """(radix passes, tie-fix passes) dev_sort runs for n keys of key_bits bits (radix.hip sort_t)"""
+    """(radix passes, run-sort passes) dev_sort runs for n keys of key_bits bits (radix.hip sort_t)"""
     all_passes = (key_bits + 7) // 8
-    need = 9 + max(int(n), 1).bit_length()
-    top = (need + 7) // 8
-    if top + 4 <= all_passes and n >= (1 << 16):
+    top = 1
+    while top < 8 and (int(n) >> (8 * top)):
+        top += 1
+    if top + 2 <= all_passes and n >= (1 << 16):
         return top, 1
     return all_passes, 0
 
@@ -401,7 +402,7 @@ def main():
             else:
                 alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
             # dev_sort: passes over the top log2(n)+9 bits (all of them if that saves fewer than four), each reading and writing
-            # every (key, weight) pair once, then one more read + write by the tie fix
+            # every (key, weight) pair once, then one more read + write by the run sort
             sort_passes[0] = _sort_passes(2 * wl.k, n_edges)
             alg["sort_edges"] = lambda launches, reads: steps * n_edges * sum(sort_passes[0]) * 2 * (8 * nw + 4)
             alg["emit_edges"] = lambda launches, reads: steps * (cnt["kmer_slots"] * 16 * nw + n_edges * (8 * nw + 4))
@@ -444,9 +445,9 @@ def main():
             passes = sort_passes[0][0]
             parts = {"sort_edges": [(exact["sort_edges"], passes, True),
                                     ("void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw), passes, True),
-                                    ("radix_chunk_kernel", passes, True)]}.get(name, [(exact[name], 1, name == "extract")])
+                                    ("radix_chunk_kernel", passes, True)]}.get(name, [(exact.get(name, name), 1, name == "extract")])
             t = pmc_traffic(parts, cfg_now) if not use_dist else None
-            return {"kernel": exact[name].replace("void ", ""), "phase": name, "bound": "hbm",
+            return {"kernel": exact.get(name, kernel_names.get(name, name)).replace("void ", ""), "phase": name, "bound": "hbm",
                     "achieved": kernels[name]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[name]["frac_of_hbm_peak"], "traffic": t["bytes_per_launch"] if t else None,
                     "traffic_detail": t, "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"],

@@ -333,13 +333,13 @@ static int bfc_set_edges(katome_builder* b, const uint64_t* d_fwd, const uint32_
         KCHECK(raw_w.alloc((E + 1) * 4)); KCHECK(raw_seq.alloc((E + 1) * 8)); KCHECK(idx.alloc((E + 1) * 4));
         KCHECK(dev_bfc_edges(d_fwd, d_w, n_lines, b->s.k, b->rc, b->edge_key.as<u64>(), raw_w.as<u32>(), raw_seq.as<u64>(), stream));
         KCHECK(dev_iota(idx.as<u32>(), E, stream));
-        KCHECK(dev_sort(b->edge_key.as<u64>(), idx.as<u32>(), E, nw, 2 * b->s.k, stream));
+        KCHECK(dev_sort_bufs(b->edge_key, &idx, E, nw, 2 * b->s.k, stream));
         KCHECK(b->edge_seq.alloc((E + 1) * 8, stream));
         KCHECK(dev_gather_u64(raw_seq.as<u64>(), idx.as<u32>(), E, b->edge_seq.as<u64>(), stream));
         KCHECK(dev_gather_u32(raw_w.as<u32>(), idx.as<u32>(), E, b->edge_weight.as<u32>(), stream));
     } else {
         KCHECK(dev_bfc_edges(d_fwd, d_w, n_lines, b->s.k, b->rc, b->edge_key.as<u64>(), b->edge_weight.as<u32>(), nullptr, stream));
-        KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), E, nw, 2 * b->s.k, stream));   // stable: a k-mer's lines stay in file order
+        KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, E, nw, 2 * b->s.k, stream));   // stable: a k-mer's lines stay in file order
     }
     b->edges_ready = true;
     return KATOME_OK;
@@ -527,12 +527,12 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 DevBuf idx(stream);
                 KCHECK(idx.alloc((b->n_edges + 1) * 4));
                 KCHECK(dev_iota(idx.as<u32>(), b->n_edges, stream));
-                KCHECK(dev_sort(b->edge_key.as<u64>(), idx.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
+                KCHECK(dev_sort_bufs(b->edge_key, &idx, b->n_edges, b->nw, 2 * b->s.k, stream));
                 KCHECK(b->edge_weight.alloc((b->n_edges + 1) * 4, stream));
                 KCHECK(b->edge_seq.alloc((b->n_edges + 1) * 8, stream));
                 KCHECK(dev_gather_seq_weight(raw_seq.as<u64>(), idx.as<u32>(), b->n_edges, b->edge_seq.as<u64>(), b->edge_weight.as<u32>(), stream));
             } else {
-                KCHECK(dev_sort(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->n_edges, b->nw, 2 * b->s.k, stream));
+                KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream));
             }
         } else {
             KCHECK(b->edge_key.alloc(16, stream)); KCHECK(b->edge_weight.alloc(16, stream));
@@ -591,7 +591,7 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
             KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
             lap("node_first");
             KCHECK(dev_iota(nperm.as<u32>(), N, stream));
-            KCHECK(dev_sort(node_first.as<u64>(), nperm.as<u32>(), N, 1, bits, stream));        // nperm[new] = old
+            KCHECK(dev_sort_bufs(node_first, &nperm, N, 1, bits, stream));        // nperm[new] = old
             lap("sort nodes");
             node_first.release();
             KCHECK(dev_invert(nperm.as<u32>(), N, new_id.as<u64>(), stream));                   // new_id[old] = new
@@ -602,7 +602,7 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         }
         KCHECK(eperm.alloc((E + 1) * 4));
         KCHECK(dev_iota(eperm.as<u32>(), E, stream));
-        KCHECK(dev_sort(b->edge_seq.as<u64>(), eperm.as<u32>(), E, 1, bits, stream));           // eperm[new] = old; edge_seq now ascending
+        KCHECK(dev_sort_bufs(b->edge_seq, &eperm, E, 1, bits, stream));           // eperm[new] = old; edge_seq now ascending
         lap("sort edges by seq");
         {
             // one 32-byte record per edge, read once at random (radix.hip dev_permute_edges); if that much scratch is not

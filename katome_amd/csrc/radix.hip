@@ -6,6 +6,8 @@
 // collections/graphs/pt_graph.rs:142-154), the endpoints of each edge (compress_kmer halves,
 // compress.rs:23-26) and the compress_edge labels (compress.rs:250-271; post-pass
 // pt_graph.rs:339-343).  All streaming, HBM-bound passes; no MFMA (integer keys).
+#include <algorithm>
+
 #include "common.h"
 
 namespace katome {
@@ -264,139 +266,193 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
 }
 
 // After a stable sort on the TOP bits only (bits [low, key_bits)) the keys are in order except inside the runs that share
-// those bits; where the keys are (nearly) distinct such runs are a handful of records.  The first record of every run
-// sorts its run in place by the full key (stable insertion sort: equal keys keep the order the passes gave them); a run
-// longer than TIE_RUN_MAX raises `overflow` and the caller falls back to the remaining passes.
-constexpr u32 TIE_RUN_MAX = 48;
-constexpr u32 TIE_TILE = 2048;                         // positions whose runs a workgroup puts right
-// A workgroup owns the runs that START in its tile; it stages the tile plus enough of what follows to hold the last such
-// run in LDS (coalesced), the first record of every run sorts its run there, and the owned range is written back.
+// those bits.  With 8 * passes >= log2(n) top bits such runs are a handful of records wherever the keys are spread out
+// (k-mers of a genome: the top 16 bases), so the remaining passes -- half of them for k = 31, three quarters for k = 63 --
+// are replaced by ONE streaming pass: every record finds its run by scanning its neighbours in LDS (left while the top
+// bits agree, then right), counts the records of the run that must precede it (smaller key, or equal key further left:
+// stable) and is written to run start + count.  A workgroup stages its tile plus a halo on both sides; a run that leaves
+// the staged window raises `overflow` and the caller falls back to the remaining passes.
+#ifndef KATOME_RUN_TILE
+#define KATOME_RUN_TILE 4096
+#endif
+#ifndef KATOME_RUN_HALO
+#define KATOME_RUN_HALO 512
+#endif
+constexpr u32 RUN_TILE = KATOME_RUN_TILE;               // records a workgroup places
+constexpr u32 RUN_HALO = KATOME_RUN_HALO;               // longest run that can be followed on either side
 template <int NW, bool HAS_VAL>
-__global__ __launch_bounds__(BLOCK) void tie_fix_kernel(u64* __restrict__ keys, u32* __restrict__ vals, u64 n, u32 low, u32* __restrict__ overflow) {
-    constexpr u32 SPAN = TIE_TILE + TIE_RUN_MAX + 1;   // [t0 - 1, t0 + TIE_TILE + TIE_RUN_MAX)
-    __shared__ u64 lk[SPAN * NW];
-    __shared__ u32 lv[HAS_VAL ? SPAN : 1];
-    __shared__ u32 first_owned, last_end;
-    const u64 n_tiles = (n + TIE_TILE - 1) / TIE_TILE;
+__global__ __launch_bounds__(BLOCK) void run_sort_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in, u64 n, u32 low,
+                                                          u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ overflow) {
+    extern __shared__ u64 lk[];                        // [(RUN_TILE + 2 * RUN_HALO) * NW]
+    constexpr u32 SPAN = RUN_TILE + 2 * RUN_HALO, PER = SPAN / BLOCK, OWN = RUN_TILE / BLOCK;
+    static_assert(SPAN % BLOCK == 0 && RUN_TILE % BLOCK == 0, "whole rows per thread");
+    const u64 n_tiles = (n + RUN_TILE - 1) / RUN_TILE;
     for (u64 tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const u64 t0 = tile * TIE_TILE;
-        const u64 g0 = t0 ? t0 - 1 : 0;                // global position of lk[0]
-        const u32 off = (u32)(t0 - g0);                // index of t0 in LDS (1, or 0 for the first tile)
-        const u32 cnt = (u32)((n - g0) < (u64)SPAN - (1 - off) ? (n - g0) : (u64)SPAN - (1 - off));
-        if (threadIdx.x == 0) { first_owned = 0xFFFFFFFFu; last_end = 0; }
-        for (u32 j = threadIdx.x; j < cnt; j += BLOCK) {
-            const Key<NW> kj = load_key<NW>(keys, g0 + j);
+        const u64 t0 = tile * RUN_TILE;
+        const u64 g0 = t0 >= RUN_HALO ? t0 - RUN_HALO : 0;
+        const u64 t1 = t0 + RUN_TILE < n ? t0 + RUN_TILE : n;
+        const u64 g1 = t1 + RUN_HALO < n ? t1 + RUN_HALO : n;
+        const u32 cnt = (u32)(g1 - g0), off = (u32)(t0 - g0), own = (u32)(t1 - t0);
+        // all loads of the tile are issued before the first one is waited for (a load per loop trip would serialise ~20
+        // memory latencies per workgroup and tile)
+        Key<NW> stage[PER];
 #pragma unroll
-            for (int q = 0; q < NW; ++q) lk[j * NW + q] = kj.w[q];
-            if (HAS_VAL) lv[j] = vals[g0 + j];
+        for (u32 r = 0; r < PER; ++r) {
+            const u32 j = r * BLOCK + threadIdx.x;
+            if (j < cnt) stage[r] = load_key<NW>(keys_in, g0 + j);
         }
-        __syncthreads();
-        const u32 tile_end = (u32)((n - t0) < (u64)TIE_TILE ? (n - t0) : (u64)TIE_TILE) + off;    // LDS index one past the tile
-        for (u32 j = off + threadIdx.x; j < tile_end; j += BLOCK) {
-            Key<NW> head;
+        u32 val[OWN];
+        if (HAS_VAL) {
 #pragma unroll
-            for (int q = 0; q < NW; ++q) head.w[q] = lk[j * NW + q];
-            head = key_shr(head, low);
-            if (g0 + j > 0) {
-                Key<NW> prev;
-#pragma unroll
-                for (int q = 0; q < NW; ++q) prev.w[q] = lk[(j - 1) * NW + q];
-                if (key_eq(key_shr(prev, low), head)) continue;                   // not the first of its run
+            for (u32 r = 0; r < OWN; ++r) {
+                const u32 i = r * BLOCK + threadIdx.x;
+                if (i < own) val[r] = vals_in[t0 + i];
             }
-            atomicMin(&first_owned, j);
-            u32 end = j + 1;
-            for (; end < cnt && end - j <= TIE_RUN_MAX; ++end) {
-                Key<NW> x;
+        }
 #pragma unroll
-                for (int q = 0; q < NW; ++q) x.w[q] = lk[end * NW + q];
-                if (!key_eq(key_shr(x, low), head)) break;
-            }
-            if (end - j > TIE_RUN_MAX) { *overflow = 1; end = j + 1; }
-            atomicMax(&last_end, end);
-            for (u32 a = j + 1; a < end; ++a) {
-                Key<NW> ka;
+        for (u32 r = 0; r < PER; ++r) {
+            const u32 j = r * BLOCK + threadIdx.x;
+            if (j < cnt) {
 #pragma unroll
-                for (int q = 0; q < NW; ++q) ka.w[q] = lk[a * NW + q];
-                const u32 va = HAS_VAL ? lv[a] : 0;
-                u32 b = a;
-                for (; b > j; --b) {
-                    Key<NW> kb;
-#pragma unroll
-                    for (int q = 0; q < NW; ++q) kb.w[q] = lk[(b - 1) * NW + q];
-                    if (!key_lt(ka, kb)) break;
-#pragma unroll
-                    for (int q = 0; q < NW; ++q) lk[b * NW + q] = kb.w[q];
-                    if (HAS_VAL) lv[b] = lv[b - 1];
-                }
-                if (b != a) {
-#pragma unroll
-                    for (int q = 0; q < NW; ++q) lk[b * NW + q] = ka.w[q];
-                    if (HAS_VAL) lv[b] = va;
-                }
+                for (int q = 0; q < NW; ++q) lk[j * NW + q] = stage[r].w[q];
             }
         }
         __syncthreads();
-        const u32 w0 = first_owned, w1 = last_end;      // owned range in LDS indices
-        if (w0 != 0xFFFFFFFFu) {
-            for (u32 j = w0 + threadIdx.x; j < w1; j += BLOCK) {
-                Key<NW> kj;
+        // A scan step is one LDS round trip whose result decides whether there is a next one, and a wave scans for as long as
+        // its longest run: U records per thread are scanned in lockstep so that U reads are in flight per step
+        constexpr u32 U = 8;
+        static_assert(OWN % U == 0, "whole groups");
 #pragma unroll
-                for (int q = 0; q < NW; ++q) kj.w[q] = lk[j * NW + q];
-                store_key<NW>(keys, g0 + j, kj);
-                if (HAS_VAL) vals[g0 + j] = lv[j];
+        for (u32 r0 = 0; r0 < OWN; r0 += U) {
+            Key<NW> key[U], top[U];
+            u32 before[U], lo[U], hi[U], live = 0, lost = 0;
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) {
+                const u32 i = (r0 + u) * BLOCK + threadIdx.x, j = off + i;
+                before[u] = 0; lo[u] = j; hi[u] = j + 1;
+                if (i < own) {
+                    live |= 1u << u;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) key[u].w[q] = lk[j * NW + q];
+                    top[u] = key_shr(key[u], low);
+                }
+            }
+            u32 go = live;
+            while (go) {                                // to the left: records of the run with a key <= this one come first
+#pragma unroll
+                for (u32 u = 0; u < U; ++u) {
+                    if (!(go & (1u << u))) continue;
+                    if (lo[u] == 0) { if (g0 > 0) lost |= 1u << u; go &= ~(1u << u); continue; }
+                    Key<NW> x;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) x.w[q] = lk[(lo[u] - 1) * NW + q];
+                    if (!key_eq(key_shr(x, low), top[u])) { go &= ~(1u << u); continue; }
+                    before[u] += key_lt(key[u], x) ? 0u : 1u;
+                    --lo[u];
+                }
+            }
+            go = live;
+            while (go) {                                // to the right: only strictly smaller keys
+#pragma unroll
+                for (u32 u = 0; u < U; ++u) {
+                    if (!(go & (1u << u))) continue;
+                    if (hi[u] == cnt) { if (g1 < n) lost |= 1u << u; go &= ~(1u << u); continue; }
+                    Key<NW> x;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) x.w[q] = lk[hi[u] * NW + q];
+                    if (!key_eq(key_shr(x, low), top[u])) { go &= ~(1u << u); continue; }
+                    before[u] += key_lt(x, key[u]) ? 1u : 0u;
+                    ++hi[u];
+                }
+            }
+#pragma unroll
+            for (u32 u = 0; u < U; ++u) {
+                if (!(live & (1u << u))) continue;
+                const u32 j = off + (r0 + u) * BLOCK + threadIdx.x;
+                u64 out = g0 + lo[u] + before[u];
+                if (lost & (1u << u)) { *overflow = 1; out = g0 + j; }   // (the result is discarded; keep the store in bounds)
+                store_key<NW>(keys_out, out, key[u]);
+                if (HAS_VAL) vals_out[out] = val[r0 + u];
             }
         }
         __syncthreads();
     }
 }
 
+// passes over the top bits before the run sort takes over: the fewest with 2^(8 * passes) >= n
+static u32 top_passes_for(u64 n) {
+    u32 t = 1;
+    while (t < 8 && (n >> (8 * t)) != 0) ++t;
+    return t;
+}
+
+// own_k / own_v (optional): the buffers that hold d_keys / d_vals.  An odd number of passes leaves the result in the
+// temporaries; with the owners given they simply take those over (no copy back: 24 B per pair saved).
 template <int NW, bool HAS_VAL>
-static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream) {
+static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream, DevBuf* own_k = nullptr, DevBuf* own_v = nullptr) {
     if (n < 2) return KATOME_OK;
     PassBuffers pb;
     KCHECK(pb.init(n, stream));
     DevBuf tk(stream), tv(stream);
-    KCHECK(tk.alloc(n * 8 * NW));
-    if (HAS_VAL) KCHECK(tv.alloc(n * 4));
+    KCHECK(tk.alloc(own_k ? std::max<size_t>(n * 8 * NW, own_k->bytes) : n * 8 * NW));       // (a swapped-in buffer must be no smaller)
+    if (HAS_VAL) KCHECK(tv.alloc(own_v ? std::max<size_t>(n * 4, own_v->bytes) : n * 4));
     u64* kin = d_keys; u64* kout = tk.as<u64>();
     u32* vin = d_vals; u32* vout = tv.as<u32>();
+    auto flip = [&]() { u64* t = kin; kin = kout; kout = t; u32* tv2 = vin; vin = vout; vout = tv2; };
     auto pass = [&](u32 shift) -> int {
         RadixDigit<NW> dg{shift, (key_bits - shift) < (u32)RADIX_BITS ? (key_bits - shift) : (u32)RADIX_BITS};
         KCHECK((radix_pass<NW, HAS_VAL>(kin, vin, n, dg, kout, vout, pb, stream)));
-        u64* t = kin; kin = kout; kout = t;
-        u32* tv2 = vin; vin = vout; vout = tv2;
+        flip();
         return KATOME_OK;
     };
-    // Enough top bits to tell (nearly) all of n keys apart -- log2(n) + 9, in whole digits -- then the short runs that
-    // share them are put right by tie_fix_kernel.  Long keys save most: 2k = 80 bits (k = 40): 5 passes instead of 10; 126: 5 of 16.
-    u32 need = 9;
-    while (need < 64 && (n >> (need - 9))) ++need;
-    const u32 top_passes = (need + RADIX_BITS - 1) / RADIX_BITS, all_passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS;
-    u32 low = 0;                                            // bits below `low` are left to the tie fix
-    // (the tie fix costs about three passes' time on edge lists, where a quarter of the records head a run of 3-5:
-    // worth it from four saved passes on, i.e. for keys of more than ~70 bits -- k > 35)
-    if (top_passes + 4 <= all_passes && n >= (1u << 16) && !getenv("KATOME_FULL_SORT")) low = (all_passes - top_passes) * RADIX_BITS;
+    const u32 all_passes = (key_bits + RADIX_BITS - 1) / RADIX_BITS, top_passes = top_passes_for(n);
+    u32 low = 0;                                            // bits below `low` are left to the run sort
+    // the run sort costs about one pass: worth it from two saved passes on
+    if (top_passes + 2 <= all_passes && n >= (1u << 16) && !getenv("KATOME_FULL_SORT")) low = key_bits - top_passes * RADIX_BITS;
     for (u32 shift = low; shift < key_bits; shift += RADIX_BITS) KCHECK(pass(shift));
     if (low) {
         DevBuf overflow(stream);
         KCHECK(overflow.alloc(16));
         KCHECK_HIP(hipMemsetAsync(overflow.p, 0, 4, stream));
-        hipLaunchKernelGGL((tie_fix_kernel<NW, HAS_VAL>), dim3(grid_for(n, TIE_TILE, 256u * 16u)), dim3(BLOCK), 0, stream, kin, vin, n, low, overflow.as<u32>());
+        const size_t lds = (size_t)(RUN_TILE + 2 * RUN_HALO) * NW * 8;
+        if (lds > (64u << 10)) KCHECK_HIP(hipFuncSetAttribute((const void*)run_sort_kernel<NW, HAS_VAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
+                           kout, vout, overflow.as<u32>());
         KCHECK_HIP(hipGetLastError());
         u32 h = 0;
         KCHECK_HIP(hipMemcpyAsync(&h, overflow.p, 4, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
-        if (h) {                                            // many keys share their top bits: the plain LSD sort, all passes
-            for (u32 shift = 0; shift < key_bits; shift += RADIX_BITS) KCHECK(pass(shift));
+        if (!h) flip();
+        else {                                              // a long run of keys sharing their top bits: the passes that were left out, then
+            for (u32 shift = 0; shift < low; shift += RADIX_BITS) {      // the top ones again (LSD order)
+                RadixDigit<NW> dg{shift, (low - shift) < (u32)RADIX_BITS ? (low - shift) : (u32)RADIX_BITS};
+                KCHECK((radix_pass<NW, HAS_VAL>(kin, vin, n, dg, kout, vout, pb, stream)));
+                flip();
+            }
+            for (u32 shift = low; shift < key_bits; shift += RADIX_BITS) KCHECK(pass(shift));
         }
     }
     if (kin != d_keys) {
-        KCHECK_HIP(hipMemcpyAsync(d_keys, kin, n * 8 * NW, hipMemcpyDeviceToDevice, stream));
-        if (HAS_VAL) KCHECK_HIP(hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, stream));
+        if (own_k && (!HAS_VAL || own_v)) {                 // the owners take the temporaries over, the old buffers go back to the cache
+            { void* q = tk.take(); const size_t b = own_k->bytes; void* old = own_k->take(); own_k->adopt(q, b); tk.adopt(old, b); }
+            if (HAS_VAL) { void* q = tv.take(); const size_t b = own_v->bytes; void* old = own_v->take(); own_v->adopt(q, b); tv.adopt(old, b); }
+        } else {
+            KCHECK_HIP(hipMemcpyAsync(d_keys, kin, n * 8 * NW, hipMemcpyDeviceToDevice, stream));
+            if (HAS_VAL) KCHECK_HIP(hipMemcpyAsync(d_vals, vin, n * 4, hipMemcpyDeviceToDevice, stream));
+        }
     }
     return KATOME_OK;      // temporaries go back to the stream-ordered cache
 }
 
+// keys (and values) held in DevBufs: sorted "in place" from the caller's point of view, but the buffers may be exchanged for
+// the sort's temporaries instead of copied back (pointers taken from them before the call are stale afterwards)
+int dev_sort_bufs(DevBuf& keys, DevBuf* vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream) {
+    if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
+    if (key_bits == 0 || key_bits > 64 * nw) { set_error("key_bits out of range"); return KATOME_E_ARG; }
+    if (keys.bytes < n * 8 * nw || (vals && vals->bytes < n * 4)) { set_error("sort: buffer too small"); return KATOME_E_ARG; }
+    if (nw == 1) return vals ? sort_t<1, true>(keys.as<u64>(), vals->as<u32>(), n, key_bits, stream, &keys, vals) : sort_t<1, false>(keys.as<u64>(), nullptr, n, key_bits, stream, &keys, nullptr);
+    return vals ? sort_t<2, true>(keys.as<u64>(), vals->as<u32>(), n, key_bits, stream, &keys, vals) : sort_t<2, false>(keys.as<u64>(), nullptr, n, key_bits, stream, &keys, nullptr);
+}
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream) {
     if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
     if (key_bits == 0 || key_bits > 64 * nw) { set_error("key_bits out of range"); return KATOME_E_ARG; }
@@ -854,6 +910,8 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
     KCHECK_HIP(hipStreamSynchronize(stream));
     u64 n_extra = 0;
     if (n_missing) {
+        // (setting the misses aside inside dst_rank_kernel was tried: 62 % of its waves hold one, and that many atomics on
+        // one cursor cost more than this second pass over edge_dst)
         DevBuf extra(stream), miss_key(stream), miss_edge(stream);
         KCHECK(extra.alloc(n_missing * 8 * NW + 16));
         KCHECK(miss_key.alloc(n_missing * 8 * NW + 16));

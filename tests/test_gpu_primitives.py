@@ -231,21 +231,28 @@ def test_synth_reads_match_cpu_definition(oracle, L, npct):
 
 
 @pytest.mark.parametrize("nw,bits", [(1, 62), (2, 126), (2, 80), (2, 100)])
-@pytest.mark.parametrize("shape", ["shared_top_bits", "short_runs", "runs_across_tiles"])
-def test_sort_by_top_bits_and_tie_fix(nw, bits, shape):
-    """dev_sort only runs the passes over the top ~log2(n)+9 bits and lets tie_fix_kernel order the runs that share them;
-    runs longer than it handles (here: every key shares its top bits) must fall back to the full sort; equal keys keep
-    their input order either way"""
+@pytest.mark.parametrize("shape", ["shared_top_bits", "short_runs", "runs_across_tiles", "runs_near_the_halo", "runs_past_the_halo"])
+def test_sort_by_top_bits_and_run_sort(nw, bits, shape):
+    """dev_sort only runs the passes over the top 8 * ceil(log2(n) / 8) bits and lets run_sort_kernel place every record
+    inside the run that shares them (radix.hip); a run longer than the staged halo (512 records either side) makes the
+    whole sort fall back to all passes; equal keys keep their input order either way"""
     from katome_amd import device as kd
     rng = np.random.default_rng(nw * 100 + bits + len(shape))
     n = 300001
-    low_bits = bits - 32                      # what the tie fix is left with (n < 2^19: 4 top passes)
+    low_bits = bits - 24                      # what the run sort is left with (2^16 <= n < 2^24: 3 top passes)
     a = np.zeros((n, nw), np.uint64)
     if shape == "shared_top_bits":            # one run of n records
-        top = np.full(n, 0x2AAAAAA, np.uint64)
+        top = np.full(n, 0x2AAAAA, np.uint64)
     elif shape == "short_runs":               # runs of ~3 with duplicates inside
         top = rng.integers(0, n // 3, n).astype(np.uint64)
-    else:                                     # runs of ~40: many cross the 2048-position tiles
+    elif shape == "runs_near_the_halo":       # runs of 300..512: followed to their ends through the halo, across tiles
+        top = np.repeat(np.arange(n // 300 + 1, dtype=np.uint64), rng.integers(300, 513, n // 300 + 1))[:n]
+        rng.shuffle(top)
+    elif shape == "runs_past_the_halo":       # a few runs of 513..3000 among short ones: fall back
+        top = rng.integers(0, n // 3, n).astype(np.uint64)
+        top[1000:1513] = 7; top[90000:93000] = 11
+        rng.shuffle(top)
+    else:                                     # runs of ~40: many cross the 4096-position tiles
         top = rng.integers(0, n // 40, n).astype(np.uint64)
     low = rng.integers(0, 50, n).astype(np.uint64) if shape != "shared_top_bits" else rng.integers(0, 1 << 20, n).astype(np.uint64)
     if nw == 1:
