@@ -1180,7 +1180,9 @@ static int build_packed_impl(const katome_settings* s, const uint8_t* packed, ui
                              const uint8_t* skip, const Finish& finish, const uint64_t* read_bytes_override = nullptr) {
     if (!s || (!packed && n_reads)) { set_error("null argument"); return KATOME_E_ARG; }
     KCHECK(check_k(s->k));
-    if (s->n_devices > 1 && n_reads && read_len >= s->k) {
+    // (KATOME_FORCE_SHARDED=1: one GPU through the sharded route as well -- a world of one rank with the transport a larger
+    // world would use; testing)
+    if ((s->n_devices > 1 || (s->n_devices == 1 && getenv("KATOME_FORCE_SHARDED"))) && n_reads && read_len >= s->k) {
         uint64_t read_bytes = 0;
         if (read_bytes_override) read_bytes = *read_bytes_override;
         else for (uint64_t r = 0; r < n_reads; ++r) if (!skip || !skip[r]) read_bytes += read_len;

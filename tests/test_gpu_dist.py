@@ -134,6 +134,24 @@ def test_too_many_devices_is_an_error():
     assert e.value.name == "E_ARG"
 
 
+@pytest.mark.parametrize("first_seen", [False, True])
+def test_thread_rank_over_rccl(oracle, monkeypatch, first_seen):
+    """the in-process driver with the RCCL transport (ncclCommInitAll, a rank thread, grouped send/recv to self): what
+    settings.n_devices > 1 uses on a multi-GPU node, here as a world of one"""
+    from katome_amd.build import GpuGraph
+    monkeypatch.setenv("KATOME_FORCE_SHARDED", "1")
+    k, rc, n, L = 31, True, 900, 150
+    ascii_reads, packed, skip = _reads(oracle, n, L, 20000, 5e-3, 2)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=1, first_seen_order=first_seen,
+                                        remove_dead_paths=first_seen)
+    ref = oracle.build_ascii(ascii_reads, k, rc, remove_dead_paths=first_seen)
+    assert rb == ref.read_bytes
+    if first_seen:
+        _same_arrays(g, ref)
+    else:
+        assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges) and g.multiset() == ref.multiset()
+
+
 def _dist_build_one_process(k, rc, packed_t, skip_t, n, L, first_seen, comm, dev=0):
     """one rank (of a world of 1) driving katome_dist_* itself, as a process-per-GPU job does"""
     from katome_amd import _lib
