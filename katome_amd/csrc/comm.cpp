@@ -143,11 +143,12 @@ struct RcclTransport : Transport {
     int allreduce(uint64_t* vals, size_t n, int op) override {
         if (n == 0) return KATOME_OK;
         KCHECK_HIP(hipSetDevice(device));
+        hipStream_t s = have_work_stream ? work_stream : ctl;
         if (red.bytes < n * 8) KCHECK(red.alloc(std::max<size_t>(n * 8, 4096), ctl));
-        KCHECK_HIP(hipMemcpyAsync(red.p, vals, n * 8, hipMemcpyHostToDevice, ctl));
-        KCHECK_NCCL(api, api->AllReduce(red.p, red.p, n, ncclUint64, op == OP_SUM ? ncclSum : op == OP_MAX ? ncclMax : ncclMin, comm, ctl));
-        KCHECK_HIP(hipMemcpyAsync(vals, red.p, n * 8, hipMemcpyDeviceToHost, ctl));
-        KCHECK_HIP(hipStreamSynchronize(ctl));
+        KCHECK_HIP(hipMemcpyAsync(red.p, vals, n * 8, hipMemcpyHostToDevice, s));
+        KCHECK_NCCL(api, api->AllReduce(red.p, red.p, n, ncclUint64, op == OP_SUM ? ncclSum : op == OP_MAX ? ncclMax : ncclMin, comm, s));
+        KCHECK_HIP(hipMemcpyAsync(vals, red.p, n * 8, hipMemcpyDeviceToHost, s));
+        KCHECK_HIP(hipStreamSynchronize(s));
         return KATOME_OK;
     }
 };

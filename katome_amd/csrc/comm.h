@@ -29,6 +29,10 @@ enum ReduceOp { OP_SUM = 0, OP_MAX = 1, OP_MIN = 2 };
 
 struct Transport {
     int rank = 0, world = 1;
+    // the stream the caller's device work (and its alltoallv calls) is ordered on; RCCL reductions are enqueued there too, so
+    // that every operation of a communicator is issued on ONE stream, in one order
+    hipStream_t work_stream = nullptr;
+    bool have_work_stream = false;
     virtual ~Transport() {}
     // element counts and offsets per peer; on return `recv` is complete for work enqueued on `stream` afterwards and
     // `send` may be overwritten by such work.  on_device = 0: host buffers (control-plane sized)
@@ -56,6 +60,7 @@ struct katome_comm {
     int exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt);
     int allgather(uint64_t v, uint64_t* out);
     int allreduce(uint64_t* vals, size_t n, int op) { return t->allreduce(vals, n, op); }
+    void use_stream(hipStream_t s) { t->work_stream = s; t->have_work_stream = true; }
     // records grouped by destination, send_cnt[p] elements for peer p, contiguous in peer order; recv likewise by source
     // (recv_cnt from exchange_counts).  Splits into rounds when a pair's message exceeds max_message_bytes.
     int exchange(const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, int on_device,

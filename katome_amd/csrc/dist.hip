@@ -60,8 +60,15 @@ __global__ __launch_bounds__(BLOCK) void scatter_u64_kernel(const u64* __restric
     KLOOP(j, n) out[pos[j]] = vals[j];
 }
 // first-seen order: node_first[node] = earliest (2 * sequence number + role) over the edges that touch it
-__global__ __launch_bounds__(BLOCK) void src_first_kernel(const u64* __restrict__ lsrc, const u64* __restrict__ seq, u64 n, u64* node_first) {
-    KLOOP(e, n) atomicMin((unsigned long long*)&node_first[lsrc[e]], (unsigned long long)(2 * seq[e]));
+// (source role: a node's out-edges are one run of the sorted edges -- its head stores the run's minimum, no atomic)
+__global__ __launch_bounds__(BLOCK) void src_first_kernel(const u64* __restrict__ lsrc, const u64* __restrict__ seq, u64 n, u64* __restrict__ node_first) {
+    KLOOP(e, n) {
+        const u64 s = lsrc[e];
+        if (e > 0 && lsrc[e - 1] == s) continue;
+        u64 m = seq[e];
+        for (u64 j = e + 1; j < n && lsrc[j] == s; ++j) m = seq[j] < m ? seq[j] : m;
+        node_first[s] = 2 * m;
+    }
 }
 __global__ __launch_bounds__(BLOCK) void dst_first_kernel(const u64* __restrict__ local, const u64* __restrict__ val, u64 n, u64* node_first) {
     KLOOP(j, n) atomicMin((unsigned long long*)&node_first[local[j]], (unsigned long long)val[j]);
@@ -397,6 +404,7 @@ int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint6
     hipStream_t stream = (hipStream_t)stream_;
     katome_builder* b = d->b;
     KCHECK_HIP(hipSetDevice(d->s.device));
+    d->comm->use_stream(stream);
     if (d->finalized) { set_error("builder already finalized"); return KATOME_E_ARG; }
     const uint32_t k = d->s.k, nw = d->nw;
     if (read_len < k) { set_error("Read is too short!"); return KATOME_E_SHORT_READ; }       // pt_graph.rs:278
@@ -468,6 +476,7 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     hipStream_t stream = (hipStream_t)stream_;
     katome_builder* b = d->b;
     KCHECK_HIP(hipSetDevice(d->s.device));
+    d->comm->use_stream(stream);
     if (d->finalized) return fill_graph(d, out);
     const int world = d->world(), rank = d->rank();
     const uint32_t nw = d->nw, k = d->s.k, node_bits = 2 * (k - 1);
@@ -608,6 +617,7 @@ int katome_dist_gather(katome_dist_builder* d, int root, katome_builder** root_b
     hipStream_t stream = (hipStream_t)stream_;
     katome_builder* b = d->b;
     KCHECK_HIP(hipSetDevice(d->s.device));
+    d->comm->use_stream(stream);
     if (root_builder) *root_builder = nullptr;
     if (!d->finalized || !d->first_seen) { set_error("katome_dist_gather: a finalized FIRST_SEEN_ORDER build only (its indices place the edges)"); return KATOME_E_ARG; }
     const int world = d->world(), rank = d->rank();

@@ -1012,12 +1012,20 @@ __global__ __launch_bounds__(BLOCK) void invert_kernel(const u32* __restrict__ p
 }
 // a node is created by the first edge insertion that touches it: as the source of the first window of a strand
 // (2*seq) or as a target (2*seq + 1) -- add_single_edge_fastaq, pt_graph.rs:180-185
-__global__ __launch_bounds__(BLOCK) void node_first_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, const u64* __restrict__ seq,
-                                                            u64 n, u64* node_first) {
+// Source role: the edges are in key order, so a node's out-edges are one run of equal src (and src ascending): the run's head
+// takes the minimum over its run and stores it plainly -- one writer per node, no atomic.  Target role: atomicMin, afterwards.
+__global__ __launch_bounds__(BLOCK) void node_first_src_kernel(const u64* __restrict__ src, const u64* __restrict__ seq, u64 n, u64* __restrict__ node_first) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
-        atomicMin((unsigned long long*)&node_first[src[i]], (unsigned long long)(2 * seq[i]));
-        atomicMin((unsigned long long*)&node_first[dst[i]], (unsigned long long)(2 * seq[i] + 1));
+        const u64 s = src[i];
+        if (i > 0 && src[i - 1] == s) continue;
+        u64 m = seq[i];
+        for (u64 j = i + 1; j < n && src[j] == s; ++j) m = seq[j] < m ? seq[j] : m;      // (<= 4 out-edges per node; BFCounter lists may repeat)
+        node_first[s] = 2 * m;
     }
+}
+__global__ __launch_bounds__(BLOCK) void node_first_dst_kernel(const u64* __restrict__ dst, const u64* __restrict__ seq, u64 n, u64* node_first) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK)
+        atomicMin((unsigned long long*)&node_first[dst[i]], (unsigned long long)(2 * seq[i] + 1));
 }
 
 int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream) {
@@ -1068,7 +1076,11 @@ int dev_invert(const uint32_t* perm, uint64_t n, uint64_t* inv, hipStream_t stre
     return KATOME_OK;
 }
 int dev_node_first(const uint64_t* src, const uint64_t* dst, const uint64_t* seq, uint64_t n, uint64_t* node_first, hipStream_t stream) {
-    if (n) hipLaunchKernelGGL(node_first_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, dst, seq, n, node_first);
+    // (edges in key order: src ascending in runs)
+    if (n) {
+        hipLaunchKernelGGL(node_first_src_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, src, seq, n, node_first);
+        hipLaunchKernelGGL(node_first_dst_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, dst, seq, n, node_first);
+    }
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
