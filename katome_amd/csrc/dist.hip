@@ -36,16 +36,48 @@ const char* const XPHASE_NAMES[X_COUNT] = {"exchange_records", "exchange_kmers",
 #define KLAUNCH(kernel, n, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid_for((n), BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, __VA_ARGS__)
 #define KLOOP(i, n) for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < (n); i += (u64)gridDim.x * BLOCK)
 
-// every record whose key was not found among the sources (rank == UINT64_MAX): its key and where it stands
+// every record whose key was not found among the sources (rank == UINT64_MAX): its key and where it stands.  One cursor
+// atomic per workgroup tile of 2048 records (the misses are a few per cent: one atomic each on a single address serialises --
+// 13 ms for 3e6 of them)
+constexpr int MISS_ITEMS = 8;
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void compact_missing_kernel(const u64* __restrict__ rank, const u64* __restrict__ keys, u64 n,
                                                                  u64* __restrict__ mk, u32* __restrict__ mpos, u64* cursor) {
-    KLOOP(j, n) {
-        if (rank[j] != ~0ull) continue;
-        const u64 m = atomicAdd((unsigned long long*)cursor, 1ull);
+    __shared__ u32 wtot[BLOCK / 64];
+    __shared__ u64 base;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u64 tile = (u64)BLOCK * MISS_ITEMS;
+    for (u64 t0 = (u64)blockIdx.x * tile; t0 < n; t0 += (u64)gridDim.x * tile) {
+        bool miss[MISS_ITEMS]; u32 mine = 0;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) mk[m * NW + q] = keys[j * NW + q];
-        mpos[m] = (u32)j;
+        for (int j = 0; j < MISS_ITEMS; ++j) {
+            const u64 i = t0 + (u64)j * BLOCK + threadIdx.x;
+            miss[j] = i < n && rank[i] == ~0ull;
+            mine += miss[j];
+        }
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) woff += wtot[w]; total += wtot[w]; }
+        if (threadIdx.x == 0 && total) base = atomicAdd((unsigned long long*)cursor, (unsigned long long)total);
+        __syncthreads();
+        if (total) {
+            u64 pos = base + woff + (incl - mine);
+#pragma unroll
+            for (int j = 0; j < MISS_ITEMS; ++j) {
+                if (!miss[j]) continue;
+                const u64 i = t0 + (u64)j * BLOCK + threadIdx.x;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) mk[pos * NW + q] = keys[i * NW + q];
+                mpos[pos] = (u32)i;
+                ++pos;
+            }
+        }
+        __syncthreads();
     }
 }
 __global__ __launch_bounds__(BLOCK) void fill_missing_kernel(u64* __restrict__ rank, const u32* __restrict__ mpos, const u64* __restrict__ mrank,
@@ -533,8 +565,9 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
         KCHECK(cursor.alloc(8));
         KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
         KCHECK(mk.alloc((nR + 1) * 8 * nw)); KCHECK(mpos.alloc((nR + 1) * 4));
-        if (nw == 1) KLAUNCH(compact_missing_kernel<1>, nR, stream, local.as<u64>(), R.as<u64>(), nR, mk.as<u64>(), mpos.as<u32>(), cursor.as<u64>());
-        else         KLAUNCH(compact_missing_kernel<2>, nR, stream, local.as<u64>(), R.as<u64>(), nR, mk.as<u64>(), mpos.as<u32>(), cursor.as<u64>());
+        const dim3 mgrid(grid_for(nR, BLOCK * MISS_ITEMS, 256u * 16u));
+        if (nw == 1) hipLaunchKernelGGL(compact_missing_kernel<1>, mgrid, dim3(BLOCK), 0, stream, local.as<u64>(), R.as<u64>(), nR, mk.as<u64>(), mpos.as<u32>(), cursor.as<u64>());
+        else         hipLaunchKernelGGL(compact_missing_kernel<2>, mgrid, dim3(BLOCK), 0, stream, local.as<u64>(), R.as<u64>(), nR, mk.as<u64>(), mpos.as<u32>(), cursor.as<u64>());
         KCHECK_HIP(hipGetLastError());
         uint64_t m = 0;
         KCHECK_HIP(hipMemcpyAsync(&m, cursor.p, 8, hipMemcpyDeviceToHost, stream));

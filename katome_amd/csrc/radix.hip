@@ -22,7 +22,13 @@ constexpr int SORT_ITEMS = KATOME_SORT_ITEMS;
 #define KATOME_SORT_WAVES 4      // workgroups per CU the scatter kernel is compiled for (register budget)
 #endif
 constexpr int SORT_TILE = BLOCK * SORT_ITEMS;      // 4096 keys per workgroup
-constexpr int CHUNK_BLOCKS = 1024;                 // workgroups per offset chunk (4M keys < 2^32)
+// workgroups per offset chunk: the chunk kernel walks a chunk's workgroups serially, the offsets kernel walks the chunks
+// serially -- about the square root of the workgroup count keeps both short (4 M keys per chunk at most: < 2^32)
+static inline unsigned chunk_blocks_for(unsigned long long nblocks) {
+    unsigned c = 64;
+    while (c < 1024 && (unsigned long long)c * c < nblocks) c <<= 1;
+    return c;
+}
 static_assert(BLOCK == RADIX, "one thread per digit in the offset kernels");
 
 template <int NW> struct RadixDigit {
@@ -89,10 +95,10 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const u64* __restrict
 
 // ---- pass 2a: per chunk of workgroups, per digit: sum; counts become exclusive prefixes inside
 // the chunk (u32), chunk_sum[chunk][digit] holds the chunk totals ---------------------------------
-__global__ __launch_bounds__(BLOCK) void radix_chunk_kernel(u32* __restrict__ counts, u64 nblocks, u64* __restrict__ chunk_sum) {
+__global__ __launch_bounds__(BLOCK) void radix_chunk_kernel(u32* __restrict__ counts, u64 nblocks, u64* __restrict__ chunk_sum, u32 chunk_blocks) {
     const u32 d = threadIdx.x;
-    const u64 b0 = (u64)blockIdx.x * CHUNK_BLOCKS;
-    const u64 b1 = b0 + CHUNK_BLOCKS < nblocks ? b0 + CHUNK_BLOCKS : nblocks;
+    const u64 b0 = (u64)blockIdx.x * chunk_blocks;
+    const u64 b1 = b0 + chunk_blocks < nblocks ? b0 + chunk_blocks : nblocks;
     u32 run = 0;
     for (u64 b = b0; b < b1; ++b) {
         u32 c = counts[b * RADIX + d];
@@ -130,7 +136,7 @@ template <int NW, bool HAS_VAL, class Digit>
 __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                u64 n, Digit dg, const u32* __restrict__ rel,
                                                                const u64* __restrict__ chunk_off, u64* __restrict__ keys_out,
-                                                               u32* __restrict__ vals_out) {
+                                                               u32* __restrict__ vals_out, u32 chunk_blocks) {
     extern __shared__ u64 smem[];
     u64* skeys = smem;                                            // [SORT_TILE * NW]; reused for the values afterwards
     __shared__ u32 whist[BLOCK / 64][RADIX];
@@ -186,7 +192,7 @@ __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) if (w < (int)wave) woff += wsum[w];
         dstart[d] = woff + incl - run;
-        gbase[d] = chunk_off[(u64)(blockIdx.x / CHUNK_BLOCKS) * RADIX + d] + rel[(u64)blockIdx.x * RADIX + d];
+        gbase[d] = chunk_off[(u64)(blockIdx.x / chunk_blocks) * RADIX + d] + rel[(u64)blockIdx.x * RADIX + d];
     }
     __syncthreads();
 
@@ -237,10 +243,12 @@ __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel
 struct PassBuffers {
     DevBuf counts, chunk, totals;
     u64 nblocks = 0, nchunks = 0;
+    u32 chunk_blocks = 64;
     int init(u64 n, hipStream_t stream) {
         counts.stream = chunk.stream = totals.stream = stream;
         nblocks = (n + SORT_TILE - 1) / SORT_TILE;
-        nchunks = (nblocks + CHUNK_BLOCKS - 1) / CHUNK_BLOCKS;
+        chunk_blocks = chunk_blocks_for(nblocks);
+        nchunks = (nblocks + chunk_blocks - 1) / chunk_blocks;
         KCHECK(counts.alloc(nblocks * RADIX * sizeof(u32)));
         KCHECK(chunk.alloc(nchunks * RADIX * sizeof(u64)));
         KCHECK(totals.alloc(RADIX * sizeof(u64)));
@@ -253,14 +261,14 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
     if (pb.nblocks > 0x7fffffffull) { set_error("radix pass: %llu keys exceed the grid limit", (unsigned long long)n); return KATOME_E_ARG; }
     dim3 block(BLOCK);
     hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
-    hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>());
+    hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>(), pb.chunk_blocks);
     hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
     const size_t lds = (size_t)SORT_TILE * NW * 8;
     if (lds > (64u << 10)) {          // three-word records: 96 KiB of the CU's 160 KiB
         KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
-                       pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout);
+                       pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
