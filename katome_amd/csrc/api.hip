@@ -582,14 +582,48 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         uint32_t bits = 1;
         while (bits < 64 && (max_seq >> bits)) ++bits;
         // (buffers are taken and given back one at a time: at C3 every one of them is 6-13 GB)
-        DevBuf new_id(stream), eperm(stream);
+        DevBuf new_id(stream), eperm(stream), node_first(stream), aos(stream);
+        KCHECK(node_first.alloc((N + 1) * 8));
+        KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
+        KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
+        lap("node_first");
+        KCHECK(eperm.alloc((E + 1) * 4));
+        if (!getenv("KATOME_SORT_NODES") && aos.alloc(E * 32 + 64) == KATOME_OK) {
+            // No sort of the nodes: every node is introduced by exactly one edge (the one whose first insertion is the node's
+            // first touch), so with the edges in sequence order the node indices are a running count (radix.hip).
+            KCHECK(dev_pack_edges_intro(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->edge_src.as<u64>(), b->edge_dst.as<u64>(),
+                                        b->edge_seq.as<u64>(), node_first.as<u64>(), E, nw, aos.p, stream));
+            node_first.release();
+            lap("pack + who introduces");
+            KCHECK(dev_iota(eperm.as<u32>(), E, stream));
+            KCHECK(dev_sort_bufs(b->edge_seq, &eperm, E, 1, bits, stream));       // eperm[new] = old; edge_seq now ascending
+            lap("sort edges by seq");
+            DevBuf cnt(stream), offs(stream), onode(stream);
+            KCHECK(cnt.alloc((E + 1) * 4));
+            KCHECK(dev_unpack_edges_intro(aos.p, eperm.as<u32>(), E, nw, b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->edge_src.as<u64>(),
+                                          b->edge_dst.as<u64>(), cnt.as<u32>(), stream));
+            aos.release(); eperm.release();
+            lap("edges to seq order");
+            KCHECK(offs.alloc((E + 2) * 8));
+            KCHECK(dev_scan_counts(cnt.as<u32>(), E, offs.as<u64>(), stream));
+            uint64_t introduced = 0;
+            KCHECK_HIP(hipMemcpyAsync(&introduced, offs.as<u64>() + E, 8, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipStreamSynchronize(stream));
+            lap("scan");
+            if (introduced != N) { set_error("first-seen order: %llu nodes introduced, %llu nodes known", (unsigned long long)introduced, (unsigned long long)N); return KATOME_E_DEVICE; }
+            cnt.release();
+            KCHECK(new_id.alloc((N + 1) * 8));
+            KCHECK(onode.alloc((N + 1) * 8 * nw));
+            KCHECK(dev_assign_nodes(b->edge_key.as<u64>(), b->edge_src.as<u64>(), b->edge_dst.as<u64>(), offs.as<u64>(), E, nw, k,
+                                    new_id.as<u64>(), onode.as<u64>(), stream));
+            { const size_t n = onode.bytes; b->node_key.adopt(onode.take(), n); }
+            lap("node indices + end points");
+        } else {
+        aos.release();
         KCHECK(new_id.alloc((N + 1) * 8));
         {
-            DevBuf node_first(stream), nperm(stream), onode(stream);
-            KCHECK(node_first.alloc((N + 1) * 8)); KCHECK(nperm.alloc((N + 1) * 4));
-            KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
-            KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
-            lap("node_first");
+            DevBuf nperm(stream), onode(stream);
+            KCHECK(nperm.alloc((N + 1) * 4));
             KCHECK(dev_iota(nperm.as<u32>(), N, stream));
             KCHECK(dev_sort_bufs(node_first, &nperm, N, 1, bits, stream));        // nperm[new] = old
             lap("sort nodes");
@@ -600,17 +634,16 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
             const size_t n = onode.bytes; b->node_key.adopt(onode.take(), n);
             lap("invert + node keys");
         }
-        KCHECK(eperm.alloc((E + 1) * 4));
         KCHECK(dev_iota(eperm.as<u32>(), E, stream));
         KCHECK(dev_sort_bufs(b->edge_seq, &eperm, E, 1, bits, stream));           // eperm[new] = old; edge_seq now ascending
         lap("sort edges by seq");
         {
             // one 32-byte record per edge, read once at random (radix.hip dev_permute_edges); if that much scratch is not
             // to be had, the four separate gathers
-            DevBuf aos(stream);
-            if (aos.alloc(E * 32 + 64) == KATOME_OK) {
+            DevBuf aos2(stream);
+            if (aos2.alloc(E * 32 + 64) == KATOME_OK) {
                 KCHECK(dev_permute_edges(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->edge_src.as<u64>(), b->edge_dst.as<u64>(),
-                                         new_id.as<u64>(), eperm.as<u32>(), E, nw, aos.p, stream));
+                                         new_id.as<u64>(), eperm.as<u32>(), E, nw, aos2.p, stream));
             } else {
                 {
                     DevBuf o(stream);
@@ -637,6 +670,7 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
                     const size_t n = o.bytes; b->edge_dst.adopt(o.take(), n);
                 }
             }
+        }
         }
         lap("edges to seq order");
         if (b->prune_weight) KCHECK(weak_edges_ordered(b, b->prune_weight, stream));

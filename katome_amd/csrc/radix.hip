@@ -1014,6 +1014,94 @@ int dev_permute_edges(uint64_t* key, uint32_t* weight, uint64_t* src, uint64_t* 
     return KATOME_OK;
 }
 
+// ---- first-seen order without sorting the nodes -------------------------------------------------------------------------
+// A node's index is the rank of its first touch (2 * seq as the source of an edge's first insertion, 2 * seq + 1 as its
+// target), and every touch belongs to exactly one edge: once the edges are in sequence order, the node indices are a running
+// count of "this edge introduces its source / its target" -- a scan over the edges instead of a sort of the nodes.
+// pack: the 32-byte record of dev_permute_edges with the OLD end points and, in `pad`, bit 0 = introduces its source,
+// bit 1 = introduces its target (node_first from dev_node_first)
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void pack_edges_intro_kernel(const u64* __restrict__ key, const u32* __restrict__ weight, const u64* __restrict__ src,
+                                                                  const u64* __restrict__ dst, const u64* __restrict__ seq,
+                                                                  const u64* __restrict__ node_first, u64 n, PackedEdge* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        PackedEdge e;
+        e.k0 = key[i * NW]; e.k1 = NW == 2 ? key[i * NW + 1] : 0;
+        const u64 s = src[i], d = dst[i], q = seq[i];
+        e.src = (u32)s; e.dst = (u32)d; e.weight = weight[i];
+        e.pad = (node_first[s] == 2 * q ? 1u : 0u) | (node_first[d] == 2 * q + 1 ? 2u : 0u);
+        out[i] = e;
+    }
+}
+// unpack in sequence order (new position i <- old position idx[i]); the flags ride in bit 32 of the (old) end points;
+// cnt[i] = nodes the edge introduces
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void unpack_edges_intro_kernel(const PackedEdge* __restrict__ in, const u32* __restrict__ idx, u64 n,
+                                                                    u64* __restrict__ key, u32* __restrict__ weight, u64* __restrict__ src,
+                                                                    u64* __restrict__ dst, u32* __restrict__ cnt) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const PackedEdge e = in[idx[i]];
+        key[i * NW] = e.k0;
+        if (NW == 2) key[i * NW + 1] = e.k1;
+        weight[i] = e.weight;
+        src[i] = (u64)e.src | ((u64)(e.pad & 1u) << 32);
+        dst[i] = (u64)e.dst | ((u64)((e.pad >> 1) & 1u) << 32);
+        cnt[i] = (e.pad & 1u) + ((e.pad >> 1) & 1u);
+    }
+}
+// offs = exclusive scan of cnt: the edge's nodes get indices offs[i] (source, if introduced) and the next one (target)
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void assign_nodes_kernel(const u64* __restrict__ key, u64* __restrict__ src, u64* __restrict__ dst,
+                                                              const u64* __restrict__ offs, u64 n, u32 k, u64* __restrict__ new_id,
+                                                              u64* __restrict__ node_key) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u64 s = src[i], d = dst[i];
+        const u32 fs = (u32)(s >> 32) & 1u, fd = (u32)(d >> 32) & 1u;
+        if (!(fs | fd)) continue;
+        const Key<NW> e = load_key<NW>(key, i);
+        const u64 base = offs[i];
+        // an end point this edge introduces has its index right here (half of all end points): marked final (bit 63), not
+        // looked up again
+        if (fs) { new_id[(u32)s] = base; store_key<NW>(node_key, base, source_node(e)); src[i] = base | (1ull << 63); }
+        if (fd) { new_id[(u32)d] = base + fs; store_key<NW>(node_key, base + fs, target_node(e, k)); dst[i] = (base + fs) | (1ull << 63); }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void remap_ends_kernel(u64* __restrict__ src, u64* __restrict__ dst, const u64* __restrict__ new_id, u64 n) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u64 s = src[i], d = dst[i];
+        src[i] = (s >> 63) ? (s & ~(1ull << 63)) : new_id[(u32)s];
+        dst[i] = (d >> 63) ? (d & ~(1ull << 63)) : new_id[(u32)d];
+    }
+}
+int dev_pack_edges_intro(const uint64_t* key, const uint32_t* weight, const uint64_t* src, const uint64_t* dst, const uint64_t* seq,
+                         const uint64_t* node_first, uint64_t n, uint32_t nw, void* aos, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    const dim3 grid(grid_for(n, BLOCK, 256u * 32u)), blk(BLOCK);
+    if (nw == 1) hipLaunchKernelGGL(pack_edges_intro_kernel<1>, grid, blk, 0, stream, key, weight, src, dst, seq, node_first, n, (PackedEdge*)aos);
+    else         hipLaunchKernelGGL(pack_edges_intro_kernel<2>, grid, blk, 0, stream, key, weight, src, dst, seq, node_first, n, (PackedEdge*)aos);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_unpack_edges_intro(const void* aos, const uint32_t* idx, uint64_t n, uint32_t nw, uint64_t* key, uint32_t* weight, uint64_t* src,
+                           uint64_t* dst, uint32_t* cnt, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    const dim3 grid(grid_for(n, BLOCK, 256u * 32u)), blk(BLOCK);
+    if (nw == 1) hipLaunchKernelGGL(unpack_edges_intro_kernel<1>, grid, blk, 0, stream, (const PackedEdge*)aos, idx, n, key, weight, src, dst, cnt);
+    else         hipLaunchKernelGGL(unpack_edges_intro_kernel<2>, grid, blk, 0, stream, (const PackedEdge*)aos, idx, n, key, weight, src, dst, cnt);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int dev_assign_nodes(const uint64_t* key, uint64_t* src, uint64_t* dst, const uint64_t* offs, uint64_t n, uint32_t nw, uint32_t k,
+                     uint64_t* new_id, uint64_t* node_key, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    const dim3 grid(grid_for(n, BLOCK, 256u * 32u)), blk(BLOCK);
+    if (nw == 1) hipLaunchKernelGGL(assign_nodes_kernel<1>, grid, blk, 0, stream, key, src, dst, offs, n, k, new_id, node_key);
+    else         hipLaunchKernelGGL(assign_nodes_kernel<2>, grid, blk, 0, stream, key, src, dst, offs, n, k, new_id, node_key);
+    hipLaunchKernelGGL(remap_ends_kernel, grid, blk, 0, stream, src, dst, new_id, n);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
 // inverse of a permutation: inv[perm[i]] = i
 __global__ __launch_bounds__(BLOCK) void invert_kernel(const u32* __restrict__ perm, u64 n, u64* __restrict__ inv) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) inv[perm[i]] = i;
