@@ -61,7 +61,8 @@ __device__ __forceinline__ void seen_store(const SeenInit& si, u64 s) {
     if (si.both) st_agent(&si.seen[2 * s + 1], si.b);
 }
 // 128-bit keys: there is no 128-bit CAS, so the high word is claimed with LOCK set, the low word
-// is stored, drained (s_waitcnt) and then the high word is re-published with OCC.  A lane never
+// is stored, drained (s_waitcnt: a hardware wait and, with its memory clobber, a compiler barrier) and then the high word is
+// re-published with OCC.  Readers take the high word first and the rest after a compiler barrier (below).  A lane never
 // waits while it holds a claim (claim and publication are one straight-line block), so lanes of
 // one wave cannot deadlock each other; a lane that meets a LOCKed slot with ITS high word simply
 // re-reads the slot on its next loop trip.
@@ -75,6 +76,9 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
         u64 cur = slots[s].hi;
         bool cached_view = true;
         if (!(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
+        // the other words are read AFTER the first one, in program order (loads of a wave are issued and returned in order, so
+        // what they see is no older): the compiler must not hoist them above it
+        asm volatile("" ::: "memory");
         if (cur == 0) {
             cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
             if (cur == 0) {
@@ -116,6 +120,9 @@ __device__ __forceinline__ u32 upsert(Slot3* slots, u64 cap, Key<3> key, u32 add
         u64 cur = slots[s].hi;
         bool cached_view = true;
         if (!(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
+        // the other words are read AFTER the first one, in program order (loads of a wave are issued and returned in order, so
+        // what they see is no older): the compiler must not hoist them above it
+        asm volatile("" ::: "memory");
         if (cur == 0) {
             cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
             if (cur == 0) {
