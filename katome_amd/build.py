@@ -277,11 +277,12 @@ class GpuContigs:
 
     @classmethod
     def create(cls, input_files, ft, reverse_complement, minimal_weight_threshold=0, device=0, first_seen_order=False,
-               remove_dead_paths=False):
+               remove_dead_paths=False, n_devices=1, ranks_share_device=False):
         """Build::create, optionally remove_dead_paths, then shrink -- the start of assemble_with_graph
         (asm/basic_assembler.rs:58-65) -> (GpuContigs, number_of_read_bytes)"""
         s = make_settings(K_SIZE, ft, reverse_complement, minimal_weight_threshold, device,
-                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths)
+                          first_seen_order=first_seen_order, remove_dead_paths=remove_dead_paths, n_devices=n_devices,
+                          ranks_share_device=ranks_share_device)
         cp = C.POINTER(_lib.Contigs)()
         _check(_lib.lib().katome_shrink_files(C.byref(s), _paths(input_files), len(input_files), C.byref(cp)))
         try:

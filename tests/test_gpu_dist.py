@@ -106,6 +106,20 @@ def test_every_stage_after_a_sharded_build(oracle, tmp_path):
     _same_arrays(g, ref)
 
 
+def test_shrink_after_a_sharded_build(oracle):
+    """katome_shrink_files with n_devices: build over three ranks in the reference's numbering, first pruning and shrink on
+    the gathered graph -- the same merged edges as the one-GPU call (and the reference's counts on the fixture)"""
+    from katome_amd.build import GpuContigs, InputFileType, set_global_k_sizes
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "data3.txt")
+    set_global_k_sizes(40)
+    one, rb1 = GpuContigs.create([path], InputFileType.Fastq, False, 0, first_seen_order=True)
+    many, rbn = GpuContigs.create([path], InputFileType.Fastq, False, 0, first_seen_order=True, n_devices=3, ranks_share_device=True)
+    assert rb1 == rbn == 23300
+    assert (many.n_nodes, many.n_edges) == (one.n_nodes, one.n_edges) == (466, 233)          # tests/shrinker.rs:33-36
+    assert many.contigs() == one.contigs()
+    assert np.array_equal(many.edge_src, one.edge_src) and np.array_equal(many.edge_dst, one.edge_dst)
+
+
 def test_inputs_the_sharded_route_does_not_take_are_built_on_one_gpu(oracle, tmp_path):
     """reads of unequal length and BFCounter input: n_devices is a resource hint, the result is the same graph"""
     from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
