@@ -555,9 +555,12 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
     // sorted edge list (radix.hip, dev_node_ids)
     KCHECK(b->edge_src.alloc((E + 1) * 8, stream));
     KCHECK(b->edge_dst.alloc((E + 1) * 8, stream));
+    DevBuf node_first(stream);                 // first-seen order: the nodes' first touches come out of the same merge
     {
         PhaseScope ps(b->prof, PH_NODE_SET, stream);
-        KCHECK(dev_node_ids(b->edge_key.as<u64>(), E, k, b->node_key, b->edge_src.as<u64>(), b->edge_dst.as<u64>(), &b->n_nodes, stream));
+        const bool fs = b->first_seen && E && b->edge_seq.p;
+        KCHECK(dev_node_ids(b->edge_key.as<u64>(), E, k, b->node_key, b->edge_src.as<u64>(), b->edge_dst.as<u64>(), &b->n_nodes, stream,
+                            fs ? b->edge_seq.as<u64>() : nullptr, fs ? &node_first : nullptr));
     }
     u64* cand = b->node_key.as<u64>();
     if (b->first_seen && E) {
@@ -582,10 +585,12 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
         uint32_t bits = 1;
         while (bits < 64 && (max_seq >> bits)) ++bits;
         // (buffers are taken and given back one at a time: at C3 every one of them is 6-13 GB)
-        DevBuf new_id(stream), eperm(stream), node_first(stream), aos(stream);
-        KCHECK(node_first.alloc((N + 1) * 8));
-        KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
-        KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
+        DevBuf new_id(stream), eperm(stream), aos(stream);
+        if (!node_first.p) {
+            KCHECK(node_first.alloc((N + 1) * 8));
+            KCHECK_HIP(hipMemsetAsync(node_first.p, 0xFF, N * 8, stream));
+            KCHECK(dev_node_first(b->edge_src.as<u64>(), b->edge_dst.as<u64>(), b->edge_seq.as<u64>(), E, node_first.as<u64>(), stream));
+        }
         lap("node_first");
         KCHECK(eperm.alloc((E + 1) * 4));
         if (!getenv("KATOME_SORT_NODES") && aos.alloc(E * 32 + 64) == KATOME_OK) {

@@ -117,8 +117,10 @@ int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uin
 int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipStream_t stream);
 int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t key_bits, const uint64_t* d_q, uint64_t nq,
              uint64_t* d_out, hipStream_t stream);
+// d_seq + node_first (first-seen order): also the nodes' first touches (dev_node_first's result), filled on the way; node_first
+// comes back EMPTY when that was not done and dev_node_first has to run
 int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src,
-                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream);
+                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream, const uint64_t* d_seq = nullptr, DevBuf* node_first = nullptr);
 int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream);
 int dev_gather_seq_weight(const uint64_t* pairs, const uint32_t* idx, uint64_t n, uint64_t* seq, uint32_t* weight, hipStream_t stream);
 int dev_gather_u32(const uint32_t* src, const uint32_t* idx, uint64_t n, uint32_t* dst, hipStream_t stream);

@@ -864,9 +864,173 @@ __global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restri
     }
 }
 
-// the distinct source (k-1)-mers of sorted edges (the run heads of key >> 2), ascending, and every edge's position among them
+// ---- targets looked up by merging ----------------------------------------------------------------------------------
+// Sorted by packed k-mer, the edges fall into four quarters by their first base, and inside a quarter the TARGETS (the low
+// 2(k-1) bits) ascend too.  The sources (ascending) are cut into segments of DST_SEG nodes; a workgroup stages its segment
+// in LDS and walks, quarter by quarter, the one contiguous stretch of edges whose targets lie in the segment's key range:
+// sources and edges are each read once, coalesced, and a target costs a binary search in LDS -- instead of a bucket look-up
+// and a binary search in HBM per edge (dst_rank_kernel) and a second pass that collects the targets not found
+// (missing_gather_kernel): those are staged in LDS and leave with one cursor atomic per MISS_CAP of them.
+constexpr u32 DST_SEG = 2048;
+constexpr u32 DST_ROWS = 2;                              // edges per thread and trip (loads in flight)
+template <int NW> struct MissCap { static constexpr u32 value = 1024 / NW; };
+static_assert(MissCap<2>::value >= DST_ROWS * BLOCK, "a whole trip of misses fits the staging buffer");
+
+template <int NW> __device__ __forceinline__ Key<NW> with_quarter(Key<NW> node, u32 q, u32 node_bits) {
+    if (NW == 1) node.w[0] |= (u64)q << node_bits;
+    else if (node_bits >= 64) node.w[0] |= (u64)q << (node_bits - 64);
+    else { node.w[NW - 1] |= (u64)q << node_bits; node.w[0] |= (u64)q >> (64 - node_bits); }      // (k = 32: node_bits = 62)
+    return node;
+}
+template <int NW> __device__ __forceinline__ u64 lower_bound_keys(const u64* __restrict__ keys, u64 n, const Key<NW>& x) {
+    u64 lo = 0, hi = n;
+    while (lo < hi) {
+        const u64 mid = (lo + hi) >> 1;
+        if (key_lt(load_key<NW>(keys, mid), x)) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// seg[q][s] = first edge of quarter q whose target is not below the first source of segment s (s = 0: the quarter's start;
+// s = n_seg: its end)
 template <int NW>
-static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edge_src, u64* n_src_out, hipStream_t stream) {
+__global__ __launch_bounds__(BLOCK) void dst_seg_kernel(const u64* __restrict__ nodes, const u64* __restrict__ keys, u64 n, u32 node_bits,
+                                                         u64 n_seg, u64* __restrict__ seg) {
+    const u64 total = 4 * (n_seg + 1);
+    for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (u64)gridDim.x * BLOCK) {
+        const u32 q = (u32)(t / (n_seg + 1));
+        const u64 s = t % (n_seg + 1);
+        Key<NW> v;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) v.w[j] = 0;
+        u64 pos;
+        if (s == n_seg) pos = q == 3 ? n : lower_bound_keys<NW>(keys, n, with_quarter(v, q + 1, node_bits));
+        else {
+            if (s) v = load_key<NW>(nodes, s * DST_SEG);
+            pos = lower_bound_keys<NW>(keys, n, with_quarter(v, q, node_bits));
+        }
+        seg[t] = pos;
+    }
+}
+// edge_dst[e] = position of the edge's target among the sources, or ~0; the targets not found go to miss_key / miss_edge
+// (unordered, as many as fit miss_cap) and are counted in *cursor
+// FIRST (first-seen order): seq[e] = sequence number of the edge's first insertion; node_first[v] (holding the source-role
+// minimum, 2*seq, or all-ones) is lowered to the first touch as a target, 2*seq + 1, with atomics in LDS only
+template <int NW, bool FIRST>
+__global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict__ nodes, u64 n_src, const u64* __restrict__ keys, u32 k,
+                                                           u64 n_seg, const u64* __restrict__ seg, u64* __restrict__ edge_dst,
+                                                           u64* __restrict__ miss_key, u64* __restrict__ miss_edge, u64 miss_cap, u64* cursor,
+                                                           const u64* __restrict__ seq, u64* __restrict__ node_first) {
+    constexpr u32 MISS_CAP = MissCap<NW>::value;
+    extern __shared__ u64 lmem[];
+    u64* ls = lmem;                                     // [DST_SEG * NW] the segment's sources
+    u64* lmk = ls + DST_SEG * NW;                       // [MISS_CAP * NW] + [MISS_CAP]: targets not found, and their edges
+    u64* lme = lmk + MISS_CAP * NW;
+    u64* lfirst = lme + MISS_CAP;                       // FIRST: [DST_SEG]
+    __shared__ u32 lmiss;
+    __shared__ u64 lbase;
+    const u32 tid = threadIdx.x;
+    auto flush = [&]() {                                // (called by every thread, between barriers)
+        const u32 m = lmiss;
+        if (tid == 0 && m) lbase = atomicAdd((unsigned long long*)cursor, (unsigned long long)m);
+        __syncthreads();
+        if (m) {
+            const u64 base = lbase;
+            for (u32 j = tid; j < m; j += BLOCK)
+                if (base + j < miss_cap) {
+                    Key<NW> x;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) x.w[w] = lmk[j * NW + w];
+                    store_key<NW>(miss_key, base + j, x);
+                    miss_edge[base + j] = lme[j];
+                }
+        }
+        __syncthreads();
+        if (tid == 0) lmiss = 0;
+        __syncthreads();
+    };
+    for (u64 sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
+        const u64 a = sg * DST_SEG;
+        const u32 cnt = (u32)((n_src - a) < (u64)DST_SEG ? (n_src - a) : (u64)DST_SEG);
+        Key<NW> stage[DST_SEG / BLOCK];
+#pragma unroll
+        for (u32 r = 0; r < DST_SEG / BLOCK; ++r) { const u32 j = r * BLOCK + tid; if (j < cnt) stage[r] = load_key<NW>(nodes, a + j); }
+#pragma unroll
+        for (u32 r = 0; r < DST_SEG / BLOCK; ++r) {
+            const u32 j = r * BLOCK + tid;
+            if (j < cnt) {
+#pragma unroll
+                for (int w = 0; w < NW; ++w) ls[j * NW + w] = stage[r].w[w];
+                if (FIRST) lfirst[j] = ~0ull;
+            }
+        }
+        if (tid == 0) lmiss = 0;
+        __syncthreads();
+        for (u32 q = 0; q < 4; ++q) {
+            const u64 lo = seg[q * (n_seg + 1) + sg], hi = seg[q * (n_seg + 1) + sg + 1];
+            for (u64 c = lo; c < hi; c += (u64)DST_ROWS * BLOCK) {
+                if (lmiss + DST_ROWS * BLOCK > MISS_CAP) flush();          // (lmiss was settled by the barrier that ended the last trip)
+                Key<NW> e[DST_ROWS]; u64 sq[DST_ROWS];
+#pragma unroll
+                for (u32 r = 0; r < DST_ROWS; ++r) {
+                    const u64 i = c + (u64)r * BLOCK + tid;
+                    if (i < hi) { e[r] = load_key<NW>(keys, i); if (FIRST) sq[r] = seq[i]; }
+                }
+#pragma unroll
+                for (u32 r = 0; r < DST_ROWS; ++r) {
+                    const u64 i = c + (u64)r * BLOCK + tid;
+                    if (i >= hi) continue;
+                    const Key<NW> d = target_node(e[r], k);
+                    u32 l = 0, h = cnt;
+                    while (l < h) {
+                        const u32 m = (l + h) >> 1;
+                        Key<NW> x;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) x.w[w] = ls[m * NW + w];
+                        if (key_lt(x, d)) l = m + 1; else h = m;
+                    }
+                    bool found = false;
+                    if (l < cnt) {
+                        Key<NW> x;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) x.w[w] = ls[l * NW + w];
+                        found = key_eq(x, d);
+                    }
+                    if (found) {
+                        edge_dst[i] = a + l;
+                        if (FIRST) atomicMin((unsigned long long*)&lfirst[l], (unsigned long long)(2 * sq[r] + 1));
+                    } else {
+                        edge_dst[i] = ~0ull;
+                        const u32 p = atomicAdd(&lmiss, 1u);
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) lmk[p * NW + w] = d.w[w];
+                        lme[p] = i;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        flush();
+        if (FIRST) {                                    // (flush ends with a barrier: the segment's minima are complete)
+            for (u32 j = tid; j < cnt; j += BLOCK) {
+                const u64 mine = lfirst[j], cur = node_first[a + j];
+                if (mine < cur) node_first[a + j] = mine;
+            }
+        }
+    }
+}
+// the targets that are no source (their ids were written by missing_rank_kernel): first touch of these nodes
+__global__ __launch_bounds__(BLOCK) void missing_first_kernel(const u64* __restrict__ miss_edge, u64 n_miss, const u64* __restrict__ edge_dst,
+                                                               const u64* __restrict__ seq, u64* node_first) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n_miss; i += (u64)gridDim.x * BLOCK) {
+        const u64 e = miss_edge[i];
+        atomicMin((unsigned long long*)&node_first[edge_dst[e]], (unsigned long long)(2 * seq[e] + 1));
+    }
+}
+
+// the distinct source (k-1)-mers of sorted edges (the run heads of key >> 2), ascending, and every edge's position among them
+// (`slack`: room kept behind them in node_key, in nodes, for the caller to append to)
+template <int NW>
+static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edge_src, u64* n_src_out, hipStream_t stream, bool with_slack = false) {
     *n_src_out = 0;
     if (E == 0) { KCHECK(node_key.alloc(16, stream)); return KATOME_OK; }
     const u64 nblocks = (E + UNIQ_TILE - 1) / UNIQ_TILE;
@@ -879,7 +1043,8 @@ static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edg
     u64 n_src = 0;
     KCHECK_HIP(hipMemcpyAsync(&n_src, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
-    KCHECK(node_key.alloc((n_src + 1) * 8 * NW, stream));
+    // (with_slack: the caller appends the nodes without out-edges -- usually a few percent -- instead of copying the lot)
+    KCHECK(node_key.alloc((n_src + (with_slack ? n_src / 8 + (1u << 16) : 0) + 1) * 8 * NW, stream));
     hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), node_key.as<u64>(), edge_src);
     KCHECK_HIP(hipGetLastError());
     *n_src_out = n_src;
@@ -891,42 +1056,83 @@ int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, Dev
     return source_ids_t<2>(d_edge_key, n_edges, node_key, d_edge_src, n_src, stream);
 }
 
+__global__ __launch_bounds__(BLOCK) void node_first_src_kernel(const u64* __restrict__ src, const u64* __restrict__ seq, u64 n, u64* __restrict__ node_first);
+
+// seq + node_first (first-seen order, both or neither): node_first[v] = the first touch of node v, 2*seq as a source, 2*seq + 1
+// as a target; left empty when the merging look-up is switched off (the caller then runs dev_node_first)
 template <int NW>
 static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64* edge_src, u64* edge_dst, u64* n_nodes,
-                      hipStream_t stream) {
+                      hipStream_t stream, const u64* seq = nullptr, DevBuf* node_first = nullptr) {
     *n_nodes = 0;
+    if (node_first) node_first->release();
     if (E == 0) { KCHECK(node_key.alloc(16, stream)); return KATOME_OK; }
     const u32 node_bits = 2 * (k - 1);
     DevBuf aux(stream);
     KCHECK(aux.alloc(16));
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 16, stream));
     u64 n_src = 0;
-    KCHECK((source_ids_t<NW>(d_edge_key, E, node_key, edge_src, &n_src, stream)));
+    KCHECK((source_ids_t<NW>(d_edge_key, E, node_key, edge_src, &n_src, stream, true)));
     u64* nodes = node_key.as<u64>();
     // targets -> positions among the sources
-    u32 B = 1;
-    while ((2ull << B) <= n_src / 8 && B < 27) ++B;
-    if (B > node_bits) B = node_bits;
-    DevBuf index(stream);
-    KCHECK(index.alloc(((1ull << B) + 2) * 8));
-    hipLaunchKernelGGL(bucket_index_kernel<NW>, dim3(grid_for(n_src + 1, BLOCK)), dim3(BLOCK), 0, stream, nodes, n_src, node_bits, B, index.as<u64>());
-    hipLaunchKernelGGL(dst_rank_kernel<NW>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, nodes, n_src, node_bits, B,
-                       index.as<u64>(), d_edge_key, E, k, edge_dst, aux.as<u64>());
-    KCHECK_HIP(hipGetLastError());
-    u64 n_missing = 0;
+    static const bool old_lookup = getenv("KATOME_DST_RANK") != nullptr;
+    const bool first = seq && node_first && !old_lookup;
+    DevBuf miss_key(stream), miss_edge(stream);
+    u64 miss_cap = 0, n_missing = 0;
+    if (!old_lookup) {
+        // merged against the sources segment by segment; the targets that are no source are set aside on the way
+        const u64 n_seg = (n_src + DST_SEG - 1) / DST_SEG;
+        DevBuf seg(stream);
+        KCHECK(seg.alloc(4 * (n_seg + 1) * 8));
+        miss_cap = E / 8 + (1u << 16);
+        if (miss_key.alloc(miss_cap * 8 * NW + 16) != KATOME_OK || miss_edge.alloc(miss_cap * 8 + 16) != KATOME_OK) {
+            miss_key.release(); miss_edge.release();
+            miss_cap = 1u << 16;
+            KCHECK(miss_key.alloc(miss_cap * 8 * NW + 16));
+            KCHECK(miss_edge.alloc(miss_cap * 8 + 16));
+        }
+        hipLaunchKernelGGL(dst_seg_kernel<NW>, dim3(grid_for(4 * (n_seg + 1), BLOCK)), dim3(BLOCK), 0, stream, nodes, d_edge_key, E, node_bits, n_seg, seg.as<u64>());
+        const size_t lds = (size_t)(DST_SEG * NW + MissCap<NW>::value * (NW + 1) + (first ? DST_SEG : 0)) * 8;
+        const dim3 grid((unsigned)std::min<u64>(n_seg, 256u * 32u));
+        if (first) {
+            // (room for the nodes without out-edges, like node_key's)
+            KCHECK(node_first->alloc(node_key.bytes / NW));
+            KCHECK_HIP(hipMemsetAsync(node_first->p, 0xFF, node_first->bytes, stream));
+            hipLaunchKernelGGL(node_first_src_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, edge_src, seq, E, node_first->as<u64>());
+            hipLaunchKernelGGL((dst_merge_kernel<NW, true>), grid, dim3(BLOCK), lds, stream, nodes, n_src, d_edge_key, k, n_seg, seg.as<u64>(), edge_dst,
+                               miss_key.as<u64>(), miss_edge.as<u64>(), miss_cap, aux.as<u64>(), seq, node_first->as<u64>());
+        } else {
+            hipLaunchKernelGGL((dst_merge_kernel<NW, false>), grid, dim3(BLOCK), lds, stream, nodes, n_src, d_edge_key, k, n_seg, seg.as<u64>(), edge_dst,
+                               miss_key.as<u64>(), miss_edge.as<u64>(), miss_cap, aux.as<u64>(), nullptr, nullptr);
+        }
+        KCHECK_HIP(hipGetLastError());
+    } else {
+        u32 B = 1;
+        while ((2ull << B) <= n_src / 8 && B < 27) ++B;
+        if (B > node_bits) B = node_bits;
+        DevBuf index(stream);
+        KCHECK(index.alloc(((1ull << B) + 2) * 8));
+        hipLaunchKernelGGL(bucket_index_kernel<NW>, dim3(grid_for(n_src + 1, BLOCK)), dim3(BLOCK), 0, stream, nodes, n_src, node_bits, B, index.as<u64>());
+        hipLaunchKernelGGL(dst_rank_kernel<NW>, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, nodes, n_src, node_bits, B,
+                           index.as<u64>(), d_edge_key, E, k, edge_dst, aux.as<u64>());
+        KCHECK_HIP(hipGetLastError());
+    }
     KCHECK_HIP(hipMemcpyAsync(&n_missing, aux.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     u64 n_extra = 0;
     if (n_missing) {
-        // (setting the misses aside inside dst_rank_kernel was tried: 62 % of its waves hold one, and that many atomics on
-        // one cursor cost more than this second pass over edge_dst)
-        DevBuf extra(stream), miss_key(stream), miss_edge(stream);
+        DevBuf extra(stream);
         KCHECK(extra.alloc(n_missing * 8 * NW + 16));
-        KCHECK(miss_key.alloc(n_missing * 8 * NW + 16));
-        KCHECK(miss_edge.alloc(n_missing * 8 + 16));
-        hipLaunchKernelGGL(missing_gather_kernel<NW>, dim3(grid_for(E, BLOCK * UNIQ_ITEMS, 256u * 16u)), dim3(BLOCK), 0, stream, d_edge_key, E, k,
-                           edge_dst, miss_key.as<u64>(), miss_edge.as<u64>(), aux.as<u64>() + 1);
-        KCHECK_HIP(hipGetLastError());
+        if (n_missing > miss_cap) {
+            // (the old look-up, or more targets without out-edges than were given room: a second pass over edge_dst collects
+            // them.  Setting them aside inside dst_rank_kernel was tried: 62 % of its waves hold one, and that many atomics
+            // on one cursor cost more than this pass)
+            miss_key.release(); miss_edge.release();
+            KCHECK(miss_key.alloc(n_missing * 8 * NW + 16));
+            KCHECK(miss_edge.alloc(n_missing * 8 + 16));
+            hipLaunchKernelGGL(missing_gather_kernel<NW>, dim3(grid_for(E, BLOCK * UNIQ_ITEMS, 256u * 16u)), dim3(BLOCK), 0, stream, d_edge_key, E, k,
+                               edge_dst, miss_key.as<u64>(), miss_edge.as<u64>(), aux.as<u64>() + 1);
+            KCHECK_HIP(hipGetLastError());
+        }
         KCHECK_HIP(hipMemcpyAsync(extra.p, miss_key.p, n_missing * 8 * NW, hipMemcpyDeviceToDevice, stream));
         KCHECK(dev_sort(extra.as<u64>(), nullptr, n_missing, NW, node_bits, stream));
         n_extra = n_missing;
@@ -934,22 +1140,39 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
         hipLaunchKernelGGL(missing_rank_kernel<NW>, dim3(grid_for(n_missing, BLOCK)), dim3(BLOCK), 0, stream, miss_key.as<u64>(),
                            miss_edge.as<u64>(), n_missing, extra.as<u64>(), n_extra, n_src, edge_dst);
         KCHECK_HIP(hipGetLastError());
+        if (first) {
+            if ((n_src + n_extra + 1) * 8 > node_first->bytes) {
+                DevBuf all(stream);
+                KCHECK(all.alloc((n_src + n_extra + 1) * 8));
+                KCHECK_HIP(hipMemcpyAsync(all.p, node_first->p, n_src * 8, hipMemcpyDeviceToDevice, stream));
+                KCHECK_HIP(hipMemsetAsync(all.as<u64>() + n_src, 0xFF, (n_extra + 1) * 8, stream));
+                const size_t bytes = all.bytes;
+                node_first->adopt(all.take(), bytes);
+            }
+            hipLaunchKernelGGL(missing_first_kernel, dim3(grid_for(n_missing, BLOCK)), dim3(BLOCK), 0, stream, miss_edge.as<u64>(), n_missing, edge_dst, seq,
+                               node_first->as<u64>());
+            KCHECK_HIP(hipGetLastError());
+        }
         // node_key = sources ++ extra
-        DevBuf all(stream);
-        KCHECK(all.alloc((n_src + n_extra + 1) * 8 * NW));
-        KCHECK_HIP(hipMemcpyAsync(all.p, nodes, n_src * 8 * NW, hipMemcpyDeviceToDevice, stream));
-        KCHECK_HIP(hipMemcpyAsync(all.as<u64>() + n_src * NW, extra.p, n_extra * 8 * NW, hipMemcpyDeviceToDevice, stream));
-        const size_t bytes = all.bytes;
-        node_key.adopt(all.take(), bytes);
+        if ((n_src + n_extra + 1) * 8 * NW <= node_key.bytes) {
+            KCHECK_HIP(hipMemcpyAsync(nodes + n_src * NW, extra.p, n_extra * 8 * NW, hipMemcpyDeviceToDevice, stream));
+        } else {
+            DevBuf all(stream);
+            KCHECK(all.alloc((n_src + n_extra + 1) * 8 * NW));
+            KCHECK_HIP(hipMemcpyAsync(all.p, nodes, n_src * 8 * NW, hipMemcpyDeviceToDevice, stream));
+            KCHECK_HIP(hipMemcpyAsync(all.as<u64>() + n_src * NW, extra.p, n_extra * 8 * NW, hipMemcpyDeviceToDevice, stream));
+            const size_t bytes = all.bytes;
+            node_key.adopt(all.take(), bytes);
+        }
     }
     *n_nodes = n_src + n_extra;
     return KATOME_OK;
 }
 
 int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src,
-                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream) {
-    if (key_words_for_k(k) == 1) return node_ids_t<1>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream);
-    return node_ids_t<2>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream);
+                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream, const uint64_t* d_seq, DevBuf* node_first) {
+    if (key_words_for_k(k) == 1) return node_ids_t<1>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream, d_seq, node_first);
+    return node_ids_t<2>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream, d_seq, node_first);
 }
 
 // ---- first-seen order: small permutation helpers ---------------------------------------------------

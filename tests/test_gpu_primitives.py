@@ -189,6 +189,54 @@ def test_source_ids(k):
     assert src.cpu().tolist() == [pos[v >> 2] for v in ints]
 
 
+def _node_ids_reference(ints, k):
+    """sources ascending, then the targets that are no source, ascending (radix.hip node_ids_t)"""
+    mask = (1 << (2 * (k - 1))) - 1
+    srcs = sorted({v >> 2 for v in ints})
+    src_set = set(srcs)
+    extra = sorted({v & mask for v in ints} - src_set)
+    pos = {v: i for i, v in enumerate(srcs + extra)}
+    return srcs + extra, [pos[v >> 2] for v in ints], [pos[v & mask] for v in ints]
+
+
+@pytest.mark.parametrize("k,n,shape", [(5, 900, "random"), (5, 1024, "all"), (9, 60000, "random"), (31, 30000, "random"),
+                                        (31, 200000, "chains"), (31, 50000, "sinks"), (32, 30000, "chains"), (40, 30000, "random"),
+                                        (40, 120000, "chains"), (63, 40000, "chains"), (31, 5000, "repeats")])
+def test_node_ids(k, n, shape):
+    """node numbering off the sorted edges: targets merged against the sources segment by segment (four quarters by first
+    base), the ones without out-edges appended -- against a dictionary on the host; with KATOME_DST_RANK unset this is the
+    merging look-up, whose segments (2048 sources) and staging buffer these sizes cross"""
+    from katome_amd import device as kd
+    from helpers import words_to_int
+    nw = kd.record_words(k)
+    rng = np.random.default_rng(1000 * k + n)
+    full = (1 << (2 * k)) - 1
+    if shape == "all":
+        ints = list(range(4 ** k))
+    elif shape == "chains":          # walks: most targets are sources too, chain ends are not
+        ints = set()
+        while len(ints) < n:
+            v = int(rng.integers(0, 2 ** 62)) * int(rng.integers(1, 2 ** 62)) & full
+            for _ in range(int(rng.integers(1, 200))):
+                ints.add(v)
+                v = ((v << 2) | int(rng.integers(0, 4))) & full
+        ints = sorted(ints)
+    elif shape == "sinks":           # all sources share their first bases: nearly every target is a node without out-edges
+        ints = sorted({(int(rng.integers(0, 2 ** 62)) & (full >> 24)) | (0x2A5 << (2 * k - 12)) for _ in range(n)})
+    else:
+        a = _keys(rng, n, nw, 2 * k)
+        ints = sorted({words_to_int(r) for r in a})
+    if shape == "repeats":           # BFCounter lists may hold a k-mer more than once (parallel edges)
+        ints = sorted(ints + ints[::3] + ints[::7])
+    edges = np.array([[(v >> 64) & (2**64 - 1), v & (2**64 - 1)][2 - nw:] for v in ints], dtype=np.uint64).reshape(-1, nw)
+    nodes, src, dst = kd.node_ids(_to_dev(edges).view(-1), k)
+    torch.cuda.synchronize()
+    want_nodes, want_src, want_dst = _node_ids_reference(ints, k)
+    assert [words_to_int(r) for r in _from_dev(nodes, nw)] == want_nodes
+    assert src.cpu().tolist() == want_src
+    assert dst.cpu().tolist() == want_dst
+
+
 @pytest.mark.parametrize("k", [3, 31, 32, 40, 63])
 def test_endpoints_and_labels(oracle, k):
     from katome_amd import device as kd
