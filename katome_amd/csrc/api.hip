@@ -617,14 +617,20 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
             lap("scan");
             if (introduced != N) { set_error("first-seen order: %llu nodes introduced, %llu nodes known", (unsigned long long)introduced, (unsigned long long)N); return KATOME_E_DEVICE; }
             cnt.release();
+            DevBuf osrc(stream), odst(stream);
             KCHECK(new_id.alloc((N + 1) * 8));
             KCHECK(onode.alloc((N + 1) * 8 * nw));
+            KCHECK(osrc.alloc((E + 1) * 8));
+            KCHECK(odst.alloc((E + 1) * 8));
             KCHECK(dev_assign_nodes(b->edge_key.as<u64>(), b->edge_src.as<u64>(), b->edge_dst.as<u64>(), offs.as<u64>(), E, nw, k,
-                                    new_id.as<u64>(), onode.as<u64>(), stream));
+                                    new_id.as<u64>(), onode.as<u64>(), osrc.as<u64>(), odst.as<u64>(), stream));
             { const size_t n = onode.bytes; b->node_key.adopt(onode.take(), n); }
+            { const size_t n = osrc.bytes; b->edge_src.adopt(osrc.take(), n); }
+            { const size_t n = odst.bytes; b->edge_dst.adopt(odst.take(), n); }
             lap("node indices + end points");
         } else {
         aos.release();
+        KCHECK(dev_clear_dst_marks(b->edge_dst.as<u64>(), E, stream));      // (the merge's marks: only the other branch reads them)
         KCHECK(new_id.alloc((N + 1) * 8));
         {
             DevBuf nperm(stream), onode(stream);

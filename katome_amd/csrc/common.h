@@ -134,8 +134,9 @@ int dev_pack_edges_intro(const uint64_t* key, const uint32_t* weight, const uint
                          const uint64_t* node_first, uint64_t n, uint32_t nw, void* aos, hipStream_t stream);
 int dev_unpack_edges_intro(const void* aos, const uint32_t* idx, uint64_t n, uint32_t nw, uint64_t* key, uint32_t* weight, uint64_t* src,
                            uint64_t* dst, uint32_t* cnt, hipStream_t stream);
-int dev_assign_nodes(const uint64_t* key, uint64_t* src, uint64_t* dst, const uint64_t* offs, uint64_t n, uint32_t nw, uint32_t k,
-                     uint64_t* new_id, uint64_t* node_key, hipStream_t stream);
+int dev_assign_nodes(const uint64_t* key, const uint64_t* src, const uint64_t* dst, const uint64_t* offs, uint64_t n, uint32_t nw, uint32_t k,
+                     uint64_t* new_id, uint64_t* node_key, uint64_t* out_src, uint64_t* out_dst, hipStream_t stream);
+int dev_clear_dst_marks(uint64_t* dst, uint64_t n, hipStream_t stream);
 int dev_node_first(const uint64_t* src, const uint64_t* dst, const uint64_t* seq, uint64_t n, uint64_t* node_first, hipStream_t stream);
 int dev_endpoints(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint64_t* d_src, uint64_t* d_dst, hipStream_t stream);
 int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream);

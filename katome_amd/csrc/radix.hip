@@ -871,9 +871,16 @@ __global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restri
 // sources and edges are each read once, coalesced, and a target costs a binary search in LDS -- instead of a bucket look-up
 // and a binary search in HBM per edge (dst_rank_kernel) and a second pass that collects the targets not found
 // (missing_gather_kernel): those are staged in LDS and leave with one cursor atomic per MISS_CAP of them.
-constexpr u32 DST_SEG = 2048;
-constexpr u32 DST_ROWS = 2;                              // edges per thread and trip (loads in flight)
-template <int NW> struct MissCap { static constexpr u32 value = 1024 / NW; };
+#ifndef KATOME_DST_SEG
+#define KATOME_DST_SEG 2048
+#endif
+#ifndef KATOME_DST_ROWS
+#define KATOME_DST_ROWS 2
+#endif
+constexpr u64 DST_IN1 = 1ull << 40;                      // first-seen order: mark in edge_dst, "the target has this in-edge only"
+constexpr u32 DST_SEG = KATOME_DST_SEG;
+constexpr u32 DST_ROWS = KATOME_DST_ROWS;                // edges per thread and trip (loads in flight)
+template <int NW> struct MissCap { static constexpr u32 value = (DST_ROWS > 2 ? 2048 : 1024) / NW; };
 static_assert(MissCap<2>::value >= DST_ROWS * BLOCK, "a whole trip of misses fits the staging buffer");
 
 template <int NW> __device__ __forceinline__ Key<NW> with_quarter(Key<NW> node, u32 q, u32 node_bits) {
@@ -925,7 +932,9 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
     u64* ls = lmem;                                     // [DST_SEG * NW] the segment's sources
     u64* lmk = ls + DST_SEG * NW;                       // [MISS_CAP * NW] + [MISS_CAP]: targets not found, and their edges
     u64* lme = lmk + MISS_CAP * NW;
-    u64* lfirst = lme + MISS_CAP;                       // FIRST: [DST_SEG]
+    u64* lfirst = lme + MISS_CAP;                       // FIRST: [DST_SEG] first touch as a target
+    u32* lonce = reinterpret_cast<u32*>(lfirst + DST_SEG);   // FIRST: two bitmaps [DST_SEG / 32]: has an in-edge, has several
+    u32* lmore = lonce + DST_SEG / 32;
     __shared__ u32 lmiss;
     __shared__ u64 lbase;
     const u32 tid = threadIdx.x;
@@ -963,6 +972,7 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
                 if (FIRST) lfirst[j] = ~0ull;
             }
         }
+        if (FIRST && tid < 2 * (DST_SEG / 32)) lonce[tid] = 0;          // (lmore follows lonce)
         if (tid == 0) lmiss = 0;
         __syncthreads();
         for (u32 q = 0; q < 4; ++q) {
@@ -997,7 +1007,11 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
                     }
                     if (found) {
                         edge_dst[i] = a + l;
-                        if (FIRST) atomicMin((unsigned long long*)&lfirst[l], (unsigned long long)(2 * sq[r] + 1));
+                        if (FIRST) {
+                            atomicMin((unsigned long long*)&lfirst[l], (unsigned long long)(2 * sq[r] + 1));
+                            const u32 bit = 1u << (l & 31);
+                            if (atomicOr(&lonce[l >> 5], bit) & bit) atomicOr(&lmore[l >> 5], bit);
+                        }
                     } else {
                         edge_dst[i] = ~0ull;
                         const u32 p = atomicAdd(&lmiss, 1u);
@@ -1015,6 +1029,18 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
                 const u64 mine = lfirst[j], cur = node_first[a + j];
                 if (mine < cur) node_first[a + j] = mine;
             }
+            // second sweep: an edge whose target has no other in-edge is marked (DST_IN1) -- with the matching mark on the
+            // source side (one out-edge) the renumbering can tell the nodes nobody will ever look up (dev_assign_nodes)
+            for (u32 q = 0; q < 4; ++q) {
+                const u64 lo = seg[q * (n_seg + 1) + sg], hi = seg[q * (n_seg + 1) + sg + 1];
+                for (u64 i = lo + tid; i < hi; i += BLOCK) {            // (the thread that wrote edge_dst[i])
+                    const u64 d = edge_dst[i];
+                    if (d == ~0ull) continue;
+                    const u32 l = (u32)(d - a), bit = 1u << (l & 31);
+                    if (!(lmore[l >> 5] & bit)) edge_dst[i] = d | DST_IN1;
+                }
+            }
+            __syncthreads();
         }
     }
 }
@@ -1091,7 +1117,7 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
             KCHECK(miss_edge.alloc(miss_cap * 8 + 16));
         }
         hipLaunchKernelGGL(dst_seg_kernel<NW>, dim3(grid_for(4 * (n_seg + 1), BLOCK)), dim3(BLOCK), 0, stream, nodes, d_edge_key, E, node_bits, n_seg, seg.as<u64>());
-        const size_t lds = (size_t)(DST_SEG * NW + MissCap<NW>::value * (NW + 1) + (first ? DST_SEG : 0)) * 8;
+        const size_t lds = (size_t)(DST_SEG * NW + MissCap<NW>::value * (NW + 1) + (first ? DST_SEG : 0)) * 8 + (first ? 2 * (DST_SEG / 32) * 4 : 0);
         const dim3 grid((unsigned)std::min<u64>(n_seg, 256u * 32u));
         if (first) {
             // (room for the nodes without out-edges, like node_key's)
@@ -1250,9 +1276,10 @@ __global__ __launch_bounds__(BLOCK) void pack_edges_intro_kernel(const u64* __re
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         PackedEdge e;
         e.k0 = key[i * NW]; e.k1 = NW == 2 ? key[i * NW + 1] : 0;
-        const u64 s = src[i], d = dst[i], q = seq[i];
+        const u64 s = src[i], dm = dst[i], d = dm & ~DST_IN1, q = seq[i];
         e.src = (u32)s; e.dst = (u32)d; e.weight = weight[i];
-        e.pad = (node_first[s] == 2 * q ? 1u : 0u) | (node_first[d] == 2 * q + 1 ? 2u : 0u);
+        const bool out1 = (i == 0 || src[i - 1] != s) && (i + 1 >= n || src[i + 1] != s);     // the source has this out-edge only
+        e.pad = (node_first[s] == 2 * q ? 1u : 0u) | (node_first[d] == 2 * q + 1 ? 2u : 0u) | ((dm & DST_IN1) ? 4u : 0u) | (out1 ? 8u : 0u);
         out[i] = e;
     }
 }
@@ -1267,14 +1294,19 @@ __global__ __launch_bounds__(BLOCK) void unpack_edges_intro_kernel(const PackedE
         key[i * NW] = e.k0;
         if (NW == 2) key[i * NW + 1] = e.k1;
         weight[i] = e.weight;
-        src[i] = (u64)e.src | ((u64)(e.pad & 1u) << 32);
-        dst[i] = (u64)e.dst | ((u64)((e.pad >> 1) & 1u) << 32);
+        src[i] = (u64)e.src | ((u64)(e.pad & 1u) << 32) | ((u64)((e.pad >> 3) & 1u) << 33);
+        dst[i] = (u64)e.dst | ((u64)((e.pad >> 1) & 1u) << 32) | ((u64)((e.pad >> 2) & 1u) << 33);
         cnt[i] = (e.pad & 1u) + ((e.pad >> 1) & 1u);
     }
 }
-// offs = exclusive scan of cnt: the edge's nodes get indices offs[i] (source, if introduced) and the next one (target)
+// offs = exclusive scan of cnt: the edge's nodes get indices offs[i] (source, if introduced) and the next one (target).
+// The indices reach the OTHER edges of a node through new_id[old index] -- a scattered write and a scattered read per node,
+// the two most expensive steps of the renumbering.  Most nodes never need either: in sequence order an edge is usually
+// followed by the next window of the same read, so a node is introduced as the target of edge i and used as the source of
+// edge i + 1 (remap_ends_kernel reads it off its neighbour); when it has no other in- or out-edge (bits 33: marks from the
+// merge and from the runs of sources) nobody else will ask for it and the write is left out as well.
 template <int NW>
-__global__ __launch_bounds__(BLOCK) void assign_nodes_kernel(const u64* __restrict__ key, u64* __restrict__ src, u64* __restrict__ dst,
+__global__ __launch_bounds__(BLOCK) void assign_nodes_kernel(const u64* __restrict__ key, const u64* __restrict__ src, const u64* __restrict__ dst,
                                                               const u64* __restrict__ offs, u64 n, u32 k, u64* __restrict__ new_id,
                                                               u64* __restrict__ node_key) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
@@ -1283,18 +1315,39 @@ __global__ __launch_bounds__(BLOCK) void assign_nodes_kernel(const u64* __restri
         if (!(fs | fd)) continue;
         const Key<NW> e = load_key<NW>(key, i);
         const u64 base = offs[i];
-        // an end point this edge introduces has its index right here (half of all end points): marked final (bit 63), not
-        // looked up again
-        if (fs) { new_id[(u32)s] = base; store_key<NW>(node_key, base, source_node(e)); src[i] = base | (1ull << 63); }
-        if (fd) { new_id[(u32)d] = base + fs; store_key<NW>(node_key, base + fs, target_node(e, k)); dst[i] = (base + fs) | (1ull << 63); }
+        if (fs) { new_id[(u32)s] = base; store_key<NW>(node_key, base, source_node(e)); }
+        if (fd) {
+            store_key<NW>(node_key, base + fs, target_node(e, k));
+            bool alone = false;                         // one in-edge (this one), one out-edge, and that one comes next
+            if (((d >> 33) & 1u) && i + 1 < n) { const u64 s1 = src[i + 1]; alone = ((s1 >> 33) & 1u) && (u32)s1 == (u32)d; }
+            if (!alone) new_id[(u32)d] = base + fs;
+        }
     }
 }
-__global__ __launch_bounds__(BLOCK) void remap_ends_kernel(u64* __restrict__ src, u64* __restrict__ dst, const u64* __restrict__ new_id, u64 n) {
+__global__ __launch_bounds__(BLOCK) void remap_ends_kernel(const u64* __restrict__ src, const u64* __restrict__ dst, const u64* __restrict__ offs,
+                                                            const u64* __restrict__ new_id, u64 n, u64* __restrict__ osrc, u64* __restrict__ odst) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         const u64 s = src[i], d = dst[i];
-        src[i] = (s >> 63) ? (s & ~(1ull << 63)) : new_id[(u32)s];
-        dst[i] = (d >> 63) ? (d & ~(1ull << 63)) : new_id[(u32)d];
+        const u32 fs = (u32)(s >> 32) & 1u, fd = (u32)(d >> 32) & 1u;
+        const u64 base = (fs | fd) ? offs[i] : 0;
+        u64 so;
+        if (fs) so = base;
+        else {
+            const u64 dp = i ? dst[i - 1] : 0;
+            if (i && ((dp >> 32) & 1u) && (u32)dp == (u32)s) so = offs[i - 1] + ((src[i - 1] >> 32) & 1u);      // introduced by the edge before
+            else so = new_id[(u32)s];
+        }
+        osrc[i] = so;
+        odst[i] = fd ? base + fs : new_id[(u32)d];
     }
+}
+__global__ __launch_bounds__(BLOCK) void clear_marks_kernel(u64* __restrict__ v, u64 n) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) v[i] &= ~DST_IN1;
+}
+int dev_clear_dst_marks(uint64_t* dst, uint64_t n, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(clear_marks_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, dst, n);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
 }
 int dev_pack_edges_intro(const uint64_t* key, const uint32_t* weight, const uint64_t* src, const uint64_t* dst, const uint64_t* seq,
                          const uint64_t* node_first, uint64_t n, uint32_t nw, void* aos, hipStream_t stream) {
@@ -1314,13 +1367,13 @@ int dev_unpack_edges_intro(const void* aos, const uint32_t* idx, uint64_t n, uin
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
-int dev_assign_nodes(const uint64_t* key, uint64_t* src, uint64_t* dst, const uint64_t* offs, uint64_t n, uint32_t nw, uint32_t k,
-                     uint64_t* new_id, uint64_t* node_key, hipStream_t stream) {
+int dev_assign_nodes(const uint64_t* key, const uint64_t* src, const uint64_t* dst, const uint64_t* offs, uint64_t n, uint32_t nw, uint32_t k,
+                     uint64_t* new_id, uint64_t* node_key, uint64_t* out_src, uint64_t* out_dst, hipStream_t stream) {
     if (n == 0) return KATOME_OK;
     const dim3 grid(grid_for(n, BLOCK, 256u * 32u)), blk(BLOCK);
     if (nw == 1) hipLaunchKernelGGL(assign_nodes_kernel<1>, grid, blk, 0, stream, key, src, dst, offs, n, k, new_id, node_key);
     else         hipLaunchKernelGGL(assign_nodes_kernel<2>, grid, blk, 0, stream, key, src, dst, offs, n, k, new_id, node_key);
-    hipLaunchKernelGGL(remap_ends_kernel, grid, blk, 0, stream, src, dst, new_id, n);
+    hipLaunchKernelGGL(remap_ends_kernel, grid, blk, 0, stream, src, dst, offs, new_id, n, out_src, out_dst);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
