@@ -64,7 +64,7 @@ def parse_args():
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
     ap.add_argument("--min-weight", type=int, default=0,
                     help="Clean::remove_weak_edges(threshold) as the edges are read out (pruner.rs:84-93; not the BASELINE metric's configuration)")
-    ap.add_argument("--table-factor", type=float, default=2.2, help="k-mer table slots per expected distinct canonical k-mer")
+    ap.add_argument("--table-factor", type=float, default=1.8, help="k-mer table slots per expected distinct canonical k-mer")
     ap.add_argument("--cpu-sample-reads", type=int, default=300_000,
                     help="reads of the workload the oracle builds on one host core (1e6 = all of C2; ~85 s there)")
     ap.add_argument("--prune", action="store_true",

@@ -466,7 +466,8 @@ int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream) {
     KCHECK(t.counter.alloc(sizeof(TableAux), stream));
     if (t.track_seen) {
         KCHECK(t.seen.alloc(cap * 16, stream));
-        KCHECK_HIP(hipMemsetAsync(t.seen.p, 0xFF, cap * 16, stream));
+        // (keys of two and three words get their pair inside the claim, before anyone can look: nothing to initialise)
+        if (nw == 1) KCHECK_HIP(hipMemsetAsync(t.seen.p, 0xFF, cap * 16, stream));
     }
     KCHECK_HIP(hipMemsetAsync(t.slots.p, 0, cap * t.slot_bytes(), stream));
     KCHECK_HIP(hipMemsetAsync(t.counter.p, 0, sizeof(TableAux), stream));
