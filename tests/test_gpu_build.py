@@ -421,6 +421,17 @@ def test_pruning_properties_at_scale():
             b.count_reads(packed, min(step, wl.reads - r0), wl.read_len, None, first_read=r0)
         dg = b.finalize()
         E0, N0 = dg.n_edges, dg.n_nodes
+        # petgraph's numbering: node indices are handed out in the order the edge list first mentions them (source before
+        # target) -- the renumbering's neighbour shortcuts and left-out table writes (radix.hip, assign_nodes_kernel) at a size
+        # where they carry nearly every node
+        mention = torch.stack([dg.edge_src, dg.edge_dst], 1).reshape(-1)
+        first = torch.full((N0,), 2 * E0, dtype=torch.int64, device=mention.device)
+        first.scatter_reduce_(0, mention, torch.arange(2 * E0, dtype=torch.int64, device=mention.device), "amin")
+        assert bool((first[1:] > first[:-1]).all()) and int(first[-1].item()) < 2 * E0
+        del mention, first
+        k0 = dg.edge_key[:, 0]
+        assert bool((dg.node_key[:, 0][dg.edge_src] == (k0 >> 2)).all())
+        assert bool((dg.node_key[:, 0][dg.edge_dst] == (k0 & ((1 << (2 * (wl.k - 1))) - 1))).all())
         built = torch.sort(dg.edge_key[:, 0].clone()).values
         weight_of = dg.edge_weight.clone()
         dg, st = b.remove_dead_paths()
