@@ -237,14 +237,31 @@ def cpu_baseline(wl, sample_reads):
     from oracle import oracle as o
     n = min(sample_reads, wl.reads)
     reads = o.synth_reads(0, n, wl.read_len, wl.genome_len, wl.err_rate, wl.n_inject_percent)
+
+    def status_kib(field):
+        try:
+            for line in open("/proc/self/status"):
+                if line.startswith(field + ":"):
+                    return int(line.split()[1])
+        except OSError:
+            pass
+        return None
+    try:                                   # restart the process's resident-set high-water mark (Linux: clear_refs 5)
+        open("/proc/self/clear_refs", "w").write("5")
+    except OSError:
+        pass
+    rss0 = status_kib("VmRSS")
     t0 = time.perf_counter()
     g = o.build_ascii(reads, wl.k, wl.reverse_complement)
     dt = time.perf_counter() - t0
+    hwm = status_kib("VmHWM")
     accepted = g.read_bytes // wl.read_len
     return {"value": accepted * wl.windows_per_read / dt, "unit": "k-mers/s", "cores": 1, "kind": "port",
             "sample": "first %d reads of workload %s (k=%d, rc=%s): %.1f s on one core of %d; %d distinct edges"
                       % (n, wl.name, wl.k, wl.reverse_complement, dt, os.cpu_count() or 0, g.n_edges),
-            "distinct_edges_per_s": g.n_edges / dt}
+            "distinct_edges_per_s": g.n_edges / dt,
+            # the graph the CPU build holds at its peak (resident-set high-water mark minus what the process held before)
+            "peak_rss_mib": round((hwm - rss0) / 1024.0, 1) if hwm is not None and rss0 is not None else None}
 
 
 def run_as_parent(args):

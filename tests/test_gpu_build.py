@@ -669,6 +669,29 @@ def test_first_seen_order_synthetic(oracle, k, rc, n, L, npct):
     b.close()
 
 
+@pytest.mark.parametrize("k,rc", [(31, True), (40, False)])
+def test_first_seen_order_when_most_nodes_have_no_out_edge(oracle, k, rc):
+    """reads of exactly k bases: every read is one edge between two nodes nothing continues, so the nodes without out-edges
+    outnumber the room the node numbering keeps behind the sources (node keys and first touches are re-housed) and the
+    targets set aside by the merge outnumber their buffer (the collecting pass runs instead) -- radix.hip node_ids_t"""
+    from katome_amd import device as kd
+    n = 160_000
+    rng = np.random.default_rng(k)
+    ascii_reads = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=(n, k))]
+    ascii_reads[1::5] = ascii_reads[0:-1:5][:len(ascii_reads[1::5])]              # some reads twice: weights above 1
+    packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc, first_seen_order=True, table_slots_hint=1 << 19)
+    b.insert(b.extract_fixed(packed, n, k, None, first_read=0))
+    dg = b.finalize()
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges) and dg.n_nodes > 1.9 * dg.n_edges * 0.95
+    assert np.array_equal(dg.edge_weight.cpu().numpy().view(np.uint32), ref.edge_weight)
+    assert np.array_equal(dg.edge_src.cpu().numpy().view(np.uint64), ref.edge_src)
+    assert np.array_equal(dg.edge_dst.cpu().numpy().view(np.uint64), ref.edge_dst)
+    assert np.array_equal(dg.edge_label.cpu().numpy(), ref.edge_label)
+    b.close()
+
+
 def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
     from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
     base = oracle.build_files([os.path.join(golden_dir, "data1.txt")], 31, False)

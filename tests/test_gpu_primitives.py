@@ -200,7 +200,7 @@ def _node_ids_reference(ints, k):
 
 
 @pytest.mark.parametrize("k,n,shape", [(5, 900, "random"), (5, 1024, "all"), (9, 60000, "random"), (31, 30000, "random"),
-                                        (31, 200000, "chains"), (31, 50000, "sinks"), (32, 30000, "chains"), (40, 30000, "random"),
+                                        (31, 200000, "chains"), (31, 50000, "sinks"), (31, 400000, "sinks"), (32, 30000, "chains"), (40, 30000, "random"),
                                         (40, 120000, "chains"), (63, 40000, "chains"), (31, 5000, "repeats")])
 def test_node_ids(k, n, shape):
     """node numbering off the sorted edges: targets merged against the sources segment by segment (four quarters by first
