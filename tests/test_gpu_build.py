@@ -2,6 +2,7 @@
 constants the reference's own tests pin (tests/golden/pinned.json).  Integer work: bit-exact."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -690,6 +691,46 @@ def test_first_seen_order_when_most_nodes_have_no_out_edge(oracle, k, rc):
     assert np.array_equal(dg.edge_dst.cpu().numpy().view(np.uint64), ref.edge_dst)
     assert np.array_equal(dg.edge_label.cpu().numpy(), ref.edge_label)
     b.close()
+
+
+_AB_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+for first_seen in (False, True):
+    reads = o.synth_reads(5, 5000, 150, 30000, 3e-3, 0)
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(31, True, first_seen_order=first_seen, table_slots_hint=1 << 16)
+    b.count_reads(packed, 5000, 150, None, first_read=0)
+    dg = b.finalize()
+    h = hashlib.sha256()
+    for t in (dg.edge_key, dg.edge_weight, dg.edge_src, dg.edge_dst, dg.node_key, dg.edge_label):
+        h.update(t.cpu().numpy().tobytes())
+    print("AB", int(first_seen), dg.n_nodes, dg.n_edges, h.hexdigest())
+    b.close()
+"""
+
+
+def test_round_one_paths_give_the_same_arrays(tmp_path):
+    """the A/B switches: edge-by-edge target look-up, node sort in first-seen builds, all radix passes --
+    each in a process of its own (the switches are read once), byte for byte against the default paths"""
+    import subprocess
+    script = tmp_path / "ab.py"
+    script.write_text(_AB_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return sorted(line for line in out.stdout.splitlines() if line.startswith("AB "))
+    want = run({})
+    assert len(want) == 2
+    for extra in ({"KATOME_DST_RANK": "1"}, {"KATOME_SORT_NODES": "1"}, {"KATOME_FULL_SORT": "1"},
+                  {"KATOME_DST_RANK": "1", "KATOME_SORT_NODES": "1"}):
+        assert run(extra) == want, extra
 
 
 def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
