@@ -517,7 +517,7 @@ def main():
                 t3 = PhaseTimer()
                 ms, _ = timed(lambda: one_build_single(wl, packed, skip_arg, recbuf, batch_reads, t3, args.first_seen_order, 0, 0.0), 2, torch)
                 line["unhinted_table"] = {"ms_per_step": ms, "kmers_per_s": kmers / (ms * 1e-3), "steps": 2,
-                                          "what": "same workload, table_slots_hint = 0 (tables grow by re-hashing)"}
+                                          "what": "same workload, table_slots_hint = 0 (the k-mer table is sized from the distinct tiles; the tile table grows by re-hashing)"}
             except Exception as e:     # noqa: BLE001
                 line["extras_error"] = "%s: %s" % (type(e).__name__, e)
             try:
