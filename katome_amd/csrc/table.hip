@@ -72,15 +72,18 @@ __device__ __forceinline__ u32 upsert(Slot2* slots, u64 cap, Key<2> key, u32 add
     for (u64 probes = 0; probes < cap;) {
         // Fast path: a plain (L1/L2-cached) read.  A slot only ever moves 0 -> hi|LOCK -> hi|OCC, so a cached
         // view can lag but never lie: if it shows OCC the key is final and its low word is in the same line;
-        // if it shows empty or LOCK the slot is re-read coherently (agent scope) before anything is decided.
+        // if it shows LOCK the slot is re-read coherently (agent scope) before anything is decided.
         u64 cur = slots[s].hi;
         bool cached_view = true;
-        if (!(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
+        // (an empty view goes straight to the claim: a failed compare-and-swap hands back the word as it is now, which is
+        // the coherent second look -- one memory-side round trip less per new key)
+        if (cur != 0 && !(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
         // the other words are read AFTER the first one, in program order (loads of a wave are issued and returned in order, so
         // what they see is no older): the compiler must not hoist them above it
         asm volatile("" ::: "memory");
         if (cur == 0) {
             cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
+            cached_view = false;
             if (cur == 0) {
                 // nobody touches the slot before the key is published: its first count is a plain store, not an atomic
                 st_agent(&slots[s].lo, key.w[1]);
@@ -119,12 +122,15 @@ __device__ __forceinline__ u32 upsert(Slot3* slots, u64 cap, Key<3> key, u32 add
     for (u64 probes = 0; probes < cap;) {
         u64 cur = slots[s].hi;
         bool cached_view = true;
-        if (!(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
+        // (an empty view goes straight to the claim: a failed compare-and-swap hands back the word as it is now, which is
+        // the coherent second look -- one memory-side round trip less per new key)
+        if (cur != 0 && !(cur & OCC)) { cur = ld_agent(&slots[s].hi); cached_view = false; }
         // the other words are read AFTER the first one, in program order (loads of a wave are issued and returned in order, so
         // what they see is no older): the compiler must not hoist them above it
         asm volatile("" ::: "memory");
         if (cur == 0) {
             cur = atomicCAS(&slots[s].hi, 0ull, key.w[0] | LOCK);
+            cached_view = false;
             if (cur == 0) {
                 st_agent(&slots[s].mid, key.w[1]);
                 st_agent(&slots[s].lo, key.w[2]);
