@@ -50,6 +50,11 @@ def pmc_traffic(parts, config):
     return {"bytes_per_launch": total, "parts": detail, "source": pmc.get("source")}
 
 
+# reads per extraction + insertion round (one launch each): 16 Mi reads make the extraction launch ~0.4 ms -- at 4 Mi
+# (0.1 ms) its start and tail cost a tenth of the rate; the records of a round take 1 GiB
+DEFAULT_BATCH_READS = 16 * 1024 * 1024
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +62,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--reads", type=int, default=0, help="override the workload's read count (same coverage)")
-    ap.add_argument("--batch-reads", type=int, default=4 * 1024 * 1024)
+    ap.add_argument("--batch-reads", type=int, default=DEFAULT_BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--first-seen-order", action="store_true",
                     help="number edges and nodes in the reference's first-seen (petgraph) order (single GPU)")
@@ -339,7 +344,7 @@ def main():
     else:
         from katome_amd import shard as ks
         comm = ks.Comm.rccl(rank, world, local_rank)
-        job = ks.DistBuild(wl, comm, batch_reads=0 if args.batch_reads == 4 * 1024 * 1024 else batch_reads, timer=timer,
+        job = ks.DistBuild(wl, comm, batch_reads=0 if args.batch_reads == DEFAULT_BATCH_READS else batch_reads, timer=timer,
                            first_seen_order=args.first_seen_order or args.prune, min_weight=args.min_weight,
                            table_factor=args.table_factor, prune=args.prune)
         accepted = job.accepted_total
@@ -447,7 +452,7 @@ def main():
             kernels[name] = entry
         cfg_now = {"reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads, "tile_span": span}
         rcs = "true" if wl.reverse_complement else "false"
-        exact = {"extract": "void extract_fixed_kernel<%d, %s>" % (nwt, rcs), "insert": "void insert_kernel<%d>" % nw,
+        exact = {"extract": "void extract_fixed_kernel<%d, %s, %d>" % (nwt, rcs, 256 if wl.stride <= 64 else 64), "insert": "void insert_kernel<%d>" % nw,
                  "insert_tiles": "void insert_kernel<%d>" % nwt,
                  "expand_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (
                      _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or span), nw, rcs),

@@ -13,14 +13,15 @@
 namespace katome {
 
 // ---------------------------------------------------------------------------------------------
-// Fixed-length reads, LDS-staged.  A workgroup (256 threads = 4 waves) owns tiles of 64 reads:
+// Fixed-length reads, LDS-staged.  A workgroup (256 threads = 4 waves) owns tiles of TR reads (256 of them when a read is
+// at most 64 bytes, else 64: with four 16-byte records per 150-base read a tile of 64 reads moves 6.5 KB per trip, and eight
+// such workgroups per CU keep half of what 8 TB/s need in flight):
 //   1. the tile's packed bytes are pulled in with 16-byte coalesced loads, each dword is
 //      byte-swapped once and parked in LDS (so every later use sees "16 bases, first base on top");
 //   2. every lane produces output records 2p, 2p+1 (NW=1) or record p (NW=2) of the tile's
 //      contiguous output range, so each wave store is 64 x 16 contiguous bytes;
 //      a record = 2*NW+1 LDS dwords -> funnel shift -> (canonical) key.
 // ---------------------------------------------------------------------------------------------
-constexpr int TILE_READS = 64;
 constexpr u32 MARK_FLAG = 1u << 31;     // or-ed into `step`: tag records with RC_MARK (first-seen-order mode)
 
 template <int NW, bool RC>
@@ -43,7 +44,7 @@ __device__ __forceinline__ Key<NW> record_from_lds(const u32* lds, const uint8_t
     return key;
 }
 
-template <int NW, bool RC>
+template <int NW, bool RC, int TILE_READS>
 __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __restrict__ packed, u64 n_reads,
                                                                u32 stride_bytes, u32 k, u32 W, u32 magicW, u32 step, u32 win0,
                                                                const uint8_t* __restrict__ skip, u64* __restrict__ out) {
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(BLOCK) void extract_fixed_kernel(const uint8_t* __r
             lds[c * 4 + 3] = __builtin_bswap32(v.w);
         }
         if (tid < 8) lds[nchunks * 4 + tid] = 0;      // windows near the tile end read past it
-        if (tid < TILE_READS) lds_skip[tid] = (skip && tid < nr) ? skip[r0 + tid] : 0;
+        for (u32 t = tid; t < (u32)TILE_READS; t += BLOCK) lds_skip[t] = (skip && t < nr) ? skip[r0 + t] : 0;
         __syncthreads();
 
         const u32 nrec = nr * W;
@@ -184,16 +185,21 @@ static int extract_fixed_t(const uint8_t* d_packed, u64 n_reads, u32 read_len, u
     const u32 stride = (read_len + 3) / 4;
     const u64 total = n_reads * (u64)W;
     if (total == 0) return KATOME_OK;
-    const bool lds_ok = stride <= 256 && (u64)TILE_READS * W < 65536 && ((uintptr_t)d_packed % 16 == 0) &&
+    const u32 tile_reads = stride <= 64 && 256ull * W < 65536 ? 256 : 64;
+    const bool lds_ok = stride <= 256 && (u64)tile_reads * W < 65536 && ((uintptr_t)d_packed % 16 == 0) &&
                         ((uintptr_t)d_records % 16 == 0);
     if (lds_ok) {
-        const u32 tile_dwords = ((TILE_READS * stride + 15) / 16) * 4;
-        const size_t lds_bytes = (tile_dwords + 8) * 4 + TILE_READS;
+        const u32 tile_dwords = ((tile_reads * stride + 15) / 16) * 4;
+        const size_t lds_bytes = (tile_dwords + 8) * 4 + tile_reads;
         const u32 magicW = (u32)((1ull << 32) / W) + 1;
-        const u64 n_tiles = (n_reads + TILE_READS - 1) / TILE_READS;
+        const u64 n_tiles = (n_reads + tile_reads - 1) / tile_reads;
         unsigned grid = (unsigned)(n_tiles < 256u * 8u ? n_tiles : 256u * 8u);
-        hipLaunchKernelGGL((extract_fixed_kernel<NW, RC>), dim3(grid), dim3(BLOCK), lds_bytes, stream, d_packed, n_reads,
-                           stride, k, W, magicW, step, win0, d_skip, d_records);
+        if (tile_reads == 256)
+            hipLaunchKernelGGL((extract_fixed_kernel<NW, RC, 256>), dim3(grid), dim3(BLOCK), lds_bytes, stream, d_packed, n_reads,
+                               stride, k, W, magicW, step, win0, d_skip, d_records);
+        else
+            hipLaunchKernelGGL((extract_fixed_kernel<NW, RC, 64>), dim3(grid), dim3(BLOCK), lds_bytes, stream, d_packed, n_reads,
+                               stride, k, W, magicW, step, win0, d_skip, d_records);
     } else {
         FixedAddr a{stride, W, d_skip, 0, step, win0};
         hipLaunchKernelGGL((extract_general_kernel<NW, RC, FixedAddr>), dim3(grid_for(total, BLOCK)), dim3(BLOCK), 0, stream,

@@ -472,8 +472,10 @@ int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream) {
     KCHECK(t.counter.alloc(sizeof(TableAux), stream));
     if (t.track_seen) {
         KCHECK(t.seen.alloc(cap * 16, stream));
-        // (keys of two and three words get their pair inside the claim, before anyone can look: nothing to initialise)
-        if (nw == 1) KCHECK_HIP(hipMemsetAsync(t.seen.p, 0xFF, cap * 16, stream));
+        // All-ones also where the pair is stored inside the claim (keys of two and three words): lower_seen looks at the pair
+        // through the caches first, and a cached line may predate the claim -- a stale all-ones only costs an atomicMin, stale
+        // left-overs of an earlier table would make it skip one it needs (seen as a 1-in-8 wrong order on a two-rank build).
+        KCHECK_HIP(hipMemsetAsync(t.seen.p, 0xFF, cap * 16, stream));
     }
     KCHECK_HIP(hipMemsetAsync(t.slots.p, 0, cap * t.slot_bytes(), stream));
     KCHECK_HIP(hipMemsetAsync(t.counter.p, 0, sizeof(TableAux), stream));
