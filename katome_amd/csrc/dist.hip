@@ -28,9 +28,9 @@
 
 namespace {
 
-enum XPhase { X_RECORDS, X_KMERS, X_TARGETS, X_IDS, X_RANK_NODES, X_RANK_EDGES, X_GATHER, X_COUNT };
+enum XPhase { X_RECORDS, X_KMERS, X_TARGETS, X_IDS, X_RANK_NODES, X_RANK_EDGES, X_GATHER, X_MID_TILES, X_COUNT };
 const char* const XPHASE_NAMES[X_COUNT] = {"exchange_records", "exchange_kmers", "exchange_targets", "exchange_ids",
-                                           "rank_nodes", "rank_edges", "gather"};
+                                           "rank_nodes", "rank_edges", "gather", "exchange_mid_tiles"};
 
 // ---- small kernels ---------------------------------------------------------------------------------------------------
 #define KLAUNCH(kernel, n, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid_for((n), BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, __VA_ARGS__)
@@ -227,17 +227,92 @@ int route_and_insert(katome_dist_builder* d, const u64* part, const u32* idx, co
                           d->first_seen ? &origin : nullptr, PH_INSERT, stream);
 }
 
-// every rank's distinct tiles -> (k-mer, count[, sequence numbers]) records -> the k-mers' owners
-int expand_and_route_kmers(katome_dist_builder* d, hipStream_t stream) {
+// Weighted records [with their two sequence numbers] to their owners, which add them to `table`: in slices of at most one
+// message's size, the same number of rounds on every rank.  core_bases == 0: the owner is a hash of the whole record.
+int route_weighted(katome_dist_builder* d, int xphase, const DevBuf& keys, const DevBuf& weights, const DevBuf& seen, uint64_t n_rec, uint32_t nwr,
+                   uint32_t core_shift, uint32_t core_bases, Table& table, bool& ready, uint64_t hint, int phase, hipStream_t stream) {
+    katome_builder* b = d->b;
+    const int world = d->world();
+    const uint64_t per_slice = std::max<uint64_t>(1, d->comm->max_message_bytes / (8 * nwr));
+    uint64_t ns = (n_rec + per_slice - 1) / per_slice;
+    KCHECK(d->comm->allreduce(&ns, 1, OP_MAX));
+    DevBuf pk(stream), pw(stream), pidx(stream), idx(stream), ppairs(stream);
+    for (uint64_t j = 0; j < ns; ++j) {
+        const uint64_t a = std::min(n_rec, j * per_slice), e = std::min(n_rec, (j + 1) * per_slice), m = e - a;
+        std::vector<uint64_t> counts(world, 0), rcnt(world, 0);
+        if (m) {
+            KCHECK(pk.alloc(m * 8 * nwr)); KCHECK(pw.alloc(m * 4));
+            if (d->first_seen) {
+                KCHECK(idx.alloc(m * 4)); KCHECK(pidx.alloc(m * 4)); KCHECK(ppairs.alloc(m * 16));
+                KCHECK(dev_iota(idx.as<u32>(), m, stream));
+                KCHECK(dev_partition(keys.as<u64>() + a * nwr, idx.as<u32>(), m, nwr, world, pk.as<u64>(), pidx.as<u32>(), counts.data(), stream, core_shift, core_bases));
+                KCHECK(dev_gather_u32(weights.as<u32>() + a, pidx.as<u32>(), sum(counts), pw.as<u32>(), stream));
+                KCHECK(dev_gather_keys(seen.as<u64>() + 2 * a, pidx.as<u32>(), sum(counts), 2, ppairs.as<u64>(), stream));
+            } else {
+                KCHECK(dev_partition(keys.as<u64>() + a * nwr, weights.as<u32>() + a, m, nwr, world, pk.as<u64>(), pw.as<u32>(), counts.data(), stream, core_shift, core_bases));
+            }
+        }
+        KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+        const uint64_t nR = sum(rcnt);
+        DevBuf rk(stream), rw(stream), rp(stream);
+        KCHECK(rk.alloc(std::max<uint64_t>(nR, 1) * 8 * nwr)); KCHECK(rw.alloc(std::max<uint64_t>(nR, 1) * 4));
+        KCHECK(d->xchg(xphase, pk.p, counts.data(), rk.p, rcnt.data(), 8 * nwr, stream));
+        KCHECK(d->xchg(xphase, pw.p, counts.data(), rw.p, rcnt.data(), 4, stream));
+        if (xphase == X_KMERS) {
+            trace_words("kmers received: keys", d->rank(), rk.p, nR * nwr, stream);
+            trace_words("kmers received: weights", d->rank(), rw.p, nR / 2, stream);
+        }
+        SeenOrigin origin;
+        if (d->first_seen) {
+            KCHECK(rp.alloc(std::max<uint64_t>(nR, 1) * 16));
+            KCHECK(d->xchg(xphase, ppairs.p, counts.data(), rp.p, rcnt.data(), 16, stream));
+            origin.pairs = rp.as<u64>(); origin.rc = d->rc;
+        }
+        if (nR) KCHECK(builder_insert(b, table, ready, nwr, hint, rk.as<u64>(), rw.as<u32>(), nR, d->first_seen ? &origin : nullptr, phase, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));           // (the receive buffers go back to the cache at the end of the round)
+    }
+    return KATOME_OK;
+}
+
+// every rank's distinct tiles -> (k-mer, count[, sequence numbers]) records -> the k-mers' owners.  `span`: the plan all ranks
+// agreed on (a rank may hold no tiles at all and still takes part in every exchange).
+int expand_and_route_kmers(katome_dist_builder* d, uint32_t span, hipStream_t stream) {
     katome_builder* b = d->b;
     const int world = d->world();
     const uint32_t nw = d->nw, k = d->s.k;
+    // Big tiles meet on their owners, but the mid tiles they are cut into are shared between big tiles that overlap (the same
+    // stretch of genome tiled from another read start) and those live on other ranks: expanded rank by rank the mid level held
+    // 2.4 x the mid tiles -- and sent 2.4 x the k-mer records -- of a one-rank build at 8 ranks (C3-like reads).  So the mid
+    // tiles are routed to owners of their own and counted there, like the big tiles before them.
+    const uint32_t span2 = mid_span(span);
+    const bool route_mid = span2 != 0 && (world > 1 || getenv("KATOME_ROUTE_MID_TILES"));
+    if (route_mid) {
+        const uint32_t kk2 = k + span2 - 1, n_sub = span / span2, nw2 = (uint32_t)key_words_for_k(kk2);
+        DevBuf mk(stream), mw(stream), ms(stream);
+        uint64_t n_mid = 0;
+        if (b->tiles_ready) {
+            KCHECK(table_occupied(b->tiles, &b->stat_tiles, stream));
+            b->stat_tile_slots = b->tiles.cap;
+            {
+                PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
+                KCHECK(table_expand_tiles_to_subtiles(b->tiles, kk2, n_sub, span2, d->rc, mk, mw, &n_mid, stream, d->first_seen ? &ms : nullptr));
+            }
+            b->tiles.release();
+        }
+        b->span = span; b->span2 = span2;
+        const uint64_t mid_hint = std::max<uint64_t>(b->s.table_slots_hint / 4, n_mid * 2);      // (a rank receives about what it sends)
+        KCHECK(route_weighted(d, X_MID_TILES, mk, mw, ms, n_mid, nw2, 0, 0, b->tiles2, b->tiles2_ready, mid_hint, PH_EXPAND_MID, stream));
+        b->tiles_ready = b->tiles2_ready;                    // (what is left to expand, if anything arrived)
+        if (b->tiles2_ready) { KCHECK(table_occupied(b->tiles2, &b->stat_tiles2, stream)); b->stat_tile2_slots = b->tiles2.cap; }
+    }
     DevBuf keys(stream), weights(stream), seen(stream);
     uint64_t n_rec = 0;
     if (b->tiles_ready) {
-        Table* last = nullptr; uint32_t last_span = 1;
-        trace_words("tiles: slots", d->rank(), b->tiles.slots.p, b->tiles.cap * b->tiles.slot_bytes() / 8, stream);
-        KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+        Table* last = &b->tiles2; uint32_t last_span = span2;
+        if (!route_mid) {
+            trace_words("tiles: slots", d->rank(), b->tiles.slots.p, b->tiles.cap * b->tiles.slot_bytes() / 8, stream);
+            KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+        }
         trace_words("last level: slots", d->rank(), last->slots.p, last->cap * last->slot_bytes() / 8, stream);
         {
             PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
@@ -247,47 +322,12 @@ int expand_and_route_kmers(katome_dist_builder* d, hipStream_t stream) {
         b->tiles.release(); b->tiles2.release();
         b->tiles_ready = false; b->tiles2_ready = false;
     }
+    if (getenv("KATOME_DIST_STATS"))
+        fprintf(stderr, "[dist] rank %d of %d: %llu distinct tiles, %llu on the last level -> %llu k-mer records to route\n", d->rank(), world,
+                (unsigned long long)b->stat_tiles, (unsigned long long)(b->span2 ? b->stat_tiles2 : b->stat_tiles), (unsigned long long)n_rec);
     trace_words("expand: record keys", d->rank(), keys.p, n_rec * nw, stream);
     trace_words("expand: record weights", d->rank(), weights.p, n_rec / 2, stream);
-    // slices of at most one message's size, the same number of rounds on every rank
-    const uint64_t per_slice = std::max<uint64_t>(1, d->comm->max_message_bytes / (8 * nw));
-    uint64_t ns = (n_rec + per_slice - 1) / per_slice;
-    KCHECK(d->comm->allreduce(&ns, 1, OP_MAX));
-    DevBuf pk(stream), pw(stream), pidx(stream), idx(stream), ppairs(stream);
-    for (uint64_t j = 0; j < ns; ++j) {
-        const uint64_t a = std::min(n_rec, j * per_slice), e = std::min(n_rec, (j + 1) * per_slice), m = e - a;
-        std::vector<uint64_t> counts(world, 0), rcnt(world, 0);
-        if (m) {
-            KCHECK(pk.alloc(m * 8 * nw)); KCHECK(pw.alloc(m * 4));
-            if (d->first_seen) {
-                KCHECK(idx.alloc(m * 4)); KCHECK(pidx.alloc(m * 4)); KCHECK(ppairs.alloc(m * 16));
-                KCHECK(dev_iota(idx.as<u32>(), m, stream));
-                KCHECK(dev_partition(keys.as<u64>() + a * nw, idx.as<u32>(), m, nw, world, pk.as<u64>(), pidx.as<u32>(), counts.data(), stream, 2, k - 2));
-                KCHECK(dev_gather_u32(weights.as<u32>() + a, pidx.as<u32>(), sum(counts), pw.as<u32>(), stream));
-                KCHECK(dev_gather_keys(seen.as<u64>() + 2 * a, pidx.as<u32>(), sum(counts), 2, ppairs.as<u64>(), stream));
-            } else {
-                KCHECK(dev_partition(keys.as<u64>() + a * nw, weights.as<u32>() + a, m, nw, world, pk.as<u64>(), pw.as<u32>(), counts.data(), stream, 2, k - 2));
-            }
-        }
-        KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
-        const uint64_t nR = sum(rcnt);
-        DevBuf rk(stream), rw(stream), rp(stream);
-        KCHECK(rk.alloc(std::max<uint64_t>(nR, 1) * 8 * nw)); KCHECK(rw.alloc(std::max<uint64_t>(nR, 1) * 4));
-        KCHECK(d->xchg(X_KMERS, pk.p, counts.data(), rk.p, rcnt.data(), 8 * nw, stream));
-        KCHECK(d->xchg(X_KMERS, pw.p, counts.data(), rw.p, rcnt.data(), 4, stream));
-        trace_words("kmers received: keys", d->rank(), rk.p, nR * nw, stream);
-        trace_words("kmers received: weights", d->rank(), rw.p, nR / 2, stream);
-        SeenOrigin origin;
-        if (d->first_seen) {
-            KCHECK(rp.alloc(std::max<uint64_t>(nR, 1) * 16));
-            KCHECK(d->xchg(X_KMERS, ppairs.p, counts.data(), rp.p, rcnt.data(), 16, stream));
-            origin.pairs = rp.as<u64>(); origin.rc = d->rc;
-        }
-        if (nR) KCHECK(builder_insert(b, b->table, b->table_ready, nw, b->s.table_slots_hint, rk.as<u64>(), rw.as<u32>(), nR,
-                                      d->first_seen ? &origin : nullptr, PH_INSERT, stream));
-        KCHECK_HIP(hipStreamSynchronize(stream));           // (the receive buffers go back to the cache at the end of the round)
-    }
-    return KATOME_OK;
+    return route_weighted(d, X_KMERS, keys, weights, seen, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream);
 }
 
 // Global rank of every value among the DISTINCT u64 values held by all ranks (sequence numbers): values are spread over the
@@ -517,7 +557,7 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     KCHECK(d->comm->allreduce(plan, 2, OP_MAX));
     const bool tiled = plan[0] > 1;
     const uint64_t total_reads = plan[1];
-    if (tiled) KCHECK(expand_and_route_kmers(d, stream));
+    if (tiled) KCHECK(expand_and_route_kmers(d, (uint32_t)plan[0], stream));
     KCHECK(katome_dev_edges(b, nullptr, nullptr, nullptr, stream));       // this rank's distinct oriented edges, ascending (+ edge_seq)
     const uint64_t E = b->n_edges;
     if (E >= (1ull << 32)) { set_error("more than 2^32 edges on one rank"); return KATOME_E_UNSUPPORTED; }

@@ -578,6 +578,12 @@ int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmer
 
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
                                   uint64_t* n_records, hipStream_t stream, DevBuf* seen) {
+    return table_expand_tiles_to_subtiles(tiles, k, span, 1, rc, keys, weights, n_records, stream, seen);
+}
+// every distinct tile -> its `span` sub-windows of `k` bases, `stride` bases apart (stride 1: its k-mers; stride > 1: the
+// shorter tiles of the next level), each with the tile's count [and its two sequence numbers]
+int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint32_t stride, bool rc, DevBuf& keys, DevBuf& weights,
+                                   uint64_t* n_records, hipStream_t stream, DevBuf* seen) {
     uint64_t occ = 0;
     KCHECK(table_occupied(tiles, &occ, stream));
     const uint32_t nwk = (uint32_t)key_words_for_k(k);
@@ -588,7 +594,7 @@ int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool 
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
-    KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, 1, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream, out_seen));
+    KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, stride, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream, out_seen));
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     return KATOME_OK;
