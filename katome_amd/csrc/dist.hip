@@ -300,7 +300,9 @@ int expand_and_route_kmers(katome_dist_builder* d, uint32_t span, hipStream_t st
             b->tiles.release();
         }
         b->span = span; b->span2 = span2;
-        const uint64_t mid_hint = std::max<uint64_t>(b->s.table_slots_hint / 4, n_mid * 2);      // (a rank receives about what it sends)
+        // (a rank receives about what it sends, and about half of that is distinct; the table grows if it is not.  Twice the
+        // slots doubled the time of the scan that expands them)
+        const uint64_t mid_hint = std::max<uint64_t>(n_mid, 1u << 16);
         KCHECK(route_weighted(d, X_MID_TILES, mk, mw, ms, n_mid, nw2, 0, 0, b->tiles2, b->tiles2_ready, mid_hint, PH_EXPAND_MID, stream));
         b->tiles_ready = b->tiles2_ready;                    // (what is left to expand, if anything arrived)
         if (b->tiles2_ready) { KCHECK(table_occupied(b->tiles2, &b->stat_tiles2, stream)); b->stat_tile2_slots = b->tiles2.cap; }
