@@ -572,11 +572,12 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
     KCHECK(b->edge_src.alloc((E + 1) * 8, stream));
     KCHECK(b->edge_dst.alloc((E + 1) * 8, stream));
     DevBuf node_first(stream);                 // first-seen order: the nodes' first touches come out of the same merge
+    uint64_t n_marked = 0;                     // ... and, for targets below this index, "this edge touches it first" as a mark in edge_dst
     {
         PhaseScope ps(b->prof, PH_NODE_SET, stream);
         const bool fs = b->first_seen && E && b->edge_seq.p;
         KCHECK(dev_node_ids(b->edge_key.as<u64>(), E, k, b->node_key, b->edge_src.as<u64>(), b->edge_dst.as<u64>(), &b->n_nodes, stream,
-                            fs ? b->edge_seq.as<u64>() : nullptr, fs ? &node_first : nullptr));
+                            fs ? b->edge_seq.as<u64>() : nullptr, fs ? &node_first : nullptr, &n_marked));
     }
     u64* cand = b->node_key.as<u64>();
     if (b->first_seen && E) {
@@ -613,7 +614,7 @@ int katome_dev_finalize(katome_builder* b, katome_dev_graph* out, void* stream_)
             // No sort of the nodes: every node is introduced by exactly one edge (the one whose first insertion is the node's
             // first touch), so with the edges in sequence order the node indices are a running count (radix.hip).
             KCHECK(dev_pack_edges_intro(b->edge_key.as<u64>(), b->edge_weight.as<u32>(), b->edge_src.as<u64>(), b->edge_dst.as<u64>(),
-                                        b->edge_seq.as<u64>(), node_first.as<u64>(), E, nw, aos.p, stream));
+                                        b->edge_seq.as<u64>(), node_first.as<u64>(), E, nw, aos.p, stream, n_marked));
             node_first.release();
             lap("pack + who introduces");
             KCHECK(dev_iota(eperm.as<u32>(), E, stream));

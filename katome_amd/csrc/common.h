@@ -120,7 +120,8 @@ int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t 
 // d_seq + node_first (first-seen order): also the nodes' first touches (dev_node_first's result), filled on the way; node_first
 // comes back EMPTY when that was not done and dev_node_first has to run
 int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src,
-                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream, const uint64_t* d_seq = nullptr, DevBuf* node_first = nullptr);
+                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream, const uint64_t* d_seq = nullptr, DevBuf* node_first = nullptr,
+                 uint64_t* n_marked = nullptr);
 int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream);
 int dev_gather_seq_weight(const uint64_t* pairs, const uint32_t* idx, uint64_t n, uint64_t* seq, uint32_t* weight, hipStream_t stream);
 int dev_gather_u32(const uint32_t* src, const uint32_t* idx, uint64_t n, uint32_t* dst, hipStream_t stream);
@@ -131,7 +132,7 @@ int dev_invert(const uint32_t* perm, uint64_t n, uint64_t* inv, hipStream_t stre
 int dev_permute_edges(uint64_t* key, uint32_t* weight, uint64_t* src, uint64_t* dst, const uint64_t* new_id, const uint32_t* idx,
                       uint64_t n, uint32_t nw, void* scratch, hipStream_t stream);
 int dev_pack_edges_intro(const uint64_t* key, const uint32_t* weight, const uint64_t* src, const uint64_t* dst, const uint64_t* seq,
-                         const uint64_t* node_first, uint64_t n, uint32_t nw, void* aos, hipStream_t stream);
+                         const uint64_t* node_first, uint64_t n, uint32_t nw, void* aos, hipStream_t stream, uint64_t n_marked = 0);
 int dev_unpack_edges_intro(const void* aos, const uint32_t* idx, uint64_t n, uint32_t nw, uint64_t* key, uint32_t* weight, uint64_t* src,
                            uint64_t* dst, uint32_t* cnt, hipStream_t stream);
 int dev_assign_nodes(const uint64_t* key, const uint64_t* src, const uint64_t* dst, const uint64_t* offs, uint64_t n, uint32_t nw, uint32_t k,

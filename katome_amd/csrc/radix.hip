@@ -763,7 +763,7 @@ __global__ __launch_bounds__(BLOCK) void src_count_kernel(const u64* __restrict_
 // taken one after the other (coalesced loads and stores); a ballot scan per row keeps the running head count.
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void src_write_kernel(const u64* __restrict__ keys, u64 n, const u64* __restrict__ block_offs,
-                                                           u64* __restrict__ nodes, u64* __restrict__ edge_src) {
+                                                           u64* __restrict__ nodes, u64* __restrict__ edge_src, u64* __restrict__ seg_edge, u32 seg_nodes) {
     __shared__ u32 wtot[UNIQ_ITEMS][BLOCK / 64];
     const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const u64 base = (u64)blockIdx.x * UNIQ_TILE;
@@ -786,7 +786,10 @@ __global__ __launch_bounds__(BLOCK) void src_write_kernel(const u64* __restrict_
         const u64 e = base + (u64)j * BLOCK + threadIdx.x;
         if (e < n) {
             const u64 pos = carry + woff + before[j];           // heads strictly before this edge
-            if (head[j]) store_key<NW>(nodes, pos, key_shr(load_key<NW>(keys, e), 2));
+            if (head[j]) {
+                store_key<NW>(nodes, pos, key_shr(load_key<NW>(keys, e), 2));
+                if (seg_edge && pos % seg_nodes == 0) seg_edge[pos / seg_nodes] = e;      // first out-edge of every seg_nodes-th source
+            }
             edge_src[e] = head[j] ? pos : pos - 1;
         }
         carry += total;
@@ -878,6 +881,8 @@ __global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restri
 #define KATOME_DST_ROWS 2
 #endif
 constexpr u64 DST_IN1 = 1ull << 40;                      // first-seen order: mark in edge_dst, "the target has this in-edge only"
+constexpr u64 DST_FD = 1ull << 41;                       // ... and "this edge is the first to touch its target" (it introduces the node)
+constexpr u64 DST_MARKS = DST_IN1 | DST_FD;
 constexpr u32 DST_SEG = KATOME_DST_SEG;
 constexpr u32 DST_ROWS = KATOME_DST_ROWS;                // edges per thread and trip (loads in flight)
 template <int NW> struct MissCap { static constexpr u32 value = (DST_ROWS > 2 ? 2048 : 1024) / NW; };
@@ -926,7 +931,8 @@ template <int NW, bool FIRST>
 __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict__ nodes, u64 n_src, const u64* __restrict__ keys, u32 k,
                                                            u64 n_seg, const u64* __restrict__ seg, u64* __restrict__ edge_dst,
                                                            u64* __restrict__ miss_key, u64* __restrict__ miss_edge, u64 miss_cap, u64* cursor,
-                                                           const u64* __restrict__ seq, u64* __restrict__ node_first) {
+                                                           const u64* __restrict__ seq, u64* __restrict__ node_first,
+                                                           const u64* __restrict__ edge_src, const u64* __restrict__ seg_edge, u64 n_edges) {
     constexpr u32 MISS_CAP = MissCap<NW>::value;
     extern __shared__ u64 lmem[];
     u64* ls = lmem;                                     // [DST_SEG * NW] the segment's sources
@@ -975,6 +981,11 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
         if (FIRST && tid < 2 * (DST_SEG / 32)) lonce[tid] = 0;          // (lmore follows lonce)
         if (tid == 0) lmiss = 0;
         __syncthreads();
+        if (FIRST) {    // source role: the segment's out-edges are one stretch of the edge list; first touch 2 * seq (pt_graph.rs:180-185)
+            const u64 e0 = seg_edge[sg], e1 = sg + 1 < n_seg ? seg_edge[sg + 1] : n_edges;
+            for (u64 e = e0 + tid; e < e1; e += BLOCK)
+                atomicMin((unsigned long long*)&lfirst[(u32)(edge_src[e] - a)], (unsigned long long)(2 * seq[e]));
+        }
         for (u32 q = 0; q < 4; ++q) {
             const u64 lo = seg[q * (n_seg + 1) + sg], hi = seg[q * (n_seg + 1) + sg + 1];
             for (u64 c = lo; c < hi; c += (u64)DST_ROWS * BLOCK) {
@@ -1025,19 +1036,20 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
         }
         flush();
         if (FIRST) {                                    // (flush ends with a barrier: the segment's minima are complete)
-            for (u32 j = tid; j < cnt; j += BLOCK) {
-                const u64 mine = lfirst[j], cur = node_first[a + j];
-                if (mine < cur) node_first[a + j] = mine;
-            }
-            // second sweep: an edge whose target has no other in-edge is marked (DST_IN1) -- with the matching mark on the
-            // source side (one out-edge) the renumbering can tell the nodes nobody will ever look up (dev_assign_nodes)
+            for (u32 j = tid; j < cnt; j += BLOCK) node_first[a + j] = lfirst[j];      // the node's first touch, either role
+            // (no barrier needed before the sweep below reads lfirst: flush ended with one, and nobody has written since)
+            // second sweep: the edge that is the first to touch its target is marked (DST_FD: what the renumbering asks of every
+            // edge, here without a look-up), and so is an edge whose target has no other in-edge (DST_IN1) -- with the matching
+            // mark on the source side (one out-edge) the renumbering can tell the nodes nobody will ever look up (dev_assign_nodes)
             for (u32 q = 0; q < 4; ++q) {
                 const u64 lo = seg[q * (n_seg + 1) + sg], hi = seg[q * (n_seg + 1) + sg + 1];
                 for (u64 i = lo + tid; i < hi; i += BLOCK) {            // (the thread that wrote edge_dst[i])
                     const u64 d = edge_dst[i];
                     if (d == ~0ull) continue;
                     const u32 l = (u32)(d - a), bit = 1u << (l & 31);
-                    if (!(lmore[l >> 5] & bit)) edge_dst[i] = d | DST_IN1;
+                    u64 marks = (lmore[l >> 5] & bit) ? 0 : DST_IN1;
+                    if (lfirst[l] == 2 * seq[i] + 1) marks |= DST_FD;
+                    if (marks) edge_dst[i] = d | marks;
                 }
             }
             __syncthreads();
@@ -1056,7 +1068,8 @@ __global__ __launch_bounds__(BLOCK) void missing_first_kernel(const u64* __restr
 // the distinct source (k-1)-mers of sorted edges (the run heads of key >> 2), ascending, and every edge's position among them
 // (`slack`: room kept behind them in node_key, in nodes, for the caller to append to)
 template <int NW>
-static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edge_src, u64* n_src_out, hipStream_t stream, bool with_slack = false) {
+static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edge_src, u64* n_src_out, hipStream_t stream, bool with_slack = false,
+                        DevBuf* seg_edge = nullptr) {
     *n_src_out = 0;
     if (E == 0) { KCHECK(node_key.alloc(16, stream)); return KATOME_OK; }
     const u64 nblocks = (E + UNIQ_TILE - 1) / UNIQ_TILE;
@@ -1071,7 +1084,9 @@ static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edg
     KCHECK_HIP(hipStreamSynchronize(stream));
     // (with_slack: the caller appends the nodes without out-edges -- usually a few percent -- instead of copying the lot)
     KCHECK(node_key.alloc((n_src + (with_slack ? n_src / 8 + (1u << 16) : 0) + 1) * 8 * NW, stream));
-    hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), node_key.as<u64>(), edge_src);
+    if (seg_edge) KCHECK(seg_edge->alloc(((n_src + DST_SEG - 1) / DST_SEG + 1) * 8));        // first out-edge of every DST_SEG-th source
+    hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), node_key.as<u64>(), edge_src,
+                       seg_edge ? seg_edge->as<u64>() : nullptr, DST_SEG);
     KCHECK_HIP(hipGetLastError());
     *n_src_out = n_src;
     return KATOME_OK;
@@ -1088,8 +1103,9 @@ __global__ __launch_bounds__(BLOCK) void node_first_src_kernel(const u64* __rest
 // as a target; left empty when the merging look-up is switched off (the caller then runs dev_node_first)
 template <int NW>
 static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64* edge_src, u64* edge_dst, u64* n_nodes,
-                      hipStream_t stream, const u64* seq = nullptr, DevBuf* node_first = nullptr) {
+                      hipStream_t stream, const u64* seq = nullptr, DevBuf* node_first = nullptr, u64* n_marked = nullptr) {
     *n_nodes = 0;
+    if (n_marked) *n_marked = 0;
     if (node_first) node_first->release();
     if (E == 0) { KCHECK(node_key.alloc(16, stream)); return KATOME_OK; }
     const u32 node_bits = 2 * (k - 1);
@@ -1097,11 +1113,13 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
     KCHECK(aux.alloc(16));
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 16, stream));
     u64 n_src = 0;
-    KCHECK((source_ids_t<NW>(d_edge_key, E, node_key, edge_src, &n_src, stream, true)));
-    u64* nodes = node_key.as<u64>();
-    // targets -> positions among the sources
     static const bool old_lookup = getenv("KATOME_DST_RANK") != nullptr;
     const bool first = seq && node_first && !old_lookup;
+    DevBuf seg_edge(stream);
+    KCHECK((source_ids_t<NW>(d_edge_key, E, node_key, edge_src, &n_src, stream, true, first ? &seg_edge : nullptr)));
+    u64* nodes = node_key.as<u64>();
+    // targets -> positions among the sources
+    if (first && n_marked) *n_marked = n_src;            // (edge_dst carries the merge's marks for the targets that are sources)
     DevBuf miss_key(stream), miss_edge(stream);
     u64 miss_cap = 0, n_missing = 0;
     if (!old_lookup) {
@@ -1121,14 +1139,14 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
         const dim3 grid((unsigned)std::min<u64>(n_seg, 256u * 32u));
         if (first) {
             // (room for the nodes without out-edges, like node_key's)
+            // (the merge writes the first touch of every source; the room behind them, for the nodes without out-edges, starts at all-ones)
             KCHECK(node_first->alloc(node_key.bytes / NW));
-            KCHECK_HIP(hipMemsetAsync(node_first->p, 0xFF, node_first->bytes, stream));
-            hipLaunchKernelGGL(node_first_src_kernel, dim3(grid_for(E, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, edge_src, seq, E, node_first->as<u64>());
+            KCHECK_HIP(hipMemsetAsync(node_first->as<u64>() + n_src, 0xFF, node_first->bytes - n_src * 8, stream));
             hipLaunchKernelGGL((dst_merge_kernel<NW, true>), grid, dim3(BLOCK), lds, stream, nodes, n_src, d_edge_key, k, n_seg, seg.as<u64>(), edge_dst,
-                               miss_key.as<u64>(), miss_edge.as<u64>(), miss_cap, aux.as<u64>(), seq, node_first->as<u64>());
+                               miss_key.as<u64>(), miss_edge.as<u64>(), miss_cap, aux.as<u64>(), seq, node_first->as<u64>(), edge_src, seg_edge.as<u64>(), E);
         } else {
             hipLaunchKernelGGL((dst_merge_kernel<NW, false>), grid, dim3(BLOCK), lds, stream, nodes, n_src, d_edge_key, k, n_seg, seg.as<u64>(), edge_dst,
-                               miss_key.as<u64>(), miss_edge.as<u64>(), miss_cap, aux.as<u64>(), nullptr, nullptr);
+                               miss_key.as<u64>(), miss_edge.as<u64>(), miss_cap, aux.as<u64>(), nullptr, nullptr, nullptr, nullptr, E);
         }
         KCHECK_HIP(hipGetLastError());
     } else {
@@ -1196,9 +1214,9 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
 }
 
 int dev_node_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src,
-                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream, const uint64_t* d_seq, DevBuf* node_first) {
-    if (key_words_for_k(k) == 1) return node_ids_t<1>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream, d_seq, node_first);
-    return node_ids_t<2>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream, d_seq, node_first);
+                 uint64_t* d_edge_dst, uint64_t* n_nodes, hipStream_t stream, const uint64_t* d_seq, DevBuf* node_first, uint64_t* n_marked) {
+    if (key_words_for_k(k) == 1) return node_ids_t<1>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream, d_seq, node_first, n_marked);
+    return node_ids_t<2>(d_edge_key, n_edges, k, node_key, d_edge_src, d_edge_dst, n_nodes, stream, d_seq, node_first, n_marked);
 }
 
 // ---- first-seen order: small permutation helpers ---------------------------------------------------
@@ -1272,14 +1290,17 @@ int dev_permute_edges(uint64_t* key, uint32_t* weight, uint64_t* src, uint64_t* 
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void pack_edges_intro_kernel(const u64* __restrict__ key, const u32* __restrict__ weight, const u64* __restrict__ src,
                                                                   const u64* __restrict__ dst, const u64* __restrict__ seq,
-                                                                  const u64* __restrict__ node_first, u64 n, PackedEdge* __restrict__ out) {
+                                                                  const u64* __restrict__ node_first, u64 n, u64 n_marked, PackedEdge* __restrict__ out) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
         PackedEdge e;
         e.k0 = key[i * NW]; e.k1 = NW == 2 ? key[i * NW + 1] : 0;
-        const u64 s = src[i], dm = dst[i], d = dm & ~DST_IN1, q = seq[i];
+        const u64 s = src[i], dm = dst[i], d = dm & ~DST_MARKS, q = seq[i];
         e.src = (u32)s; e.dst = (u32)d; e.weight = weight[i];
         const bool out1 = (i == 0 || src[i - 1] != s) && (i + 1 >= n || src[i + 1] != s);     // the source has this out-edge only
-        e.pad = (node_first[s] == 2 * q ? 1u : 0u) | (node_first[d] == 2 * q + 1 ? 2u : 0u) | ((dm & DST_IN1) ? 4u : 0u) | (out1 ? 8u : 0u);
+        // (targets below n_marked carry the answer as a mark from the merge; the others -- nodes without out-edges, or no merge --
+        // are looked up: node_first[s] is read in order, node_first[d] is not)
+        const bool fd = d < n_marked ? (dm & DST_FD) != 0 : node_first[d] == 2 * q + 1;
+        e.pad = (node_first[s] == 2 * q ? 1u : 0u) | (fd ? 2u : 0u) | ((dm & DST_IN1) ? 4u : 0u) | (out1 ? 8u : 0u);
         out[i] = e;
     }
 }
@@ -1342,7 +1363,7 @@ __global__ __launch_bounds__(BLOCK) void remap_ends_kernel(const u64* __restrict
     }
 }
 __global__ __launch_bounds__(BLOCK) void clear_marks_kernel(u64* __restrict__ v, u64 n) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) v[i] &= ~DST_IN1;
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) v[i] &= ~DST_MARKS;
 }
 int dev_clear_dst_marks(uint64_t* dst, uint64_t n, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(clear_marks_kernel, dim3(grid_for(n, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, dst, n);
@@ -1350,11 +1371,11 @@ int dev_clear_dst_marks(uint64_t* dst, uint64_t n, hipStream_t stream) {
     return KATOME_OK;
 }
 int dev_pack_edges_intro(const uint64_t* key, const uint32_t* weight, const uint64_t* src, const uint64_t* dst, const uint64_t* seq,
-                         const uint64_t* node_first, uint64_t n, uint32_t nw, void* aos, hipStream_t stream) {
+                         const uint64_t* node_first, uint64_t n, uint32_t nw, void* aos, hipStream_t stream, uint64_t n_marked) {
     if (n == 0) return KATOME_OK;
     const dim3 grid(grid_for(n, BLOCK, 256u * 32u)), blk(BLOCK);
-    if (nw == 1) hipLaunchKernelGGL(pack_edges_intro_kernel<1>, grid, blk, 0, stream, key, weight, src, dst, seq, node_first, n, (PackedEdge*)aos);
-    else         hipLaunchKernelGGL(pack_edges_intro_kernel<2>, grid, blk, 0, stream, key, weight, src, dst, seq, node_first, n, (PackedEdge*)aos);
+    if (nw == 1) hipLaunchKernelGGL(pack_edges_intro_kernel<1>, grid, blk, 0, stream, key, weight, src, dst, seq, node_first, n, n_marked, (PackedEdge*)aos);
+    else         hipLaunchKernelGGL(pack_edges_intro_kernel<2>, grid, blk, 0, stream, key, weight, src, dst, seq, node_first, n, n_marked, (PackedEdge*)aos);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
