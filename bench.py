@@ -459,7 +459,7 @@ def main():
                  "expand_mid_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (
                      nwt, _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or 1), rcs),
                  "sort_edges": "void radix_scatter_kernel<%d, true, RadixDigit<%d> >" % (nw, nw),
-                 "emit_edges": "void emit_edges_kernel<%d, %s>" % (nw, rcs)}
+                 "emit_edges": "void emit_edges_kernel<%d, %s, %d>" % (nw, rcs, 4 if (args.first_seen_order or args.prune or nw > 1) else 8)}
 
         def roof(name):
             # phases made of several launches of one kernel (the 8 scatter passes of the edge sort, the slot

@@ -395,12 +395,22 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
 // (pt_graph.rs:282-308), so both orientations are edges with the same weight, and a k-mer that is
 // its own reverse complement (even k only) was added twice per window.
 // ---------------------------------------------------------------------------------------------
-constexpr int EMIT_ITEMS = 8;
+// slots per thread and tile: 8 when an edge is 12 bytes, 4 when it travels with its sequence number (LDS for the tile's edges)
+template <int EMIT_ITEMS> struct EmitCap { static constexpr u32 value = BLOCK * EMIT_ITEMS * 2; };    // edges a tile of slots can yield
 
-template <int NW, bool RC>
+// A tile of BLOCK * EMIT_ITEMS slots is read in rows (coalesced), the edges it yields are numbered by a block scan, parked in
+// LDS in that order and written out as one contiguous stretch behind a cursor (one atomic per tile): every store instruction
+// covers consecutive addresses.  (Each thread writing its own few edges straight to HBM -- neighbouring lanes a variable number
+// of records apart -- cost 1.5 x the algorithmic bytes in partial lines.)
+template <int NW, bool RC, int EMIT_ITEMS>
 __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf<NW>::type* __restrict__ slots, u64 cap, u32 k,
                                                             u32 min_weight, u64* __restrict__ out_keys, u32* __restrict__ out_w,
                                                             u64* cursor, const u64* __restrict__ seen, u64* __restrict__ out_seq) {
+    constexpr u32 EMIT_CAP = EmitCap<EMIT_ITEMS>::value;
+    extern __shared__ u64 lmem[];
+    u64* lk = lmem;                                       // [EMIT_CAP * NW] keys
+    u64* ls = lk + EMIT_CAP * NW;                         // seen: [EMIT_CAP * 2] {sequence number, weight}; else [EMIT_CAP / 2] weights (u32)
+    u32* lw = reinterpret_cast<u32*>(ls);
     __shared__ u32 wave_tot[BLOCK / 64];
     __shared__ u64 block_base;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -433,8 +443,7 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) wave_off += wave_tot[w]; total += wave_tot[w]; }
         if (tid == 0) block_base = total ? atomicAdd(cursor, (u64)total) : 0;
-        __syncthreads();
-        u64 pos = block_base + wave_off + (incl - mine);
+        u32 pos = wave_off + (incl - mine);
 #pragma unroll
         for (int j = 0; j < EMIT_ITEMS; ++j) {
             if (!nemit[j]) continue;
@@ -447,17 +456,24 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
                 if (RC && nemit[j] == 1) s0 = s0 < s1 ? s0 : s1;      // both strands are the same edge
             }
 #pragma unroll
-            for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = key[j].w[q];
-            if (seen) { out_seq[2 * pos] = s0; out_seq[2 * pos + 1] = w; }   // first-seen order: {sequence number, weight} side by side
-            else out_w[pos] = w;
+            for (int q = 0; q < NW; ++q) lk[pos * NW + q] = key[j].w[q];
+            if (seen) { ls[2 * pos] = s0; ls[2 * pos + 1] = w; }      // first-seen order: {sequence number, weight} side by side
+            else lw[pos] = w;
             ++pos;
             if (nemit[j] == 2) {
 #pragma unroll
-                for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rc.w[q];
-                if (seen) { out_seq[2 * pos] = s1; out_seq[2 * pos + 1] = w; }
-                else out_w[pos] = w;
+                for (int q = 0; q < NW; ++q) lk[pos * NW + q] = rc.w[q];
+                if (seen) { ls[2 * pos] = s1; ls[2 * pos + 1] = w; }
+                else lw[pos] = w;
                 ++pos;
             }
+        }
+        __syncthreads();
+        if (total) {
+            const u64 base = block_base;
+            for (u32 i = tid; i < total * NW; i += BLOCK) out_keys[base * NW + i] = lk[i];
+            if (seen) { for (u32 i = tid; i < total * 2; i += BLOCK) out_seq[base * 2 + i] = ls[i]; }
+            else { for (u32 i = tid; i < total; i += BLOCK) out_w[base + i] = lw[i]; }
         }
         __syncthreads();
     }
@@ -613,14 +629,22 @@ int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf&
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
-    dim3 grid(grid_for(t.cap, BLOCK * EMIT_ITEMS, 256u * 16u)), block(BLOCK);
+    const int items = (seen || t.nw > 1) ? 4 : 8;          // (LDS per workgroup: 24-64 KiB)
+    dim3 grid(grid_for(t.cap, BLOCK * items, 256u * 16u)), block(BLOCK);
+    const size_t lds = (size_t)BLOCK * items * 2 * (8 * t.nw + (seen ? 16 : 4));
+#define KATOME_EMIT(NWV, RCV, ITEMS)                                                                                                      \
+    do {                                                                                                                                  \
+        if (lds > (64u << 10)) KCHECK_HIP(hipFuncSetAttribute((const void*)emit_edges_kernel<NWV, RCV, ITEMS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((emit_edges_kernel<NWV, RCV, ITEMS>), grid, block, lds, stream, t.slots.as<SlotOf<NWV>::type>(), t.cap, k, min_weight,      \
+                           keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);                                          \
+    } while (0)
     if (t.nw == 1) {
-        if (rc) hipLaunchKernelGGL((emit_edges_kernel<1, true>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
-        else    hipLaunchKernelGGL((emit_edges_kernel<1, false>), grid, block, 0, stream, t.slots.as<Slot1>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
+        if (seen) { if (rc) KATOME_EMIT(1, true, 4); else KATOME_EMIT(1, false, 4); }
+        else      { if (rc) KATOME_EMIT(1, true, 8); else KATOME_EMIT(1, false, 8); }
     } else {
-        if (rc) hipLaunchKernelGGL((emit_edges_kernel<2, true>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
-        else    hipLaunchKernelGGL((emit_edges_kernel<2, false>), grid, block, 0, stream, t.slots.as<Slot2>(), t.cap, k, min_weight, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seq);
+        if (rc) KATOME_EMIT(2, true, 4); else KATOME_EMIT(2, false, 4);
     }
+#undef KATOME_EMIT
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_edges, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
