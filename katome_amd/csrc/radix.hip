@@ -751,10 +751,10 @@ template <int NW> __device__ __forceinline__ bool is_src_head(const u64* keys, u
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void src_count_kernel(const u64* __restrict__ keys, u64 n, u32* __restrict__ block_counts) {
     __shared__ u32 wsum[BLOCK / 64];
-    const u64 base = (u64)blockIdx.x * UNIQ_TILE + (u64)threadIdx.x * UNIQ_ITEMS;
+    const u64 base = (u64)blockIdx.x * UNIQ_TILE + threadIdx.x;          // rows of BLOCK consecutive edges: coalesced loads
     u32 mine = 0;
 #pragma unroll
-    for (int j = 0; j < UNIQ_ITEMS; ++j) if (base + j < n && is_src_head<NW>(keys, base + j)) ++mine;
+    for (int j = 0; j < UNIQ_ITEMS; ++j) if (base + (u64)j * BLOCK < n && is_src_head<NW>(keys, base + (u64)j * BLOCK)) ++mine;
     u32 total;
     (void)block_excl_scan(mine, wsum, total);
     if (threadIdx.x == 0) block_counts[blockIdx.x] = total;
@@ -994,40 +994,51 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
 #pragma unroll
                 for (u32 r = 0; r < DST_ROWS; ++r) {
                     const u64 i = c + (u64)r * BLOCK + tid;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) e[r].w[w] = 0;
+                    sq[r] = 0;
                     if (i < hi) { e[r] = load_key<NW>(keys, i); if (FIRST) sq[r] = seq[i]; }
+                }
+                // the searches of a thread's edges advance in lockstep, a fixed number of halving steps each (branch-free lower
+                // bound): DST_ROWS independent LDS reads are in flight per step
+                Key<NW> d[DST_ROWS]; u32 l[DST_ROWS];
+#pragma unroll
+                for (u32 r = 0; r < DST_ROWS; ++r) { d[r] = target_node(e[r], k); l[r] = 0; }
+#pragma unroll
+                for (u32 step = DST_SEG; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (u32 r = 0; r < DST_ROWS; ++r) {
+                        const u32 idx = l[r] + step;
+                        const bool in = idx <= cnt;
+                        Key<NW> x;
+#pragma unroll
+                        for (int w = 0; w < NW; ++w) x.w[w] = ls[(in ? idx - 1 : 0) * NW + w];
+                        if (in && key_lt(x, d[r])) l[r] = idx;
+                    }
                 }
 #pragma unroll
                 for (u32 r = 0; r < DST_ROWS; ++r) {
                     const u64 i = c + (u64)r * BLOCK + tid;
                     if (i >= hi) continue;
-                    const Key<NW> d = target_node(e[r], k);
-                    u32 l = 0, h = cnt;
-                    while (l < h) {
-                        const u32 m = (l + h) >> 1;
-                        Key<NW> x;
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) x.w[w] = ls[m * NW + w];
-                        if (key_lt(x, d)) l = m + 1; else h = m;
-                    }
                     bool found = false;
-                    if (l < cnt) {
+                    if (l[r] < cnt) {
                         Key<NW> x;
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) x.w[w] = ls[l * NW + w];
-                        found = key_eq(x, d);
+                        for (int w = 0; w < NW; ++w) x.w[w] = ls[l[r] * NW + w];
+                        found = key_eq(x, d[r]);
                     }
                     if (found) {
-                        edge_dst[i] = a + l;
+                        edge_dst[i] = a + l[r];
                         if (FIRST) {
-                            atomicMin((unsigned long long*)&lfirst[l], (unsigned long long)(2 * sq[r] + 1));
-                            const u32 bit = 1u << (l & 31);
-                            if (atomicOr(&lonce[l >> 5], bit) & bit) atomicOr(&lmore[l >> 5], bit);
+                            atomicMin((unsigned long long*)&lfirst[l[r]], (unsigned long long)(2 * sq[r] + 1));
+                            const u32 bit = 1u << (l[r] & 31);
+                            if (atomicOr(&lonce[l[r] >> 5], bit) & bit) atomicOr(&lmore[l[r] >> 5], bit);
                         }
                     } else {
                         edge_dst[i] = ~0ull;
                         const u32 p = atomicAdd(&lmiss, 1u);
 #pragma unroll
-                        for (int w = 0; w < NW; ++w) lmk[p * NW + w] = d.w[w];
+                        for (int w = 0; w < NW; ++w) lmk[p * NW + w] = d[r].w[w];
                         lme[p] = i;
                     }
                 }
@@ -1528,25 +1539,34 @@ int dev_bfc_edges(const uint64_t* d_fwd, const uint32_t* d_w, uint64_t n, uint32
     return KATOME_OK;
 }
 
-// compress_edge format: [pad][ceil(k/4) bytes].  A workgroup builds the labels of 256 edges in
-// LDS and streams them out as whole dwords (the byte stride is odd for most k).
+// compress_edge format: [pad][ceil(k/4) bytes].  A workgroup builds the labels of LABEL_ITEMS * 256 edges in LDS and streams
+// them out as whole dwords (the byte stride is odd for most k); four keys per thread are loaded before the first is used (with
+// 256 edges per trip a workgroup moved 4 KB and a CU had too few bytes in flight: 8.1 ms for C3's 27.6 GB).
+constexpr u32 LABEL_ITEMS = 4;
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void labels_kernel(const u64* __restrict__ ek, u64 n, u32 k, uint8_t* __restrict__ out) {
     extern __shared__ u32 lbuf[];
     uint8_t* lb = reinterpret_cast<uint8_t*>(lbuf);
     const u32 stride = label_stride_for_k(k), nb = stride - 1, pad = label_pad_for_k(k);
-    const u64 ntiles = (n + BLOCK - 1) / BLOCK;
+    constexpr u32 TILE = BLOCK * LABEL_ITEMS;
+    const u64 ntiles = (n + TILE - 1) / TILE;
     for (u64 t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const u64 e0 = t * BLOCK;
-        const u32 cnt = (u32)((n - e0) < (u64)BLOCK ? (n - e0) : (u64)BLOCK);
-        if (threadIdx.x < cnt) {
-            Key<NW> key = load_key<NW>(ek, e0 + threadIdx.x);
-            uint8_t* p = lb + threadIdx.x * stride;
-            p[0] = (uint8_t)pad;
-            for (u32 i = 0; i < nb; ++i) p[1 + i] = label_byte(key, k, i);
+        const u64 e0 = t * TILE;
+        const u32 cnt = (u32)((n - e0) < (u64)TILE ? (n - e0) : (u64)TILE);
+        Key<NW> key[LABEL_ITEMS];
+#pragma unroll
+        for (u32 r = 0; r < LABEL_ITEMS; ++r) { const u32 j = r * BLOCK + threadIdx.x; if (j < cnt) key[r] = load_key<NW>(ek, e0 + j); }
+#pragma unroll
+        for (u32 r = 0; r < LABEL_ITEMS; ++r) {
+            const u32 j = r * BLOCK + threadIdx.x;
+            if (j < cnt) {
+                uint8_t* p = lb + j * stride;
+                p[0] = (uint8_t)pad;
+                for (u32 i = 0; i < nb; ++i) p[1 + i] = label_byte(key[r], k, i);
+            }
         }
         __syncthreads();
-        const u64 byte0 = e0 * stride;                 // BLOCK*stride is a multiple of 4 -> dword aligned
+        const u64 byte0 = e0 * stride;                 // TILE*stride is a multiple of 4 -> dword aligned
         const u32 nbytes = cnt * stride;
         u32* o32 = reinterpret_cast<u32*>(out + byte0);
         for (u32 i = threadIdx.x; i < nbytes / 4; i += BLOCK) o32[i] = lbuf[i];
@@ -1556,8 +1576,8 @@ __global__ __launch_bounds__(BLOCK) void labels_kernel(const u64* __restrict__ e
 }
 int dev_labels(const uint64_t* d_edge_key, uint64_t n, uint32_t k, uint8_t* d_label, hipStream_t stream) {
     if (n == 0) return KATOME_OK;
-    const size_t lds = (size_t)BLOCK * label_stride_for_k(k) + 16;
-    dim3 grid(grid_for(n, BLOCK)), block(BLOCK);
+    const size_t lds = (size_t)BLOCK * LABEL_ITEMS * label_stride_for_k(k) + 16;
+    dim3 grid(grid_for(n, BLOCK * LABEL_ITEMS, 256u * 16u)), block(BLOCK);
     if ((uintptr_t)d_label % 4) { set_error("label buffer must be 4-byte aligned"); return KATOME_E_ARG; }
     if (key_words_for_k(k) == 1) hipLaunchKernelGGL(labels_kernel<1>, grid, block, lds, stream, d_edge_key, n, k, d_label);
     else                         hipLaunchKernelGGL(labels_kernel<2>, grid, block, lds, stream, d_edge_key, n, k, d_label);
