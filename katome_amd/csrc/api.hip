@@ -298,7 +298,7 @@ int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, h
 }
 
 // every distinct tile adds its count to its k-mers; afterwards the tile tables are released
-static int expand_tiles(katome_builder* b, hipStream_t stream) {
+int expand_tiles(katome_builder* b, hipStream_t stream) {
     if (!b->tiles_ready) return KATOME_OK;
     Table* last = nullptr; uint32_t last_span = 1;
     KCHECK(expand_to_last_level(b, &last, &last_span, stream));

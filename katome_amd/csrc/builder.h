@@ -86,4 +86,5 @@ int builder_insert(katome_builder* b, Table& table, bool& ready, uint32_t nw, ui
                    const uint32_t* d_weights, uint64_t n, SeenOrigin* origin, int phase, hipStream_t stream);
 // big tiles -> mid tiles (when the span is large); leaves the tiles that hold k-mers directly in `*last`
 int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, hipStream_t stream);
+int expand_tiles(katome_builder* b, hipStream_t stream);       // every distinct tile adds its count to its k-mers (b->table); the tile tables go
 uint32_t mid_span(uint32_t span);      // span of the mid tiles a big tile is broken into (0: expanded directly)

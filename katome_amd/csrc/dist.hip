@@ -23,6 +23,7 @@
 #include <string>
 #include <vector>
 
+#include <cstring>
 #include "builder.h"
 #include "comm.h"
 
@@ -164,6 +165,10 @@ struct katome_dist_builder {
     uint32_t read_len = 0, W = 0, span = 1, tiles_per_read = 0, rest = 0, nwt = 1;
     uint64_t reads_end = 0;                  // one past the last read this rank has added (first-seen: bounds the sequence numbers)
     bool finalized = false;
+    // Which records travel.  Few ranks share few links: every rank counts its own reads down to k-mers and
+    // sends each DISTINCT k-mer once ("local first": one exchange, 12 B per k-mer and rank).  Many ranks: tiles, mid tiles and
+    // k-mer records are routed to owners level by level (no level is counted twice, at the price of three exchanges).
+    bool local_first = false;
     // this rank's share of the numbered graph
     DevBuf edge_src, edge_dst, edge_label, node_key, edge_gid, node_gid;
     uint64_t n_edges = 0, n_nodes = 0, total_edges = 0, total_nodes = 0, node_base = 0;
@@ -453,6 +458,8 @@ int katome_dist_create(const katome_settings* s, katome_comm* comm, katome_dist_
     katome_dist_builder* d = new (std::nothrow) katome_dist_builder();
     if (!d) { katome_builder_destroy(b); set_error("out of host memory"); return KATOME_E_OOM; }
     d->s = *s; d->comm = comm; d->b = b; d->nw = b->nw; d->rc = b->rc; d->first_seen = b->first_seen;
+    d->local_first = comm->world() <= 4;
+    if (const char* e = getenv("KATOME_DIST_ROUTE")) d->local_first = strcmp(e, "local") == 0 ? true : strcmp(e, "tiles") == 0 ? false : d->local_first;
     *out = d;
     return KATOME_OK;
 }
@@ -494,6 +501,48 @@ int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint6
     const int world = d->world();
     const bool tiled = d->span > 1;
     const uint32_t per_read = tiled ? d->tiles_per_read : d->W, nwr = tiled ? d->nwt : nw, stride = (read_len + 3) / 4;
+    if (d->local_first) {
+        // this rank's reads are counted here, exactly as a one-GPU build counts them (tiles + the windows after them; the
+        // sequence numbers are those of the GLOBAL read order: first_read is this rank's offset in it) -- no exchange yet
+        uint64_t batch = batch_reads ? batch_reads : (16ull << 20);
+        batch = std::max<uint64_t>(64, batch / 64 * 64);
+        const uint64_t cap_reads = std::min(batch, std::max<uint64_t>(n_reads, 1));
+        const uint32_t first_rest = tiled ? d->tiles_per_read * d->span : 0;
+        DevBuf recbuf(stream);
+        KCHECK(recbuf.alloc(cap_reads * std::max<uint32_t>(per_read, d->rest) * 8 * nwr + 64));
+        for (uint64_t r0 = 0; r0 < n_reads; r0 += batch) {
+            const uint64_t nr = std::min(batch, n_reads - r0);
+            const uint8_t* p = d_packed + r0 * stride;
+            const uint8_t* sk = d_skip ? d_skip + r0 : nullptr;
+            SeenOrigin origin;
+            origin.read0 = first_read + r0; origin.windows = d->W; origin.rc = d->rc;
+            {
+                PhaseScope ps(b->prof, PH_EXTRACT, stream);
+                KCHECK(launch_extract_fixed(k, d->rc, p, nr, read_len, sk, recbuf.as<u64>(), stream, tiled ? d->span : 1, d->first_seen && d->rc));
+            }
+            origin.per_read = per_read; origin.span = tiled ? d->span : 1; origin.win0 = 0;
+            if (tiled) {
+                b->span = d->span;
+                KCHECK(builder_insert(b, b->tiles, b->tiles_ready, d->nwt, b->s.table_slots_hint / 4, recbuf.as<u64>(), nullptr, nr * per_read,
+                                      d->first_seen ? &origin : nullptr, PH_INSERT_TILES, stream));
+            } else {
+                KCHECK(builder_insert(b, b->table, b->table_ready, nw, b->s.table_slots_hint, recbuf.as<u64>(), nullptr, nr * per_read,
+                                      d->first_seen ? &origin : nullptr, PH_INSERT, stream));
+            }
+            if (tiled && d->rest) {                                // the windows after the last whole tile of every read
+                {
+                    PhaseScope ps(b->prof, PH_EXTRACT, stream);
+                    KCHECK(launch_extract_fixed(k, d->rc, p, nr, read_len, sk, recbuf.as<u64>(), stream, 1, d->first_seen && d->rc, first_rest, d->rest));
+                }
+                origin.per_read = d->rest; origin.span = 1; origin.win0 = first_rest;
+                KCHECK(builder_insert(b, b->table, b->table_ready, nw, b->s.table_slots_hint, recbuf.as<u64>(), nullptr, nr * d->rest,
+                                      d->first_seen ? &origin : nullptr, PH_INSERT, stream));
+            }
+            KCHECK_HIP(hipStreamSynchronize(stream));
+        }
+        d->reads_end = std::max(d->reads_end, first_read + n_reads);
+        return KATOME_OK;
+    }
     // tile records are small (a few per read): large batches mean few exchange rounds
     uint64_t batch = batch_reads ? batch_reads : (tiled ? (16ull << 20) : (4ull << 20));
     batch = std::max<uint64_t>(64, batch / 64 * 64);
@@ -559,7 +608,21 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     KCHECK(d->comm->allreduce(plan, 2, OP_MAX));
     const bool tiled = plan[0] > 1;
     const uint64_t total_reads = plan[1];
-    if (tiled) KCHECK(expand_and_route_kmers(d, (uint32_t)plan[0], stream));
+    if (d->local_first) {
+        // every rank finishes its own counting; its DISTINCT k-mers (count, earliest sequence numbers) go to their owners, which
+        // add them up in a fresh table
+        if (b->tiles_ready) KCHECK(expand_tiles(b, stream));
+        DevBuf keys(stream), weights(stream), pairs(stream);
+        uint64_t n_rec = 0;
+        if (b->table_ready) {
+            PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
+            KCHECK(table_to_records(b->table, keys, weights, &n_rec, stream, d->first_seen ? &pairs : nullptr));
+        }
+        b->table.release(); b->table_ready = false;
+        if (getenv("KATOME_DIST_STATS"))
+            fprintf(stderr, "[dist] rank %d of %d: %llu distinct k-mers of its own reads to route\n", rank, world, (unsigned long long)n_rec);
+        KCHECK(route_weighted(d, X_KMERS, keys, weights, pairs, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream));
+    } else if (tiled) KCHECK(expand_and_route_kmers(d, (uint32_t)plan[0], stream));
     KCHECK(katome_dev_edges(b, nullptr, nullptr, nullptr, stream));       // this rank's distinct oriented edges, ascending (+ edge_seq)
     const uint64_t E = b->n_edges;
     if (E >= (1ull << 32)) { set_error("more than 2^32 edges on one rank"); return KATOME_E_UNSUPPORTED; }

@@ -479,6 +479,64 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
     }
 }
 
+// every key of a table with its count [and its two sequence numbers], compacted behind a cursor (one atomic per tile of slots;
+// the tile's records go through LDS so that they leave as one contiguous stretch, like emit_edges_kernel's)
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void table_records_kernel(const typename SlotOf<NW>::type* __restrict__ slots, u64 cap, u64* __restrict__ out_keys,
+                                                               u32* __restrict__ out_w, u64* cursor, const u64* __restrict__ seen, u64* __restrict__ out_seen) {
+    constexpr int ITEMS = 4;
+    constexpr u32 CAP = BLOCK * ITEMS;
+    extern __shared__ u64 lmem[];
+    u64* lk = lmem;                                       // [CAP * NW]
+    u64* lp = lk + CAP * NW;                              // [CAP * 2] the pairs (first-seen order only)
+    u32* lw = reinterpret_cast<u32*>(lp + (seen ? CAP * 2 : 0));       // [CAP]
+    __shared__ u32 wave_tot[BLOCK / 64];
+    __shared__ u64 block_base;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 tile = (u64)CAP;
+    for (u64 t0 = (u64)blockIdx.x * tile; t0 < cap; t0 += (u64)gridDim.x * tile) {
+        Key<NW> key[ITEMS]; u32 cnt[ITEMS]; bool have[ITEMS]; u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            const u64 i = t0 + (u64)j * BLOCK + tid;
+            have[j] = false; cnt[j] = 0;
+            if (i < cap) {
+                typename SlotOf<NW>::type s = slots[i];
+                have[j] = slot_key(s, key[j]);
+                cnt[j] = s.count;
+            }
+            mine += have[j];
+        }
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        u32 wave_off = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) wave_off += wave_tot[w]; total += wave_tot[w]; }
+        if (tid == 0) block_base = total ? atomicAdd(cursor, (u64)total) : 0;
+        u32 pos = wave_off + (incl - mine);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) {
+            if (!have[j]) continue;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) lk[pos * NW + q] = key[j].w[q];
+            lw[pos] = cnt[j];
+            if (seen) { const u64 slot = t0 + (u64)j * BLOCK + tid; lp[2 * pos] = seen[2 * slot]; lp[2 * pos + 1] = seen[2 * slot + 1]; }
+            ++pos;
+        }
+        __syncthreads();
+        if (total) {
+            const u64 base = block_base;
+            for (u32 i = tid; i < total * NW; i += BLOCK) out_keys[base * NW + i] = lk[i];
+            for (u32 i = tid; i < total; i += BLOCK) out_w[base + i] = lw[i];
+            if (seen) { for (u32 i = tid; i < total * 2; i += BLOCK) out_seen[base * 2 + i] = lp[i]; }
+        }
+        __syncthreads();
+    }
+}
+
 // ---- host side --------------------------------------------------------------------------------
 
 int table_alloc(Table& t, uint32_t nw, uint64_t cap, hipStream_t stream) {
@@ -611,6 +669,28 @@ int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, stride, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream, out_seen));
+    KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+// (key, count[, both sequence numbers]) of every key in the table: what a rank of the sharded build sends to the keys' owners
+int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, DevBuf* seen_pairs) {
+    uint64_t occ = 0;
+    KCHECK(table_occupied(t, &occ, stream));
+    KCHECK(keys.alloc((occ + 1) * 8 * t.nw, stream));
+    KCHECK(weights.alloc((occ + 1) * 4, stream));
+    const u64* seen = nullptr; u64* out_seen = nullptr;
+    if (seen_pairs && t.track_seen) { KCHECK(seen_pairs->alloc((occ + 1) * 16, stream)); seen = t.seen.as<u64>(); out_seen = seen_pairs->as<u64>(); }
+    DevBuf cursor(stream);
+    KCHECK(cursor.alloc(8));
+    KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    const u32 cap_rec = BLOCK * 4;
+    const size_t lds = (size_t)cap_rec * (8 * t.nw + 4 + (seen ? 16 : 0));
+    dim3 grid(grid_for(t.cap, cap_rec, 256u * 16u)), block(BLOCK);
+    if (t.nw == 1) hipLaunchKernelGGL(table_records_kernel<1>, grid, block, lds, stream, t.slots.as<Slot1>(), t.cap, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seen);
+    else           hipLaunchKernelGGL(table_records_kernel<2>, grid, block, lds, stream, t.slots.as<Slot2>(), t.cap, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), seen, out_seen);
+    KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     return KATOME_OK;

@@ -181,6 +181,21 @@ def _dist_build_one_process(k, rc, packed_t, skip_t, n, L, first_seen, comm, dev
     return d, g
 
 
+@pytest.mark.parametrize("route", ["local", "tiles"])
+@pytest.mark.parametrize("world,k,rc,L", [(2, 31, True, 150), (3, 31, True, 150), (8, 31, True, 150), (2, 63, True, 150), (4, 40, False, 100)])
+def test_both_routes_of_the_sharded_build(oracle, monkeypatch, route, world, k, rc, L):
+    """Few ranks count their own reads and route distinct k-mers ("local"), many route tiles, mid tiles and k-mer records level by
+    level ("tiles"); the library picks by world size, KATOME_DIST_ROUTE overrides.  Either way, at every world size: the
+    reference's numbering, all four arrays index for index."""
+    from katome_amd.build import GpuGraph
+    monkeypatch.setenv("KATOME_DIST_ROUTE", route)
+    n = 1500
+    ascii_reads, packed, skip = _reads(oracle, n, L, 9000, 3e-3, 1)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world,
+                                        ranks_share_device=True, first_seen_order=True)
+    _same_arrays(g, oracle.build_ascii(ascii_reads, k, rc))
+
+
 def test_rccl_transport_at_world_size_one(oracle):
     """RCCL itself (ncclCommInitRank from a unique id, grouped send/recv to self, allreduce): the process-per-GPU route
     of bench.py with one rank -- same graph as the oracle's, exchange accounting readable"""
@@ -204,7 +219,7 @@ def test_rccl_transport_at_world_size_one(oracle):
     stats = (C.c_uint64 * (4 * nx))()
     assert L_.katome_dist_exchange_read(d, stats) == 0
     names = [L_.katome_dist_exchange_name(i).decode() for i in range(nx)]
-    assert "exchange_records" in names and stats[4 * names.index("exchange_records")] > 0      # calls were counted
+    assert "exchange_kmers" in names and stats[4 * names.index("exchange_kmers")] > 0      # calls were counted (one rank is "few ranks": its own reads are counted locally, distinct k-mers routed)
     L_.katome_dist_destroy(d)
     L_.katome_comm_destroy(comm)
 
