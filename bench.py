@@ -487,7 +487,10 @@ def main():
                        "reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads,
                        "tile_span": span, "order": "first-seen (petgraph)" if (args.first_seen_order or args.prune) else "by packed key",
                        "min_weight": args.min_weight,
-                       "parallelism": "reads sharded by index over %d GPU(s), k-mers routed by hash (all-to-all)" % world
+                       "parallelism": "reads sharded by index over %d GPU(s); %s" % (
+                           world, "every rank counts its reads, distinct k-mers routed by hash (one all-to-all)"
+                           if os.environ.get("KATOME_DIST_ROUTE", "local" if world <= 4 else "tiles") == "local"
+                           else "tiles, mid tiles and k-mer records routed by hash (three all-to-alls)")
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
             "roofline": roofline, "roofline_extract": roof("extract"), "kernels": kernels, "counts": cnt,
