@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="c3")
     ap.add_argument("--reads", type=int, default=0, help="override the workload's read count (same coverage)")
+    ap.add_argument("--genome-len", type=int, default=0,
+                    help="with --reads: keep this genome length instead of scaling it with the reads (a rank's share of a bigger job)")
     ap.add_argument("--batch-reads", type=int, default=DEFAULT_BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--first-seen-order", action="store_true",
@@ -324,6 +326,9 @@ def main():
     wl = WORKLOADS[args.workload]
     if args.reads:
         wl = wl.scaled(args.reads)
+        if args.genome_len:
+            import dataclasses
+            wl = dataclasses.replace(wl, genome_len=args.genome_len, name="%s/genome %d" % (wl.name, args.genome_len))
 
     from katome_amd import device as kd
     timer = PhaseTimer()
@@ -489,7 +494,7 @@ def main():
                        "min_weight": args.min_weight,
                        "parallelism": "reads sharded by index over %d GPU(s); %s" % (
                            world, "every rank counts its reads, distinct k-mers routed by hash (one all-to-all)"
-                           if os.environ.get("KATOME_DIST_ROUTE", "local" if world <= 4 else "tiles") == "local"
+                           if os.environ.get("KATOME_DIST_ROUTE", "local" if world <= 2 else "tiles") == "local"
                            else "tiles, mid tiles and k-mer records routed by hash (three all-to-alls)")
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
