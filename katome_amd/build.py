@@ -180,13 +180,7 @@ class GpuGraph:
         self.node_key = arr(g.node_key, (nn, nw), np.uint64)
         # first-seen index each edge had before remove_dead_paths / remove_weak_edges re-numbered it (None: age == index)
         self.edge_age = arr(g.edge_age, (ne,), np.uint32) if bool(g.edge_age) else None
-        st = _lib.Stats()
-        _check(_lib.lib().katome_graph_stats(gptr, C.byref(st)))
-        self._stats = CollectionStats(
-            node_count=st.node_count, edge_count=st.edge_count, max_edge_weight=st.max_edge_weight,
-            avg_edge_weight=st.avg_edge_weight, max_in_degree=st.max_in_degree, max_out_degree=st.max_out_degree,
-            avg_out_degree=st.avg_out_degree, incoming_vert_count=st.incoming_vert_count,
-            outgoing_vert_count=st.outgoing_vert_count, capacity=(nn, ne))
+        self._gptr, self._owner, self._stats = gptr, owner, None      # (stats: on the first stats() call, as in the reference)
 
     # ---- Build::create (builder.rs:42-54) ----------------------------------------------------
     @classmethod
@@ -231,6 +225,15 @@ class GpuGraph:
 
     # ---- Stats<CollectionStats> (stats/collections.rs:137-168) ---------------------------------
     def stats(self) -> CollectionStats:
+        # a pass over the host arrays (degrees, weights): Stats::stats is its own call in the reference too, not part of create
+        if self._stats is None:
+            st = _lib.Stats()
+            _check(_lib.lib().katome_graph_stats(self._gptr, C.byref(st)))
+            self._stats = CollectionStats(
+                node_count=st.node_count, edge_count=st.edge_count, max_edge_weight=st.max_edge_weight,
+                avg_edge_weight=st.avg_edge_weight, max_in_degree=st.max_in_degree, max_out_degree=st.max_out_degree,
+                avg_out_degree=st.avg_out_degree, incoming_vert_count=st.incoming_vert_count,
+                outgoing_vert_count=st.outgoing_vert_count, capacity=(self.n_nodes, self.n_edges))
         return self._stats
 
     # ---- helpers for parity checks --------------------------------------------------------------

@@ -9,6 +9,8 @@
 #include <chrono>
 #include <new>
 #include <string>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -978,12 +980,16 @@ static void build_lap(const char* what, bool reset = false) {
 // thread takes page faults (~9 GB/s measured on the MI355X box; into touched pages, pinned or not, the same copy runs at
 // ~55 GB/s), so large arrays are taken 2 MiB-aligned, offered to the kernel as huge pages and first touched by several
 // threads at once.  Released with free().
-static void* host_result_alloc(size_t bytes) {
+static void* host_result_reserve(size_t bytes) {          // (pages not touched yet)
     const size_t big = (size_t)64 << 20, huge = (size_t)2 << 20;
     if (bytes < big) return malloc(std::max<size_t>(bytes, 1));
     void* p = nullptr;
     if (posix_memalign(&p, huge, (bytes + huge - 1) / huge * huge) != 0) return nullptr;
     (void)madvise(p, bytes, MADV_HUGEPAGE);
+    return p;
+}
+static void host_result_touch(void* p, size_t bytes) {
+    if (bytes < ((size_t)64 << 20)) return;
     unsigned T = std::thread::hardware_concurrency();
     T = std::max(1u, std::min(T ? T : 4u, 16u));
     const size_t pages = (bytes + 4095) / 4096, per = (pages + T - 1) / T;
@@ -994,7 +1000,41 @@ static void* host_result_alloc(size_t bytes) {
             for (size_t pg = t * per; pg < std::min(pages, (t + 1) * per); ++pg) c[pg * 4096] = 0;
         });
     for (auto& x : th) x.join();
+}
+static void* host_result_alloc(size_t bytes) {
+    void* p = host_result_reserve(bytes);
+    if (p) host_result_touch(p, bytes);
     return p;
+}
+
+// Several result arrays: while array i comes over PCIe, the pages of array i + 1 are being touched (a third of the time of
+// a 7 GB graph was the touching, done array by array in front of each copy).
+struct HostCopy { void** dst; const void* src; size_t bytes; void* h = nullptr; };
+template <class Owner> static int d2h_all(Owner* o, std::vector<HostCopy>& jobs) {
+    for (auto& j : jobs) {
+        j.h = host_result_reserve(j.bytes);
+        if (!j.h) { set_error("out of host memory"); return KATOME_E_OOM; }
+        o->mem.push_back(j.h);
+        *j.dst = j.h;
+    }
+    std::mutex m; std::condition_variable cv; size_t touched = 0;
+    std::thread toucher([&]() {
+        for (auto& j : jobs) {
+            host_result_touch(j.h, j.bytes);
+            { std::lock_guard<std::mutex> lk(m); ++touched; }
+            cv.notify_all();
+        }
+    });
+    int rc = KATOME_OK;
+    for (size_t i = 0; i < jobs.size(); ++i) {
+        { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&]() { return touched > i; }); }
+        if (rc == KATOME_OK && jobs[i].bytes && hipMemcpy(jobs[i].h, jobs[i].src, jobs[i].bytes, hipMemcpyDeviceToHost) != hipSuccess) {
+            set_error("device -> host copy failed: %s", hipGetErrorString(hipGetLastError()));
+            rc = KATOME_E_DEVICE;
+        }
+    }
+    toucher.join();
+    return rc;
 }
 
 template <class T, class Owner> static int d2h(Owner* o, const T** dst, const void* d_src, size_t count) {
@@ -1038,16 +1078,15 @@ static int graph_to_host(katome_builder* b, uint64_t read_bytes, katome_graph** 
     katome_graph* g = &o->g;
     g->n_nodes = dg.n_nodes; g->n_edges = dg.n_edges; g->read_bytes = read_bytes;
     g->k = b->s.k; g->key_words = dg.key_words; g->label_stride = dg.label_stride;
-    int rc = KATOME_OK;
-    if ((rc = d2h(o, &g->edge_src, dg.d_edge_src, dg.n_edges)) || (rc = d2h(o, &g->edge_dst, dg.d_edge_dst, dg.n_edges)) ||
-        (rc = d2h(o, &g->edge_weight, dg.d_edge_weight, dg.n_edges)) ||
-        (rc = d2h(o, &g->edge_label, dg.d_edge_label, dg.n_edges * (size_t)dg.label_stride)) ||
-        (rc = d2h(o, &g->edge_key, dg.d_edge_key, dg.n_edges * dg.key_words)) ||
-        (rc = d2h(o, &g->node_key, dg.d_node_key, dg.n_nodes * dg.key_words)) ||
-        (dg.d_edge_age && (rc = d2h(o, &g->edge_age, dg.d_edge_age, dg.n_edges)))) {
-        katome_graph_free(g);
-        return rc;
-    }
+    std::vector<HostCopy> jobs = {
+        {(void**)&g->edge_src, dg.d_edge_src, dg.n_edges * 8}, {(void**)&g->edge_dst, dg.d_edge_dst, dg.n_edges * 8},
+        {(void**)&g->edge_weight, dg.d_edge_weight, dg.n_edges * 4},
+        {(void**)&g->edge_label, dg.d_edge_label, dg.n_edges * (size_t)dg.label_stride},
+        {(void**)&g->edge_key, dg.d_edge_key, dg.n_edges * 8 * (size_t)dg.key_words},
+        {(void**)&g->node_key, dg.d_node_key, dg.n_nodes * 8 * (size_t)dg.key_words}};
+    if (dg.d_edge_age) jobs.push_back({(void**)&g->edge_age, dg.d_edge_age, dg.n_edges * 4});
+    const int rc = d2h_all(o, jobs);
+    if (rc) { katome_graph_free(g); return rc; }
     build_lap("graph to host arrays");
     *out = g;
     return KATOME_OK;
@@ -1259,6 +1298,7 @@ static int build_packed_impl(const katome_settings* s, const uint8_t* packed, ui
     }
     katome_builder* b = nullptr;
     KCHECK(katome_builder_create(s, &b));
+    build_lap("", true);
     int rc = KATOME_OK;
     do {
         const uint32_t stride = (read_len + 3) / 4, W = read_len >= s->k ? read_len - s->k + 1 : 0;
