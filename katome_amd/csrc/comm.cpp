@@ -244,7 +244,7 @@ int katome_comm::allgather(uint64_t v, uint64_t* out) {
 }
 
 int katome_comm::exchange(const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, int on_device,
-                          hipStream_t stream) {
+                          hipStream_t stream, bool one_round) {
     const int w = world();
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> so(w, 0), ro(w, 0);
@@ -256,7 +256,8 @@ int katome_comm::exchange(const void* send, const uint64_t* send_cnt, void* recv
     }
     const uint64_t chunk = std::max<uint64_t>(1, max_message_bytes / elem_bytes);
     uint64_t rounds = 1;
-    if (w > 1) {                                                   // every rank must run the same number of rounds
+    if (one_round) rounds = 1;
+    else if (w > 1) {                                              // every rank must run the same number of rounds
         KCHECK(t->allreduce(&biggest, 1, OP_MAX));
         rounds = std::max<uint64_t>(1, (biggest + chunk - 1) / chunk);
     } else rounds = std::max<uint64_t>(1, (biggest + chunk - 1) / chunk);

@@ -63,8 +63,9 @@ struct katome_comm {
     void use_stream(hipStream_t s) { t->work_stream = s; t->have_work_stream = true; }
     // records grouped by destination, send_cnt[p] elements for peer p, contiguous in peer order; recv likewise by source
     // (recv_cnt from exchange_counts).  Splits into rounds when a pair's message exceeds max_message_bytes.
+    // one_round: the caller knows that no pair's message exceeds max_message_bytes on any rank (no agreement needed)
     int exchange(const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, int on_device,
-                 hipStream_t stream);
+                 hipStream_t stream, bool one_round = false);
 };
 
 namespace katome {

@@ -169,6 +169,7 @@ struct katome_dist_builder {
     // sends each DISTINCT k-mer once ("local first": one exchange, 12 B per k-mer and rank).  Many ranks: tiles, mid tiles and
     // k-mer records are routed to owners level by level (no level is counted twice, at the price of three exchanges).
     bool local_first = false;
+    hipStream_t xstream = nullptr;           // the exchanges of route_weighted run here, beside the insertions on the build's stream
     // this rank's share of the numbered graph
     DevBuf edge_src, edge_dst, edge_label, node_key, edge_gid, node_gid;
     uint64_t n_edges = 0, n_nodes = 0, total_edges = 0, total_nodes = 0, node_base = 0;
@@ -180,12 +181,13 @@ struct katome_dist_builder {
     // (RCCL only enqueues: with the builder's profile switched on the exchange is timed with HIP events on its stream)
     struct XEvent { int phase; hipEvent_t a, b; };
     std::vector<XEvent> xevents;
-    int xchg(int phase, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, hipStream_t stream) {
+    int xchg(int phase, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, hipStream_t stream,
+             bool one_round = false) {
         const katome::ExchangeStats before = comm->stats;
         hipEvent_t ea = nullptr, eb = nullptr;
         const bool timed = b->prof.on && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
         if (timed) (void)hipEventRecord(ea, stream);
-        const int rc = comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream);
+        const int rc = comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream, one_round);
         if (timed) { (void)hipEventRecord(eb, stream); xevents.push_back({phase, ea, eb}); }
         if (rc != KATOME_OK) return rc;
         katome::ExchangeStats& x = xstats[phase];
@@ -195,7 +197,10 @@ struct katome_dist_builder {
         for (int p = 0; p < world(); ++p) if (p != rank()) x.max_pair_bytes = std::max<uint64_t>(x.max_pair_bytes, send_cnt[p] * elem_bytes);
         return KATOME_OK;
     }
-    ~katome_dist_builder() { for (auto& e : xevents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } }
+    ~katome_dist_builder() {
+        for (auto& e : xevents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+        if (xstream) { (void)hipSetDevice(s.device); dev_retire_stream(xstream); (void)hipStreamDestroy(xstream); }
+    }
 };
 
 namespace {
@@ -232,51 +237,85 @@ int route_and_insert(katome_dist_builder* d, const u64* part, const u32* idx, co
                           d->first_seen ? &origin : nullptr, PH_INSERT, stream);
 }
 
-// Weighted records [with their two sequence numbers] to their owners, which add them to `table`: in slices of at most one
-// message's size, the same number of rounds on every rank.  core_bases == 0: the owner is a hash of the whole record.
+// Weighted records [with their two sequence numbers] to their owners, which add them to `table`: in slices of at most a quarter
+// of one message's size, the same number of rounds on every rank.  core_bases == 0: the owner is a hash of the whole record.
+// Software pipeline over the slices: slice j is partitioned on the build's stream, exchanged on the exchange stream (every
+// operation of the communicator goes there for the duration), and added to the table on the build's stream again -- while
+// slice j + 1 is already on the links.  Two sets of buffers; events order the two streams (a buffer is written again only
+// behind the wait for the exchange or the insertion that read it, both of which the build's stream has passed by then).
 int route_weighted(katome_dist_builder* d, int xphase, const DevBuf& keys, const DevBuf& weights, const DevBuf& seen, uint64_t n_rec, uint32_t nwr,
                    uint32_t core_shift, uint32_t core_bases, Table& table, bool& ready, uint64_t hint, int phase, hipStream_t stream) {
     katome_builder* b = d->b;
     const int world = d->world();
-    const uint64_t per_slice = std::max<uint64_t>(1, d->comm->max_message_bytes / (8 * nwr));
+    const uint64_t per_slice = std::max<uint64_t>(1, d->comm->max_message_bytes / 4 / (8 * nwr));
     uint64_t ns = (n_rec + per_slice - 1) / per_slice;
     KCHECK(d->comm->allreduce(&ns, 1, OP_MAX));
-    DevBuf pk(stream), pw(stream), pidx(stream), idx(stream), ppairs(stream);
-    for (uint64_t j = 0; j < ns; ++j) {
-        const uint64_t a = std::min(n_rec, j * per_slice), e = std::min(n_rec, (j + 1) * per_slice), m = e - a;
-        std::vector<uint64_t> counts(world, 0), rcnt(world, 0);
-        if (m) {
-            KCHECK(pk.alloc(m * 8 * nwr)); KCHECK(pw.alloc(m * 4));
-            if (d->first_seen) {
-                KCHECK(idx.alloc(m * 4)); KCHECK(pidx.alloc(m * 4)); KCHECK(ppairs.alloc(m * 16));
-                KCHECK(dev_iota(idx.as<u32>(), m, stream));
-                KCHECK(dev_partition(keys.as<u64>() + a * nwr, idx.as<u32>(), m, nwr, world, pk.as<u64>(), pidx.as<u32>(), counts.data(), stream, core_shift, core_bases));
-                KCHECK(dev_gather_u32(weights.as<u32>() + a, pidx.as<u32>(), sum(counts), pw.as<u32>(), stream));
-                KCHECK(dev_gather_keys(seen.as<u64>() + 2 * a, pidx.as<u32>(), sum(counts), 2, ppairs.as<u64>(), stream));
-            } else {
-                KCHECK(dev_partition(keys.as<u64>() + a * nwr, weights.as<u32>() + a, m, nwr, world, pk.as<u64>(), pw.as<u32>(), counts.data(), stream, core_shift, core_bases));
-            }
-        }
-        KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
-        const uint64_t nR = sum(rcnt);
-        DevBuf rk(stream), rw(stream), rp(stream);
-        KCHECK(rk.alloc(std::max<uint64_t>(nR, 1) * 8 * nwr)); KCHECK(rw.alloc(std::max<uint64_t>(nR, 1) * 4));
-        KCHECK(d->xchg(xphase, pk.p, counts.data(), rk.p, rcnt.data(), 8 * nwr, stream));
-        KCHECK(d->xchg(xphase, pw.p, counts.data(), rw.p, rcnt.data(), 4, stream));
+    if (ns == 0) return KATOME_OK;
+    if (!d->xstream) KCHECK_HIP(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+    hipStream_t X = d->xstream;
+    struct Slot {
+        DevBuf pk, pw, pidx, idx, ppairs, rk, rw, rp;
+        std::vector<uint64_t> counts, rcnt;
+        uint64_t nR = 0;
+        hipEvent_t parted = nullptr, arrived = nullptr;
+        explicit Slot(hipStream_t s) : pk(s), pw(s), pidx(s), idx(s), ppairs(s), rk(s), rw(s), rp(s) {}
+        ~Slot() { if (parted) (void)hipEventDestroy(parted); if (arrived) (void)hipEventDestroy(arrived); }
+    };
+    Slot slot[2] = {Slot(stream), Slot(stream)};
+    for (auto& sl : slot) {
+        KCHECK_HIP(hipEventCreateWithFlags(&sl.parted, hipEventDisableTiming));
+        KCHECK_HIP(hipEventCreateWithFlags(&sl.arrived, hipEventDisableTiming));
+    }
+    d->comm->use_stream(X);
+    auto insert_slice = [&](Slot& sl) -> int {
+        KCHECK_HIP(hipStreamWaitEvent(stream, sl.arrived, 0));
         if (xphase == X_KMERS) {
-            trace_words("kmers received: keys", d->rank(), rk.p, nR * nwr, stream);
-            trace_words("kmers received: weights", d->rank(), rw.p, nR / 2, stream);
+            trace_words("kmers received: keys", d->rank(), sl.rk.p, sl.nR * nwr, stream);
+            trace_words("kmers received: weights", d->rank(), sl.rw.p, sl.nR / 2, stream);
         }
         SeenOrigin origin;
-        if (d->first_seen) {
-            KCHECK(rp.alloc(std::max<uint64_t>(nR, 1) * 16));
-            KCHECK(d->xchg(xphase, ppairs.p, counts.data(), rp.p, rcnt.data(), 16, stream));
-            origin.pairs = rp.as<u64>(); origin.rc = d->rc;
+        if (d->first_seen) { origin.pairs = sl.rp.as<u64>(); origin.rc = d->rc; }
+        if (sl.nR) KCHECK(builder_insert(b, table, ready, nwr, hint, sl.rk.as<u64>(), sl.rw.as<u32>(), sl.nR, d->first_seen ? &origin : nullptr, phase, stream));
+        return KATOME_OK;
+    };
+    int rc = KATOME_OK;
+    for (uint64_t j = 0; j < ns && rc == KATOME_OK; ++j) {
+        Slot& sl = slot[j & 1];
+        const uint64_t a = std::min(n_rec, j * per_slice), e = std::min(n_rec, (j + 1) * per_slice), m = e - a;
+        sl.counts.assign(world, 0); sl.rcnt.assign(world, 0);
+        // (a) partition slice j by owner, on the build's stream
+        if (m) {
+            if ((rc = sl.pk.alloc(m * 8 * nwr)) || (rc = sl.pw.alloc(m * 4))) break;
+            if (d->first_seen) {
+                if ((rc = sl.idx.alloc(m * 4)) || (rc = sl.pidx.alloc(m * 4)) || (rc = sl.ppairs.alloc(m * 16))) break;
+                if ((rc = dev_iota(sl.idx.as<u32>(), m, stream))) break;
+                if ((rc = dev_partition(keys.as<u64>() + a * nwr, sl.idx.as<u32>(), m, nwr, world, sl.pk.as<u64>(), sl.pidx.as<u32>(), sl.counts.data(), stream, core_shift, core_bases))) break;
+                if ((rc = dev_gather_u32(weights.as<u32>() + a, sl.pidx.as<u32>(), sum(sl.counts), sl.pw.as<u32>(), stream))) break;
+                if ((rc = dev_gather_keys(seen.as<u64>() + 2 * a, sl.pidx.as<u32>(), sum(sl.counts), 2, sl.ppairs.as<u64>(), stream))) break;
+            } else {
+                if ((rc = dev_partition(keys.as<u64>() + a * nwr, weights.as<u32>() + a, m, nwr, world, sl.pk.as<u64>(), sl.pw.as<u32>(), sl.counts.data(), stream, core_shift, core_bases))) break;
+            }
         }
-        if (nR) KCHECK(builder_insert(b, table, ready, nwr, hint, rk.as<u64>(), rw.as<u32>(), nR, d->first_seen ? &origin : nullptr, phase, stream));
-        KCHECK_HIP(hipStreamSynchronize(stream));           // (the receive buffers go back to the cache at the end of the round)
+        if (hipEventRecord(sl.parted, stream) != hipSuccess) { set_error("event record failed"); rc = KATOME_E_DEVICE; break; }
+        // (b) exchange it, on the exchange stream
+        if ((rc = d->comm->exchange_counts(sl.counts.data(), sl.rcnt.data()))) break;
+        sl.nR = sum(sl.rcnt);
+        if ((rc = sl.rk.alloc(std::max<uint64_t>(sl.nR, 1) * 8 * nwr)) || (rc = sl.rw.alloc(std::max<uint64_t>(sl.nR, 1) * 4))) break;
+        if (d->first_seen && (rc = sl.rp.alloc(std::max<uint64_t>(sl.nR, 1) * 16))) break;
+        if (hipStreamWaitEvent(X, sl.parted, 0) != hipSuccess) { set_error("event wait failed"); rc = KATOME_E_DEVICE; break; }
+        // (a slice is a quarter of a message on every rank: one round, nothing to agree on)
+        if ((rc = d->xchg(xphase, sl.pk.p, sl.counts.data(), sl.rk.p, sl.rcnt.data(), 8 * nwr, X, true))) break;
+        if ((rc = d->xchg(xphase, sl.pw.p, sl.counts.data(), sl.rw.p, sl.rcnt.data(), 4, X, true))) break;
+        if (d->first_seen && (rc = d->xchg(xphase, sl.ppairs.p, sl.counts.data(), sl.rp.p, sl.rcnt.data(), 16, X, true))) break;
+        if (hipEventRecord(sl.arrived, X) != hipSuccess) { set_error("event record failed"); rc = KATOME_E_DEVICE; break; }
+        // (c) meanwhile: the slice before goes into the table
+        if (j > 0) rc = insert_slice(slot[(j - 1) & 1]);
     }
-    return KATOME_OK;
+    if (rc == KATOME_OK) rc = insert_slice(slot[(ns - 1) & 1]);
+    (void)hipStreamSynchronize(X);
+    (void)hipStreamSynchronize(stream);                       // (the buffers go back to the cache behind everything that used them)
+    d->comm->use_stream(stream);
+    return rc;
 }
 
 // every rank's distinct tiles -> (k-mer, count[, sequence numbers]) records -> the k-mers' owners.  `span`: the plan all ranks
