@@ -1108,7 +1108,6 @@ int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, Dev
     return source_ids_t<2>(d_edge_key, n_edges, node_key, d_edge_src, n_src, stream);
 }
 
-__global__ __launch_bounds__(BLOCK) void node_first_src_kernel(const u64* __restrict__ src, const u64* __restrict__ seq, u64 n, u64* __restrict__ node_first);
 
 // seq + node_first (first-seen order, both or neither): node_first[v] = the first touch of node v, 2*seq as a source, 2*seq + 1
 // as a target; left empty when the merging look-up is switched off (the caller then runs dev_node_first)
