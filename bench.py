@@ -416,6 +416,7 @@ def main():
         alg = {"extract": lambda launches, reads: reads * per_read_extract,
                "insert": lambda launches, reads: reads * (rest if span > 1 else W) * (8 * nw + 16 * nw),
                "insert_tiles": lambda launches, reads: reads * tiles * (8 * nwt + 16 * nwt)}
+        sorted_last_level = False
         if not use_dist and cnt:
             # expansion: one scan of the tile table + a 16*NW-byte slot touch per (distinct tile, k-mer) pair;
             # edge sort: ceil(2k/8) passes, each reading and writing every (key, weight) pair once
@@ -428,6 +429,16 @@ def main():
                     cnt["mid_tile_slots"] * 16 * nwm + cnt["distinct_mid_tiles"] * ms2 * 16 * nw)
             else:
                 alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
+            sorted_last_level = bool(cnt.get("distinct_kmers")) and not cnt.get("kmer_slots")
+            if sorted_last_level:
+                # the last level was counted by sorting (table.hip, lds_count_kernel; no k-mer table): one scan of the last tile
+                # table, a 12-byte record written per (tile, k-mer) pair, two partition passes (histogram read 8 B, scatter read
+                # and write 12 B each), the group index (8 B), the counting pass (12 B read) and 12 B written per edge
+                last_slots, last_tiles, last_span, last_nw = ((cnt["mid_tile_slots"], cnt["distinct_mid_tiles"], ms2, nwm) if ms2
+                                                              else (cnt["tile_slots"], cnt["distinct_tiles"], span, nwt))
+                n_rec = last_tiles * last_span
+                alg["expand_tiles"] = lambda launches, reads: steps * (last_slots * 16 * last_nw + n_rec * (12 + 2 * (8 + 12 + 12) + 8 + 12)
+                                                                       + n_edges * 12)
             # dev_sort: passes over the top log2(n)+9 bits (all of them if that saves fewer than four), each reading and writing
             # every (key, weight) pair once, then one more read + write by the run sort
             sort_passes[0] = _sort_passes(2 * wl.k, n_edges)
@@ -472,7 +483,15 @@ def main():
             passes = sort_passes[0][0]
             parts = {"sort_edges": [(exact["sort_edges"], passes, True),
                                     ("void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw), passes, True),
-                                    ("radix_chunk_kernel", passes, True)]}.get(name, [(exact.get(name, name), 1, name == "extract")])
+                                    ("radix_chunk_kernel", passes, True)]}
+            if sorted_last_level:          # (the phase is five kernels: records, two partition passes with their histograms, index, counting)
+                exact["expand_tiles"] = "void lds_count_kernel<%s>" % rcs
+                parts["expand_tiles"] = [("void tiles_to_records_kernel<%d, 1, %s>" % (
+                                              _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or span), rcs), 1, True),
+                                         ("void radix_scatter_kernel<1, true, HashDigit<1> >", 2, True),
+                                         ("void radix_hist_kernel<1, HashDigit<1> >", 2, True),
+                                         ("hash_group_index_kernel", 1, True), (exact["expand_tiles"], 1, False)]
+            parts = parts.get(name, [(exact.get(name, name), 1, name == "extract")])
             t = pmc_traffic(parts, cfg_now) if not use_dist else None
             return {"kernel": exact.get(name, kernel_names.get(name, name)).replace("void ", ""), "phase": name, "bound": "hbm",
                     "achieved": kernels[name]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",

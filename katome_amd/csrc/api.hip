@@ -524,8 +524,37 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (!b->edges_ready) {
         b->n_edges = 0;
-        KCHECK(expand_tiles(b, stream));
-        if (b->table_ready) {
+        // Counting the last level by sorting instead of in a table (table.hip, lds_count_kernel): one-word k-mers, by packed key,
+        // nothing in the k-mer table yet (no left-over windows), enough tiles to be worth the extra launches
+        static const int sorted_count = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
+        bool counted = false;
+        if (sorted_count && b->tiles_ready && !b->table_ready && !b->first_seen && b->nw == 1) {
+            uint64_t n_tiles = 0;
+            KCHECK(table_occupied(b->tiles, &n_tiles, stream));
+            const uint64_t bound = n_tiles * b->span;        // the k-mer records can be no more than this
+            if ((bound >= (1ull << 22) || (sorted_count == 2 && bound)) && (bound >> 21) <= 2900) {      // (2: however few -- tests)
+                Table* last = nullptr; uint32_t last_span = 1;
+                KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+                DevBuf rk(stream), rw(stream);
+                uint64_t n_rec = 0, distinct = 0;
+                {
+                    PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                    KCHECK(table_tiles_to_records_fast(*last, b->s.k, last_span, b->rc, rk, rw, &n_rec, stream));
+                    b->tiles.release(); b->tiles2.release();
+                    b->tiles_ready = false; b->tiles2_ready = false;
+                    const int rc = records_to_edges_sorted(rk, rw, n_rec, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
+                    if (rc != KATOME_OK) return rc;
+                }
+                b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+                for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
+                rk.release(); rw.release();
+                PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
+                KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream));
+                counted = true;
+            }
+        }
+        if (!counted) KCHECK(expand_tiles(b, stream));
+        if (!counted && b->table_ready) {
             KCHECK(table_occupied(b->table, &b->stat_kmers, stream));
             b->stat_kmer_slots = b->table.cap;
             DevBuf raw_w(stream), raw_seq(stream);
@@ -552,7 +581,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             } else {
                 KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream));
             }
-        } else {
+        } else if (!counted) {
             KCHECK(b->edge_key.alloc(16, stream)); KCHECK(b->edge_weight.alloc(16, stream));
         }
         b->edges_ready = true;

@@ -231,6 +231,9 @@ int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmer
 // (seen: when the tile table tracks first-seen order, the records' two sequence numbers, [n][2])
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
                                   uint64_t* n_records, hipStream_t stream, DevBuf* seen = nullptr);
+int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream);
+int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
+                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream);
 int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, DevBuf* seen_pairs = nullptr);
 int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint32_t stride, bool rc, DevBuf& keys, DevBuf& weights,
                                    uint64_t* n_records, hipStream_t stream, DevBuf* seen = nullptr);

@@ -9,6 +9,7 @@
 //
 // Random-access kernel: algorithmic traffic per insertion = 8*NW B record + 16*NW B slot
 // (key compare + weight read-modify-write).  Integer/atomic work, no MFMA.
+#include <vector>
 #include "common.h"
 
 namespace katome {
@@ -448,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
         for (int j = 0; j < EMIT_ITEMS; ++j) {
             if (!nemit[j]) continue;
             Key<NW> rc = RC ? revcomp(key[j], k) : key[j];
-            u32 w = (RC && nemit[j] == 1) ? cnt[j] * 2u : cnt[j];     // self-complementary k-mer
+            const u32 w = cnt[j] << ((RC && nemit[j] == 1) ? 1u : 0u);      // self-complementary k-mer (as a shift: see lds_count_kernel)
             u64 s0 = 0, s1 = 0;
             if (seen) {
                 const u64 slot = t0 + (u64)j * BLOCK + tid;
@@ -535,6 +536,188 @@ __global__ __launch_bounds__(BLOCK) void table_records_kernel(const typename Slo
         }
         __syncthreads();
     }
+}
+
+// Distinct tiles -> (sub-window, count) records, for the sorted counting below: a workgroup takes 2048 slots per trip (rows of
+// 256: coalesced), parks the occupied tiles in LDS, takes its stretch of the output with one cursor atomic and deals the
+// (tile, sub-window) pairs out over the lanes -- consecutive lanes write consecutive records.  (expand_tiles_kernel does the
+// same 256 slots at a time: two barriers and an atomic per ~600 records, which is fine beside table upserts and 3x too slow
+// for a streaming pass.)
+constexpr u32 TR_ITEMS = 8;
+template <int NWT, int NWK, bool RC>
+__global__ __launch_bounds__(BLOCK) void tiles_to_records_kernel(const typename SlotOf<NWT>::type* __restrict__ tiles, u64 tile_cap, u32 k, u32 span,
+                                                                  u32 stride, u64* __restrict__ out_keys, u32* __restrict__ out_w, u64* cursor) {
+    __shared__ u64 lkey[BLOCK * TR_ITEMS * NWT];
+    __shared__ u32 lcnt[BLOCK * TR_ITEMS];
+    __shared__ u32 wtot[BLOCK / 64];
+    __shared__ u64 bbase;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 trip = (u64)BLOCK * TR_ITEMS;
+    for (u64 t0 = (u64)blockIdx.x * trip; t0 < tile_cap; t0 += (u64)gridDim.x * trip) {
+        Key<NWT> tk[TR_ITEMS]; u32 tc[TR_ITEMS]; bool have[TR_ITEMS]; u32 mine = 0;
+#pragma unroll
+        for (u32 j = 0; j < TR_ITEMS; ++j) {
+            const u64 i = t0 + (u64)j * BLOCK + tid;
+            have[j] = false; tc[j] = 0;
+            if (i < tile_cap) {
+                typename SlotOf<NWT>::type s = tiles[i];
+                have[j] = slot_key(s, tk[j]);
+                tc[j] = s.count;
+            }
+            mine += have[j];
+        }
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (u32 w = 0; w < BLOCK / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+        u32 at = woff + (incl - mine);
+#pragma unroll
+        for (u32 j = 0; j < TR_ITEMS; ++j) {
+            if (!have[j]) continue;
+#pragma unroll
+            for (int q = 0; q < NWT; ++q) lkey[at * NWT + q] = tk[j].w[q];
+            lcnt[at] = tc[j];
+            ++at;
+        }
+        if (tid == 0 && total) bbase = atomicAdd((unsigned long long*)cursor, (unsigned long long)total * span);
+        __syncthreads();
+        const u32 pairs = total * span;
+        const u64 base = bbase;
+        for (u32 p = tid; p < pairs; p += BLOCK) {
+            const u32 t = p / span, o = p - t * span;
+            Key<NWT> tile;
+#pragma unroll
+            for (int q = 0; q < NWT; ++q) tile.w[q] = lkey[t * NWT + q];
+            Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, stride, o);
+            if (RC) x = canonical(x, k);
+#pragma unroll
+            for (int q = 0; q < NWK; ++q) out_keys[(base + p) * NWK + q] = x.w[q];
+            out_w[base + p] = lcnt[t];
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The last level without device-scope atomics.  The (k-mer, count) records of the distinct tiles are ordered by the top 16
+// bits of their hash (two stable 8-bit passes of radix.hip, HashDigit), which cuts them into 65536 groups; a workgroup takes a
+// group and counts it in an LDS table -- compare-and-swap and add in LDS --, in R sub-rounds by the next hash bits so that a
+// sub-round's keys fit the table even if every record were a new key (nothing can overflow), re-reading the group from
+// L2 / Infinity Cache; a sub-round's keys leave as oriented edges straight away (both strands, the remove_weak_edges
+// threshold), as one contiguous stretch behind a cursor.
+// ---------------------------------------------------------------------------------------------
+#ifndef KATOME_LC_SLOTS
+#define KATOME_LC_SLOTS 8192
+#endif
+constexpr u32 LC_SLOTS = KATOME_LC_SLOTS;      // LDS table: 8 B key + 4 B count per slot (8192: 96 KiB, one workgroup of 1024 per CU)
+constexpr u32 LC_FILL = LC_SLOTS / 4096 * 2900;   // records a sub-round may hold at most on average (all new: load 0.71)
+constexpr u32 LC_THREADS = LC_SLOTS / 8;
+constexpr u32 LC_MAX_SUB = 5;                  // up to 32 sub-rounds
+
+// index[g] = first record whose hash has top 16 bits >= g (records ordered by those bits), g = 0 .. 65536
+__global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __restrict__ keys, u64 n, u64* __restrict__ index) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i <= n; i += (u64)gridDim.x * BLOCK) {
+        Key<1> a, c;
+        long long prev = -1, cur = 65536;
+        if (i > 0) { a.w[0] = keys[i - 1]; prev = (long long)(hash_key(a) >> 48); }
+        if (i < n) { c.w[0] = keys[i]; cur = (long long)(hash_key(c) >> 48); }
+        for (long long g = prev + 1; g <= cur; ++g) index[g] = i;
+    }
+}
+
+template <bool RC>
+__global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index,
+                                                                u32 sub_bits, u32 k, u32 min_weight, u64* out_keys,
+                                                                u32* out_w, u64 out_cap, unsigned long long* cursor,
+                                                                unsigned long long* distinct, u32* err) {
+    extern __shared__ unsigned long long lc_mem[];
+    unsigned long long* lkey = lc_mem;                                   // [LC_SLOTS]
+    u32* lcnt = reinterpret_cast<u32*>(lc_mem + LC_SLOTS);               // [LC_SLOTS]
+    __shared__ u32 wtot[LC_THREADS / 64];
+    __shared__ unsigned long long base_sh;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u32 R = 1u << sub_bits;
+    u32 my_distinct = 0;
+    for (u32 g = blockIdx.x; g < 65536u; g += gridDim.x) {
+        const u64 lo = index[g], hi = index[g + 1];
+        if (lo == hi) continue;
+        for (u32 r = 0; r < R; ++r) {
+            for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
+            __syncthreads();
+            constexpr u32 LU = 4;                            // records in flight per thread (the group is re-read from L2 / Infinity Cache)
+            for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
+                u64 kv[LU]; u32 wv[LU];
+#pragma unroll
+                for (u32 u = 0; u < LU; ++u) { const u64 i = i0 + (u64)u * LC_THREADS; kv[u] = 0; wv[u] = 0; if (i < hi) { kv[u] = keys[i]; wv[u] = wts[i]; } }
+#pragma unroll
+                for (u32 u = 0; u < LU; ++u) {
+                    const u64 i = i0 + (u64)u * LC_THREADS;
+                    if (i >= hi) continue;
+                    Key<1> key; key.w[0] = kv[u];
+                    const u64 h = hash_key(key);
+                    if (sub_bits && ((h >> (48 - sub_bits)) & (R - 1)) != r) continue;
+                    const unsigned long long want = key.w[0] | OCC;
+                    u32 s = (u32)(h >> 20) & (LC_SLOTS - 1);
+                    u32 probes = 0;
+                    for (; probes < LC_SLOTS; ++probes) {
+                        const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
+                        if (cur == 0ull || cur == want) { atomicAdd(&lcnt[s], wv[u]); break; }
+                        s = (s + 1) & (LC_SLOTS - 1);
+                    }
+                    if (probes == LC_SLOTS) *err = 3;        // (cannot happen: a sub-round holds fewer records than slots)
+                }
+            }
+            __syncthreads();
+            // read-out: every thread owns LC_SLOTS / LC_THREADS consecutive slots
+            constexpr u32 PER = LC_SLOTS / LC_THREADS;
+            Key<1> kk[PER]; u32 cc[PER], ne[PER]; u32 mine = 0;
+#pragma unroll
+            for (u32 j = 0; j < PER; ++j) {
+                const u32 sidx = tid * PER + j;
+                const unsigned long long v = lkey[sidx];
+                ne[j] = 0; cc[j] = 0; kk[j].w[0] = 0;
+                if (v & OCC) {
+                    kk[j].w[0] = v & KEYBITS; cc[j] = lcnt[sidx];
+                    ++my_distinct;
+                    ne[j] = 1;
+                    if (RC && !key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 2;
+                    if (((RC && ne[j] == 1) ? cc[j] * 2u : cc[j]) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
+                }
+                mine += ne[j];
+            }
+            u32 incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            u32 woff = 0, total = 0;
+#pragma unroll
+            for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+            if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+            __syncthreads();
+            u64 pos = base_sh + woff + (incl - mine);
+#pragma unroll
+            for (u32 j = 0; j < PER; ++j) {
+                if (!ne[j]) continue;
+                // (self-complementary k-mer: both strands are one edge.  Written as a shift: as `ne == 1 ? 2 * c : c` hipcc 7.2
+                // lowered the select to a switch on ne whose default arm left the weight register unset for the ne == 2 lanes)
+                const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);
+                if (pos < out_cap) { out_keys[pos] = kk[j].w[0]; out_w[pos] = w; }
+                ++pos;
+                if (ne[j] == 2) {
+                    if (pos < out_cap) { out_keys[pos] = revcomp(kk[j], k).w[0]; out_w[pos] = w; }
+                    ++pos;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    my_distinct = wave_sum(my_distinct);
+    if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -693,6 +876,77 @@ int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_record
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+// the (k-mer, count) records of every distinct tile of the last level (no sequence numbers), written by the streaming kernel
+int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream) {
+    uint64_t occ = 0;
+    KCHECK(table_occupied(tiles, &occ, stream));
+    const uint32_t nwk = (uint32_t)key_words_for_k(k);
+    if (nwk != 1 || tiles.nw < 1 || tiles.nw > 2) return table_expand_tiles_to_records(tiles, k, span, rc, keys, weights, n_records, stream, nullptr);
+    KCHECK(keys.alloc((occ * span + 1) * 8 * nwk, stream));
+    KCHECK(weights.alloc((occ * span + 1) * 4, stream));
+    DevBuf cursor(stream);
+    KCHECK(cursor.alloc(8));
+    KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
+    if (tiles.nw == 1) {
+        if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, true>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        else    hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, false>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+    } else {
+        if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<2, 1, true>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        else    hipLaunchKernelGGL((tiles_to_records_kernel<2, 1, false>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+    }
+    KCHECK_HIP(hipGetLastError());
+    KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+// (k-mer, count) records in any order -> oriented edges (both strands with rc, weights summed per k-mer, threshold applied): counted
+// by sorting instead of in a table (see lds_count_kernel).  keys/weights: the records (consumed).  KATOME_E_UNSUPPORTED when
+// the input is out of the kernel's range (the caller counts in the table instead).
+int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
+                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
+    *n_edges = 0; *n_distinct = 0;
+    if (key_words_for_k(k) != 1) return KATOME_E_UNSUPPORTED;
+    u32 sub_bits = 0;
+    while (sub_bits <= LC_MAX_SUB && (n >> (16 + sub_bits)) > LC_FILL) ++sub_bits;
+    if (sub_bits > LC_MAX_SUB) return KATOME_E_UNSUPPORTED;
+    const u64* ko = nullptr; const u32* wo = nullptr;
+    {
+        DevBuf kb(stream), wb(stream);
+        KCHECK(kb.alloc((n + 1) * 8)); KCHECK(wb.alloc((n + 1) * 4));
+        // two passes: the first one's output goes to the scratch, the second one's lands in keys / weights again
+        KCHECK(dev_region_order(keys.as<u64>(), weights.as<u32>(), n, 1, 2, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, stream));
+    }
+    DevBuf index(stream), aux(stream);
+    KCHECK(index.alloc(65537 * 8));
+    KCHECK(aux.alloc(64));
+    KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+    hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for(n + 1, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, ko, n, index.as<u64>());
+    const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
+    KCHECK(edge_key.alloc(out_cap * 8, stream));
+    KCHECK(edge_weight.alloc(out_cap * 4, stream));
+    unsigned long long* cursor = aux.as<unsigned long long>();
+    unsigned long long* distinct = cursor + 1;
+    u32* err = reinterpret_cast<u32*>(cursor + 2);
+    const size_t lds = (size_t)LC_SLOTS * 12;
+    if (lds > (48u << 10)) {
+        KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    if (rc) hipLaunchKernelGGL((lds_count_kernel<true>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
+                               edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
+    else    hipLaunchKernelGGL((lds_count_kernel<false>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
+                               edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
+    KCHECK_HIP(hipGetLastError());
+    uint64_t h[3] = {0, 0, 0};
+    KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    if ((uint32_t)h[2]) { set_error("counting in LDS: a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
+    *n_edges = h[0]; *n_distinct = h[1];
     return KATOME_OK;
 }
 
