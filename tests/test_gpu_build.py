@@ -728,8 +728,9 @@ def test_round_one_paths_give_the_same_arrays(tmp_path):
         return sorted(line for line in out.stdout.splitlines() if line.startswith("AB "))
     want = run({})
     assert len(want) == 2
+    # (KATOME_SORTED_COUNT=2: the last level counted by sorting however small the input -- by default only from 4 M records on)
     for extra in ({"KATOME_DST_RANK": "1"}, {"KATOME_SORT_NODES": "1"}, {"KATOME_FULL_SORT": "1"},
-                  {"KATOME_DST_RANK": "1", "KATOME_SORT_NODES": "1"}):
+                  {"KATOME_DST_RANK": "1", "KATOME_SORT_NODES": "1"}, {"KATOME_SORTED_COUNT": "2"}, {"KATOME_SORTED_COUNT": "0"}):
         assert run(extra) == want, extra
 
 
