@@ -455,6 +455,8 @@ def main():
                         "emit_edges": "emit_edges_kernel", "sort_edges": "radix sort (edges)",
                         "node_set": "endpoints + radix sort + unique", "rank": "bucket_index + rank_kernel",
                         "labels": "labels_kernel"}
+        if sorted_last_level:
+            kernel_names["expand_tiles"] = "tiles_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_kernel (no k-mer table; the edges are written here)"
         kernels = {}
         reads_per_rank_step = wl.reads / world
         for name, ph in phases.items():
