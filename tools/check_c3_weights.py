@@ -1,3 +1,5 @@
+"""One build of N C3-like reads by packed key: edge count, weight sum against 2 * reads * windows, strictly ascending keys, table counts
+(which level was counted where).  usage: python tools/check_c3_weights.py [reads=60000000]; KATOME_SORTED_COUNT=0 for the table path."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
