@@ -17,11 +17,18 @@ constexpr int RADIX = 1 << RADIX_BITS;
 #ifndef KATOME_SORT_ITEMS
 #define KATOME_SORT_ITEMS 16
 #endif
-constexpr int SORT_ITEMS = KATOME_SORT_ITEMS;
+#ifndef KATOME_SORT_ITEMS_WIDE
+#define KATOME_SORT_ITEMS_WIDE 8
+#endif
 #ifndef KATOME_SORT_WAVES
 #define KATOME_SORT_WAVES 4      // workgroups per CU the scatter kernel is compiled for (register budget)
 #endif
-constexpr int SORT_TILE = BLOCK * SORT_ITEMS;      // 4096 keys per workgroup
+// keys per thread and per workgroup tile: 4096 one-word keys, 2048 wider ones -- the same 32 KiB of LDS and the same
+// 128 bytes per digit run either way (a 64 KiB tile of 128-bit keys left two workgroups per CU: C5's passes 13.5 -> 10 ms)
+template <int NW> struct SortTile {
+    static constexpr int ITEMS = NW == 1 ? KATOME_SORT_ITEMS : KATOME_SORT_ITEMS_WIDE;
+    static constexpr int KEYS = BLOCK * ITEMS;
+};
 // workgroups per offset chunk: the chunk kernel walks a chunk's workgroups serially, the offsets kernel walks the chunks
 // serially -- about the square root of the workgroup count keeps both short (4 M keys per chunk at most: < 2^32)
 static inline unsigned chunk_blocks_for(unsigned long long nblocks) {
@@ -83,6 +90,7 @@ __global__ __launch_bounds__(BLOCK) void radix_hist_kernel(const u64* __restrict
     const u32 tid = threadIdx.x;
     h[tid] = 0;
     __syncthreads();
+    constexpr int SORT_ITEMS = SortTile<NW>::ITEMS, SORT_TILE = SortTile<NW>::KEYS;
     const u64 base = (u64)blockIdx.x * SORT_TILE;
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; ++j) {
@@ -137,6 +145,7 @@ __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel
                                                                u64 n, Digit dg, const u32* __restrict__ rel,
                                                                const u64* __restrict__ chunk_off, u64* __restrict__ keys_out,
                                                                u32* __restrict__ vals_out, u32 chunk_blocks) {
+    constexpr int SORT_ITEMS = SortTile<NW>::ITEMS, SORT_TILE = SortTile<NW>::KEYS;
     extern __shared__ u64 smem[];
     u64* skeys = smem;                                            // [SORT_TILE * NW]; reused for the values afterwards
     __shared__ u32 whist[BLOCK / 64][RADIX];
@@ -244,9 +253,10 @@ struct PassBuffers {
     DevBuf counts, chunk, totals;
     u64 nblocks = 0, nchunks = 0;
     u32 chunk_blocks = 64;
-    int init(u64 n, hipStream_t stream) {
+    int init(u64 n, int nw, hipStream_t stream) {
         counts.stream = chunk.stream = totals.stream = stream;
-        nblocks = (n + SORT_TILE - 1) / SORT_TILE;
+        const u64 tile = nw == 1 ? SortTile<1>::KEYS : SortTile<2>::KEYS;
+        nblocks = (n + tile - 1) / tile;
         chunk_blocks = chunk_blocks_for(nblocks);
         nchunks = (nblocks + chunk_blocks - 1) / chunk_blocks;
         KCHECK(counts.alloc(nblocks * RADIX * sizeof(u32)));
@@ -263,7 +273,7 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
     hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
     hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>(), pb.chunk_blocks);
     hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
-    const size_t lds = (size_t)SORT_TILE * NW * 8;
+    const size_t lds = (size_t)SortTile<NW>::KEYS * NW * 8;
     if (lds > (64u << 10)) {          // three-word records: 96 KiB of the CU's 160 KiB
         KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
@@ -286,12 +296,18 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
 #ifndef KATOME_RUN_HALO
 #define KATOME_RUN_HALO 512
 #endif
-constexpr u32 RUN_TILE = KATOME_RUN_TILE;               // records a workgroup places
+#ifndef KATOME_RUN_TILE_WIDE
+#define KATOME_RUN_TILE_WIDE 2048
+#endif
+// records a workgroup places: 4096 one-word keys (40 KiB staged with the halo), 2048 wider ones (48 KiB; 4096 of them
+// took 80 KiB and left one workgroup per CU: C5's run sort 28 -> 15 ms)
+template <int NW> struct RunTile { static constexpr u32 KEYS = NW == 1 ? KATOME_RUN_TILE : KATOME_RUN_TILE_WIDE; };
 constexpr u32 RUN_HALO = KATOME_RUN_HALO;               // longest run that can be followed on either side
 template <int NW, bool HAS_VAL>
 __global__ __launch_bounds__(BLOCK) void run_sort_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in, u64 n, u32 low,
                                                           u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ overflow) {
     extern __shared__ u64 lk[];                        // [(RUN_TILE + 2 * RUN_HALO) * NW]
+    constexpr u32 RUN_TILE = RunTile<NW>::KEYS;
     constexpr u32 SPAN = RUN_TILE + 2 * RUN_HALO, PER = SPAN / BLOCK, OWN = RUN_TILE / BLOCK;
     static_assert(SPAN % BLOCK == 0 && RUN_TILE % BLOCK == 0, "whole rows per thread");
     const u64 n_tiles = (n + RUN_TILE - 1) / RUN_TILE;
@@ -400,7 +416,7 @@ template <int NW, bool HAS_VAL>
 static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream, DevBuf* own_k = nullptr, DevBuf* own_v = nullptr) {
     if (n < 2) return KATOME_OK;
     PassBuffers pb;
-    KCHECK(pb.init(n, stream));
+    KCHECK(pb.init(n, NW, stream));
     DevBuf tk(stream), tv(stream);
     KCHECK(tk.alloc(own_k ? std::max<size_t>(n * 8 * NW, own_k->bytes) : n * 8 * NW));       // (a swapped-in buffer must be no smaller)
     if (HAS_VAL) KCHECK(tv.alloc(own_v ? std::max<size_t>(n * 4, own_v->bytes) : n * 4));
@@ -422,6 +438,7 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
         DevBuf overflow(stream);
         KCHECK(overflow.alloc(16));
         KCHECK_HIP(hipMemsetAsync(overflow.p, 0, 4, stream));
+        constexpr u32 RUN_TILE = RunTile<NW>::KEYS;
         const size_t lds = (size_t)(RUN_TILE + 2 * RUN_HALO) * NW * 8;
         if (lds > (64u << 10)) KCHECK_HIP(hipFuncSetAttribute((const void*)run_sort_kernel<NW, HAS_VAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
@@ -479,7 +496,7 @@ int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32
     for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
     if (n == 0) return KATOME_OK;
     PassBuffers pb;
-    KCHECK(pb.init(n, stream));
+    KCHECK(pb.init(n, (int)nw, stream));
     if (nw == 1) {
         OwnerDigit<1> dg{n_parts, core_shift, core_bases};
         if (v_in) KCHECK((radix_pass<1, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
@@ -508,7 +525,7 @@ int dev_partition_range(const uint64_t* d_vals, const uint32_t* idx_in, uint64_t
     for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
     if (n == 0) return KATOME_OK;
     PassBuffers pb;
-    KCHECK(pb.init(n, stream));
+    KCHECK(pb.init(n, 1, stream));
     RangeDigit dg{d_bounds, n_parts};
     KCHECK((radix_pass<1, true>(d_vals, idx_in, n, dg, d_out, idx_out, pb, stream)));
     u64 totals[RADIX];
@@ -525,7 +542,7 @@ template <int NW>
 static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u64* ka, u64* kb, u32* wa, u32* wb,
                           const u64** k_out, const u32** w_out, hipStream_t stream) {
     PassBuffers pb;
-    KCHECK(pb.init(n, stream));
+    KCHECK(pb.init(n, NW, stream));
     const u64* kin = d_in; const u32* win = w_in;
     u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
     for (int p = 0; p < passes; ++p) {
