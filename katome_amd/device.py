@@ -5,6 +5,7 @@ Used by bench.py (inputs resident in HBM before the timed region); the multi-GPU
 pt_graph.rs:277-315,172-198,333-345): extract -> insert -> finalize.
 """
 import ctypes as C
+import weakref
 
 import torch
 
@@ -25,11 +26,40 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+class _ViewOwner:
+    """owner of library memory that zero-copy views point into: close() while views are alive is put off until the last
+    of them is gone (the library would hand the memory to the next build underneath them)"""
+
+    _views = 0
+    _close_pending = False
+
+    def _retain_view(self):
+        self._views += 1
+
+    def _release_view(self):
+        self._views -= 1
+        if self._views == 0 and self._close_pending:
+            self._close_pending = False
+            self._destroy()
+
+    def close(self):
+        if self._views > 0:
+            self._close_pending = True
+        else:
+            self._destroy()
+
+    def _destroy(self):
+        raise NotImplementedError
+
+
 class _DevArray:
     """zero-copy view of library-owned device memory (kept alive by `owner`)"""
 
     def __init__(self, ptr, shape, typestr, owner):
         self.owner = owner
+        if isinstance(owner, _ViewOwner):
+            owner._retain_view()
+            weakref.finalize(self, owner._release_view)
         self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False),
                                          "version": 2, "strides": None}
 
@@ -93,7 +123,7 @@ class DeviceContigs:
         return out
 
 
-class Builder:
+class Builder(_ViewOwner):
     """one GPU's share of a build"""
 
     def __init__(self, k, reverse_complement, device=0, table_slots_hint=0, first_seen_order=False):
@@ -124,14 +154,14 @@ class Builder:
         return dict(distinct_tiles=out[0], tile_slots=out[1], distinct_kmers=out[2], kmer_slots=out[3],
                     distinct_mid_tiles=out[4], mid_tile_slots=out[5], span=out[6], mid_span=out[7])
 
-    def close(self):
+    def _destroy(self):
         if self._h:
             _lib.lib().katome_builder_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
         try:
-            self.close()
+            self._destroy()
         except Exception:
             pass
 

@@ -12,7 +12,7 @@ import torch.distributed as dist
 
 from . import _lib
 from .build import KatomePanic, make_settings
-from .device import Builder, _ptr, _stream, _view
+from .device import Builder, _ViewOwner, _ptr, _stream, _view
 
 
 def _check(status):
@@ -173,17 +173,29 @@ class _InnerBuilder(Builder):
     """the single-GPU builder underneath a ShardedBuilder (owned by it): profile counters, and -- on the root after
     gather() -- the stages of device.Builder"""
 
-    def __init__(self, handle, k, rc, device):     # noqa: super().__init__ would create a builder
+    def __init__(self, handle, k, rc, device, parent=None):     # noqa: super().__init__ would create a builder
+        self.parent = parent                       # the memory behind this builder's views is the parent's to free
         self.k, self.rc, self.device = k, bool(rc), device
         self.nw = _lib.lib().katome_record_words(k)
         self._h = C.c_void_p(handle)
         self.tdev = torch.device("cuda", device)
 
+    def _retain_view(self):
+        if self.parent is not None:
+            self.parent._retain_view()
+
+    def _release_view(self):
+        if self.parent is not None:
+            self.parent._release_view()
+
     def close(self):
         self._h = C.c_void_p()                     # not ours to destroy
 
+    def _destroy(self):
+        pass
 
-class ShardedBuilder:
+
+class ShardedBuilder(_ViewOwner):
     """one rank's share of a sharded build (katome_dist_*); every method is collective"""
 
     def __init__(self, comm, k, reverse_complement, device=0, table_slots_hint=0, first_seen_order=False):
@@ -194,7 +206,11 @@ class ShardedBuilder:
         self._h = C.c_void_p()
         _check(_lib.lib().katome_dist_create(C.byref(s), comm._h, C.byref(self._h)))
         self.tdev = torch.device("cuda", device)
-        self.inner = _InnerBuilder(_lib.lib().katome_dist_inner(self._h), k, reverse_complement, device)
+
+    @property
+    def inner(self):
+        """the rank's single-GPU builder (a fresh handle wrapper per access: no reference cycle with this object)"""
+        return _InnerBuilder(_lib.lib().katome_dist_inner(self._h), self.k, self.rc, self.device, parent=self)
 
     def add_reads(self, packed, first_read, n_reads, read_len, skip=None, batch_reads=0):
         _check(_lib.lib().katome_dist_add_reads(self._h, _ptr(packed), first_read, n_reads, read_len, _ptr(skip), batch_reads, _stream()))
@@ -212,7 +228,7 @@ class ShardedBuilder:
         remove_dead_paths / remove_weak_edges / standardize_* / shrink / graph() work (None elsewhere)"""
         h = C.c_void_p()
         _check(_lib.lib().katome_dist_gather(self._h, root, C.byref(h), _stream()))
-        return _InnerBuilder(h.value, self.k, self.rc, self.device) if h.value else None
+        return _InnerBuilder(h.value, self.k, self.rc, self.device, parent=self) if h.value else None
 
     def exchange_stats(self):
         """{phase: dict(calls, bytes_out, max_message_bytes, ms)} since the last read"""
@@ -224,14 +240,14 @@ class ShardedBuilder:
                                                              max_message_bytes=out[4 * i + 2], ms=out[4 * i + 3] / 1000.0)
                 for i in range(n) if out[4 * i]}
 
-    def close(self):
+    def _destroy(self):
         if self._h:
             _lib.lib().katome_dist_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
         try:
-            self.close()
+            self._destroy()
         except Exception:
             pass
 

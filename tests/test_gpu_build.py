@@ -829,3 +829,32 @@ def test_build_and_stages_on_a_side_stream(oracle):
         assert np.array_equal(dg.edge_dst.cpu().numpy().view(np.uint64), ref.edge_dst)
         b.close()
     side.synchronize()
+
+
+def test_close_waits_for_the_views_of_the_graph(oracle):
+    """Builder.close() with views of its arrays still alive: the library keeps the memory until the last view is gone, so
+    a later build cannot be cut out of the same segments underneath them"""
+    from katome_amd import device as kd
+    n, L, k = 4000, 150, 31
+
+    def build(seed):
+        ascii_reads = oracle.synth_reads(seed, n, L, 40000, 2e-3, 0)
+        packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1).copy()).cuda()
+        b = kd.Builder(k, True, table_slots_hint=1 << 16)
+        b.count_reads(packed, n, L, None)
+        dg = b.finalize()
+        b.close()                                  # put off: dg's arrays are views into the builder's memory
+        return b, dg
+
+    b1, g1 = build(1)
+    assert b1._h and b1._close_pending and b1._views > 0
+    keys = g1.edge_key.clone()
+    labels = g1.edge_label.clone()
+    others = [build(s) for s in (2, 3, 4)]
+    torch.cuda.synchronize()
+    assert torch.equal(g1.edge_key, keys) and torch.equal(g1.edge_label, labels)
+    del g1, keys, labels
+    assert not b1._h and b1._views == 0            # the last view took the builder with it
+    builders = [b for b, _ in others]
+    del others
+    assert all(not b._h for b in builders)
