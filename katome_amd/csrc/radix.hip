@@ -1003,64 +1003,79 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
             for (u64 e = e0 + tid; e < e1; e += BLOCK)
                 atomicMin((unsigned long long*)&lfirst[(u32)(edge_src[e] - a)], (unsigned long long)(2 * seq[e]));
         }
-        for (u32 q = 0; q < 4; ++q) {
-            const u64 lo = seg[q * (n_seg + 1) + sg], hi = seg[q * (n_seg + 1) + sg + 1];
-            for (u64 c = lo; c < hi; c += (u64)DST_ROWS * BLOCK) {
-                if (lmiss + DST_ROWS * BLOCK > MISS_CAP) flush();          // (lmiss was settled by the barrier that ended the last trip)
-                Key<NW> e[DST_ROWS]; u64 sq[DST_ROWS];
+        // the four stretches (one per quarter) are walked as one list of `total` edges, so that a trip is full whatever the
+        // quarters' sizes, and the loads of the next trip are issued before this one's searches (a segment was a chain of
+        // ~9 memory round trips: two per quarter, the second nearly empty)
+        const u64 lo0 = seg[sg], lo1 = seg[(n_seg + 1) + sg], lo2 = seg[2 * (n_seg + 1) + sg], lo3 = seg[3 * (n_seg + 1) + sg];
+        const u64 c1 = seg[sg + 1] - lo0, c2 = c1 + (seg[(n_seg + 1) + sg + 1] - lo1), c3 = c2 + (seg[2 * (n_seg + 1) + sg + 1] - lo2);
+        const u64 total = c3 + (seg[3 * (n_seg + 1) + sg + 1] - lo3);
+        auto edge_of = [&](u64 v) -> u64 { return v < c1 ? lo0 + v : v < c2 ? lo1 + (v - c1) : v < c3 ? lo2 + (v - c2) : lo3 + (v - c3); };
+        Key<NW> e[DST_ROWS], en[DST_ROWS]; u64 sq[DST_ROWS], sqn[DST_ROWS], ei[DST_ROWS], ein[DST_ROWS];
+        auto fetch = [&](u64 c, Key<NW>* ek, u64* es, u64* ex) {
 #pragma unroll
-                for (u32 r = 0; r < DST_ROWS; ++r) {
-                    const u64 i = c + (u64)r * BLOCK + tid;
+            for (u32 r = 0; r < DST_ROWS; ++r) {
+                const u64 v = c + (u64)r * BLOCK + tid;
 #pragma unroll
-                    for (int w = 0; w < NW; ++w) e[r].w[w] = 0;
-                    sq[r] = 0;
-                    if (i < hi) { e[r] = load_key<NW>(keys, i); if (FIRST) sq[r] = seq[i]; }
-                }
-                // the searches of a thread's edges advance in lockstep, a fixed number of halving steps each (branch-free lower
-                // bound): DST_ROWS independent LDS reads are in flight per step
-                Key<NW> d[DST_ROWS]; u32 l[DST_ROWS];
-#pragma unroll
-                for (u32 r = 0; r < DST_ROWS; ++r) { d[r] = target_node(e[r], k); l[r] = 0; }
-#pragma unroll
-                for (u32 step = DST_SEG; step >= 1; step >>= 1) {
-#pragma unroll
-                    for (u32 r = 0; r < DST_ROWS; ++r) {
-                        const u32 idx = l[r] + step;
-                        const bool in = idx <= cnt;
-                        Key<NW> x;
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) x.w[w] = ls[(in ? idx - 1 : 0) * NW + w];
-                        if (in && key_lt(x, d[r])) l[r] = idx;
-                    }
-                }
-#pragma unroll
-                for (u32 r = 0; r < DST_ROWS; ++r) {
-                    const u64 i = c + (u64)r * BLOCK + tid;
-                    if (i >= hi) continue;
-                    bool found = false;
-                    if (l[r] < cnt) {
-                        Key<NW> x;
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) x.w[w] = ls[l[r] * NW + w];
-                        found = key_eq(x, d[r]);
-                    }
-                    if (found) {
-                        edge_dst[i] = a + l[r];
-                        if (FIRST) {
-                            atomicMin((unsigned long long*)&lfirst[l[r]], (unsigned long long)(2 * sq[r] + 1));
-                            const u32 bit = 1u << (l[r] & 31);
-                            if (atomicOr(&lonce[l[r] >> 5], bit) & bit) atomicOr(&lmore[l[r] >> 5], bit);
-                        }
-                    } else {
-                        edge_dst[i] = ~0ull;
-                        const u32 p = atomicAdd(&lmiss, 1u);
-#pragma unroll
-                        for (int w = 0; w < NW; ++w) lmk[p * NW + w] = d[r].w[w];
-                        lme[p] = i;
-                    }
-                }
-                __syncthreads();
+                for (int w = 0; w < NW; ++w) ek[r].w[w] = 0;
+                es[r] = 0; ex[r] = ~0ull;
+                if (v < total) { const u64 i = edge_of(v); ex[r] = i; ek[r] = load_key<NW>(keys, i); if (FIRST) es[r] = seq[i]; }
             }
+        };
+        fetch(0, e, sq, ei);
+        for (u64 c = 0; c < total; c += (u64)DST_ROWS * BLOCK) {
+            fetch(c + (u64)DST_ROWS * BLOCK, en, sqn, ein);
+            // the searches of a thread's edges advance in lockstep, a fixed number of halving steps each (branch-free lower
+            // bound): DST_ROWS independent LDS reads are in flight per step
+            Key<NW> d[DST_ROWS]; u32 l[DST_ROWS];
+#pragma unroll
+            for (u32 r = 0; r < DST_ROWS; ++r) { d[r] = target_node(e[r], k); l[r] = 0; }
+#pragma unroll
+            for (u32 step = DST_SEG; step >= 1; step >>= 1) {
+#pragma unroll
+                for (u32 r = 0; r < DST_ROWS; ++r) {
+                    const u32 idx = l[r] + step;
+                    const bool in = idx <= cnt;
+                    Key<NW> x;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) x.w[w] = ls[(in ? idx - 1 : 0) * NW + w];
+                    if (in && key_lt(x, d[r])) l[r] = idx;
+                }
+            }
+#pragma unroll
+            for (u32 r = 0; r < DST_ROWS; ++r) {
+                const u64 i = ei[r];
+                if (i == ~0ull) continue;
+                bool found = false;
+                if (l[r] < cnt) {
+                    Key<NW> x;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) x.w[w] = ls[l[r] * NW + w];
+                    found = key_eq(x, d[r]);
+                }
+                if (found) {
+                    edge_dst[i] = a + l[r];
+                    if (FIRST) {
+                        atomicMin((unsigned long long*)&lfirst[l[r]], (unsigned long long)(2 * sq[r] + 1));
+                        const u32 bit = 1u << (l[r] & 31);
+                        if (atomicOr(&lonce[l[r] >> 5], bit) & bit) atomicOr(&lmore[l[r] >> 5], bit);
+                    }
+                } else {
+                    edge_dst[i] = ~0ull;
+                    const u32 p = atomicAdd(&lmiss, 1u);
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) lmk[p * NW + w] = d[r].w[w];
+                    lme[p] = i;
+                }
+            }
+            // room for another trip's misses?  Every wave must decide the same, so the count is read between two barriers: a
+            // wave that ran ahead into the next trip could otherwise add to it before a slower one had looked (with the loads
+            // prefetched that did happen: waves parted ways at flush()'s barriers and the grid never finished)
+            __syncthreads();
+            const u32 staged = lmiss;
+            __syncthreads();
+            if (staged + DST_ROWS * BLOCK > MISS_CAP) flush();
+#pragma unroll
+            for (u32 r = 0; r < DST_ROWS; ++r) { e[r] = en[r]; sq[r] = sqn[r]; ei[r] = ein[r]; }
         }
         flush();
         if (FIRST) {                                    // (flush ends with a barrier: the segment's minima are complete)
@@ -1069,16 +1084,14 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
             // second sweep: the edge that is the first to touch its target is marked (DST_FD: what the renumbering asks of every
             // edge, here without a look-up), and so is an edge whose target has no other in-edge (DST_IN1) -- with the matching
             // mark on the source side (one out-edge) the renumbering can tell the nodes nobody will ever look up (dev_assign_nodes)
-            for (u32 q = 0; q < 4; ++q) {
-                const u64 lo = seg[q * (n_seg + 1) + sg], hi = seg[q * (n_seg + 1) + sg + 1];
-                for (u64 i = lo + tid; i < hi; i += BLOCK) {            // (the thread that wrote edge_dst[i])
-                    const u64 d = edge_dst[i];
-                    if (d == ~0ull) continue;
-                    const u32 l = (u32)(d - a), bit = 1u << (l & 31);
-                    u64 marks = (lmore[l >> 5] & bit) ? 0 : DST_IN1;
-                    if (lfirst[l] == 2 * seq[i] + 1) marks |= DST_FD;
-                    if (marks) edge_dst[i] = d | marks;
-                }
+            for (u64 v = tid; v < total; v += BLOCK) {              // (the thread that wrote edge_dst[i])
+                const u64 i = edge_of(v);
+                const u64 d = edge_dst[i];
+                if (d == ~0ull) continue;
+                const u32 l = (u32)(d - a), bit = 1u << (l & 31);
+                u64 marks = (lmore[l >> 5] & bit) ? 0 : DST_IN1;
+                if (lfirst[l] == 2 * seq[i] + 1) marks |= DST_FD;
+                if (marks) edge_dst[i] = d | marks;
             }
             __syncthreads();
         }

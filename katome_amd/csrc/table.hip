@@ -429,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void emit_edges_kernel(const typename SlotOf
                     nemit[j] = 1;
                     if (RC && !key_eq(revcomp(key[j], k), key[j])) nemit[j] = 2;
                     // Clean::remove_weak_edges (pruner.rs:89-92): edges below the threshold are not emitted
-                    if (((RC && nemit[j] == 1) ? cnt[j] * 2u : cnt[j]) < min_weight) nemit[j] = 0;
+                    if ((cnt[j] << ((RC && nemit[j] == 1) ? 1u : 0u)) < min_weight) nemit[j] = 0;
                 }
             }
             mine += nemit[j];
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                     ++my_distinct;
                     ne[j] = 1;
                     if (RC && !key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 2;
-                    if (((RC && ne[j] == 1) ? cc[j] * 2u : cc[j]) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
+                    if ((cc[j] << ((RC && ne[j] == 1) ? 1u : 0u)) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
                 }
                 mine += ne[j];
             }
