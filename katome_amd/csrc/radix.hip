@@ -983,6 +983,25 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
     for (u64 sg = blockIdx.x; sg < n_seg; sg += gridDim.x) {
         const u64 a = sg * DST_SEG;
         const u32 cnt = (u32)((n_src - a) < (u64)DST_SEG ? (n_src - a) : (u64)DST_SEG);
+        // the four stretches (one per quarter) are walked as one list of `total` edges, so that a trip is full whatever the
+        // quarters' sizes, and the loads of the next trip are issued before this one's searches (a segment was a chain of
+        // ~9 memory round trips: two per quarter, the second nearly empty)
+        const u64 lo0 = seg[sg], lo1 = seg[(n_seg + 1) + sg], lo2 = seg[2 * (n_seg + 1) + sg], lo3 = seg[3 * (n_seg + 1) + sg];
+        const u64 c1 = seg[sg + 1] - lo0, c2 = c1 + (seg[(n_seg + 1) + sg + 1] - lo1), c3 = c2 + (seg[2 * (n_seg + 1) + sg + 1] - lo2);
+        const u64 total = c3 + (seg[3 * (n_seg + 1) + sg + 1] - lo3);
+        auto edge_of = [&](u64 v) -> u64 { return v < c1 ? lo0 + v : v < c2 ? lo1 + (v - c1) : v < c3 ? lo2 + (v - c2) : lo3 + (v - c3); };
+        Key<NW> e[DST_ROWS], en[DST_ROWS]; u64 sq[DST_ROWS], sqn[DST_ROWS], ei[DST_ROWS], ein[DST_ROWS];
+        auto fetch = [&](u64 c, Key<NW>* ek, u64* es, u64* ex) {
+#pragma unroll
+            for (u32 r = 0; r < DST_ROWS; ++r) {
+                const u64 v = c + (u64)r * BLOCK + tid;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) ek[r].w[w] = 0;
+                es[r] = 0; ex[r] = ~0ull;
+                if (v < total) { const u64 i = edge_of(v); ex[r] = i; ek[r] = load_key<NW>(keys, i); if (FIRST) es[r] = seq[i]; }
+            }
+        };
+        fetch(0, e, sq, ei);                            // (in flight together with the segment's sources below)
         Key<NW> stage[DST_SEG / BLOCK];
 #pragma unroll
         for (u32 r = 0; r < DST_SEG / BLOCK; ++r) { const u32 j = r * BLOCK + tid; if (j < cnt) stage[r] = load_key<NW>(nodes, a + j); }
@@ -1003,25 +1022,6 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
             for (u64 e = e0 + tid; e < e1; e += BLOCK)
                 atomicMin((unsigned long long*)&lfirst[(u32)(edge_src[e] - a)], (unsigned long long)(2 * seq[e]));
         }
-        // the four stretches (one per quarter) are walked as one list of `total` edges, so that a trip is full whatever the
-        // quarters' sizes, and the loads of the next trip are issued before this one's searches (a segment was a chain of
-        // ~9 memory round trips: two per quarter, the second nearly empty)
-        const u64 lo0 = seg[sg], lo1 = seg[(n_seg + 1) + sg], lo2 = seg[2 * (n_seg + 1) + sg], lo3 = seg[3 * (n_seg + 1) + sg];
-        const u64 c1 = seg[sg + 1] - lo0, c2 = c1 + (seg[(n_seg + 1) + sg + 1] - lo1), c3 = c2 + (seg[2 * (n_seg + 1) + sg + 1] - lo2);
-        const u64 total = c3 + (seg[3 * (n_seg + 1) + sg + 1] - lo3);
-        auto edge_of = [&](u64 v) -> u64 { return v < c1 ? lo0 + v : v < c2 ? lo1 + (v - c1) : v < c3 ? lo2 + (v - c2) : lo3 + (v - c3); };
-        Key<NW> e[DST_ROWS], en[DST_ROWS]; u64 sq[DST_ROWS], sqn[DST_ROWS], ei[DST_ROWS], ein[DST_ROWS];
-        auto fetch = [&](u64 c, Key<NW>* ek, u64* es, u64* ex) {
-#pragma unroll
-            for (u32 r = 0; r < DST_ROWS; ++r) {
-                const u64 v = c + (u64)r * BLOCK + tid;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) ek[r].w[w] = 0;
-                es[r] = 0; ex[r] = ~0ull;
-                if (v < total) { const u64 i = edge_of(v); ex[r] = i; ek[r] = load_key<NW>(keys, i); if (FIRST) es[r] = seq[i]; }
-            }
-        };
-        fetch(0, e, sq, ei);
         for (u64 c = 0; c < total; c += (u64)DST_ROWS * BLOCK) {
             fetch(c + (u64)DST_ROWS * BLOCK, en, sqn, ein);
             // the searches of a thread's edges advance in lockstep, a fixed number of halving steps each (branch-free lower
