@@ -243,8 +243,36 @@ int route_and_insert(katome_dist_builder* d, const u64* part, const u32* idx, co
 // operation of the communicator goes there for the duration), and added to the table on the build's stream again -- while
 // slice j + 1 is already on the links.  Two sets of buffers; events order the two streams (a buffer is written again only
 // behind the wait for the exchange or the insertion that read it, both of which the build's stream has passed by then).
+// what arrived, kept as records instead of being counted in a table (the last level counted by sorting, table.hip)
+struct Collected {
+    DevBuf keys, weights;
+    uint64_t n = 0, cap = 0;
+    explicit Collected(hipStream_t s) : keys(s), weights(s) {}
+    int append(const void* k, const void* w, uint64_t m, uint32_t nwr, uint64_t guess, hipStream_t stream) {
+        if (n + m > cap) {                                   // (a rank receives about what it sends: rarely more than one growth)
+            const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(cap + cap / 2, n + m), guess + guess / 8 + (1u << 20));
+            DevBuf nk(stream), nwt(stream);
+            KCHECK(nk.alloc((want + 1) * 8 * nwr)); KCHECK(nwt.alloc((want + 1) * 4));
+            if (n) {
+                KCHECK_HIP(hipMemcpyAsync(nk.p, keys.p, n * 8 * nwr, hipMemcpyDeviceToDevice, stream));
+                KCHECK_HIP(hipMemcpyAsync(nwt.p, weights.p, n * 4, hipMemcpyDeviceToDevice, stream));
+            }
+            keys.release(); weights.release();
+            { const size_t bytes = nk.bytes; keys.adopt(nk.take(), bytes); }
+            { const size_t bytes = nwt.bytes; weights.adopt(nwt.take(), bytes); }
+            cap = want;
+        }
+        KCHECK_HIP(hipMemcpyAsync((char*)keys.p + n * 8 * nwr, k, m * 8 * nwr, hipMemcpyDeviceToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync((char*)weights.p + n * 4, w, m * 4, hipMemcpyDeviceToDevice, stream));
+        n += m;
+        return KATOME_OK;
+    }
+};
+
+// `collect`: the records that arrive are appended there instead of being added to `table`
 int route_weighted(katome_dist_builder* d, int xphase, const DevBuf& keys, const DevBuf& weights, const DevBuf& seen, uint64_t n_rec, uint32_t nwr,
-                   uint32_t core_shift, uint32_t core_bases, Table& table, bool& ready, uint64_t hint, int phase, hipStream_t stream) {
+                   uint32_t core_shift, uint32_t core_bases, Table& table, bool& ready, uint64_t hint, int phase, hipStream_t stream,
+                   Collected* collect = nullptr) {
     katome_builder* b = d->b;
     const int world = d->world();
     const uint64_t per_slice = std::max<uint64_t>(1, d->comm->max_message_bytes / 4 / (8 * nwr));
@@ -275,7 +303,8 @@ int route_weighted(katome_dist_builder* d, int xphase, const DevBuf& keys, const
         }
         SeenOrigin origin;
         if (d->first_seen) { origin.pairs = sl.rp.as<u64>(); origin.rc = d->rc; }
-        if (sl.nR) KCHECK(builder_insert(b, table, ready, nwr, hint, sl.rk.as<u64>(), sl.rw.as<u32>(), sl.nR, d->first_seen ? &origin : nullptr, phase, stream));
+        if (sl.nR && collect) KCHECK(collect->append(sl.rk.p, sl.rw.p, sl.nR, nwr, n_rec, stream));
+        else if (sl.nR) KCHECK(builder_insert(b, table, ready, nwr, hint, sl.rk.as<u64>(), sl.rw.as<u32>(), sl.nR, d->first_seen ? &origin : nullptr, phase, stream));
         return KATOME_OK;
     };
     int rc = KATOME_OK;
@@ -316,6 +345,38 @@ int route_weighted(katome_dist_builder* d, int xphase, const DevBuf& keys, const
     (void)hipStreamSynchronize(stream);                       // (the buffers go back to the cache behind everything that used them)
     d->comm->use_stream(stream);
     return rc;
+}
+
+// may the k-mer records that arrive be kept and counted by sorting (katome_dev_edges' rule: one-word k-mers by packed key,
+// nothing in the k-mer table yet)?
+bool may_collect(const katome_dist_builder* d) {
+    static const int sorted_count = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
+    return sorted_count && !d->first_seen && d->nw == 1 && !d->b->table_ready;
+}
+// the collected records of this rank's k-mers -> its sorted edges (lds_count_kernel), or, out of that kernel's range, into the
+// k-mer table after all.  No collective in here: every rank decides for itself.
+int count_collected(katome_dist_builder* d, Collected& c, hipStream_t stream) {
+    static const int sorted_count = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
+    katome_builder* b = d->b;
+    if (c.n == 0) return KATOME_OK;
+    if ((c.n >= (1ull << 22) || sorted_count == 2) && (c.n >> 21) <= 2900) {
+        uint64_t distinct = 0;
+        int rc;
+        {
+            PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+            rc = records_to_edges_sorted(c.keys, c.weights, c.n, d->s.k, d->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
+        }
+        if (rc == KATOME_OK) {
+            b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+            c.keys.release(); c.weights.release();
+            PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
+            KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * d->s.k, stream));
+            b->edges_ready = true;
+            return KATOME_OK;
+        }
+        if (rc != KATOME_E_UNSUPPORTED) return rc;
+    }
+    return builder_insert(b, b->table, b->table_ready, d->nw, b->s.table_slots_hint, c.keys.as<u64>(), c.weights.as<u32>(), c.n, nullptr, PH_INSERT, stream);
 }
 
 // every rank's distinct tiles -> (k-mer, count[, sequence numbers]) records -> the k-mers' owners.  `span`: the plan all ranks
@@ -362,7 +423,8 @@ int expand_and_route_kmers(katome_dist_builder* d, uint32_t span, hipStream_t st
         trace_words("last level: slots", d->rank(), last->slots.p, last->cap * last->slot_bytes() / 8, stream);
         {
             PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-            KCHECK(table_expand_tiles_to_records(*last, k, last_span, d->rc, keys, weights, &n_rec, stream, d->first_seen ? &seen : nullptr));
+            if (d->first_seen) KCHECK(table_expand_tiles_to_records(*last, k, last_span, d->rc, keys, weights, &n_rec, stream, &seen));
+            else KCHECK(table_tiles_to_records_fast(*last, k, last_span, d->rc, keys, weights, &n_rec, stream));      // (same records, any order)
         }
         trace_words("last level after: slots", d->rank(), last->slots.p, last->cap * last->slot_bytes() / 8, stream);
         b->tiles.release(); b->tiles2.release();
@@ -373,6 +435,12 @@ int expand_and_route_kmers(katome_dist_builder* d, uint32_t span, hipStream_t st
                 (unsigned long long)b->stat_tiles, (unsigned long long)(b->span2 ? b->stat_tiles2 : b->stat_tiles), (unsigned long long)n_rec);
     trace_words("expand: record keys", d->rank(), keys.p, n_rec * nw, stream);
     trace_words("expand: record weights", d->rank(), weights.p, n_rec / 2, stream);
+    if (may_collect(d)) {
+        Collected got(stream);
+        KCHECK(route_weighted(d, X_KMERS, keys, weights, seen, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream, &got));
+        keys.release(); weights.release();
+        return count_collected(d, got, stream);
+    }
     return route_weighted(d, X_KMERS, keys, weights, seen, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream);
 }
 
@@ -650,9 +718,27 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     if (d->local_first) {
         // every rank finishes its own counting; its DISTINCT k-mers (count, earliest sequence numbers) go to their owners, which
         // add them up in a fresh table
-        if (b->tiles_ready) KCHECK(expand_tiles(b, stream));
         DevBuf keys(stream), weights(stream), pairs(stream);
         uint64_t n_rec = 0;
+        static const int sorted_count = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
+        if (b->tiles_ready && may_collect(d)) {
+            // the rank's own distinct k-mers by sorting (as katome_dev_edges does, but one record per canonical k-mer: no strands yet)
+            uint64_t n_tiles = 0;
+            KCHECK(table_occupied(b->tiles, &n_tiles, stream));
+            const uint64_t bound = n_tiles * b->span;
+            if ((bound >= (1ull << 22) || (sorted_count == 2 && bound)) && (bound >> 21) <= 2900) {
+                Table* last = nullptr; uint32_t last_span = 1;
+                KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+                DevBuf rk(stream), rw(stream);
+                uint64_t n_win = 0, distinct = 0;
+                PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                KCHECK(table_tiles_to_records_fast(*last, k, last_span, d->rc, rk, rw, &n_win, stream));
+                b->tiles.release(); b->tiles2.release();
+                b->tiles_ready = false; b->tiles2_ready = false;
+                KCHECK(records_to_edges_sorted(rk, rw, n_win, k, false, 0, keys, weights, &n_rec, &distinct, stream));
+            }
+        }
+        if (b->tiles_ready) KCHECK(expand_tiles(b, stream));
         if (b->table_ready) {
             PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
             KCHECK(table_to_records(b->table, keys, weights, &n_rec, stream, d->first_seen ? &pairs : nullptr));
@@ -660,7 +746,12 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
         b->table.release(); b->table_ready = false;
         if (getenv("KATOME_DIST_STATS"))
             fprintf(stderr, "[dist] rank %d of %d: %llu distinct k-mers of its own reads to route\n", rank, world, (unsigned long long)n_rec);
-        KCHECK(route_weighted(d, X_KMERS, keys, weights, pairs, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream));
+        if (may_collect(d)) {
+            Collected got(stream);
+            KCHECK(route_weighted(d, X_KMERS, keys, weights, pairs, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream, &got));
+            keys.release(); weights.release();
+            KCHECK(count_collected(d, got, stream));
+        } else KCHECK(route_weighted(d, X_KMERS, keys, weights, pairs, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream));
     } else if (tiled) KCHECK(expand_and_route_kmers(d, (uint32_t)plan[0], stream));
     KCHECK(katome_dev_edges(b, nullptr, nullptr, nullptr, stream));       // this rank's distinct oriented edges, ascending (+ edge_seq)
     const uint64_t E = b->n_edges;
