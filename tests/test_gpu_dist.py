@@ -330,3 +330,57 @@ def test_process_per_rank_in_reference_order(oracle, tmp_path, world, k, rc, L, 
     assert int(r0["root_nodes"]) == want.n_nodes
     assert np.array_equal(r0["root_label"], want.edge_label) and np.array_equal(r0["root_weight"], want.edge_weight)
     assert np.array_equal(r0["root_src"].astype(np.uint64), want.edge_src) and np.array_equal(r0["root_dst"].astype(np.uint64), want.edge_dst)
+
+
+_SORTED_SHARDED_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii, int_to_kmer
+from oracle import oracle as o
+from katome_amd.build import GpuGraph
+from katome_amd import shard as ks
+for world, k, rc, n, L in ((2, 31, True, 1200, 150), (3, 21, False, 900, 100), (8, 31, True, 1500, 150), (4, 15, True, 700, 53)):
+    reads = o.synth_reads(11, n, L, 9000, 4e-3, 0)
+    packed = pack_reads_ascii(reads)
+    g, _ = GpuGraph.create_from_packed(packed, n, L, skip=None, reverse_complement=rc, k=k, n_devices=world, ranks_share_device=True)
+    ref = o.build_ascii(reads, k, rc)
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges), (world, k, g.n_nodes, g.n_edges, ref.n_nodes, ref.n_edges)
+    assert g.multiset() == ref.multiset(), (world, k)
+    print("SS", world, k, g.n_nodes, g.n_edges, hashlib.sha256(repr(g.multiset()).encode()).hexdigest())
+# Clean::remove_weak_edges as the edges are counted (one rank over RCCL: the route of bench.py)
+k, rc, n, L, thr = 31, True, 2000, 150, 2
+reads = o.synth_reads(12, n, L, 4000, 4e-3, 0)
+pt = torch.from_numpy(np.concatenate([pack_reads_ascii(reads).reshape(-1), np.zeros(32, np.uint8)])).cuda()
+comm = ks.Comm.rccl(0, 1, 0)
+sb = ks.ShardedBuilder(comm, k, rc)
+sb.remove_weak_edges(thr)
+sb.add_reads(pt, 0, n, L, None, 0)
+g = sb.finalize()
+ref = o.build_ascii(reads, k, rc, remove_weak_edges=thr)
+got = sorted(zip((int_to_kmer(int(v) & ((1 << 64) - 1), k) for v in g.edge_key.cpu().numpy().reshape(-1).tolist()),
+                 (int(w) for w in g.edge_weight.cpu().numpy().view(np.uint32))))
+assert got == ref.multiset() and len(got) > 100, (len(got), ref.n_edges)
+print("SS weak", len(got), hashlib.sha256(repr(got).encode()).hexdigest())
+del g
+sb.close(); comm.close()
+"""
+
+
+@pytest.mark.parametrize("route", ["local", "tiles"])
+def test_sharded_routes_with_the_last_level_counted_by_sorting(tmp_path, route):
+    """by packed key the k-mer records that reach their owners are kept and counted by sorting (from 4 M records on; forced here
+    with KATOME_SORTED_COUNT=2, in a process of its own: the switch is read once) -- same graph as the oracle's and as the
+    k-mer table's (KATOME_SORTED_COUNT=0), with and without the remove_weak_edges threshold, ranks without reads included"""
+    import subprocess
+    script = tmp_path / "ss.py"
+    script.write_text(_SORTED_SHARDED_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ, KATOME_DIST_ROUTE=route, **extra)
+        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return sorted(line for line in out.stdout.splitlines() if line.startswith("SS "))
+    forced = run({"KATOME_SORTED_COUNT": "2"})
+    assert len(forced) == 5
+    assert run({"KATOME_SORTED_COUNT": "0"}) == forced
