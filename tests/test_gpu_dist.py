@@ -352,6 +352,7 @@ k, rc, n, L, thr = 31, True, 2000, 150, 2
 reads = o.synth_reads(12, n, L, 4000, 4e-3, 0)
 pt = torch.from_numpy(np.concatenate([pack_reads_ascii(reads).reshape(-1), np.zeros(32, np.uint8)])).cuda()
 comm = ks.Comm.rccl(0, 1, 0)
+comm.set_max_message_bytes(1 << 16)            # many slices: the collected records arrive piecemeal
 sb = ks.ShardedBuilder(comm, k, rc)
 sb.remove_weak_edges(thr)
 sb.add_reads(pt, 0, n, L, None, 0)
