@@ -851,6 +851,14 @@ int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+    if (!out_seen && tiles.nw == 2 && nwk == 2) {
+        // two-word tiles into two-word sub-tiles without sequence numbers (C3's 60-mers into 36-mers on the sharded route): the
+        // compacting kernel of the last level, 3.0 -> 0.6 ms for an eighth of C3
+        dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
+        if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<2, 2, true>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, stride, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        else    hipLaunchKernelGGL((tiles_to_records_kernel<2, 2, false>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, stride, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
+        KCHECK_HIP(hipGetLastError());
+    } else
     KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, stride, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream, out_seen));
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
