@@ -179,14 +179,14 @@ int katome_dev_partition_core(int device, const uint64_t* d_records, const uint3
 uint32_t katome_key_owner(const uint64_t* key, uint32_t key_words, uint32_t core_shift, uint32_t core_bases, uint32_t n_parts) {
     if (key_words == 1) {
         Key<1> a; a.w[0] = key[0];
-        return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
+        return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : whole_key_owner(a, n_parts));
     }
     if (key_words == 3) {
         Key<3> a; a.w[0] = key[0]; a.w[1] = key[1]; a.w[2] = key[2];
-        return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
+        return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : whole_key_owner(a, n_parts));
     }
     Key<2> a; a.w[0] = key[0]; a.w[1] = key[1];
-    return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : hash_to_range(hash_key(a), n_parts));
+    return (uint32_t)(core_bases ? core_owner(a, core_shift, core_bases, n_parts) : whole_key_owner(a, n_parts));
 }
 
 }  // extern "C"

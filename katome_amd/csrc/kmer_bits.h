@@ -188,6 +188,11 @@ template <int NW> KD Key<NW> canonical_flip(const Key<NW>& a, u32 k, bool& flipp
 // middle (k-2)-mer: shared by the k-mer and its reverse complement (so a stored canonical k-mer and both oriented edges
 // it stands for agree) and equal to the last k-2 bases of its source node.  For a (k-1)-mer node, shift = 0 and
 // core = k-2 name that same tail: every out-edge of a node lives on the rank that owns the node.
+// Owner of a record among n ranks by the whole record (tiles, mid tiles).  NOT hash_to_range(hash_key(.)): the owner's table
+// puts a key at slot mulhi(hash_key, capacity), so a rank that owned one hash RANGE would fill one n-th of its table with all
+// of its keys (eight ranks: the mid-tile table, sized for what arrives, ran 8 x over its load limit in that stretch and an
+// insert of 1.6 M records took 2 s).  A second mix makes the owner independent of the slot.
+template <int NW> KD u64 whole_key_owner(const Key<NW>& a, u64 n) { return hash_to_range(mix64(hash_key(a) ^ 0x5851F42D4C957F2Dull), n); }
 template <int NW> KD u64 core_owner(const Key<NW>& a, u32 shift, u32 core, u64 n) {
     const Key<NW> m = key_low_bits(key_shr(a, shift), 2 * core);
     return hash_to_range(hash_key(canonical(m, core)), n);

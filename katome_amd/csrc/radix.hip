@@ -49,7 +49,7 @@ template <int NW> struct OwnerDigit {
         if (!key_valid(k0)) return (u32)n_parts;
         Key<NW> k = k0;
         k.w[0] &= ~RC_MARK;              // first-seen-order records carry the orientation they dropped: not part of the key
-        return core_bases ? (u32)core_owner(k, core_shift, core_bases, n_parts) : (u32)hash_to_range(hash_key(k), n_parts);
+        return core_bases ? (u32)core_owner(k, core_shift, core_bases, n_parts) : (u32)whole_key_owner(k, n_parts);
     }
 };
 // owner = the part of an ascending list of u64 values a value falls into: bounds[p] = first value of part p + 1

@@ -74,7 +74,7 @@ void hs_label(const uint64_t* in, uint32_t k, uint8_t* out) {
     for (uint32_t i = 0; i < nb; ++i) out[1 + i] = key_words_for_k(k) == 1 ? label_byte(ld<1>(in), k, i) : label_byte(ld<2>(in), k, i);
 }
 uint64_t hs_hash(const uint64_t* in, int nw) { return nw == 1 ? hash_key(ld<1>(in)) : nw == 2 ? hash_key(ld<2>(in)) : hash_key(ld<3>(in)); }
-uint64_t hs_owner(const uint64_t* in, int nw, uint64_t n) { return hash_to_range(hs_hash(in, nw), n); }
+uint64_t hs_owner(const uint64_t* in, int nw, uint64_t n) { return nw == 1 ? whole_key_owner(ld<1>(in), n) : nw == 2 ? whole_key_owner(ld<2>(in), n) : whole_key_owner(ld<3>(in), n); }
 uint64_t hs_core_owner(const uint64_t* in, int nw, uint32_t shift, uint32_t core, uint64_t n) {
     return nw == 1 ? core_owner(ld<1>(in), shift, core, n) : core_owner(ld<2>(in), shift, core, n);
 }

@@ -107,7 +107,7 @@ def test_rank_in_sorted(nw, bits):
 @pytest.mark.parametrize("k", [31, 40])
 @pytest.mark.parametrize("n_parts", [1, 2, 8])
 def test_partition_by_owner(k, n_parts):
-    """records grouped by owner = mulhi(mix(key), n_parts); invalid records dropped; multiset kept"""
+    """records grouped by owner = mulhi(mix(hash(key) ^ c), n_parts) (kmer_bits.h whole_key_owner); invalid records dropped; multiset kept"""
     import ctypes as C
     from katome_amd import device as kd
     from helpers import hostshim

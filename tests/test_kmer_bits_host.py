@@ -104,6 +104,24 @@ def test_digits_and_owner_ranges():
                 assert 0 <= L.hs_owner(w, nw, n) < n
 
 
+def test_owner_of_a_record_is_independent_of_its_table_slot():
+    """a rank's table puts a key at mulhi(hash, capacity); if the owner were mulhi(hash, ranks) as well, every key of a rank would
+    land in one n-th of its table (eight thread ranks: a mid-tile insert of 1.6 M records took 2 s).  The keys one rank owns
+    spread evenly over the table's stretches."""
+    L = hostshim()
+    rng = random.Random(11)
+    ranks, stretches = 8, 16
+    for nw in (1, 2, 3):
+        hist = [[0] * stretches for _ in range(ranks)]
+        for _ in range(16000):
+            w = shim_words(rng.getrandbits(60 * nw), nw)
+            hist[L.hs_owner(w, nw, ranks)][(L.hs_hash(w, nw) * stretches) >> 64] += 1
+        for r in range(ranks):
+            n = sum(hist[r])
+            assert 1600 < n < 2400
+            assert max(hist[r]) < 2.0 * n / stretches and min(hist[r]) > 0.5 * n / stretches, (nw, r, hist[r])
+
+
 def test_splitmix_matches_oracle(oracle):
     L = hostshim()
     for x in (0, 1, 2 ** 63, 0x6B61746F6D650001, 2 ** 64 - 1):

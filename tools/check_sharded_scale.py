@@ -1,0 +1,54 @@
+"""A sharded build (thread ranks sharing the card, both routes) against the one-GPU build of the same reads, at a size where
+the routes run in slices and the last level is counted by sorting on its own (>= 4 M records): edge multiset by an
+order-free checksum, node set, and every edge's end points.  usage: python tools/check_sharded_scale.py [reads=8000000] [world=4] [routes=tiles,local]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from katome_amd import device as kd  # noqa: E402
+from katome_amd.build import GpuGraph  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+L, k = 150, 31
+packed_d, _ = kd.synth_reads(0, n, L, n // 2, 1e-3, 0, device=0)
+packed = packed_d.cpu().numpy()
+del packed_d
+torch.cuda.empty_cache()
+M = np.uint64(0x9E3779B97F4A7C15)
+
+
+def digest(g):
+    key = g.edge_key.reshape(-1)
+    h = (key * M) ^ (key >> np.uint64(29))
+    s = int((h * g.edge_weight.astype(np.uint64)).sum(dtype=np.uint64))
+    x = int(np.bitwise_xor.reduce(h + g.edge_weight.astype(np.uint64)))
+    nk = g.node_key.reshape(-1)
+    ns = int(((nk * M) ^ (nk >> np.uint64(31))).sum(dtype=np.uint64))
+    mask = np.uint64((1 << (2 * (k - 1))) - 1)
+    ok_src = bool((nk[g.edge_src.astype(np.int64)] == (key >> np.uint64(2))).all())
+    ok_dst = bool((nk[g.edge_dst.astype(np.int64)] == (key & mask)).all())
+    return (g.n_nodes, g.n_edges, s, x, ns, int(g.edge_weight.sum(dtype=np.uint64))), ok_src and ok_dst
+
+
+t0 = time.time()
+one, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k)
+want, ok = digest(one)
+print("one GPU  ", want, "end points ok:", ok, "%.1f s" % (time.time() - t0), flush=True)
+del one
+bad = not ok
+for route in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("tiles", "local")):
+    os.environ["KATOME_DIST_ROUTE"] = route
+    t0 = time.time()
+    g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=True)
+    got, ok = digest(g)
+    print("%d ranks %s" % (world, route), got, "end points ok:", ok, "same:", got == want, "%.1f s" % (time.time() - t0), flush=True)
+    bad |= (got != want) or not ok
+    del g
+print("OK" if not bad else "MISMATCH")
+sys.exit(1 if bad else 0)
