@@ -1,6 +1,6 @@
 """A sharded build (thread ranks sharing the card, both routes) against the one-GPU build of the same reads, at a size where
 the routes run in slices and the last level is counted by sorting on its own (>= 4 M records): edge multiset by an
-order-free checksum, node set, and every edge's end points.  usage: python tools/check_sharded_scale.py [reads=8000000] [world=4] [routes=tiles,local]"""
+order-free checksum, node set, and every edge's end points.  usage: python tools/check_sharded_scale.py [reads=8000000] [world=4] [routes=tiles,local] [table_slots_hint=0]"""
 import os
 import sys
 import time
@@ -16,6 +16,7 @@ from katome_amd.build import GpuGraph  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 L, k = 150, 31
+hint = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 packed_d, _ = kd.synth_reads(0, n, L, n // 2, 1e-3, 0, device=0)
 packed = packed_d.cpu().numpy()
 del packed_d
@@ -45,7 +46,8 @@ bad = not ok
 for route in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("tiles", "local")):
     os.environ["KATOME_DIST_ROUTE"] = route
     t0 = time.time()
-    g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=True)
+    g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=True,
+                                        table_slots_hint=hint)
     got, ok = digest(g)
     print("%d ranks %s" % (world, route), got, "end points ok:", ok, "same:", got == want, "%.1f s" % (time.time() - t0), flush=True)
     bad |= (got != want) or not ok
