@@ -385,3 +385,20 @@ def test_sharded_routes_with_the_last_level_counted_by_sorting(tmp_path, route):
     forced = run({"KATOME_SORTED_COUNT": "2"})
     assert len(forced) == 5
     assert run({"KATOME_SORTED_COUNT": "0"}) == forced
+
+
+def test_sharded_build_at_a_size_where_the_routes_run_in_earnest():
+    """8 thread ranks on 8 M reads through the level-by-level route against the one-GPU build of the same reads (order-free
+    checksums of edges, weights, nodes; every edge's end points) -- and in reasonable time: while a tile's owner was the hash
+    range its table slot came from, every rank crowded its keys into an eighth of its tables and this build took 40 s"""
+    import subprocess
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_sharded_scale.py"), "8000000", "8", "tiles"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    assert "same: True" in out.stdout and "OK" in out.stdout.splitlines()[-1]
+    took = [float(line.split()[-2]) for line in out.stdout.splitlines() if line.startswith("8 ranks")]
+    assert took and took[0] < 15.0, out.stdout
+    assert time.time() - t0 < 120
