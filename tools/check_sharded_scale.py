@@ -1,6 +1,7 @@
 """A sharded build (thread ranks sharing the card, both routes) against the one-GPU build of the same reads, at a size where
 the routes run in slices and the last level is counted by sorting on its own (>= 4 M records): edge multiset by an
-order-free checksum, node set, and every edge's end points.  usage: python tools/check_sharded_scale.py [reads=8000000] [world=4] [routes=tiles,local] [table_slots_hint=0]"""
+order-free checksum, node set, and every edge's end points.  usage: python tools/check_sharded_scale.py [reads=8000000] [world=4] [routes=tiles,local] [table_slots_hint=0] [k=31] [fs]
+(fs: the reference's numbering + remove_dead_paths on the gathered graph; every array must equal the one-GPU build's)"""
 import os
 import sys
 import time
@@ -15,7 +16,9 @@ from katome_amd.build import GpuGraph  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
 world = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-L, k = 150, 31
+L = 150
+k = int(sys.argv[5]) if len(sys.argv) > 5 else 31
+fs = len(sys.argv) > 6 and sys.argv[6] == "fs"
 hint = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 packed_d, _ = kd.synth_reads(0, n, L, n // 2, 1e-3, 0, device=0)
 packed = packed_d.cpu().numpy()
@@ -37,6 +40,31 @@ def digest(g):
     return (g.n_nodes, g.n_edges, s, x, ns, int(g.edge_weight.sum(dtype=np.uint64))), ok_src and ok_dst
 
 
+if fs:
+    import hashlib
+
+    def arrays(g):
+        h = hashlib.sha256()
+        for a in (g.edge_key, g.edge_weight, g.edge_src, g.edge_dst, g.node_key, g.edge_label):
+            h.update(np.ascontiguousarray(a).tobytes())
+        return g.n_nodes, g.n_edges, h.hexdigest()
+    t0 = time.time()
+    one, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, first_seen_order=True, remove_dead_paths=True)
+    want = arrays(one)
+    print("one GPU  ", want, "%.1f s" % (time.time() - t0), flush=True)
+    del one
+    bad = False
+    for route in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("tiles", "local")):
+        os.environ["KATOME_DIST_ROUTE"] = route
+        t0 = time.time()
+        g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=True,
+                                            first_seen_order=True, remove_dead_paths=True, table_slots_hint=hint)
+        got = arrays(g)
+        print("%d ranks %s" % (world, route), got, "same:", got == want, "%.1f s" % (time.time() - t0), flush=True)
+        bad |= got != want
+        del g
+    print("OK" if not bad else "MISMATCH")
+    sys.exit(1 if bad else 0)
 t0 = time.time()
 one, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k)
 want, ok = digest(one)
