@@ -187,6 +187,7 @@ __global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, u64* __restric
         }
         __syncthreads();
         const u32 have = cnt;
+        __syncthreads();                                                   // (everybody has looked before thread 0 may reset the count)
         const bool last = v0 + step >= N;
         if (have > INPUT_BUF - BLOCK || (last && have)) {                  // one claim on the shared counter per ~2000 vertices
             if (threadIdx.x == 0) { base = atomicAdd((unsigned long long*)&totals[2], (unsigned long long)have); cnt = 0; }
