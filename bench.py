@@ -27,6 +27,19 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E p
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # written from tools/profile_round.sh output
 
 
+def source_id():
+    """identifies the kernels the library was built from: sha256 over the HIP/C++ sources and headers.  Stored in
+    profiles/pmc_latest.json when the PMC passes are taken; traffic from passes taken on other sources is refused"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "katome_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(parts, config):
     """HBM bytes per launch of a phase from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
     separate runs, KiB per dispatch) -- only when they were taken on this very configuration.
@@ -38,6 +51,8 @@ def pmc_traffic(parts, config):
     except Exception:
         return None
     if any(pmc.get("config", {}).get(k) != config.get(k) for k in ("reads", "read_len", "k", "batch_reads", "tile_span")):
+        return None
+    if pmc.get("source_id") != source_id():          # counters of other kernels than the ones that run now: stale
         return None
     total, detail = 0.0, []
     for kernel_name, mult, streaming in parts:
@@ -72,8 +87,8 @@ def parse_args():
     ap.add_argument("--min-weight", type=int, default=0,
                     help="Clean::remove_weak_edges(threshold) as the edges are read out (pruner.rs:84-93; not the BASELINE metric's configuration)")
     ap.add_argument("--table-factor", type=float, default=1.8, help="k-mer table slots per expected distinct canonical k-mer")
-    ap.add_argument("--cpu-sample-reads", type=int, default=300_000,
-                    help="reads of the workload the oracle builds on one host core (1e6 = all of C2; ~85 s there)")
+    ap.add_argument("--cpu-sample-reads", type=int, default=600_000,
+                    help="reads of the workload the oracle builds on one host core (600 k of C3: ~55 s, 122 M edges; 1e6 = all of C2, ~85 s)")
     ap.add_argument("--prune", action="store_true",
                     help="BASELINE config 5: Prunable::remove_dead_paths after the build (reference order; N > 1: on the gathered graph)")
     ap.add_argument("--no-extras", action="store_true",
@@ -453,13 +468,16 @@ def main():
                         "expand_mid_tiles": "expand_tiles_kernel (big tiles -> mid tiles)",
                         "region_order": "radix_hist_kernel+radix_scatter_kernel (HashDigit)",
                         "emit_edges": "emit_edges_kernel", "sort_edges": "radix sort (edges)",
-                        "node_set": "endpoints + radix sort + unique", "rank": "bucket_index + rank_kernel",
+                        "node_set": "src_count/src_write_kernel + dst_seg_kernel + dst_merge_kernel (+ missing_rank_kernel)", "rank": "bucket_index + rank_kernel",
                         "labels": "labels_kernel"}
         if sorted_last_level:
             kernel_names["expand_tiles"] = "tiles_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_kernel (no k-mer table; the edges are written here)"
-        kernels = {}
+        kernels = {}                      # phases of the build (one or several launches each)
+        kernel_launches = {}              # single kernels timed launch by launch inside the phases (library: KernelScope)
         reads_per_rank_step = wl.reads / world
         for name, ph in phases.items():
+            if name.startswith("k:"):
+                continue
             entry = {"kernel": kernel_names.get(name, name), "launches_per_step": ph["launches"] / args.steps,
                      "avg_ms": ph["avg_ms"], "ms_per_step": ph["total_ms"] / args.steps}
             if name in alg:
@@ -478,30 +496,79 @@ def main():
                      nwt, _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or 1), rcs),
                  "sort_edges": "void radix_scatter_kernel<%d, true, RadixDigit<%d> >" % (nw, nw),
                  "emit_edges": "void emit_edges_kernel<%d, %s, %d>" % (nw, rcs, 4 if (args.first_seen_order or args.prune or nw > 1) else 8)}
+        # per-kernel algorithmic bytes of ONE launch (the default build on one GPU only: other routes run the same kernels on
+        # other record counts), and the name rocprofv3 lists the kernel under
+        kalg, kexact = {}, {}
+        if not use_dist and cnt and not (args.first_seen_order or args.prune):
+            pair = 8 * nw + 4
+            kalg.update({"radix_scatter_kernel<RadixDigit>": n_edges * 2 * pair, "radix_hist_kernel<RadixDigit>": n_edges * 8 * nw,
+                         "run_sort_kernel": n_edges * 2 * pair,
+                         "src_count+src_write": (n_edges * (2 * 8 * nw + 8) + n_nodes * 8 * nw) / 2.0,       # two launches, each reads the keys
+                         "dst_merge_kernel": n_edges * (8 * nw + 8) + n_nodes * 8 * nw})
+            kexact.update({"radix_scatter_kernel<RadixDigit>": exact["sort_edges"],
+                           "radix_hist_kernel<RadixDigit>": "void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw),
+                           "run_sort_kernel": "void run_sort_kernel<%d, true>" % nw, "dst_merge_kernel": "void dst_merge_kernel<%d, false>" % nw})
+            if sorted_last_level:
+                ms2 = cnt.get("mid_span", 0)
+                last_slots, last_tiles, last_span, last_nw = ((cnt["mid_tile_slots"], cnt["distinct_mid_tiles"], ms2, _katome_lib().katome_tile_words(wl.k, ms2)) if ms2
+                                                              else (cnt["tile_slots"], cnt["distinct_tiles"], span, nwt))
+                n_rec = last_tiles * last_span
+                kalg.update({"radix_scatter_kernel<HashDigit>": n_rec * 2 * 12, "radix_hist_kernel<HashDigit>": n_rec * 8,
+                             "tiles_to_records_kernel": last_slots * 16 * last_nw + n_rec * 12, "hash_group_index_kernel": n_rec * 8,
+                             "lds_count_kernel": n_rec * 12 + n_edges * 12})
+                kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<1, true, HashDigit<1> >",
+                               "radix_hist_kernel<HashDigit>": "void radix_hist_kernel<1, HashDigit<1> >",
+                               "tiles_to_records_kernel": "void tiles_to_records_kernel<%d, 1, %s>" % (last_nw, rcs),
+                               "hash_group_index_kernel": "hash_group_index_kernel", "lds_count_kernel": "void lds_count_kernel<%s>" % rcs})
+        for name, ph in phases.items():
+            if not name.startswith("k:"):
+                continue
+            kn = name[2:]
+            entry = {"launches_per_step": ph["launches"] / args.steps, "avg_ms": ph["avg_ms"], "ms_per_step": ph["total_ms"] / args.steps}
+            if kn in kalg:
+                entry["alg_bytes_per_launch"] = kalg[kn]
+                entry["achieved_GBs"] = kalg[kn] / (ph["avg_ms"] * 1e-3) / 1e9
+                entry["frac_of_hbm_peak"] = entry["achieved_GBs"] / HBM_PEAK_GBS
+            kernel_launches[kn] = entry
 
-        def roof(name):
-            # phases made of several launches of one kernel (the 8 scatter passes of the edge sort, the slot
-            # ranges of the expansion) are priced per phase: bytes of the phase / time of the phase
+        def roof_phase(name):
+            # a PHASE made of several launches (the passes of the edge sort, the five kernels of the sorted last level): bytes of
+            # the phase / time of the phase.  Not `roofline` (that is one kernel, below); kept under `roofline_phase`
             passes = sort_passes[0][0]
             parts = {"sort_edges": [(exact["sort_edges"], passes, True),
                                     ("void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw), passes, True),
                                     ("radix_chunk_kernel", passes, True)]}
+            label = kernel_names.get(name, name)
             if sorted_last_level:          # (the phase is five kernels: records, two partition passes with their histograms, index, counting)
-                exact["expand_tiles"] = "void lds_count_kernel<%s>" % rcs
-                parts["expand_tiles"] = [("void tiles_to_records_kernel<%d, 1, %s>" % (
-                                              _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or span), rcs), 1, True),
-                                         ("void radix_scatter_kernel<1, true, HashDigit<1> >", 2, True),
-                                         ("void radix_hist_kernel<1, HashDigit<1> >", 2, True),
-                                         ("hash_group_index_kernel", 1, True), (exact["expand_tiles"], 1, False)]
+                parts["expand_tiles"] = [(kexact["tiles_to_records_kernel"], 1, True), (kexact["radix_scatter_kernel<HashDigit>"], 2, True),
+                                         (kexact["radix_hist_kernel<HashDigit>"], 2, True), ("hash_group_index_kernel", 1, True),
+                                         (kexact["lds_count_kernel"], 1, False)]
+            single = name not in parts
             parts = parts.get(name, [(exact.get(name, name), 1, name == "extract")])
             t = pmc_traffic(parts, cfg_now) if not use_dist else None
-            return {"kernel": exact.get(name, kernel_names.get(name, name)).replace("void ", ""), "phase": name, "bound": "hbm",
+            return {"kernel": exact[name].replace("void ", "") if (single and name in exact) else None, "kernels": label, "phase": name, "bound": "hbm",
                     "achieved": kernels[name]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": kernels[name]["frac_of_hbm_peak"], "traffic": t["bytes_per_launch"] if t else None,
                     "traffic_detail": t, "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"],
                     "avg_launch_ms": kernels[name]["avg_ms"], "ms_per_step": kernels[name]["ms_per_step"]}
+
+        def roof_kernel(kn):
+            e = kernel_launches[kn]
+            streaming = kn != "lds_count_kernel"
+            t = pmc_traffic([(kexact[kn], 1, streaming)], cfg_now) if kn in kexact and not use_dist else None
+            return {"kernel": kexact.get(kn, kn).replace("void ", ""), "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": e["frac_of_hbm_peak"], "traffic": t["bytes_per_launch"] if t else None, "traffic_detail": t,
+                    "alg_bytes_per_launch": e["alg_bytes_per_launch"], "avg_launch_ms": e["avg_ms"],
+                    "launches_per_step": e["launches_per_step"], "ms_per_step": e["ms_per_step"],
+                    "timed": "HIP events around every launch of this kernel on the build's stream (library KernelScope)"}
+        # `roofline` = the ONE kernel the step spends most time in: a kernel timed launch by launch, or a phase that is one kernel
+        multi = {"sort_edges", "node_set"} | ({"expand_tiles"} if sorted_last_level else set())
+        cands = [("k", kn, e["ms_per_step"]) for kn, e in kernel_launches.items() if "alg_bytes_per_launch" in e]
+        cands += [("p", n, e["ms_per_step"]) for n, e in kernels.items() if e.get("alg_bytes_per_launch", 0) > 0 and n not in multi]
+        kind, dom_name, _ = max(cands, key=lambda c: c[2])
+        roofline = roof_kernel(dom_name) if kind == "k" else roof_phase(dom_name)
         dom = max((n for n in kernels if kernels[n].get("alg_bytes_per_launch", 0) > 0), key=lambda n: kernels[n]["ms_per_step"])
-        roofline = roof(dom)
+        roof = roof_phase
         line = {
             "metric": "k-mers/s", "value": kmers / (ms_per_step * 1e-3), "unit": "k-mers/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -519,7 +586,8 @@ def main():
                            else "tiles, mid tiles and k-mer records routed by hash (three all-to-alls)")
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
-            "roofline": roofline, "roofline_extract": roof("extract"), "kernels": kernels, "counts": cnt,
+            "roofline": roofline, "roofline_phase": roof_phase(dom), "roofline_extract": roof_phase("extract"),
+            "kernels": kernels, "kernel_launches": kernel_launches, "counts": cnt, "source_id": source_id(),
         }
         if args.prune:
             line["config"]["pruner"] = "remove_dead_paths after the build (reference order%s)" % (", on the graph gathered to rank 0" if use_dist else "")

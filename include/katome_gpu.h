@@ -389,6 +389,10 @@ int katome_dev_edges(katome_builder *b, uint64_t **d_edge_key, uint32_t **d_edge
 /* The library keeps freed device blocks for reuse (hipMalloc/hipFree of multi-GiB buffers are slow);
  * this hands them back to the driver.                                                         */
 int katome_dev_release_cache(int device);
+/* out[0] = bytes the library holds from the driver on `device` (all segments), out[1] = how many of them are free
+ * (cached), out[2] = blocks handed out and not yet returned.  After katome_dev_release_cache() out[0] is what live
+ * builders / results still pin -- 0 when everything was closed.                                                   */
+int katome_dev_cache_stats(int device, uint64_t out[3]);
 
 /* ---- multi-GPU: the sharded build, one rank per GPU -------------------------------------------------------
  * The reference is one sequential loop (builder.rs:152-160); what shards is the read set.  Reads are split contiguously by

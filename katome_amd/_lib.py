@@ -137,6 +137,7 @@ SYMBOLS = {
     "katome_dev_remove_dead_paths": (_i, [_vp, C.POINTER(DevGraph), C.POINTER(PruneStats), _vp]),
     "katome_dev_edges": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
     "katome_dev_release_cache": (_i, [_i]),
+    "katome_dev_cache_stats": (_i, [_i, u64p]),
     "katome_dev_sort": (_i, [_i, _vp, _vp, _u64, _u32, _u32, _vp]),
     "katome_dev_unique": (_i, [_i, _vp, _u64, _u32, u64p, _vp]),
     "katome_dev_rank": (_i, [_i, _vp, _u64, _u32, _u32, _vp, _u64, _vp, _vp]),

@@ -874,6 +874,12 @@ int katome_dev_release_cache(int device) {
     return KATOME_OK;
 }
 
+int katome_dev_cache_stats(int device, uint64_t out[3]) {
+    if (!out) { set_error("null argument"); return KATOME_E_ARG; }
+    dev_cache_stats(device, out);
+    return KATOME_OK;
+}
+
 int katome_dev_sort(int device, uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t key_words, uint32_t key_bits, void* stream) {
     KCHECK(use_device(device));
     return dev_sort(d_keys, d_vals, n, key_words, key_bits, (hipStream_t)stream);

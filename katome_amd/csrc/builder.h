@@ -8,26 +8,6 @@
 
 using namespace katome;
 
-// optional per-phase HIP-event timing on the caller's stream (bench.py's roofline figures)
-enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
-             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_SHRINK, PH_COUNT };
-static const char* const PHASE_NAMES[PH_COUNT] = {"extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set",
-                                                  "rank", "labels", "insert_tiles", "expand_tiles", "expand_mid_tiles", "first_seen_order", "remove_dead_paths", "shrink"};
-struct Profiler {
-    bool on = false;
-    struct Ev { int phase; hipEvent_t a, b; };
-    std::vector<Ev> evs;
-    ~Profiler() { clear(); }
-    void clear() { for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } evs.clear(); }
-};
-struct PhaseScope {
-    Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase;
-    PhaseScope(Profiler& prof, int ph, hipStream_t st) : p(prof.on ? &prof : nullptr), s(st), phase(ph) {
-        if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
-    }
-    ~PhaseScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b}); } }
-};
-
 struct katome_builder {
     katome_settings s;
     Profiler prof;

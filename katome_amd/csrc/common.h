@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 #include "../../include/katome_gpu.h"
 #include "kmer_bits.h"
@@ -38,6 +39,7 @@ size_t dev_cached_bytes();
 // call before hipStreamDestroy: cached blocks remember the stream they were last used on
 void dev_retire_stream(hipStream_t stream);
 void dev_release_cache(int device);
+void dev_cache_stats(int device, uint64_t out[3]);   // {bytes held from the driver, of them free, live blocks} on `device`
 
 // device buffer with RAII; `stream` is the stream the buffer's users are ordered on
 struct DevBuf {
@@ -65,6 +67,46 @@ struct DevBuf {
     void* take() { void* q = p; p = nullptr; bytes = 0; return q; }
     void adopt(void* q, size_t n) { release(); p = q; bytes = n; }
     template <class T> T* as() const { return (T*)p; }
+};
+
+// Optional HIP-event timing on the stream the kernels are launched on (bench.py's roofline figures).  PHASES bracket a step of
+// the build (several launches); the K_* entries bracket ONE kernel launch each, so that a kernel's own average duration can be
+// priced against its algorithmic bytes -- the free-standing primitives (radix.hip, table.hip) find the builder's profiler
+// through a thread-local pointer that the enclosing PhaseScope sets.
+enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
+             PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_SHRINK,
+             K_SORT_SCATTER, K_SORT_HIST, K_RUN_SORT, K_HASH_SCATTER, K_HASH_HIST, K_OWNER_SCATTER, K_OWNER_HIST, K_PASS_OFFSETS,
+             K_RECORDS, K_GROUP_INDEX, K_LDS_COUNT, K_SRC_IDS, K_DST_MERGE, K_EXPAND, PH_COUNT };
+static const char* const PHASE_NAMES[PH_COUNT] = {
+    "extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set", "rank", "labels", "insert_tiles", "expand_tiles",
+    "expand_mid_tiles", "first_seen_order", "remove_dead_paths", "shrink",
+    "k:radix_scatter_kernel<RadixDigit>", "k:radix_hist_kernel<RadixDigit>", "k:run_sort_kernel", "k:radix_scatter_kernel<HashDigit>",
+    "k:radix_hist_kernel<HashDigit>", "k:radix_scatter_kernel<OwnerDigit>", "k:radix_hist_kernel<OwnerDigit>", "k:radix_chunk+offsets",
+    "k:tiles_to_records_kernel", "k:hash_group_index_kernel", "k:lds_count_kernel", "k:src_count+src_write", "k:dst_merge_kernel",
+    "k:expand_tiles_kernel"};
+struct Profiler {
+    bool on = false;
+    struct Ev { int phase; hipEvent_t a, b; };
+    std::vector<Ev> evs;
+    ~Profiler() { clear(); }
+    void clear() { for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } evs.clear(); }
+};
+inline Profiler*& current_profiler() { static thread_local Profiler* p = nullptr; return p; }
+struct PhaseScope {
+    Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase; Profiler* outer;
+    PhaseScope(Profiler& prof, int ph, hipStream_t st) : p(prof.on ? &prof : nullptr), s(st), phase(ph), outer(current_profiler()) {
+        if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
+        if (p) current_profiler() = p;
+    }
+    ~PhaseScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b}); current_profiler() = outer; } }
+};
+// one kernel launch (or a couple of tiny ones) inside a phase; a no-op unless a profiling PhaseScope is open on this thread
+struct KernelScope {
+    Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase;
+    KernelScope(int ph, hipStream_t st) : p(current_profiler()), s(st), phase(ph) {
+        if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
+    }
+    ~KernelScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b}); } }
 };
 
 inline int use_device(int device) {

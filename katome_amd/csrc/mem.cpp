@@ -86,4 +86,12 @@ void dev_release_cache(int device) {
     c.pool.release_free_segments(device);
 }
 
+void dev_cache_stats(int device, uint64_t out[3]) {
+    Cache& c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    out[0] = c.pool.segment_bytes_on(device);
+    out[1] = c.pool.free_bytes_on(device);
+    out[2] = c.pool.live_blocks_on(device);
+}
+
 }  // namespace katome

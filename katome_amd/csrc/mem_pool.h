@@ -98,6 +98,16 @@ public:
         return t;
     }
     size_t segment_bytes() const { return segment_bytes_; }            // everything taken from the backend
+    size_t segment_bytes_on(int device) const {                        // ... on one device: its free + its live blocks
+        size_t t = free_bytes_on(device);
+        for (const auto& kv : live_) if (kv.second->device == device) t += kv.second->bytes;
+        return t;
+    }
+    size_t live_blocks_on(int device) const {
+        size_t t = 0;
+        for (const auto& kv : live_) if (kv.second->device == device) ++t;
+        return t;
+    }
     size_t live_blocks() const { return live_.size(); }
     size_t free_blocks() const { return free_.size(); }
 

@@ -266,19 +266,34 @@ struct PassBuffers {
     }
 };
 
+// which per-kernel timer (common.h K_*) a pass with this digit reports to
+template <class Digit> struct DigitTimers { static constexpr int HIST = K_SORT_HIST, SCATTER = K_SORT_SCATTER; };
+template <int NW> struct DigitTimers<HashDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
+template <int NW> struct DigitTimers<OwnerDigit<NW>> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
+template <> struct DigitTimers<RangeDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
+
 template <int NW, bool HAS_VAL, class Digit>
 static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout, u32* vout, PassBuffers& pb, hipStream_t stream) {
     if (pb.nblocks > 0x7fffffffull) { set_error("radix pass: %llu keys exceed the grid limit", (unsigned long long)n); return KATOME_E_ARG; }
     dim3 block(BLOCK);
-    hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
-    hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>(), pb.chunk_blocks);
-    hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
+    {
+        KernelScope ks(DigitTimers<Digit>::HIST, stream);
+        hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
+    }
+    {
+        KernelScope ks(K_PASS_OFFSETS, stream);
+        hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>(), pb.chunk_blocks);
+        hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
+    }
     const size_t lds = (size_t)SortTile<NW>::KEYS * NW * 8;
     if (lds > (64u << 10)) {          // three-word records: 96 KiB of the CU's 160 KiB
         KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
-                       pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks);
+    {
+        KernelScope ks(DigitTimers<Digit>::SCATTER, stream);
+        hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
+                           pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks);
+    }
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
@@ -441,8 +456,11 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
         constexpr u32 RUN_TILE = RunTile<NW>::KEYS;
         const size_t lds = (size_t)(RUN_TILE + 2 * RUN_HALO) * NW * 8;
         if (lds > (64u << 10)) KCHECK_HIP(hipFuncSetAttribute((const void*)run_sort_kernel<NW, HAS_VAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
-                           kout, vout, overflow.as<u32>());
+        {
+            KernelScope ks(K_RUN_SORT, stream);
+            hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
+                               kout, vout, overflow.as<u32>());
+        }
         KCHECK_HIP(hipGetLastError());
         u32 h = 0;
         KCHECK_HIP(hipMemcpyAsync(&h, overflow.p, 4, hipMemcpyDeviceToHost, stream));
@@ -1118,16 +1136,22 @@ static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edg
     DevBuf counts(stream), offs(stream);
     KCHECK(counts.alloc(nblocks * 4));
     KCHECK(offs.alloc((nblocks + 1) * 8));
-    hipLaunchKernelGGL(src_count_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, counts.as<u32>());
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<u32>(), nblocks, offs.as<u64>());
+    {
+        KernelScope ks(K_SRC_IDS, stream);
+        hipLaunchKernelGGL(src_count_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, counts.as<u32>());
+        hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<u32>(), nblocks, offs.as<u64>());
+    }
     u64 n_src = 0;
     KCHECK_HIP(hipMemcpyAsync(&n_src, offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     // (with_slack: the caller appends the nodes without out-edges -- usually a few percent -- instead of copying the lot)
     KCHECK(node_key.alloc((n_src + (with_slack ? n_src / 8 + (1u << 16) : 0) + 1) * 8 * NW, stream));
     if (seg_edge) KCHECK(seg_edge->alloc(((n_src + DST_SEG - 1) / DST_SEG + 1) * 8));        // first out-edge of every DST_SEG-th source
-    hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), node_key.as<u64>(), edge_src,
-                       seg_edge ? seg_edge->as<u64>() : nullptr, DST_SEG);
+    {
+        KernelScope ks(K_SRC_IDS, stream);
+        hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), node_key.as<u64>(), edge_src,
+                           seg_edge ? seg_edge->as<u64>() : nullptr, DST_SEG);
+    }
     KCHECK_HIP(hipGetLastError());
     *n_src_out = n_src;
     return KATOME_OK;
@@ -1177,6 +1201,7 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
         hipLaunchKernelGGL(dst_seg_kernel<NW>, dim3(grid_for(4 * (n_seg + 1), BLOCK)), dim3(BLOCK), 0, stream, nodes, d_edge_key, E, node_bits, n_seg, seg.as<u64>());
         const size_t lds = (size_t)(DST_SEG * NW + MissCap<NW>::value * (NW + 1) + (first ? DST_SEG : 0)) * 8 + (first ? 2 * (DST_SEG / 32) * 4 : 0);
         const dim3 grid((unsigned)std::min<u64>(n_seg, 256u * 32u));
+        KernelScope ks(K_DST_MERGE, stream);
         if (first) {
             // (room for the nodes without out-edges, like node_key's)
             // (the merge writes the first touch of every source; the room behind them, for the nodes without out-edges, starts at all-ones)

@@ -808,6 +808,7 @@ static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint3
     TableAux* aux = kmers ? kmers->counter.as<TableAux>() : nullptr;
     if (slot1 <= slot0) return KATOME_OK;
     dim3 grid(grid_for(slot1 - slot0, BLOCK, 256u * 32u)), block(BLOCK);
+    KernelScope ks(K_EXPAND, stream);
 #define KATOME_EXPAND(NWT, NWK, RCV)                                                                                          \
     hipLaunchKernelGGL((expand_tiles_kernel<NWT, NWK, RCV, TO_TABLE>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), \
                        slot0, slot1, k, span, stride, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
@@ -899,6 +900,7 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
+    KernelScope ks(K_RECORDS, stream);
     if (tiles.nw == 1) {
         if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, true>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
         else    hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, false>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
@@ -933,7 +935,10 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     KCHECK(index.alloc(65537 * 8));
     KCHECK(aux.alloc(64));
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
-    hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for(n + 1, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, ko, n, index.as<u64>());
+    {
+        KernelScope ks(K_GROUP_INDEX, stream);
+        hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for(n + 1, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, ko, n, index.as<u64>());
+    }
     const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
     KCHECK(edge_key.alloc(out_cap * 8, stream));
     KCHECK(edge_weight.alloc(out_cap * 4, stream));
@@ -945,10 +950,13 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    if (rc) hipLaunchKernelGGL((lds_count_kernel<true>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
-                               edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
-    else    hipLaunchKernelGGL((lds_count_kernel<false>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
-                               edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
+    {
+        KernelScope ks(K_LDS_COUNT, stream);
+        if (rc) hipLaunchKernelGGL((lds_count_kernel<true>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
+                                   edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
+        else    hipLaunchKernelGGL((lds_count_kernel<false>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
+                                   edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
+    }
     KCHECK_HIP(hipGetLastError());
     uint64_t h[3] = {0, 0, 0};
     KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));

@@ -380,8 +380,16 @@ def rank_in_sorted(sorted_keys, queries, key_bits, key_words, device=0):
 
 
 def release_cache(device=0):
-    """hand the library's cached device blocks back to the driver"""
+    """hand the library's cached device blocks back to the driver -> bytes the library still holds afterwards (what live
+    builders, results and views pin; 0 when everything was closed)"""
     _check(_lib.lib().katome_dev_release_cache(device))
+    return cache_stats(device)["held_bytes"]
+
+
+def cache_stats(device=0):
+    out = (C.c_uint64 * 3)()
+    _check(_lib.lib().katome_dev_cache_stats(device, out))
+    return dict(held_bytes=int(out[0]), free_bytes=int(out[1]), live_blocks=int(out[2]))
 
 
 def source_ids(edge_keys, k, device=0):

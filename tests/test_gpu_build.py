@@ -240,6 +240,18 @@ def test_c2_in_full_equals_oracle(oracle):
         assert getattr(st, f) == ref.stats[f], f
     assert round(st.avg_edge_weight, 2) == round(ref.stats["avg_edge_weight"], 2)          # stats/collections.rs:71-89
     assert round(st.avg_out_degree, 2) == round(ref.stats["avg_out_degree"], 2)
+    # the same input in the reference's own numbering (petgraph indices in first-seen order, pt_graph.rs:149,194): the four
+    # arrays of the oracle's sequential build, index for index -- 1.1e7 edges, where the renumbering's neighbour shortcuts and
+    # left-out table writes (radix.hip) carry most nodes
+    del g, gl, gw, rl, rw
+    clean = ascii_reads.copy()
+    clean[clean == ord("N")] = ord("C")
+    g, rb = GpuGraph.create_from_packed(pack_reads_ascii(clean).reshape(-1), wl.reads, wl.read_len,
+                                        skip=has_n.astype(np.uint8), reverse_complement=True, k=wl.k, first_seen_order=True)
+    del clean
+    assert rb == ref.read_bytes and (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    assert np.array_equal(g.edge_src, ref.edge_src) and np.array_equal(g.edge_dst, ref.edge_dst)
+    assert np.array_equal(g.edge_weight, ref.edge_weight) and np.array_equal(g.edge_label, ref.edge_label)
 
 
 def test_high_multiplicity_and_table_growth(oracle):
@@ -320,6 +332,42 @@ def test_properties_at_scale():
     b.close(); b2.close()
 
 
+def _need_whole_gpu(need_gib=200):
+    """the at-size tests need most of an MI355X.  On a card of that size with less than that free, something an earlier test
+    left behind holds the memory (library cache, a builder whose close() was put off by live views): that is a failure to
+    look at, not a reason to skip -- the skip hid the k=63 at-size test from the driver's run in round 2."""
+    from katome_amd import device as kd
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    kd.release_cache()
+    free_b, total_b = torch.cuda.mem_get_info()
+    if free_b >= need_gib << 30:
+        return
+    msg = "needs %d GiB free, has %.1f of %.1f GiB; the library still holds %r" % (
+        need_gib, free_b / 2**30, total_b / 2**30, kd.cache_stats())
+    if total_b >= 250 << 30:
+        pytest.fail(msg)
+    pytest.skip(msg)
+
+
+def _close_and_release(b):
+    """close a builder whose views the caller has dropped, and give the library's cache back: nothing may stay behind"""
+    from katome_amd import device as kd
+    import gc
+    import sys
+    if sys.exc_info()[0] is not None:              # a failing test: its traceback keeps the views alive; report that failure, not this
+        b.close()
+        kd.release_cache()
+        return
+    gc.collect()                                   # views kept alive by reference cycles would put the close off
+    b.close()
+    assert not b._h, "Builder.close() was put off: %d views of its memory are still alive" % b._views
+    torch.cuda.empty_cache()
+    held = kd.release_cache()
+    assert held < (1 << 30), "the library still holds %.1f GiB after release_cache(): %r" % (held / 2**30, kd.cache_stats())
+
+
 def _chunked_all(fn, n, step=1 << 26):
     return all(bool(fn(i, min(n, i + step))) for i in range(0, n, step))
 
@@ -332,12 +380,11 @@ def test_properties_at_full_c3_size():
     from katome_amd import device as kd
     from katome_amd.workloads import WORKLOADS
     wl = WORKLOADS["c3"]
-    free_b, _total = torch.cuda.mem_get_info()
-    if free_b < 200 * (1 << 30):
-        pytest.skip("needs a whole MI355X (200 GiB free)")
+    _need_whole_gpu()
     packed, _skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, 0)
     b = kd.Builder(wl.k, True, table_slots_hint=int(wl.expected_distinct_canonical() * 2.2))
-    try:
+
+    def body():                                     # the views of the result die with this frame, before the close
         step = 4 << 20
         for r0 in range(0, wl.reads, step):
             b.count_reads(packed, min(step, wl.reads - r0), wl.read_len, None, first_read=r0)
@@ -363,9 +410,11 @@ def test_properties_at_full_c3_size():
             y |= (3 - ((x >> (2 * i)) & 3)) << (2 * (k - 1 - i))
         r = kd.rank_in_sorted(dg.edge_key.reshape(-1), y.contiguous(), 2 * k, 1)
         assert bool((r >= 0).all()) and bool((dg.edge_weight[r] == dg.edge_weight[sample]).all())
+    try:
+        body()
     finally:
-        b.close()
-        kd.release_cache()
+        del packed, _skip
+        _close_and_release(b)
 
 
 def test_properties_at_c5_share_size():
@@ -374,12 +423,11 @@ def test_properties_at_c5_share_size():
     from katome_amd import device as kd
     from katome_amd.workloads import WORKLOADS
     wl = WORKLOADS["c5"].scaled(100_000_000)
-    free_b, _total = torch.cuda.mem_get_info()
-    if free_b < 200 * (1 << 30):
-        pytest.skip("needs a whole MI355X (200 GiB free)")
+    _need_whole_gpu()
     packed, _skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, 0)
     b = kd.Builder(wl.k, True, table_slots_hint=int(wl.expected_distinct_canonical() * 2.2))
-    try:
+
+    def body():
         span, tiles, rest = b.tile_plan(wl.read_len)
         assert (span, tiles, rest) == (28, 3, 4) and b.tile_words(span) == 3
         step = 4 << 20
@@ -402,9 +450,11 @@ def test_properties_at_c5_share_size():
         n_src = int(dg.edge_src[-1].item()) + 1
         assert bool(less(nh[:n_src - 1], nl[:n_src - 1], nh[1:n_src], nl[1:n_src]).all())
         assert bool(less(nh[n_src:-1], nl[n_src:-1], nh[n_src + 1:], nl[n_src + 1:]).all())
+    try:
+        body()
     finally:
-        b.close()
-        kd.release_cache()
+        del packed, _skip
+        _close_and_release(b)
 
 
 def test_pruning_properties_at_scale():
@@ -416,7 +466,8 @@ def test_pruning_properties_at_scale():
     wl = WORKLOADS["c3"].scaled(20_000_000)
     packed, _skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, 0)
     b = kd.Builder(wl.k, True, first_seen_order=True, table_slots_hint=int(wl.expected_distinct_canonical() * 2.2))
-    try:
+
+    def body():
         step = 4 << 20
         for r0 in range(0, wl.reads, step):
             b.count_reads(packed, min(step, wl.reads - r0), wl.read_len, None, first_read=r0)
@@ -451,9 +502,11 @@ def test_pruning_properties_at_scale():
         assert bool(touched.all())                                       # no node without an edge is left behind
         dg2, st2 = b.remove_dead_paths()
         assert (dg2.n_edges, dg2.n_nodes, st2["passes"], st2["removed_edges"]) == (E, N, 1, 0)
+    try:
+        body()
     finally:
-        b.close()
-        kd.release_cache()
+        del packed, _skip
+        _close_and_release(b)
 
 
 @pytest.mark.parametrize("k,L,rc", [(31, 150, True), (31, 150, False), (31, 100, True), (32, 75, True), (12, 51, True),

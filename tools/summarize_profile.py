@@ -66,14 +66,16 @@ if pmc:
         n = max(f[1], w[1], 1)
         summary[k] = {"dispatches": n, "fetch_kib": f[0] / max(f[1], 1), "write_kib": w[0] / max(w[1], 1)}
         lines.append("| %s | %d | %.0f | %.0f |" % (k, n, summary[k]["fetch_kib"], summary[k]["write_kib"]))
-    cfg = {}
+    cfg, src = {}, None
     try:
-        cfg = json.load(open(os.path.join(out_dir, "bench_under_pmc_FETCH_SIZE.json")))["config"]
+        line = json.load(open(os.path.join(out_dir, "bench_under_pmc_FETCH_SIZE.json")))
+        cfg, src = line["config"], line.get("source_id")
     except Exception:
         pass
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of "
                          "`bench.py --steps 1 --warmup 0`; per-dispatch averages, KiB; profiles/%s_summary.md" % tag,
                "config": {k: cfg.get(k) for k in ("reads", "read_len", "k", "batch_reads", "tile_span")},
+               "source_id": src,        # bench.py source_id(): the kernels these counters were taken on
                "kernels": summary}, open(os.path.join(out_dir, "pmc_summary.json"), "w"), indent=1)
     lines.append("")
 for f in ("bench_under_trace.json",):
