@@ -109,13 +109,14 @@ class PhaseTimer:
         self.counts = {}
 
     def add(self, prof):
-        for name, (ms, launches) in prof.items():
-            a = self.acc.setdefault(name, [0.0, 0])
+        for name, (ms, launches, work) in prof.items():
+            a = self.acc.setdefault(name, [0.0, 0, 0])
             a[0] += ms
             a[1] += launches
+            a[2] += work
 
     def collect(self):
-        out = {n: {"launches": c, "total_ms": ms, "avg_ms": ms / c} for n, (ms, c) in self.acc.items() if c}
+        out = {n: {"launches": c, "total_ms": ms, "avg_ms": ms / c, "work": w} for n, (ms, c, w) in self.acc.items() if c}
         self.acc = {}
         return out
 
@@ -498,13 +499,12 @@ def main():
                  "emit_edges": "void emit_edges_kernel<%d, %s, %d>" % (nw, rcs, 4 if (args.first_seen_order or args.prune or nw > 1) else 8)}
         # per-kernel algorithmic bytes of ONE launch (the default build on one GPU only: other routes run the same kernels on
         # other record counts), and the name rocprofv3 lists the kernel under
-        kalg, kexact = {}, {}
+        kalg, kexact = {}, {}       # kalg: algorithmic bytes per ELEMENT the kernel processes (keys of a pass, slots of a scan)
         if not use_dist and cnt and not (args.first_seen_order or args.prune):
             pair = 8 * nw + 4
-            kalg.update({"radix_scatter_kernel<RadixDigit>": n_edges * 2 * pair, "radix_hist_kernel<RadixDigit>": n_edges * 8 * nw,
-                         "run_sort_kernel": n_edges * 2 * pair,
-                         "src_count+src_write": (n_edges * (2 * 8 * nw + 8) + n_nodes * 8 * nw) / 2.0,       # two launches, each reads the keys
-                         "dst_merge_kernel": n_edges * (8 * nw + 8) + n_nodes * 8 * nw})
+            kalg.update({"radix_scatter_kernel<RadixDigit>": 2 * pair, "radix_hist_kernel<RadixDigit>": 8 * nw, "run_sort_kernel": 2 * pair,
+                         "src_count+src_write": (2 * 8 * nw + 8 + 8 * nw * n_nodes / max(n_edges, 1)) / 2.0,       # two launches, each reads the keys
+                         "dst_merge_kernel": 8 * nw + 8 + 8 * nw * n_nodes / max(n_edges, 1)})
             kexact.update({"radix_scatter_kernel<RadixDigit>": exact["sort_edges"],
                            "radix_hist_kernel<RadixDigit>": "void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw),
                            "run_sort_kernel": "void run_sort_kernel<%d, true>" % nw, "dst_merge_kernel": "void dst_merge_kernel<%d, false>" % nw})
@@ -513,9 +513,9 @@ def main():
                 last_slots, last_tiles, last_span, last_nw = ((cnt["mid_tile_slots"], cnt["distinct_mid_tiles"], ms2, _katome_lib().katome_tile_words(wl.k, ms2)) if ms2
                                                               else (cnt["tile_slots"], cnt["distinct_tiles"], span, nwt))
                 n_rec = last_tiles * last_span
-                kalg.update({"radix_scatter_kernel<HashDigit>": n_rec * 2 * 12, "radix_hist_kernel<HashDigit>": n_rec * 8,
-                             "tiles_to_records_kernel": last_slots * 16 * last_nw + n_rec * 12, "hash_group_index_kernel": n_rec * 8,
-                             "lds_count_kernel": n_rec * 12 + n_edges * 12})
+                kalg.update({"radix_scatter_kernel<HashDigit>": 2 * 12, "radix_hist_kernel<HashDigit>": 8,
+                             "tiles_to_records_kernel": 16 * last_nw + 12.0 * n_rec / last_slots, "hash_group_index_kernel": 8,
+                             "lds_count_kernel": 12 + 12.0 * n_edges / n_rec})
                 kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<1, true, HashDigit<1> >",
                                "radix_hist_kernel<HashDigit>": "void radix_hist_kernel<1, HashDigit<1> >",
                                "tiles_to_records_kernel": "void tiles_to_records_kernel<%d, 1, %s>" % (last_nw, rcs),
@@ -524,10 +524,15 @@ def main():
             if not name.startswith("k:"):
                 continue
             kn = name[2:]
-            entry = {"launches_per_step": ph["launches"] / args.steps, "avg_ms": ph["avg_ms"], "ms_per_step": ph["total_ms"] / args.steps}
-            if kn in kalg:
-                entry["alg_bytes_per_launch"] = kalg[kn]
-                entry["achieved_GBs"] = kalg[kn] / (ph["avg_ms"] * 1e-3) / 1e9
+            entry = {"launches_per_step": ph["launches"] / args.steps, "avg_ms": ph["avg_ms"], "ms_per_step": ph["total_ms"] / args.steps,
+                     "elements_per_step": ph["work"] / args.steps}
+            if kn in kalg and ph["work"]:
+                # launches of one kernel may differ in size (the edge sort's passes and the small sort of the nodes without out-edges):
+                # the rate is all their bytes over all their time; "per launch" figures are the averages
+                total_bytes = kalg[kn] * ph["work"]
+                entry["alg_bytes_per_element"] = kalg[kn]
+                entry["alg_bytes_per_launch"] = total_bytes / ph["launches"]
+                entry["achieved_GBs"] = total_bytes / (ph["total_ms"] * 1e-3) / 1e9
                 entry["frac_of_hbm_peak"] = entry["achieved_GBs"] / HBM_PEAK_GBS
             kernel_launches[kn] = entry
 

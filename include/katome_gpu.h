@@ -183,6 +183,9 @@ void katome_builder_destroy(katome_builder *b);
  * synchronises the device and clears the record.                                            */
 int  katome_builder_profile(katome_builder *b, int enable);
 int  katome_builder_profile_read(katome_builder *b, double *total_ms, uint64_t *launches);
+/* same, plus work[i] = elements processed by the launches of entry i (the per-kernel entries "k:...": keys of a sort pass,
+ * slots of a table scan ...), so that launches of different sizes add up to one rate                              */
+int  katome_builder_profile_read_work(katome_builder *b, double *total_ms, uint64_t *launches, uint64_t *work);
 uint32_t katome_phase_count(void);
 const char *katome_phase_name(uint32_t phase);
 
@@ -440,6 +443,8 @@ typedef struct {
     uint64_t *d_node_key;                 /* [n_nodes][key_words]                                                    */
     uint64_t *d_edge_id, *d_node_id;      /* FIRST_SEEN_ORDER: the reference's (petgraph) index of every edge / node of
                                              this rank; NULL by packed key                                           */
+    uint64_t *d_edge_age;                 /* after katome_dist_remove_dead_paths: the index each edge had when it was built
+                                             (= its place in petgraph's adjacency lists, see katome_graph.edge_age); else NULL */
 } katome_dist_graph;
 /* settings as for katome_builder_create (settings.device = this rank's GPU; table_slots_hint for the WHOLE build);
  * the communicator stays the caller's.  Every call below is collective: all ranks make it, in the same order.        */
@@ -459,6 +464,15 @@ int  katome_dist_finalize(katome_dist_builder *d, katome_dist_graph *out, void *
  * katome_dev_finalize.  The pruning of BASELINE config 5 runs this way: its walks and swap-removes depend on the global
  * numbering; the whole graph has to fit the root's HBM (< 2^32 edges).                           */
 int  katome_dist_gather(katome_dist_builder *d, int root, katome_builder **root_builder, void *stream);
+/* Prunable::remove_dead_paths (pruner.rs:36-82) on the SHARDED graph of a finalized FIRST_SEEN_ORDER build, no gather: walkers
+ * hop from owner to owner along first out-edges (one all-to-all per step, < 2k steps), marked (position, count) pairs go to
+ * rank 0, which replays petgraph's swap_removes on 64-bit positions and answers where every candidate edge / node ends up
+ * (katome_amd/csrc/dist_prune.hip).  The graph may hold more than 2^32 edges (a rank's share may not).  Afterwards `out`
+ * describes this rank's share of the pruned graph: d_edge_id / d_node_id are the indices the reference's PtGraph would hold,
+ * d_edge_age the edges' ages.  Collective.                                                                              */
+int  katome_dist_remove_dead_paths(katome_dist_builder *d, katome_dist_graph *out, katome_prune_stats *stats, void *stream);
+/* this rank's share of the graph as it stands (after katome_dist_finalize / katome_dist_remove_dead_paths) */
+int  katome_dist_current_graph(katome_dist_builder *d, katome_dist_graph *out);
 /* the rank's single-GPU builder underneath (per-phase kernel timing: katome_builder_profile*) */
 katome_builder *katome_dist_inner(katome_dist_builder *d);
 /* exchange accounting since the last read: katome_dist_exchange_count() phases named by katome_dist_exchange_name(),
@@ -490,6 +504,14 @@ int katome_dev_replay_edge_removals(int device, const uint32_t *d_pos, const uin
  * longer than it follows: katome_dev_remove_dead_paths then runs the sequential replay on the host; nothing is written)} */
 int katome_dev_replay_node_removals(int device, const uint32_t *d_die, uint64_t m, uint64_t n_nodes, uint32_t *d_move_to,
                                     uint32_t *d_move_from, uint64_t *counts, void *stream);
+/* the same two replays on 64-bit positions (0xFFFFFFFFFFFFFFFF: stays): what katome_dist_remove_dead_paths runs on rank 0 for
+ * a graph sharded over several GPUs, which may hold more than 2^32 edges (BASELINE config 5: 1.1e10).  Only the marked
+ * entries and the tail positions that disappear are touched, so n_edges / n_nodes are not bounded by any buffer.         */
+int katome_dev_replay_edge_removals64(int device, const uint64_t *d_pos, const uint32_t *d_mult, uint64_t u, uint64_t n_edges,
+                                      uint64_t *d_victims, uint64_t *d_move_to, uint64_t *d_move_from, uint64_t *counts,
+                                      void *stream);
+int katome_dev_replay_node_removals64(int device, const uint64_t *d_die, uint64_t m, uint64_t n_nodes, uint64_t *d_move_to,
+                                      uint64_t *d_move_from, uint64_t *counts, void *stream);
 /* exclusive prefix sums of m u32 counts as u64: d_offs[i] = counts[0] + .. + counts[i-1], d_offs[m] = the total   */
 int katome_dev_scan_counts(int device, const uint32_t *d_counts, uint64_t m, uint64_t *d_offs, void *stream);
 /* in-place unique of sorted keys; returns the new count (synchronises)                     */

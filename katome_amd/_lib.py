@@ -70,7 +70,7 @@ class DistGraph(C.Structure):
                 ("node_base", C.c_uint64), ("key_words", C.c_uint32), ("label_stride", C.c_uint32),
                 ("d_edge_key", C.c_void_p), ("d_edge_weight", C.c_void_p), ("d_edge_src", C.c_void_p),
                 ("d_edge_dst", C.c_void_p), ("d_edge_label", C.c_void_p), ("d_node_key", C.c_void_p),
-                ("d_edge_id", C.c_void_p), ("d_node_id", C.c_void_p)]
+                ("d_edge_id", C.c_void_p), ("d_node_id", C.c_void_p), ("d_edge_age", C.c_void_p)]
 
 
 # the caller's transport (katome_comm_callbacks)
@@ -101,6 +101,7 @@ SYMBOLS = {
     "katome_builder_counts": (_i, [_vp, u64p]),
     "katome_builder_profile": (_i, [_vp, _i]),
     "katome_builder_profile_read": (_i, [_vp, C.POINTER(_dbl), u64p]),
+    "katome_builder_profile_read_work": (_i, [_vp, C.POINTER(_dbl), u64p, u64p]),
     "katome_phase_count": (_u32, []),
     "katome_phase_name": (C.c_char_p, [_u32]),
     "katome_dev_extract_fixed": (_i, [_vp, _vp, _u64, _u32, _vp, _vp, _vp]),
@@ -134,6 +135,8 @@ SYMBOLS = {
     "katome_dev_scan_counts": (_i, [_i, _vp, _u64, _vp, _vp]),
     "katome_dev_replay_node_removals": (_i, [_i, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
     "katome_dev_replay_edge_removals": (_i, [_i, _vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
+    "katome_dev_replay_node_removals64": (_i, [_i, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),
+    "katome_dev_replay_edge_removals64": (_i, [_i, _vp, _vp, _u64, _u64, _vp, _vp, _vp, _vp, _vp]),
     "katome_dev_remove_dead_paths": (_i, [_vp, C.POINTER(DevGraph), C.POINTER(PruneStats), _vp]),
     "katome_dev_edges": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
     "katome_dev_release_cache": (_i, [_i]),
@@ -163,6 +166,8 @@ SYMBOLS = {
     "katome_dist_finalize": (_i, [_vp, C.POINTER(DistGraph), _vp]),
     "katome_dist_gather": (_i, [_vp, _i, C.POINTER(_vp), _vp]),
     "katome_dist_inner": (_vp, [_vp]),
+    "katome_dist_remove_dead_paths": (_i, [_vp, C.POINTER(DistGraph), C.POINTER(PruneStats), _vp]),
+    "katome_dist_current_graph": (_i, [_vp, C.POINTER(DistGraph)]),
     "katome_dist_exchange_count": (_u32, []),
     "katome_dist_exchange_name": (C.c_char_p, [_u32]),
     "katome_dist_exchange_read": (_i, [_vp, u64p]),

@@ -855,17 +855,20 @@ int katome_builder_profile(katome_builder* b, int enable) {
 }
 uint32_t katome_phase_count(void) { return PH_COUNT; }
 const char* katome_phase_name(uint32_t phase) { return phase < PH_COUNT ? PHASE_NAMES[phase] : ""; }
-int katome_builder_profile_read(katome_builder* b, double* total_ms, uint64_t* launches) {
+int katome_builder_profile_read_work(katome_builder* b, double* total_ms, uint64_t* launches, uint64_t* work) {
     if (!b || !total_ms || !launches) { set_error("null argument"); return KATOME_E_ARG; }
     KCHECK_HIP(hipSetDevice(b->s.device));
     KCHECK_HIP(hipDeviceSynchronize());
-    for (int i = 0; i < PH_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < PH_COUNT; ++i) { total_ms[i] = 0; launches[i] = 0; if (work) work[i] = 0; }
     for (auto& e : b->prof.evs) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { total_ms[e.phase] += ms; launches[e.phase] += 1; }
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { total_ms[e.phase] += ms; launches[e.phase] += 1; if (work) work[e.phase] += e.work; }
     }
     b->prof.clear();
     return KATOME_OK;
+}
+int katome_builder_profile_read(katome_builder* b, double* total_ms, uint64_t* launches) {
+    return katome_builder_profile_read_work(b, total_ms, launches, nullptr);
 }
 
 int katome_dev_release_cache(int device) {
@@ -917,6 +920,44 @@ int katome_dev_replay_node_removals(int device, const uint32_t* d_die, uint64_t 
     if (moves) {
         KCHECK_HIP(hipMemcpyAsync(d_move_to, to.p, moves * 4, hipMemcpyDeviceToDevice, stream));
         KCHECK_HIP(hipMemcpyAsync(d_move_from, from.p, moves * 4, hipMemcpyDeviceToDevice, stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    counts[0] = moves; counts[1] = left; counts[2] = (uint64_t)fell_back;
+    return KATOME_OK;
+}
+// the same two replays on 64-bit positions (dist_prune.hip: a graph sharded over several GPUs may hold more than 2^32 edges);
+// only the marked entries and the tail that disappears are touched, so n_edges / n_nodes may be far beyond any buffer here
+int katome_dev_replay_edge_removals64(int device, const uint64_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t n_edges,
+                                      uint64_t* d_victims, uint64_t* d_move_to, uint64_t* d_move_from, uint64_t* counts, void* stream_) {
+    KCHECK(use_device(device));
+    if (!counts || (u && (!d_pos || !d_mult || !d_victims || !d_move_to || !d_move_from))) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    ReplayScratch sc(stream);
+    DevBuf victims(stream), to(stream), from(stream);
+    uint64_t m = 0, left = n_edges, moves = 0, dups = 0;
+    KCHECK(dev_replay_edges64(d_pos, d_mult, u, n_edges, sc, victims, to, from, &m, &left, &moves, &dups, stream));
+    if (m) KCHECK_HIP(hipMemcpyAsync(d_victims, victims.p, m * 8, hipMemcpyDeviceToDevice, stream));
+    if (moves) {
+        KCHECK_HIP(hipMemcpyAsync(d_move_to, to.p, moves * 8, hipMemcpyDeviceToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(d_move_from, from.p, moves * 8, hipMemcpyDeviceToDevice, stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    counts[0] = m; counts[1] = moves; counts[2] = left; counts[3] = dups;
+    return KATOME_OK;
+}
+int katome_dev_replay_node_removals64(int device, const uint64_t* d_die, uint64_t m, uint64_t n_nodes, uint64_t* d_move_to, uint64_t* d_move_from,
+                                      uint64_t* counts, void* stream_) {
+    KCHECK(use_device(device));
+    if (!counts || (m && (!d_die || !d_move_to || !d_move_from))) { set_error("null argument"); return KATOME_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    NodeReplayScratch sc(stream);
+    DevBuf to(stream), from(stream);
+    uint64_t moves = 0, left = n_nodes;
+    int fell_back = 0;
+    KCHECK(dev_replay_nodes64(d_die, m, n_nodes, sc, to, from, &moves, &left, &fell_back, stream));
+    if (moves) {
+        KCHECK_HIP(hipMemcpyAsync(d_move_to, to.p, moves * 8, hipMemcpyDeviceToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(d_move_from, from.p, moves * 8, hipMemcpyDeviceToDevice, stream));
     }
     KCHECK_HIP(hipStreamSynchronize(stream));
     counts[0] = moves; counts[1] = left; counts[2] = (uint64_t)fell_back;
@@ -1193,6 +1234,10 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
         set_error("n_devices > 1: shrink and the stages after the build need KATOME_FLAG_FIRST_SEEN_ORDER (they run on the graph gathered in the reference's numbering)");
         return KATOME_E_ARG;
     }
+    // first-seen order: shrink and the staged pipeline still run on the graph gathered to the first GPU; the build itself and
+    // remove_dead_paths do not (KATOME_DIST_PRUNE=gather: the gathered route for those too)
+    const char* prune_route = getenv("KATOME_DIST_PRUNE");
+    const bool direct = first_seen && !finish.contigs && !(finish.stages && *finish.stages) && !(prune_route && !strcmp(prune_route, "gather"));
     std::vector<int> devices(n);
     for (int r = 0; r < n; ++r) devices[r] = share ? s->device : s->device + r;
     std::vector<katome_comm*> comms(n, nullptr);
@@ -1235,7 +1280,7 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
             d_packed.release(); d_skip.release();
             katome_dist_graph g;
             if ((rc = katome_dist_finalize(d, &g, stream))) break;
-            if (first_seen) {
+            if (first_seen && !direct) {
                 katome_builder* root = nullptr;
                 if ((rc = katome_dist_gather(d, 0, &root, stream))) break;
                 if (r == 0) {
@@ -1243,6 +1288,13 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
                     rc = finish(root, read_bytes);
                 }
                 break;
+            }
+            // the reference's numbering without a gather: remove_dead_paths (if asked for) on the sharded graph, then every rank
+            // puts its edges and nodes at their indices in the host arrays
+            bool pruned = false;
+            if (first_seen && (s->flags & KATOME_FLAG_REMOVE_DEAD_PATHS)) {
+                if ((rc = katome_dist_remove_dead_paths(d, &g, nullptr, stream))) break;
+                pruned = true;
             }
             // by packed key: rank by rank
             sh.n_edges[r] = g.n_edges; sh.node_base[r] = g.node_base; sh.n_nodes[r] = g.n_nodes;
@@ -1262,13 +1314,49 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
                     hg->edge_label = (uint8_t*)take(std::max<uint64_t>(g.total_edges, 1) * (size_t)g.label_stride);
                     hg->edge_key = (uint64_t*)take(std::max<uint64_t>(g.total_edges, 1) * 8 * g.key_words);
                     hg->node_key = (uint64_t*)take(std::max<uint64_t>(g.total_nodes, 1) * 8 * g.key_words);
+                    if (pruned) hg->edge_age = (uint32_t*)take(std::max<uint64_t>(g.total_edges, 1) * 4);
                     if (sh.alloc_rc) { set_error("out of host memory"); katome_graph_free(hg); o = nullptr; }
                 }
                 sh.owner = o;
             }
             if (!sync->barrier()) { set_error("another rank of this build failed"); rc = KATOME_E_DEVICE; break; }
             if (!sh.owner) { rc = sh.alloc_rc ? sh.alloc_rc : KATOME_E_OOM; break; }
-            {
+            if (first_seen) {
+                // every edge / node at its petgraph index: the rank's share comes over in its own order and is placed on the host
+                katome_graph* hg = &sh.owner->g;
+                const uint64_t E = g.n_edges, N = g.n_nodes;
+                const uint32_t nwk = g.key_words, ls = g.label_stride;
+                std::vector<uint64_t> id(E), src(E), dst(E), key(E * nwk), nid(N), nkey(N * nwk), age(pruned ? E : 0);
+                std::vector<uint32_t> w(E);
+                std::vector<uint8_t> lab(E * (size_t)ls);
+                hipError_t e = hipSuccess;
+                auto down = [&](void* h, const void* dv, size_t bytes) { if (bytes && e == hipSuccess) e = hipMemcpyAsync(h, dv, bytes, hipMemcpyDeviceToHost, stream); };
+                down(id.data(), g.d_edge_id, E * 8); down(src.data(), g.d_edge_src, E * 8); down(dst.data(), g.d_edge_dst, E * 8);
+                down(w.data(), g.d_edge_weight, E * 4); down(lab.data(), g.d_edge_label, E * (size_t)ls); down(key.data(), g.d_edge_key, E * 8 * nwk);
+                down(nid.data(), g.d_node_id, N * 8); down(nkey.data(), g.d_node_key, N * 8 * nwk);
+                if (pruned) down(age.data(), g.d_edge_age, E * 8);
+                if (e == hipSuccess) e = hipStreamSynchronize(stream);
+                if (e != hipSuccess) { set_error("D2H copy failed: %s", hipGetErrorString(e)); rc = KATOME_E_DEVICE; break; }
+                uint64_t* h_src = const_cast<uint64_t*>(hg->edge_src); uint64_t* h_dst = const_cast<uint64_t*>(hg->edge_dst);
+                uint32_t* h_w = const_cast<uint32_t*>(hg->edge_weight); uint8_t* h_lab = const_cast<uint8_t*>(hg->edge_label);
+                uint64_t* h_key = const_cast<uint64_t*>(hg->edge_key); uint64_t* h_nkey = const_cast<uint64_t*>(hg->node_key);
+                uint32_t* h_age = const_cast<uint32_t*>(hg->edge_age);
+                bool bad = false;
+                for (uint64_t i = 0; i < E; ++i) {
+                    const uint64_t at = id[i];
+                    if (at >= hg->n_edges) { bad = true; break; }
+                    h_src[at] = src[i]; h_dst[at] = dst[i]; h_w[at] = w[i];
+                    memcpy(h_lab + at * ls, lab.data() + i * (size_t)ls, ls);
+                    for (uint32_t q = 0; q < nwk; ++q) h_key[at * nwk + q] = key[i * nwk + q];
+                    if (pruned) { if (age[i] > 0xFFFFFFFFull) bad = true; h_age[at] = (uint32_t)age[i]; }
+                }
+                for (uint64_t j = 0; j < N && !bad; ++j) {
+                    const uint64_t at = nid[j];
+                    if (at >= hg->n_nodes) { bad = true; break; }
+                    for (uint32_t q = 0; q < nwk; ++q) h_nkey[at * nwk + q] = nkey[j * nwk + q];
+                }
+                if (bad) { set_error("sharded build: an index does not fit the host result (katome_graph.edge_age is 32 bits wide)"); rc = KATOME_E_UNSUPPORTED; }
+            } else {
                 uint64_t e0 = 0;
                 for (int p = 0; p < r; ++p) e0 += sh.n_edges[p];
                 katome_graph* hg = &sh.owner->g;
@@ -1305,7 +1393,7 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
     for (int r = 0; r < n && !rc; ++r)
         if (sh.rc[r] && sh.err[r] != "another rank of this build failed") { rc = sh.rc[r]; set_error("rank %d of %d: %s", r, n, sh.err[r].c_str()); }
     for (int r = 0; r < n && !rc; ++r) if (sh.rc[r]) { rc = sh.rc[r]; set_error("rank %d of %d: %s", r, n, sh.err[r].c_str()); }
-    if (!first_seen) {
+    if (!first_seen || direct) {
         if (rc == KATOME_OK && sh.owner && finish.graph) *finish.graph = &sh.owner->g;
         else if (sh.owner) katome_graph_free(&sh.owner->g);
     }

@@ -86,7 +86,7 @@ static const char* const PHASE_NAMES[PH_COUNT] = {
     "k:expand_tiles_kernel"};
 struct Profiler {
     bool on = false;
-    struct Ev { int phase; hipEvent_t a, b; };
+    struct Ev { int phase; hipEvent_t a, b; uint64_t work; };      // work: elements the launch processed (K_* entries)
     std::vector<Ev> evs;
     ~Profiler() { clear(); }
     void clear() { for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } evs.clear(); }
@@ -98,15 +98,15 @@ struct PhaseScope {
         if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
         if (p) current_profiler() = p;
     }
-    ~PhaseScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b}); current_profiler() = outer; } }
+    ~PhaseScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b, 0}); current_profiler() = outer; } }
 };
 // one kernel launch (or a couple of tiny ones) inside a phase; a no-op unless a profiling PhaseScope is open on this thread
 struct KernelScope {
-    Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase;
-    KernelScope(int ph, hipStream_t st) : p(current_profiler()), s(st), phase(ph) {
+    Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase; uint64_t work;
+    KernelScope(int ph, hipStream_t st, uint64_t elements = 0) : p(current_profiler()), s(st), phase(ph), work(elements) {
         if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
     }
-    ~KernelScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b}); } }
+    ~KernelScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b, work}); } }
 };
 
 inline int use_device(int device) {
@@ -206,12 +206,17 @@ struct ReplayScratch {
 int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t n_edges, ReplayScratch& scratch, DevBuf& victims,
                      DevBuf& move_to, DevBuf& move_from, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups,
                      hipStream_t stream);
+int dev_replay_edges64(const uint64_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t n_edges, ReplayScratch& scratch, DevBuf& victims,
+                       DevBuf& move_to, DevBuf& move_from, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups,
+                       hipStream_t stream);
 struct NodeReplayScratch {
     DevBuf counts, offs, first, hole, dead, flags;
     explicit NodeReplayScratch(hipStream_t stream) : counts(stream), offs(stream), first(stream), hole(stream), dead(stream), flags(stream) {}
 };
 int dev_replay_nodes(const uint32_t* d_die, uint64_t m, uint64_t n_nodes, NodeReplayScratch& scratch, DevBuf& move_to, DevBuf& move_from,
                      uint64_t* n_moves, uint64_t* n_left, int* fell_back, hipStream_t stream);
+int dev_replay_nodes64(const uint64_t* d_die, uint64_t m, uint64_t n_nodes, NodeReplayScratch& scratch, DevBuf& move_to, DevBuf& move_from,
+                       uint64_t* n_moves, uint64_t* n_left, int* fell_back, hipStream_t stream);
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream);
 // Clean::remove_weak_edges with petgraph's retain_edges / retain_nodes numbering, same graph, in place
 int dev_remove_weak_edges_ordered(PruneGraph& g, uint32_t threshold, hipStream_t stream);

@@ -24,14 +24,12 @@
 #include <vector>
 
 #include <cstring>
-#include "builder.h"
-#include "comm.h"
+#include "dist_builder.h"
+
+const char* const XPHASE_NAMES[X_COUNT] = {"exchange_records", "exchange_kmers", "exchange_targets", "exchange_ids",
+                                           "rank_nodes", "rank_edges", "gather", "exchange_mid_tiles", "prune"};
 
 namespace {
-
-enum XPhase { X_RECORDS, X_KMERS, X_TARGETS, X_IDS, X_RANK_NODES, X_RANK_EDGES, X_GATHER, X_MID_TILES, X_COUNT };
-const char* const XPHASE_NAMES[X_COUNT] = {"exchange_records", "exchange_kmers", "exchange_targets", "exchange_ids",
-                                           "rank_nodes", "rank_edges", "gather", "exchange_mid_tiles"};
 
 // ---- small kernels ---------------------------------------------------------------------------------------------------
 #define KLAUNCH(kernel, n, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid_for((n), BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, __VA_ARGS__)
@@ -128,6 +126,11 @@ __global__ __launch_bounds__(BLOCK) void place_kernel(const u64* __restrict__ gi
     KLOOP(j, n) out[gid[j]] = in[j];
 }
 
+// out[pos[j]] = v for the entries [a, b) of a partitioned list (the owner rank of a segment's look-ups)
+__global__ __launch_bounds__(BLOCK) void scatter_const_kernel(const u32* __restrict__ pos, u64 a, u64 b, u64 v, u64* __restrict__ out) {
+    KLOOP(j, b - a) out[pos[a + j]] = v;
+}
+
 uint64_t sum(const std::vector<uint64_t>& v) { uint64_t t = 0; for (uint64_t x : v) t += x; return t; }
 
 // KATOME_DIST_TRACE=1: order-free checksum of a device array of u64 words at the checkpoints of a sharded build (stderr)
@@ -153,55 +156,6 @@ void trace_words(const char* what, int rank, const void* d_ptr, uint64_t n_words
 }
 
 }  // namespace
-
-struct katome_dist_builder {
-    katome_settings s;
-    katome_comm* comm = nullptr;
-    katome_builder* b = nullptr;             // this rank's single-GPU builder (tables, sorted edges)
-    uint32_t nw = 1;
-    bool rc = false, first_seen = false;
-    // the plan, the same on every rank (a function of k and the read length)
-    bool planned = false;
-    uint32_t read_len = 0, W = 0, span = 1, tiles_per_read = 0, rest = 0, nwt = 1;
-    uint64_t reads_end = 0;                  // one past the last read this rank has added (first-seen: bounds the sequence numbers)
-    bool finalized = false;
-    // Which records travel.  Few ranks share few links: every rank counts its own reads down to k-mers and
-    // sends each DISTINCT k-mer once ("local first": one exchange, 12 B per k-mer and rank).  Many ranks: tiles, mid tiles and
-    // k-mer records are routed to owners level by level (no level is counted twice, at the price of three exchanges).
-    bool local_first = false;
-    hipStream_t xstream = nullptr;           // the exchanges of route_weighted run here, beside the insertions on the build's stream
-    // this rank's share of the numbered graph
-    DevBuf edge_src, edge_dst, edge_label, node_key, edge_gid, node_gid;
-    uint64_t n_edges = 0, n_nodes = 0, total_edges = 0, total_nodes = 0, node_base = 0;
-    katome::ExchangeStats xstats[X_COUNT];
-
-    int world() const { return comm->world(); }
-    int rank() const { return comm->rank(); }
-    // all-to-all of records grouped by destination, accounted to `phase`
-    // (RCCL only enqueues: with the builder's profile switched on the exchange is timed with HIP events on its stream)
-    struct XEvent { int phase; hipEvent_t a, b; };
-    std::vector<XEvent> xevents;
-    int xchg(int phase, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, hipStream_t stream,
-             bool one_round = false) {
-        const katome::ExchangeStats before = comm->stats;
-        hipEvent_t ea = nullptr, eb = nullptr;
-        const bool timed = b->prof.on && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
-        if (timed) (void)hipEventRecord(ea, stream);
-        const int rc = comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream, one_round);
-        if (timed) { (void)hipEventRecord(eb, stream); xevents.push_back({phase, ea, eb}); }
-        if (rc != KATOME_OK) return rc;
-        katome::ExchangeStats& x = xstats[phase];
-        x.calls += comm->stats.calls - before.calls; x.bytes_out += comm->stats.bytes_out - before.bytes_out;
-        x.bytes_in += comm->stats.bytes_in - before.bytes_in;
-        if (!timed) x.ms += comm->stats.ms - before.ms;
-        for (int p = 0; p < world(); ++p) if (p != rank()) x.max_pair_bytes = std::max<uint64_t>(x.max_pair_bytes, send_cnt[p] * elem_bytes);
-        return KATOME_OK;
-    }
-    ~katome_dist_builder() {
-        for (auto& e : xevents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
-        if (xstream) { (void)hipSetDevice(s.device); dev_retire_stream(xstream); (void)hipStreamDestroy(xstream); }
-    }
-};
 
 namespace {
 
@@ -517,6 +471,7 @@ int fill_graph(katome_dist_builder* d, katome_dist_graph* out) {
     out->d_node_key = d->node_key.as<u64>();
     out->d_edge_id = d->first_seen ? d->edge_gid.as<u64>() : nullptr;
     out->d_node_id = d->first_seen ? d->node_gid.as<u64>() : nullptr;
+    out->d_edge_age = d->edge_age.p ? d->edge_age.as<u64>() : nullptr;
     return KATOME_OK;
 }
 
@@ -582,6 +537,12 @@ void katome_dist_destroy(katome_dist_builder* d) {
 }
 
 katome_builder* katome_dist_inner(katome_dist_builder* d) { return d ? d->b : nullptr; }
+
+int katome_dist_current_graph(katome_dist_builder* d, katome_dist_graph* out) {
+    if (!d) { set_error("null argument"); return KATOME_E_ARG; }
+    if (!d->finalized) { set_error("katome_dist_current_graph: not finalized"); return KATOME_E_ARG; }
+    return fill_graph(d, out);
+}
 
 int katome_dist_remove_weak_edges(katome_dist_builder* d, uint32_t threshold) {
     if (!d) { set_error("null argument"); return KATOME_E_ARG; }
@@ -860,6 +821,21 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
         KLAUNCH(map_ids_kernel, E, stream, lsrc.as<u64>(), E, id_map, base, d->edge_src.as<u64>());
     }
     KCHECK_HIP(hipGetLastError());
+    if (d->first_seen) {
+        // for the stages that run on the sharded graph (dist_prune.hip): where every edge's target lives -- owner rank (the
+        // segment its look-up travelled in) and the node's local index there (the owner's answer, unmapped)
+        KCHECK(d->xchg(X_IDS, local.p, rcnt.data(), back.p, counts.data(), 8, stream));
+        KCHECK(d->edge_dlocal.alloc((E + 1) * 8, stream)); KCHECK(d->edge_drank.alloc((E + 1) * 8, stream));
+        if (E) KLAUNCH(scatter_u64_kernel, E, stream, back.as<u64>(), porigin.as<u32>(), E, d->edge_dlocal.as<u64>());
+        uint64_t off = 0;
+        for (int p = 0; p < world; ++p) {
+            if (counts[p]) KLAUNCH(scatter_const_kernel, counts[p], stream, porigin.as<u32>(), off, off + counts[p], (u64)p, d->edge_drank.as<u64>());
+            off += counts[p];
+        }
+        KCHECK_HIP(hipGetLastError());
+        { const size_t bytes = lsrc.bytes; d->edge_lsrc.stream = stream; d->edge_lsrc.adopt(lsrc.take(), bytes); }
+        d->n_src = n_src;
+    }
     if (d->first_seen) {                                     // petgraph edge index = rank of the edge's first insertion (pt_graph.rs:194)
         const uint64_t max_seq = 2 * (total_reads + 1) * 2 * (uint64_t)std::max<uint32_t>(d->W, 1) + 2;
         KCHECK(d->edge_gid.alloc((E + 1) * 8, stream));

@@ -548,10 +548,11 @@ constexpr long long CLAMP_NONE = -(1ll << 60);
 // entries are numbered r = 0.. from the top: r <-> ascending index u - 1 - r.  MODE 0: the workgroup's composed function
 // -> agg[block].  MODE 1: carry[block] is what precedes the workgroup; size_before[i] for every entry of it, and the
 // count left after the very last entry -> totals[3].
-template <int MODE>
-__global__ __launch_bounds__(BLOCK) void replay_scan_kernel(const u32* __restrict__ pos, const u32* __restrict__ mult, u64 u, u64 n_edges,
+// (I: the index type -- u32 on one GPU, u64 for the positions of a graph sharded over several, dist_prune.hip)
+template <int MODE, class I>
+__global__ __launch_bounds__(BLOCK) void replay_scan_kernel(const I* __restrict__ pos, const u32* __restrict__ mult, u64 u, u64 n_edges,
                                                             Clamp* __restrict__ agg, const Clamp* __restrict__ carry,
-                                                            u32* __restrict__ size_before, u64* __restrict__ totals) {
+                                                            I* __restrict__ size_before, u64* __restrict__ totals) {
     __shared__ Clamp part[BLOCK];
     const u32 tid = threadIdx.x;
     const u64 r0 = ((u64)blockIdx.x * BLOCK + tid) * REPLAY_ITEMS;
@@ -583,7 +584,7 @@ __global__ __launch_bounds__(BLOCK) void replay_scan_kernel(const u32* __restric
         const u64 r = r0 + j;
         if (r < u) {
             const u64 i = u - 1 - r;
-            size_before[i] = (u32)n;
+            size_before[i] = (I)n;
             const long long left = n - (long long)mult[i], d = pos[i];
             n = left > d ? left : d;
             if (i == 0) totals[3] = (u64)n;
@@ -611,35 +612,38 @@ __global__ __launch_bounds__(BLOCK) void replay_spine_kernel(const Clamp* __rest
     if (tid) run = part[tid - 1];
     for (u64 b = b0; b < b1; ++b) { carry[b] = run; run = clamp_then(run, agg[b]); }
 }
-__global__ __launch_bounds__(BLOCK) void iota_from_kernel(u32* __restrict__ out, u64 n, u32 first) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) out[i] = first + (u32)i;
+template <class I>
+__global__ __launch_bounds__(BLOCK) void iota_from_kernel(I* __restrict__ out, u64 n, I first) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) out[i] = first + (I)i;
 }
 // marked positions inside the tail [M, n): where their last occupant comes from; totals[4] = entries below M
-__global__ __launch_bounds__(BLOCK) void replay_links_kernel(const u32* __restrict__ pos, const u32* __restrict__ mult,
-                                                             const u32* __restrict__ size_before, u64 u, u64 M, u32* __restrict__ jump,
+template <class I>
+__global__ __launch_bounds__(BLOCK) void replay_links_kernel(const I* __restrict__ pos, const u32* __restrict__ mult,
+                                                             const I* __restrict__ size_before, u64 u, u64 M, I* __restrict__ jump,
                                                              u64* __restrict__ totals) {
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < u; i += (u64)gridDim.x * BLOCK) {
         const u64 d = pos[i];
         if (d < M) continue;
         if (i == 0 || pos[i - 1] < M) totals[4] = i;
         const long long left = (long long)size_before[i] - (long long)mult[i];
-        if (left > (long long)d) jump[d - M] = (u32)left;          // (else the entry ends by taking the last edge itself)
+        if (left > (long long)d) jump[d - M] = (I)left;          // (else the entry ends by taking the last edge itself)
     }
 }
 // victims in removal order, the moves into the marked positions that stay, the removals owed to repeated indices
-__global__ __launch_bounds__(BLOCK) void replay_emit_kernel(const u32* __restrict__ pos, const u32* __restrict__ mult,
-                                                            const u32* __restrict__ size_before, u64 u, u64 n_edges, u64 M,
-                                                            const u32* __restrict__ jump, u32* __restrict__ victims,
-                                                            u32* __restrict__ move_to, u32* __restrict__ move_from, u64* __restrict__ totals) {
+template <class I>
+__global__ __launch_bounds__(BLOCK) void replay_emit_kernel(const I* __restrict__ pos, const u32* __restrict__ mult,
+                                                            const I* __restrict__ size_before, u64 u, u64 n_edges, u64 M,
+                                                            const I* __restrict__ jump, I* __restrict__ victims,
+                                                            I* __restrict__ move_to, I* __restrict__ move_from, u64* __restrict__ totals) {
     u32 dups = 0;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < u; i += (u64)gridDim.x * BLOCK) {
         const u64 d = pos[i], S = size_before[i];
         const long long left = (long long)S - (long long)mult[i];
         const u64 after = left > (long long)d ? (u64)left : d, e = S - after, first = n_edges - S;
-        victims[first] = (u32)d;
+        victims[first] = (I)d;
         for (u64 j = 1; j < e; ++j) victims[first + j] = jump[S - j - M];
         dups += (u32)(e - 1);
-        if (d < M) { move_to[i] = (u32)d; move_from[i] = jump[after - M]; }
+        if (d < M) { move_to[i] = (I)d; move_from[i] = jump[after - M]; }
     }
     dups = wave_sum(dups);
     if ((threadIdx.x & 63) == 0 && dups) atomicAdd((unsigned long long*)&totals[5], (unsigned long long)dups);
@@ -656,10 +660,12 @@ __global__ __launch_bounds__(BLOCK) void replay_emit_kernel(const u32* __restric
 // chains have one or two links, so the holes are found in a few rounds: every removal whose chain runs over known
 // holes settles, the rest wait for the next round.  When an edge removal takes both endpoints, the endpoint at the
 // larger current position goes first (pruner.rs:206-225) -- both positions are chain ends at the same removal number.
-constexpr u32 UNRESOLVED = 0xFFFFFFFFu;
+template <class I> struct IdxNone { static constexpr I value = (I)~(I)0; };      // REPLAY_NONE / "hole not known yet" in either index width
 constexpr u32 CHAIN_CAP = 1u << 13;        // links followed per chain before the pass is handed to the host replay
 
-__global__ __launch_bounds__(BLOCK) void die_count_kernel(const u32* __restrict__ die, u64 m, u32* __restrict__ counts) {
+template <class I>
+__global__ __launch_bounds__(BLOCK) void die_count_kernel(const I* __restrict__ die, u64 m, u32* __restrict__ counts) {
+    constexpr I NONE32 = IdxNone<I>::value;
     __shared__ u32 total;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
@@ -673,8 +679,10 @@ __global__ __launch_bounds__(BLOCK) void die_count_kernel(const u32* __restrict_
     if (threadIdx.x == 0) counts[blockIdx.x] = total;
 }
 // first[t] = nodes removed before edge removal t; dead[] marks the tail nodes that die
-__global__ __launch_bounds__(BLOCK) void die_first_kernel(const u32* __restrict__ die, u64 m, const u64* __restrict__ block_offs, u64 base_pos,
-                                                          u32* __restrict__ first, unsigned char* __restrict__ dead) {
+template <class I>
+__global__ __launch_bounds__(BLOCK) void die_first_kernel(const I* __restrict__ die, u64 m, const u64* __restrict__ block_offs, u64 base_pos,
+                                                          I* __restrict__ first, unsigned char* __restrict__ dead) {
+    constexpr I NONE32 = IdxNone<I>::value;
     __shared__ u32 wsum[BLOCK / 64];
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const u64 base = ((u64)blockIdx.x * BLOCK + tid) * MARK_ITEMS;
@@ -683,7 +691,7 @@ __global__ __launch_bounds__(BLOCK) void die_first_kernel(const u32* __restrict_
     for (int j = 0; j < MARK_ITEMS; ++j) {
         cnt[j] = 0;
         if (base + j < m) {
-            const u32 a = die[2 * (base + j)], b = die[2 * (base + j) + 1];
+            const I a = die[2 * (base + j)], b = die[2 * (base + j) + 1];
             cnt[j] = (a != NONE32) + (b != NONE32);
             if (a != NONE32 && a >= base_pos) dead[a - base_pos] = 1;
             if (b != NONE32 && b >= base_pos) dead[b - base_pos] = 1;
@@ -699,37 +707,41 @@ __global__ __launch_bounds__(BLOCK) void die_first_kernel(const u32* __restrict_
     for (u32 w = 0; w < wave; ++w) woff += wsum[w];
     u64 run = block_offs[blockIdx.x] + woff + incl - c;
 #pragma unroll
-    for (int j = 0; j < MARK_ITEMS; ++j) if (base + j < m) { first[base + j] = (u32)run; run += cnt[j]; }
+    for (int j = 0; j < MARK_ITEMS; ++j) if (base + j < m) { first[base + j] = (I)run; run += cnt[j]; }
 }
 // position at removal number s of the node that started at x (alive then); false: a hole on the way is not known yet
-__device__ __forceinline__ bool node_position(u32 x, u64 s, u64 N, u64 base_pos, const u32* hole, u32* flags, u32& out) {
+template <class I>
+__device__ __forceinline__ bool node_position(I x, u64 s, u64 N, u64 base_pos, const I* hole, u32* flags, I& out) {
+    constexpr I UNRESOLVED = IdxNone<I>::value;
     u64 q = x;
     u32 links = 0;
     while (q >= base_pos && N - 1 - q < s) {
-        const u32 h = hole[q - base_pos];
+        const I h = hole[q - base_pos];
         if (h == UNRESOLVED) return false;
         if (h == q) break;                                   // (the occupant died here; no live node follows this link)
         q = h;
         if (++links > CHAIN_CAP) { flags[1] = 1; return false; }
     }
-    out = (u32)q;
+    out = (I)q;
     return true;
 }
-__global__ __launch_bounds__(BLOCK) void node_holes_kernel(const u32* __restrict__ die, const u32* __restrict__ first, u64 m, u64 N,
-                                                           u64 base_pos, u32* hole, u32* flags /* [0] something waits, [1] chain too long */) {
+template <class I>
+__global__ __launch_bounds__(BLOCK) void node_holes_kernel(const I* __restrict__ die, const I* __restrict__ first, u64 m, u64 N,
+                                                           u64 base_pos, I* hole, u32* flags /* [0] something waits, [1] chain too long */) {
+    constexpr I NONE32 = IdxNone<I>::value, UNRESOLVED = IdxNone<I>::value;
     bool waits = false;
     for (u64 t = (u64)blockIdx.x * BLOCK + threadIdx.x; t < m; t += (u64)gridDim.x * BLOCK) {
-        const u32 a = die[2 * t], b = die[2 * t + 1];
+        const I a = die[2 * t], b = die[2 * t + 1];
         if (a == NONE32 && b == NONE32) continue;
         const u64 s = first[t], last = N - 1 - s;
         if (hole[last - base_pos] != UNRESOLVED) continue;                   // settled in an earlier round
         if (a != NONE32 && b != NONE32) {
-            u32 pa, pb;
+            I pa, pb;
             if (!node_position(a, s, N, base_pos, hole, flags, pa) || !node_position(b, s, N, base_pos, hole, flags, pb)) { waits = true; continue; }
             hole[last - 1 - base_pos] = pa < pb ? pa : pb;                      // the second to go (it cannot be the one sitting last)
             hole[last - base_pos] = pa < pb ? pb : pa;
         } else {
-            u32 p;
+            I p;
             if (!node_position(a != NONE32 ? a : b, s, N, base_pos, hole, flags, p)) { waits = true; continue; }
             hole[last - base_pos] = p;
         }
@@ -737,9 +749,11 @@ __global__ __launch_bounds__(BLOCK) void node_holes_kernel(const u32* __restrict
     if (waits) flags[0] = 1;
 }
 // the tail nodes that stay: where each ends up
-__global__ __launch_bounds__(BLOCK) void node_moves_kernel(const unsigned char* __restrict__ dead, u64 M, u64 base_pos, const u32* __restrict__ hole,
-                                                           u32* __restrict__ move_to, u32* __restrict__ move_from, u64* __restrict__ count,
+template <class I>
+__global__ __launch_bounds__(BLOCK) void node_moves_kernel(const unsigned char* __restrict__ dead, u64 M, u64 base_pos, const I* __restrict__ hole,
+                                                           I* __restrict__ move_to, I* __restrict__ move_from, u64* __restrict__ count,
                                                            u32* flags) {
+    constexpr I UNRESOLVED = IdxNone<I>::value;
     __shared__ u32 wcnt[BLOCK / 64];
     __shared__ u64 bbase;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -751,7 +765,7 @@ __global__ __launch_bounds__(BLOCK) void node_moves_kernel(const unsigned char* 
         if (stays) {
             u32 links = 0;
             while (q >= base_pos) {
-                const u32 h = hole[q - base_pos];
+                const I h = hole[q - base_pos];
                 if (h == UNRESOLVED || h == q || ++links > CHAIN_CAP) { flags[1] = 1; stays = false; break; }
                 q = h;
             }
@@ -769,7 +783,7 @@ __global__ __launch_bounds__(BLOCK) void node_moves_kernel(const unsigned char* 
             u32 woff = 0;
             for (u32 w = 0; w < wave; ++w) woff += wcnt[w];
             const u64 at = bbase + woff + __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull));
-            move_to[at] = (u32)q; move_from[at] = (u32)(base_pos + i);
+            move_to[at] = (I)q; move_from[at] = (I)(base_pos + i);
         }
         __syncthreads();
     }
@@ -795,12 +809,14 @@ int upload(DevBuf& d, const U32Buf& h, hipStream_t stream) {
 
 }  // namespace
 
-__global__ void retain_jump_kernel(u32* __restrict__ jump, u64 u, u64 M, u32* __restrict__ changed);
+template <class I> __global__ void retain_jump_kernel(I* __restrict__ jump, u64 u, u64 M, u32* __restrict__ changed);
 
 // remove_paths' edge removals (pruner.rs:199-217) for marked positions d_pos[u] (ascending) listed d_mult[] times each,
 // of E edges: victims in removal order, the moves (to[i] <- from[i]) that fill the marked positions below the new count
-int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t E, ReplayScratch& sc, DevBuf& d_victims, DevBuf& to_e,
-                     DevBuf& from_e, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups, hipStream_t stream) {
+template <class I>
+static int replay_edges_t(const I* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t E, ReplayScratch& sc, DevBuf& d_victims, DevBuf& to_e,
+                          DevBuf& from_e, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups, hipStream_t stream) {
+    constexpr size_t W = sizeof(I);
     *n_removed = 0; *n_left = E; *n_moves = 0; *n_dups = 0;
     if (u == 0) return KATOME_OK;
     DevBuf &agg = sc.agg, &carry = sc.carry, &size_before = sc.size_before, &jump = sc.jump, &totals = sc.totals;
@@ -808,37 +824,37 @@ int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, 
     KCHECK_HIP(hipMemsetAsync(totals.p, 0, 64, stream));
     const u64 nb = (u + (u64)BLOCK * REPLAY_ITEMS - 1) / ((u64)BLOCK * REPLAY_ITEMS);
     KCHECK(ensure(agg, nb * sizeof(Clamp) + 16, stream)); KCHECK(ensure(carry, nb * sizeof(Clamp) + 16, stream));
-    KCHECK(ensure(size_before, u * 4 + 16, stream));
-    hipLaunchKernelGGL(replay_scan_kernel<0>, dim3((unsigned)nb), dim3(BLOCK), 0, stream, d_pos, d_mult, u, E,
-                       agg.as<Clamp>(), (const Clamp*)nullptr, (u32*)nullptr, totals.as<u64>());
+    KCHECK(ensure(size_before, u * W + 16, stream));
+    hipLaunchKernelGGL((replay_scan_kernel<0, I>), dim3((unsigned)nb), dim3(BLOCK), 0, stream, d_pos, d_mult, u, E,
+                       agg.as<Clamp>(), (const Clamp*)nullptr, (I*)nullptr, totals.as<u64>());
     hipLaunchKernelGGL(replay_spine_kernel, dim3(1), dim3(BLOCK), 0, stream, agg.as<Clamp>(), nb, carry.as<Clamp>());
-    hipLaunchKernelGGL(replay_scan_kernel<1>, dim3((unsigned)nb), dim3(BLOCK), 0, stream, d_pos, d_mult, u, E,
-                       (Clamp*)nullptr, carry.as<Clamp>(), size_before.as<u32>(), totals.as<u64>());
+    hipLaunchKernelGGL((replay_scan_kernel<1, I>), dim3((unsigned)nb), dim3(BLOCK), 0, stream, d_pos, d_mult, u, E,
+                       (Clamp*)nullptr, carry.as<Clamp>(), size_before.as<I>(), totals.as<u64>());
     KCHECK_HIP(hipGetLastError());
     u64 left = 0;
     KCHECK_HIP(hipMemcpyAsync(&left, totals.as<u64>() + 3, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     const u64 E_new = left, m = E - E_new;
-    KCHECK(ensure(jump, m * 4 + 16, stream));
-    KCHECK(ensure(d_victims, m * 4 + 16, stream));
-    KCHECK(ensure(to_e, u * 4 + 16, stream)); KCHECK(ensure(from_e, u * 4 + 16, stream));
+    KCHECK(ensure(jump, m * W + 16, stream));
+    KCHECK(ensure(d_victims, m * W + 16, stream));
+    KCHECK(ensure(to_e, u * W + 16, stream)); KCHECK(ensure(from_e, u * W + 16, stream));
     const u64 all = u;                                           // totals[4]: entries below the new count (default: all)
     KCHECK_HIP(hipMemcpyAsync(totals.as<u64>() + 4, &all, 8, hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(iota_from_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<u32>(), m, (u32)E_new);
-    hipLaunchKernelGGL(replay_links_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos, d_mult,
-                       size_before.as<u32>(), u, E_new, jump.as<u32>(), totals.as<u64>());
+    hipLaunchKernelGGL(iota_from_kernel<I>, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<I>(), m, (I)E_new);
+    hipLaunchKernelGGL(replay_links_kernel<I>, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos, d_mult,
+                       size_before.as<I>(), u, E_new, jump.as<I>(), totals.as<u64>());
     for (int round = 0; round < 64; ++round) {
         KCHECK_HIP(hipMemsetAsync(totals.as<u64>() + 6, 0, 8, stream));
         for (int rep = 0; rep < 2; ++rep)
-            hipLaunchKernelGGL(retain_jump_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<u32>(), m, E_new,
+            hipLaunchKernelGGL(retain_jump_kernel<I>, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, jump.as<I>(), m, E_new,
                                reinterpret_cast<u32*>(totals.as<u64>() + 6));
         u64 changed = 0;
         KCHECK_HIP(hipMemcpyAsync(&changed, totals.as<u64>() + 6, 8, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
         if (!changed) break;
     }
-    hipLaunchKernelGGL(replay_emit_kernel, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos, d_mult,
-                       size_before.as<u32>(), u, E, E_new, jump.as<u32>(), d_victims.as<u32>(), to_e.as<u32>(), from_e.as<u32>(),
+    hipLaunchKernelGGL(replay_emit_kernel<I>, dim3(grid_for(u, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_pos, d_mult,
+                       size_before.as<I>(), u, E, E_new, jump.as<I>(), d_victims.as<I>(), to_e.as<I>(), from_e.as<I>(),
                        totals.as<u64>());
     KCHECK_HIP(hipGetLastError());
     u64 h2[2] = {0, 0};
@@ -847,43 +863,54 @@ int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, 
     *n_removed = m; *n_left = E_new; *n_moves = h2[0]; *n_dups = h2[1];
     return KATOME_OK;
 }
+int dev_replay_edges(const uint32_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t E, ReplayScratch& sc, DevBuf& d_victims, DevBuf& to_e,
+                     DevBuf& from_e, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups, hipStream_t stream) {
+    return replay_edges_t<u32>(d_pos, d_mult, u, E, sc, d_victims, to_e, from_e, n_removed, n_left, n_moves, n_dups, stream);
+}
+// the same replay on 64-bit positions: a graph sharded over several GPUs has more than 2^32 edges (BASELINE config 5)
+int dev_replay_edges64(const uint64_t* d_pos, const uint32_t* d_mult, uint64_t u, uint64_t E, ReplayScratch& sc, DevBuf& d_victims, DevBuf& to_e,
+                       DevBuf& from_e, uint64_t* n_removed, uint64_t* n_left, uint64_t* n_moves, uint64_t* n_dups, hipStream_t stream) {
+    return replay_edges_t<u64>(d_pos, d_mult, u, E, sc, d_victims, to_e, from_e, n_removed, n_left, n_moves, n_dups, stream);
+}
 
 // remove_single_node after every removed edge (pruner.rs:206-225) for die[2t], die[2t+1] (the endpoints edge removal t
 // leaves without edges, REPLAY_NONE = stays), of N nodes: the moves to[i] <- from[i] of the tail nodes that stay.
 // *fell_back = 1: a chain was too long for the device form; nothing was produced and the caller runs the host replay.
-int dev_replay_nodes(const uint32_t* d_die, uint64_t m, uint64_t N, NodeReplayScratch& sc, DevBuf& to_n, DevBuf& from_n, uint64_t* n_moves,
-                     uint64_t* n_left, int* fell_back, hipStream_t stream) {
+template <class I>
+static int replay_nodes_t(const I* d_die, uint64_t m, uint64_t N, NodeReplayScratch& sc, DevBuf& to_n, DevBuf& from_n, uint64_t* n_moves,
+                          uint64_t* n_left, int* fell_back, hipStream_t stream) {
+    constexpr size_t W = sizeof(I);
     *n_moves = 0; *n_left = N; *fell_back = 0;
     if (m == 0) return KATOME_OK;
     const u64 nblocks = (m + (u64)BLOCK * MARK_ITEMS - 1) / ((u64)BLOCK * MARK_ITEMS);
     KCHECK(ensure(sc.counts, nblocks * 4 + 16, stream)); KCHECK(ensure(sc.offs, (nblocks + 1) * 8 + 16, stream));
     KCHECK(ensure(sc.flags, 32, stream));
-    hipLaunchKernelGGL(die_count_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_die, m, sc.counts.as<u32>());
+    hipLaunchKernelGGL(die_count_kernel<I>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_die, m, sc.counts.as<u32>());
     KCHECK(dev_scan_counts(sc.counts.as<u32>(), nblocks, sc.offs.as<u64>(), stream));
     u64 M = 0;
     KCHECK_HIP(hipMemcpyAsync(&M, sc.offs.as<u64>() + nblocks, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     if (M == 0) return KATOME_OK;
     const u64 base_pos = N - M;
-    KCHECK(ensure(sc.first, m * 4 + 16, stream)); KCHECK(ensure(sc.hole, M * 4 + 16, stream)); KCHECK(ensure(sc.dead, M + 16, stream));
-    KCHECK(ensure(to_n, M * 4 + 16, stream)); KCHECK(ensure(from_n, M * 4 + 16, stream));
-    KCHECK_HIP(hipMemsetAsync(sc.hole.p, 0xFF, M * 4, stream));
+    KCHECK(ensure(sc.first, m * W + 16, stream)); KCHECK(ensure(sc.hole, M * W + 16, stream)); KCHECK(ensure(sc.dead, M + 16, stream));
+    KCHECK(ensure(to_n, M * W + 16, stream)); KCHECK(ensure(from_n, M * W + 16, stream));
+    KCHECK_HIP(hipMemsetAsync(sc.hole.p, 0xFF, M * W, stream));
     KCHECK_HIP(hipMemsetAsync(sc.dead.p, 0, M, stream));
-    hipLaunchKernelGGL(die_first_kernel, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_die, m, sc.offs.as<u64>(), base_pos, sc.first.as<u32>(),
+    hipLaunchKernelGGL(die_first_kernel<I>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_die, m, sc.offs.as<u64>(), base_pos, sc.first.as<I>(),
                        sc.dead.as<unsigned char>());
     u32 h_flags[2] = {1, 0};
     for (int round = 0; round < 256 && h_flags[0] && !h_flags[1]; ++round) {
         KCHECK_HIP(hipMemsetAsync(sc.flags.p, 0, 32, stream));
-        hipLaunchKernelGGL(node_holes_kernel, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_die, sc.first.as<u32>(), m, N, base_pos,
-                           sc.hole.as<u32>(), sc.flags.as<u32>());
+        hipLaunchKernelGGL(node_holes_kernel<I>, dim3(grid_for(m, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, d_die, sc.first.as<I>(), m, N, base_pos,
+                           sc.hole.as<I>(), sc.flags.as<u32>());
         KCHECK_HIP(hipGetLastError());
         KCHECK_HIP(hipMemcpyAsync(h_flags, sc.flags.p, 8, hipMemcpyDeviceToHost, stream));
         KCHECK_HIP(hipStreamSynchronize(stream));
     }
     if (h_flags[0] || h_flags[1]) { *fell_back = 1; return KATOME_OK; }
     KCHECK_HIP(hipMemsetAsync(sc.flags.p, 0, 32, stream));
-    hipLaunchKernelGGL(node_moves_kernel, dim3(grid_for(M, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, sc.dead.as<unsigned char>(), M, base_pos,
-                       sc.hole.as<u32>(), to_n.as<u32>(), from_n.as<u32>(), reinterpret_cast<u64*>(sc.flags.as<u32>() + 4), sc.flags.as<u32>());
+    hipLaunchKernelGGL(node_moves_kernel<I>, dim3(grid_for(M, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, sc.dead.as<unsigned char>(), M, base_pos,
+                       sc.hole.as<I>(), to_n.as<I>(), from_n.as<I>(), reinterpret_cast<u64*>(sc.flags.as<u32>() + 4), sc.flags.as<u32>());
     KCHECK_HIP(hipGetLastError());
     u32 h_end[6] = {0, 0, 0, 0, 0, 0};
     KCHECK_HIP(hipMemcpyAsync(h_end, sc.flags.p, 24, hipMemcpyDeviceToHost, stream));
@@ -892,6 +919,14 @@ int dev_replay_nodes(const uint32_t* d_die, uint64_t m, uint64_t N, NodeReplaySc
     *n_moves = (u64)h_end[4] | ((u64)h_end[5] << 32);
     *n_left = base_pos;
     return KATOME_OK;
+}
+int dev_replay_nodes(const uint32_t* d_die, uint64_t m, uint64_t N, NodeReplayScratch& sc, DevBuf& to_n, DevBuf& from_n, uint64_t* n_moves,
+                     uint64_t* n_left, int* fell_back, hipStream_t stream) {
+    return replay_nodes_t<u32>(d_die, m, N, sc, to_n, from_n, n_moves, n_left, fell_back, stream);
+}
+int dev_replay_nodes64(const uint64_t* d_die, uint64_t m, uint64_t N, NodeReplayScratch& sc, DevBuf& to_n, DevBuf& from_n, uint64_t* n_moves,
+                       uint64_t* n_left, int* fell_back, hipStream_t stream) {
+    return replay_nodes_t<u64>(d_die, m, N, sc, to_n, from_n, n_moves, n_left, fell_back, stream);
 }
 
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream) {
@@ -1168,12 +1203,13 @@ __global__ __launch_bounds__(BLOCK) void retain_links_kernel(const u32* __restri
         }
     }
 }
-__global__ __launch_bounds__(BLOCK) void retain_jump_kernel(u32* __restrict__ jump, u64 u, u64 M, u32* __restrict__ changed) {
+template <class I>
+__global__ __launch_bounds__(BLOCK) void retain_jump_kernel(I* __restrict__ jump, u64 u, u64 M, u32* __restrict__ changed) {
     bool any = false;
     for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < u; i += (u64)gridDim.x * BLOCK) {
-        const u32 v = jump[i];
-        if (v == (u32)(M + i)) continue;                             // not flagged, or removed while last: a fixed point
-        const u32 w = jump[v - M];
+        const I v = jump[i];
+        if (v == (I)(M + i)) continue;                             // not flagged, or removed while last: a fixed point
+        const I w = jump[v - M];
         if (w != v) { jump[i] = w; any = true; }
     }
     if (any) *changed = 1;

@@ -277,11 +277,11 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
     if (pb.nblocks > 0x7fffffffull) { set_error("radix pass: %llu keys exceed the grid limit", (unsigned long long)n); return KATOME_E_ARG; }
     dim3 block(BLOCK);
     {
-        KernelScope ks(DigitTimers<Digit>::HIST, stream);
+        KernelScope ks(DigitTimers<Digit>::HIST, stream, n);
         hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
     }
     {
-        KernelScope ks(K_PASS_OFFSETS, stream);
+        KernelScope ks(K_PASS_OFFSETS, stream, n);
         hipLaunchKernelGGL(radix_chunk_kernel, dim3((unsigned)pb.nchunks), block, 0, stream, pb.counts.as<u32>(), pb.nblocks, pb.chunk.as<u64>(), pb.chunk_blocks);
         hipLaunchKernelGGL(radix_offsets_kernel, dim3(1), block, 0, stream, pb.chunk.as<u64>(), pb.nchunks, pb.totals.as<u64>());
     }
@@ -290,7 +290,7 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
         KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     {
-        KernelScope ks(DigitTimers<Digit>::SCATTER, stream);
+        KernelScope ks(DigitTimers<Digit>::SCATTER, stream, n);
         hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
                            pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks);
     }
@@ -457,7 +457,7 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
         const size_t lds = (size_t)(RUN_TILE + 2 * RUN_HALO) * NW * 8;
         if (lds > (64u << 10)) KCHECK_HIP(hipFuncSetAttribute((const void*)run_sort_kernel<NW, HAS_VAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {
-            KernelScope ks(K_RUN_SORT, stream);
+            KernelScope ks(K_RUN_SORT, stream, n);
             hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
                                kout, vout, overflow.as<u32>());
         }
@@ -1137,7 +1137,7 @@ static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edg
     KCHECK(counts.alloc(nblocks * 4));
     KCHECK(offs.alloc((nblocks + 1) * 8));
     {
-        KernelScope ks(K_SRC_IDS, stream);
+        KernelScope ks(K_SRC_IDS, stream, E);
         hipLaunchKernelGGL(src_count_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, counts.as<u32>());
         hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, stream, counts.as<u32>(), nblocks, offs.as<u64>());
     }
@@ -1148,7 +1148,7 @@ static int source_ids_t(const u64* d_edge_key, u64 E, DevBuf& node_key, u64* edg
     KCHECK(node_key.alloc((n_src + (with_slack ? n_src / 8 + (1u << 16) : 0) + 1) * 8 * NW, stream));
     if (seg_edge) KCHECK(seg_edge->alloc(((n_src + DST_SEG - 1) / DST_SEG + 1) * 8));        // first out-edge of every DST_SEG-th source
     {
-        KernelScope ks(K_SRC_IDS, stream);
+        KernelScope ks(K_SRC_IDS, stream, E);
         hipLaunchKernelGGL(src_write_kernel<NW>, dim3((unsigned)nblocks), dim3(BLOCK), 0, stream, d_edge_key, E, offs.as<u64>(), node_key.as<u64>(), edge_src,
                            seg_edge ? seg_edge->as<u64>() : nullptr, DST_SEG);
     }
@@ -1201,7 +1201,7 @@ static int node_ids_t(const u64* d_edge_key, u64 E, u32 k, DevBuf& node_key, u64
         hipLaunchKernelGGL(dst_seg_kernel<NW>, dim3(grid_for(4 * (n_seg + 1), BLOCK)), dim3(BLOCK), 0, stream, nodes, d_edge_key, E, node_bits, n_seg, seg.as<u64>());
         const size_t lds = (size_t)(DST_SEG * NW + MissCap<NW>::value * (NW + 1) + (first ? DST_SEG : 0)) * 8 + (first ? 2 * (DST_SEG / 32) * 4 : 0);
         const dim3 grid((unsigned)std::min<u64>(n_seg, 256u * 32u));
-        KernelScope ks(K_DST_MERGE, stream);
+        KernelScope ks(K_DST_MERGE, stream, E);
         if (first) {
             // (room for the nodes without out-edges, like node_key's)
             // (the merge writes the first touch of every source; the room behind them, for the nodes without out-edges, starts at all-ones)

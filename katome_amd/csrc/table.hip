@@ -808,7 +808,7 @@ static int expand_launch(Table& tiles, u64 slot0, u64 slot1, Table* kmers, uint3
     TableAux* aux = kmers ? kmers->counter.as<TableAux>() : nullptr;
     if (slot1 <= slot0) return KATOME_OK;
     dim3 grid(grid_for(slot1 - slot0, BLOCK, 256u * 32u)), block(BLOCK);
-    KernelScope ks(K_EXPAND, stream);
+    KernelScope ks(K_EXPAND, stream, slot1 - slot0);
 #define KATOME_EXPAND(NWT, NWK, RCV)                                                                                          \
     hipLaunchKernelGGL((expand_tiles_kernel<NWT, NWK, RCV, TO_TABLE>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), \
                        slot0, slot1, k, span, stride, kmers ? kmers->slots.as<SlotOf<NWK>::type>() : nullptr, kmers ? kmers->cap : 0,     \
@@ -900,7 +900,7 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
-    KernelScope ks(K_RECORDS, stream);
+    KernelScope ks(K_RECORDS, stream, tiles.cap);
     if (tiles.nw == 1) {
         if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, true>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
         else    hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, false>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
@@ -936,7 +936,7 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     KCHECK(aux.alloc(64));
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
     {
-        KernelScope ks(K_GROUP_INDEX, stream);
+        KernelScope ks(K_GROUP_INDEX, stream, n);
         hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for(n + 1, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, ko, n, index.as<u64>());
     }
     const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
@@ -951,7 +951,7 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     {
-        KernelScope ks(K_LDS_COUNT, stream);
+        KernelScope ks(K_LDS_COUNT, stream, n);
         if (rc) hipLaunchKernelGGL((lds_count_kernel<true>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
                                    edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
         else    hipLaunchKernelGGL((lds_count_kernel<false>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,

@@ -140,12 +140,13 @@ class Builder(_ViewOwner):
         _check(_lib.lib().katome_builder_profile(self._h, 1 if enable else 0))
 
     def profile_read(self):
-        """{phase: (total_ms, launches)} since the last read; synchronises"""
+        """{phase: (total_ms, launches, elements processed)} since the last read; synchronises.  Entries "k:<kernel>" are
+        single kernels timed launch by launch inside the phases (elements: keys of a pass, slots of a scan ...)"""
         L = _lib.lib()
         n = L.katome_phase_count()
-        ms, cnt = (C.c_double * n)(), (C.c_uint64 * n)()
-        _check(L.katome_builder_profile_read(self._h, ms, cnt))
-        return {L.katome_phase_name(i).decode(): (ms[i], int(cnt[i])) for i in range(n) if cnt[i]}
+        ms, cnt, work = (C.c_double * n)(), (C.c_uint64 * n)(), (C.c_uint64 * n)()
+        _check(L.katome_builder_profile_read_work(self._h, ms, cnt, work))
+        return {L.katome_phase_name(i).decode(): (ms[i], int(cnt[i]), int(work[i])) for i in range(n) if cnt[i]}
 
     def counts(self):
         """{distinct_tiles, tile_slots, distinct_kmers, kmer_slots} of the last edges()/finalize()"""
@@ -359,6 +360,31 @@ def replay_node_removals(die, n_nodes, device=0):
     frm = torch.empty(max(2 * m, 1), dtype=torch.int32, device=die.device)
     counts = (C.c_uint64 * 3)()
     _check(_lib.lib().katome_dev_replay_node_removals(device, _ptr(die), m, n_nodes, _ptr(to), _ptr(frm), C.cast(counts, C.c_void_p), _stream()))
+    moves, left, gave_up = (int(x) for x in counts)
+    return to[:moves], frm[:moves], left, bool(gave_up)
+
+
+def replay_edge_removals64(pos, mult, n_edges, device=0):
+    """replay_edge_removals on 64-bit positions (int64 tensors; the positions of a graph sharded over several GPUs)"""
+    u = pos.numel()
+    marks = int(mult.to(torch.int64).sum().item()) if u else 0
+    victims = torch.empty(max(marks, 1), dtype=torch.int64, device=pos.device)
+    to = torch.empty(max(u, 1), dtype=torch.int64, device=pos.device)
+    frm = torch.empty(max(u, 1), dtype=torch.int64, device=pos.device)
+    counts = (C.c_uint64 * 4)()
+    _check(_lib.lib().katome_dev_replay_edge_removals64(device, _ptr(pos), _ptr(mult), u, n_edges, _ptr(victims), _ptr(to), _ptr(frm),
+                                                        C.cast(counts, C.c_void_p), _stream()))
+    m, moves, left, dups = (int(x) for x in counts)
+    return victims[:m], to[:moves], frm[:moves], left, dups
+
+
+def replay_node_removals64(die, n_nodes, device=0):
+    """replay_node_removals on 64-bit positions (-1 = stays)"""
+    m = die.numel() // 2
+    to = torch.empty(max(2 * m, 1), dtype=torch.int64, device=die.device)
+    frm = torch.empty(max(2 * m, 1), dtype=torch.int64, device=die.device)
+    counts = (C.c_uint64 * 3)()
+    _check(_lib.lib().katome_dev_replay_node_removals64(device, _ptr(die), m, n_nodes, _ptr(to), _ptr(frm), C.cast(counts, C.c_void_p), _stream()))
     moves, left, gave_up = (int(x) for x in counts)
     return to[:moves], frm[:moves], left, bool(gave_up)
 

@@ -167,6 +167,8 @@ class RankGraph:
         self.node_key = _view(g.d_node_key, (nn, nw), "<i8", owner, device)
         self.edge_id = _view(g.d_edge_id, (ne,), "<i8", owner, device) if g.d_edge_id else None
         self.node_id = _view(g.d_node_id, (nn,), "<i8", owner, device) if g.d_node_id else None
+        # after remove_dead_paths on the sharded graph: the index each edge had when it was built (petgraph's adjacency order)
+        self.edge_age = _view(g.d_edge_age, (ne,), "<i8", owner, device) if g.d_edge_age else None
 
 
 class _InnerBuilder(Builder):
@@ -222,6 +224,13 @@ class ShardedBuilder(_ViewOwner):
         g = _lib.DistGraph()
         _check(_lib.lib().katome_dist_finalize(self._h, C.byref(g), _stream()))
         return RankGraph(g, self, self.tdev)
+
+    def remove_dead_paths(self):
+        """Prunable::remove_dead_paths (pruner.rs:36-82) on the sharded graph, no gather (katome_dist_remove_dead_paths)
+        -> (this rank's share of the pruned graph, stats dict)"""
+        g, st = _lib.DistGraph(), _lib.PruneStats()
+        _check(_lib.lib().katome_dist_remove_dead_paths(self._h, C.byref(g), C.byref(st), _stream()))
+        return RankGraph(g, self, self.tdev), {f: getattr(st, f) for f, _ in _lib.PruneStats._fields_}
 
     def gather(self, root=0):
         """FIRST_SEEN_ORDER: the whole graph to `root` in the reference's index order -> on the root a builder on which
@@ -280,11 +289,9 @@ class DistBuild:
             b.add_reads(self.packed, self.first, self.n_local, wl.read_len, self.skip, self.batch_reads)
             g = b.finalize()
             n_edges, n_nodes = g.total_edges, g.total_nodes
-            if self.prune:                                  # BASELINE config 5: the pruner pass, on the gathered graph
-                root = b.gather(0)
-                if root is not None:
-                    dg, _ = root.remove_dead_paths()
-                    n_edges, n_nodes = dg.n_edges, dg.n_nodes
+            if self.prune:                                  # BASELINE config 5: the pruner pass, on the sharded graph
+                pg, _ = b.remove_dead_paths()
+                n_edges, n_nodes = pg.total_edges, pg.total_nodes
             if self.timer is not None:
                 self.timer.add(b.inner.profile_read())
                 for name, x in b.exchange_stats().items():

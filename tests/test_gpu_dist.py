@@ -74,15 +74,20 @@ def test_sharded_build_in_reference_order_equals_oracle(oracle, world, k, rc, n,
     _same_arrays(g, ref)
 
 
+@pytest.mark.parametrize("prune_route", ["sharded", "gather"])
 @pytest.mark.parametrize("world,k,rc,n,L,genome,err", [(2, 63, True, 400, 150, 4000, 5e-4), (4, 63, True, 900, 150, 9000, 3e-4),
                                                        (8, 63, False, 600, 150, 4000, 5e-4), (2, 63, True, 400, 150, 4000, 5e-3),
                                                        (3, 31, True, 1500, 150, 9000, 1e-2), (2, 40, False, 800, 100, 5000, 2e-3)])
-def test_config5_shape_pruned_on_the_sharded_route(oracle, world, k, rc, n, L, genome, err):
+def test_config5_shape_pruned_on_the_sharded_route(oracle, monkeypatch, world, k, rc, n, L, genome, err, prune_route):
     """BASELINE config 5's shape: k=63 (two-word keys, three-word tiles), reads sharded over the ranks, then the reference's
     first pruning -- Prunable::remove_dead_paths (pruner.rs:36-82), whose walks follow petgraph's adjacency and whose
-    swap_removes re-number by index -- on the graph gathered to one rank in the reference's numbering.  Index for index
-    against the oracle's literal petgraph."""
+    swap_removes re-number by index.  "sharded": on the sharded graph itself (katome_dist_remove_dead_paths: walkers hop
+    between the owners, the index replays run on 64-bit positions; no gather, every rank writes its share of the result);
+    "gather": on the graph gathered to one rank (KATOME_DIST_PRUNE=gather).  Index for index against the oracle's literal
+    petgraph, ages included."""
     from katome_amd.build import GpuGraph
+    if prune_route == "gather":
+        monkeypatch.setenv("KATOME_DIST_PRUNE", "gather")
     ascii_reads, packed, skip = _reads(oracle, n, L, genome, err, 1)
     g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world,
                                         ranks_share_device=True, first_seen_order=True, remove_dead_paths=True)
@@ -90,6 +95,8 @@ def test_config5_shape_pruned_on_the_sharded_route(oracle, world, k, rc, n, L, g
     full = oracle.build_ascii(ascii_reads, k, rc)
     assert ref.n_edges < full.n_edges and (ref.n_edges > 0 or err > 1e-3)   # something was pruned; at the high error rate: everything
     _same_arrays(g, ref)
+    if ref.n_edges:
+        assert g.edge_age is not None and np.array_equal(g.edge_age.astype(np.uint64) + 1, ref.edge_slot)
 
 
 def test_every_stage_after_a_sharded_build(oracle, tmp_path):
@@ -254,6 +261,15 @@ def _process_rank(rank, world, port, k, rc, n_reads, read_len, first_seen, prune
                    src=g.edge_src.cpu().numpy(), dst=g.edge_dst.cpu().numpy(), node_key=g.node_key.cpu().numpy().view(np.uint64))
         if first_seen:
             out.update(edge_id=g.edge_id.cpu().numpy(), node_id=g.node_id.cpu().numpy(), label=g.edge_label.cpu().numpy())
+        if first_seen and prune == 2:              # remove_dead_paths on the sharded graph: every rank keeps its share
+            del g
+            pg, st = b.remove_dead_paths()
+            out.update(p_total_nodes=pg.total_nodes, p_total_edges=pg.total_edges, p_edge_id=pg.edge_id.cpu().numpy(),
+                       p_node_id=pg.node_id.cpu().numpy(), p_label=pg.edge_label.cpu().numpy(), p_src=pg.edge_src.cpu().numpy(),
+                       p_dst=pg.edge_dst.cpu().numpy(), p_weight=pg.edge_weight.cpu().numpy().view(np.uint32),
+                       p_age=pg.edge_age.cpu().numpy(), p_passes=st["passes"], p_removed=st["removed_edges"])
+            del pg
+        elif first_seen:
             root = b.gather(0)
             assert (root is not None) == (rank == 0)
             if root is not None:
@@ -330,6 +346,35 @@ def test_process_per_rank_in_reference_order(oracle, tmp_path, world, k, rc, L, 
     assert int(r0["root_nodes"]) == want.n_nodes
     assert np.array_equal(r0["root_label"], want.edge_label) and np.array_equal(r0["root_weight"], want.edge_weight)
     assert np.array_equal(r0["root_src"].astype(np.uint64), want.edge_src) and np.array_equal(r0["root_dst"].astype(np.uint64), want.edge_dst)
+
+
+@pytest.mark.parametrize("world,k,rc,L", [(2, 31, True, 150), (3, 63, True, 150), (4, 40, False, 103)])
+def test_process_per_rank_pruned_without_a_gather(oracle, tmp_path, world, k, rc, L):
+    """one process per rank (bench.py's shape; exchanges over gloo), katome_dist_remove_dead_paths on the sharded graph: the
+    ranks' shares put side by side by their indices are the oracle's pruned petgraph -- every index exactly once, the right
+    edge, end points, weight and age at each"""
+    n_reads = 6000
+    _spawn(world, k, rc, n_reads, L, True, 2, str(tmp_path))
+    ascii_reads = oracle.synth_reads(0, n_reads, L, 60000, 2e-3, 2)
+    want = oracle.build_ascii(ascii_reads, k, rc, remove_dead_paths=True)
+    full = oracle.build_ascii(ascii_reads, k, rc)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert 0 < want.n_edges < full.n_edges
+    label = np.zeros_like(want.edge_label)
+    src, dst = np.full(want.n_edges, -1, np.int64), np.full(want.n_edges, -1, np.int64)
+    weight, age = np.zeros(want.n_edges, np.uint32), np.zeros(want.n_edges, np.int64)
+    seen_e, seen_n = np.zeros(want.n_edges, np.int32), np.zeros(want.n_nodes, np.int32)
+    for p in parts:
+        assert (int(p["p_total_nodes"]), int(p["p_total_edges"])) == (want.n_nodes, want.n_edges)
+        assert int(p["p_removed"]) == full.n_edges - want.n_edges and int(p["p_passes"]) >= 2
+        ids = p["p_edge_id"]
+        np.add.at(seen_e, ids, 1)
+        np.add.at(seen_n, p["p_node_id"], 1)
+        label[ids], src[ids], dst[ids], weight[ids], age[ids] = p["p_label"], p["p_src"], p["p_dst"], p["p_weight"], p["p_age"]
+    assert (seen_e == 1).all() and (seen_n == 1).all()
+    assert np.array_equal(label, want.edge_label) and np.array_equal(weight, want.edge_weight)
+    assert np.array_equal(src.astype(np.uint64), want.edge_src) and np.array_equal(dst.astype(np.uint64), want.edge_dst)
+    assert np.array_equal(age.astype(np.uint64) + 1, want.edge_slot)
 
 
 _SORTED_SHARDED_SCRIPT = r"""

@@ -498,3 +498,86 @@ def test_node_removal_replay_on_the_device(seed):
         return
     assert left == want_left
     assert dict(zip(to.cpu().tolist(), frm.cpu().tolist())) == want_moves and to.numel() == len(want_moves)
+
+
+# ---- the same two replays on 64-bit positions: what katome_dist_remove_dead_paths runs on rank 0 (dist_prune.hip) ----------
+def _sparse_edge_removals(pos, mult, n):
+    """_naive_edge_removals without the array: only touched positions are kept (n may be 2^33)"""
+    occ = {}
+    victims, dups = [], 0
+    for d, c in sorted(zip(pos, mult), reverse=True):
+        for r in range(c):
+            if d < n:
+                victims.append(occ.get(d, d))
+                dups += r != 0
+                occ[d] = occ.get(n - 1, n - 1)
+                n -= 1
+    return victims, {p: v for p, v in occ.items() if p < n and v != p}, n, dups
+
+
+def _sparse_node_removals(die, n):
+    occ, where = {}, {}
+    for a, b in die:
+        gone = sorted((v for v in (a, b) if v >= 0), key=lambda v: where.get(v, v), reverse=True)
+        for v in gone:
+            p = where.pop(v, v)
+            last = occ.get(n - 1, n - 1)
+            n -= 1
+            if p < n:
+                occ[p] = last
+                where[last] = p
+    return {p: v for p, v in occ.items() if p < n and v != p}, n
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_edge_removal_replay_beyond_32_bit_indices(seed):
+    """BASELINE config 5 in full holds 1.1e10 edges: more than 2^32 indices.  The replay only touches the marked entries and
+    the tail that disappears, so a graph of 2^33 + n edges is replayed here with marks at both ends of the index range
+    (katome_dev_replay_edge_removals64) and compared with the literal swap_remove loop kept sparse.  seed % 3 == 0: small
+    totals, where the 64-bit form must agree with the 32-bit one entry for entry."""
+    from katome_amd import device as kd
+    rng = np.random.default_rng(9000 + seed)
+    small = seed % 3 == 0
+    n_edges = int(rng.integers(1000, 30000)) if small else (1 << 33) + int(rng.integers(1, 1 << 20))
+    tail = np.unique(n_edges - 1 - rng.integers(0, 6000, int(rng.integers(1, 4000))))
+    low = np.unique(rng.integers(0, min(n_edges, 1 << 34) // 2, int(rng.integers(0, 3000))))
+    pos = np.unique(np.concatenate([low, tail[tail >= 0]]))
+    mult = rng.integers(1, (2, 5, 30)[seed % 3] + 1, len(pos))
+    want_v, want_moves, want_left, want_dups = _sparse_edge_removals(pos.tolist(), mult.tolist(), n_edges)
+    d_pos = torch.from_numpy(pos.astype(np.int64)).cuda()
+    d_mult = torch.from_numpy(mult.astype(np.int64)).to(torch.int32).cuda()
+    v, to, frm, left, dups = kd.replay_edge_removals64(d_pos, d_mult, n_edges)
+    assert left == want_left and dups == want_dups
+    assert v.cpu().tolist() == want_v
+    assert dict(zip(to.cpu().tolist(), frm.cpu().tolist())) == want_moves and to.numel() == len(want_moves)
+    if small:
+        v32, to32, frm32, left32, dups32 = kd.replay_edge_removals(d_pos.to(torch.int32), d_mult, n_edges)
+        assert (left32, dups32) == (left, dups) and v32.cpu().tolist() == want_v
+        assert dict(zip(to32.cpu().tolist(), frm32.cpu().tolist())) == want_moves
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_node_removal_replay_beyond_32_bit_indices(seed):
+    from katome_amd import device as kd
+    rng = np.random.default_rng(9500 + seed)
+    n_nodes = (1 << 33) + int(rng.integers(1, 1 << 20))
+    n_die = int(rng.integers(1, 5000))
+    tail = (n_nodes - 1 - rng.choice(8000, size=min(n_die, 8000) // 2 + 1, replace=False)).tolist()
+    low = rng.choice(1 << 32, size=n_die // 2 + 1, replace=False).tolist()
+    dying = [int(x) for x in rng.permutation(np.array(tail + low, dtype=np.int64))]
+    die = []
+    while dying:
+        kind = rng.integers(0, 4)
+        if kind == 0 and len(dying) >= 2:
+            die.append((dying.pop(), dying.pop()))
+        elif kind == 1:
+            die.append((dying.pop(), -1))
+        elif kind == 2:
+            die.append((-1, dying.pop()))
+        else:
+            die.append((-1, -1))
+    want_moves, want_left = _sparse_node_removals(die, n_nodes)
+    d_die = torch.tensor(die, dtype=torch.int64).reshape(-1).cuda()
+    to, frm, left, gave_up = kd.replay_node_removals64(d_die, n_nodes)
+    assert not gave_up and left == want_left
+    assert dict(zip(to.cpu().tolist(), frm.cpu().tolist())) == want_moves and to.numel() == len(want_moves)

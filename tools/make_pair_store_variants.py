@@ -6,6 +6,7 @@ gpurun):
   libkatome_gpu_v2.so   pair read AFTER the stores, two 8-byte plain stores
   libkatome_gpu_v3.so   pair read BEFORE the stores, one 16-byte plain store
   libkatome_gpu_v4.so   pair read BEFORE the stores, two 8-byte plain stores (shipped: two 8-byte agent-scope stores)
+  libkatome_gpu_v5.so   as v1, with `s_waitcnt vmcnt(0)` between the key/weight stores and the LDS read of the pair
 
 Run a first-seen-order sharded build against each with KATOME_LIB=build_variants/libkatome_gpu_vN.so (tools/check_pair_store.py).
 """
@@ -25,11 +26,11 @@ STORE16 = ("ulonglong2 v; v.x = flipped ? seq_rev : seq_fwd; v.y = flipped ? seq
 STORE8 = ("kmer_seen[2 * (bbase + p)] = flipped ? seq_rev : seq_fwd; kmer_seen[2 * (bbase + p) + 1] = flipped ? seq_fwd : seq_rev;")
 
 
-def variant(src, late, wide):
+def variant(src, late, wide, wait=False):
     a = src.index("                if (tile_seen) {        // (kmer_seen is the records'")
     b = src.index("        __syncthreads();\n    }\n    if (TO_TABLE) {")
     body = "                if (tile_seen) {\n                    %s\n                    %s\n                }\n            }\n        }\n" % (
-        LATE if late else "", STORE16 if wide else STORE8)
+        ('asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ' if wait else "") + (LATE if late else ""), STORE16 if wide else STORE8)
     out = src[:a] + body + src[b:]
     if late:
         assert EARLY in out
@@ -41,9 +42,10 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     src = open(os.path.join(CSRC, "table.hip")).read()
     objs = [os.path.join(CSRC, "build", f) for f in sorted(os.listdir(os.path.join(CSRC, "build"))) if f.endswith(".o") and f != "table.o"]
-    for name, late, wide in (("v1", True, True), ("v2", True, False), ("v3", False, True), ("v4", False, False)):
+    for name, late, wide, wait in (("v1", True, True, False), ("v2", True, False, False), ("v3", False, True, False), ("v4", False, False, False),
+                                   ("v5", True, True, True)):
         hip = os.path.join(OUT, "table_%s.hip" % name)
-        open(hip, "w").write(variant(src, late, wide))
+        open(hip, "w").write(variant(src, late, wide, wait))
         obj = os.path.join(OUT, "table_%s.o" % name)
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function",
                                "-I", CSRC, "-c", hip, "-o", obj])
