@@ -233,6 +233,13 @@ __global__ __launch_bounds__(BLOCK) void die_dst_kernel(const u64* __restrict__ 
         if (d) { X[at] = 2 * (t1 - 1) + 1; Y[at] = npos[b]; alive_n[b] = 0; }
     }
 }
+// the last-touch marks are per pass: cleared where this pass set them, once every removal has spoken
+__global__ __launch_bounds__(BLOCK) void untouch_src_kernel(const u32* __restrict__ dead_e, u64 n, const u64* __restrict__ lsrc, u32* last_touch) {
+    WLOOP(i, n) if (i < n) last_touch[(u32)lsrc[dead_e[i]]] = 0;
+}
+__global__ __launch_bounds__(BLOCK) void untouch_dst_kernel(const u64* __restrict__ msgA, u64 n, u32* last_touch) {
+    WLOOP(i, n) if (i < n) last_touch[(u32)(msgA[i] & LOW56)] = 0;
+}
 __global__ __launch_bounds__(BLOCK) void fill64_kernel(u64* __restrict__ p, u64 n, u64 v) { WLOOP(i, n) if (i < n) p[i] = v; }
 __global__ __launch_bounds__(BLOCK) void scatter64_kernel(const u64* __restrict__ at, const u64* __restrict__ val, u64 n, u64* __restrict__ out) {
     WLOOP(i, n) if (i < n) out[at[i]] = val[i];
@@ -544,6 +551,8 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
                             npos.as<u64>(), alive_n.as<unsigned char>(), X.as<u64>(), Y.as<u64>(), cur);
         if (losses.n) KLAUNCH(die_dst_kernel, losses.n, stream, losses.a.as<u64>(), losses.b.as<u64>(), losses.n, indeg.as<u32>(), outdeg.as<u32>(), last_touch.as<u32>(),
                               npos.as<u64>(), alive_n.as<unsigned char>(), X.as<u64>(), Y.as<u64>(), cur);
+        if (n_dead) KLAUNCH(untouch_src_kernel, n_dead, stream, dead_e.as<u32>(), n_dead, lsrc, last_touch.as<u32>());
+        if (losses.n) KLAUNCH(untouch_dst_kernel, losses.n, stream, losses.a.as<u64>(), losses.n, last_touch.as<u32>());
         KCHECK_HIP(hipGetLastError());
         KCHECK(read_cursors(h, 1));
         Routed dies(stream);

@@ -61,6 +61,12 @@ __device__ __forceinline__ void seen_store(const SeenInit& si, u64 s) {
     st_agent(&si.seen[2 * s], si.a);
     if (si.both) st_agent(&si.seen[2 * s + 1], si.b);
 }
+// (Publication with C++ release/acquire atomics at agent scope instead of the waitcnt below was built and measured in round 3
+// -- tools/make_publish_variant.py, KATOME_LIB=build_variants/libkatome_gpu_ra.so: on gfx950 a release store is
+// `buffer_wbl2 sc1; s_waitcnt; store` and an acquire load `load sc1; s_waitcnt; buffer_inv sc1` -- an L2 write-back / invalidate
+// per upsert: C3's tile insertion 41.7 -> 1029 ms, the mid-tile expansion 45 -> 1105 ms per build (profiles/r03_summary.md).
+// The payload words are agent-scope (sc1, write-through) stores already; what the protocol needs between them and the
+// publishing store is their completion, which is what `s_waitcnt vmcnt(0)` is.)
 // 128-bit keys: there is no 128-bit CAS, so the high word is claimed with LOCK set, the low word
 // is stored, drained (s_waitcnt: a hardware wait and, with its memory clobber, a compiler barrier) and then the high word is
 // re-published with OCC.  Readers take the high word first and the rest after a compiler barrier (below).  A lane never
@@ -373,10 +379,29 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
                 for (int q = 0; q < NWK; ++q) out_keys[(bbase + p) * NWK + q] = x.w[q];
                 out_w[bbase + p] = lcnt[t];
                 if (tile_seen) {        // (kmer_seen is the records' [n][2] output here)
-                    // Two 8-byte stores whose values were read from LDS BEFORE the key and weight stores above were issued.
-                    // With the pair read from LDS after those stores (into the registers that had held their addresses) and
-                    // written as one 16-byte store, about one tile in 5000 came out with the buffer's previous contents in
-                    // place of its keys on MI355X (hipcc 7.2; found by comparing with the same expansion without numbers).
+                    // The pair is read from LDS ABOVE (seq_fwd / seq_rev), before the key and weight stores.  Written the obvious
+                    // way -- lseen read here, after those stores -- this kernel puts wrong keys into ~0.2 % of the records
+                    // (hipcc 7.2, gfx950; round 2's "one tile in 5000").  What round 3 established, with the library built in
+                    // eight variants of these few lines (tools/make_pair_store_variants.py, tools/check_pair_store.py: a 4-rank
+                    // first-seen build of 2 M reads against the one-GPU build, three runs each, profiles/r03_pair_store.md):
+                    //   * late read + one 16-byte store (v1) and late read + two 8-byte plain stores (v2, which the compiler merges
+                    //     into the same dwordx4 store): wrong every run (18.52 M edges instead of 18.41 M);
+                    //   * early read with either store form (v3, v4; the shipped form is v4 with agent-scope stores): right;
+                    //   * late read behind `s_waitcnt vmcnt(0)` (v5), behind `s_waitcnt vmcnt(1)` (v8) and behind an EMPTY
+                    //     `asm volatile("" ::: "memory")` (v7): all right.
+                    // v7 adds no instruction at the spot, so it is not the hardware timing of the stores; and the sequence the bad
+                    // variants share -- global_store_dwordx2 v[8:9], v[6:7]; global_store_dword v[6:7], v22; s_cbranch_vccnz;
+                    // ds_read_b128 v[6:9] (the LDS pair loaded into both stores' address registers) -- does not lose or redirect a
+                    // single store out of 1e8 when it stands alone in inline assembly (tools/probe_vmem_lds_war.hip: bare, with the
+                    // branch, on the library's exact registers with broadcast LDS addresses and a partly active wave).  What v7 and
+                    // v5 change in the ISA besides registers is that `bbase` (the workgroup's cursor claim, in LDS) is loaded again
+                    // inside the loop for the three store addresses, where v1-v4 all load it once in the loop pre-header: the bad
+                    // variants are the ones where one register pair loaded before the loop feeds the addresses of stores on BOTH
+                    // sides of an LDS load inside the loop.  The ISA of v1 was read line by line against v7 (barriers, waitcnts,
+                    // exec masks, SGPR carry-outs of v_mad_u64_u32): no difference that explains it was found, so the cause is
+                    // narrowed to this code shape, not diagnosed.  The other 16-byte stores of the library (extract.hip,
+                    // emit_edges_kernel, tiles_to_records_kernel, table_records_kernel) do not have it: their LDS reads all
+                    // precede their global stores within a trip (checked in the ISA; tests compare them with the oracle).
                     __hip_atomic_store(&kmer_seen[2 * (bbase + p)], flipped ? seq_rev : seq_fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&kmer_seen[2 * (bbase + p) + 1], flipped ? seq_fwd : seq_rev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -618,14 +643,17 @@ constexpr u32 LC_FILL = LC_SLOTS / 4096 * 2900;   // records a sub-round may hol
 constexpr u32 LC_THREADS = LC_SLOTS / 8;
 constexpr u32 LC_MAX_SUB = 5;                  // up to 32 sub-rounds
 
-// index[g] = first record whose hash has top 16 bits >= g (records ordered by those bits), g = 0 .. 65536
+// index[g] = first record whose hash has top 16 bits >= g (records ordered by those bits), g = 0 .. 65536: one binary search
+// per group boundary (31 dependent reads each, 65537 of them) instead of a pass over all the records (3.4 ms at C3)
 __global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __restrict__ keys, u64 n, u64* __restrict__ index) {
-    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i <= n; i += (u64)gridDim.x * BLOCK) {
-        Key<1> a, c;
-        long long prev = -1, cur = 65536;
-        if (i > 0) { a.w[0] = keys[i - 1]; prev = (long long)(hash_key(a) >> 48); }
-        if (i < n) { c.w[0] = keys[i]; cur = (long long)(hash_key(c) >> 48); }
-        for (long long g = prev + 1; g <= cur; ++g) index[g] = i;
+    for (u64 g = (u64)blockIdx.x * BLOCK + threadIdx.x; g <= 65536; g += (u64)gridDim.x * BLOCK) {
+        u64 lo = 0, hi = n;                                   // first i with (hash(keys[i]) >> 48) >= g
+        while (lo < hi) {
+            const u64 mid = lo + ((hi - lo) >> 1);
+            Key<1> a; a.w[0] = keys[mid];
+            if ((hash_key(a) >> 48) < g) lo = mid + 1; else hi = mid;
+        }
+        index[g] = lo;
     }
 }
 
@@ -937,7 +965,7 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
     {
         KernelScope ks(K_GROUP_INDEX, stream, n);
-        hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for(n + 1, BLOCK, 256u * 32u)), dim3(BLOCK), 0, stream, ko, n, index.as<u64>());
+        hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for(65537, BLOCK)), dim3(BLOCK), 0, stream, ko, n, index.as<u64>());
     }
     const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
     KCHECK(edge_key.alloc(out_cap * 8, stream));

@@ -40,7 +40,7 @@ def child(reads):
 def main():
     reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
     only = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else None       # e.g. "0,1,5" (0 = the shipped library)
-    libs = [None] + [os.path.join(ROOT, "build_variants", "libkatome_gpu_v%d.so" % v) for v in (1, 2, 3, 4, 5)]
+    libs = [None] + [os.path.join(ROOT, "build_variants", "libkatome_gpu_v%d.so" % v) for v in (1, 2, 3, 4, 5, 7, 8)]
     for i, lib in enumerate(libs):
         if only is not None and i not in only:
             continue
