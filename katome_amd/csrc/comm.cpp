@@ -227,12 +227,13 @@ int make_rccl_comms_all(const int* devices, int n, katome_comm** out) {
 
 using namespace katome;
 
-int katome_comm::exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt) {
+int katome_comm::exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt, uint64_t* global_max) {
     const int w = world(), r = rank();
     std::vector<uint64_t> m((size_t)w * w, 0);                     // m[src][dst]; everybody fills its own row
     for (int p = 0; p < w; ++p) m[(size_t)r * w + p] = send_cnt[p];
     KCHECK(t->allreduce(m.data(), m.size(), OP_SUM));
     for (int p = 0; p < w; ++p) recv_cnt[p] = m[(size_t)p * w + r];
+    if (global_max) { uint64_t mx = 0; for (uint64_t v : m) mx = std::max(mx, v); *global_max = mx; }
     return KATOME_OK;
 }
 
@@ -244,7 +245,7 @@ int katome_comm::allgather(uint64_t v, uint64_t* out) {
 }
 
 int katome_comm::exchange(const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, int on_device,
-                          hipStream_t stream, bool one_round) {
+                          hipStream_t stream, bool one_round, uint64_t known_max) {
     const int w = world();
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> so(w, 0), ro(w, 0);
@@ -258,7 +259,8 @@ int katome_comm::exchange(const void* send, const uint64_t* send_cnt, void* recv
     uint64_t rounds = 1;
     if (one_round) rounds = 1;
     else if (w > 1) {                                              // every rank must run the same number of rounds
-        KCHECK(t->allreduce(&biggest, 1, OP_MAX));
+        if (known_max != MAX_UNKNOWN) biggest = known_max;         // (the count matrix was seen whole: no second agreement)
+        else KCHECK(t->allreduce(&biggest, 1, OP_MAX));
         rounds = std::max<uint64_t>(1, (biggest + chunk - 1) / chunk);
     } else rounds = std::max<uint64_t>(1, (biggest + chunk - 1) / chunk);
     if (rounds == 1) {

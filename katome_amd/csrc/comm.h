@@ -57,15 +57,18 @@ struct katome_comm {
     int rank() const { return t->rank; }
     int world() const { return t->world; }
     // all-to-all of one u64 per peer
-    int exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt);
+    // (global_max, optional: the largest single (rank -> peer) count of the whole matrix -- every rank sees all of it --, which
+    // exchange() would otherwise agree on with a reduction of its own: pass it on as `known_max`)
+    int exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt, uint64_t* global_max = nullptr);
     int allgather(uint64_t v, uint64_t* out);
     int allreduce(uint64_t* vals, size_t n, int op) { return t->allreduce(vals, n, op); }
     void use_stream(hipStream_t s) { t->work_stream = s; t->have_work_stream = true; }
     // records grouped by destination, send_cnt[p] elements for peer p, contiguous in peer order; recv likewise by source
     // (recv_cnt from exchange_counts).  Splits into rounds when a pair's message exceeds max_message_bytes.
     // one_round: the caller knows that no pair's message exceeds max_message_bytes on any rank (no agreement needed)
+    static constexpr uint64_t MAX_UNKNOWN = ~0ull;
     int exchange(const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, int on_device,
-                 hipStream_t stream, bool one_round = false);
+                 hipStream_t stream, bool one_round = false, uint64_t known_max = MAX_UNKNOWN);
 };
 
 namespace katome {

@@ -166,15 +166,16 @@ int route_and_insert(katome_dist_builder* d, const u64* part, const u32* idx, co
     katome_builder* b = d->b;
     const int world = d->world();
     std::vector<uint64_t> rcnt(world, 0);
-    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+    uint64_t pair_max = 0;
+    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data(), &pair_max));
     const uint64_t nR = sum(rcnt);
     DevBuf recv(stream), ridx(stream);
     KCHECK(recv.alloc(std::max<uint64_t>(nR, 1) * 8 * nwr));
-    KCHECK(d->xchg(X_RECORDS, part, counts.data(), recv.p, rcnt.data(), 8 * nwr, stream));
+    KCHECK(d->xchg(X_RECORDS, part, counts.data(), recv.p, rcnt.data(), 8 * nwr, stream, false, pair_max));
     SeenOrigin origin;
     if (d->first_seen) {
         KCHECK(ridx.alloc(std::max<uint64_t>(nR, 1) * 4));
-        KCHECK(d->xchg(X_RECORDS, idx, counts.data(), ridx.p, rcnt.data(), 4, stream));
+        KCHECK(d->xchg(X_RECORDS, idx, counts.data(), ridx.p, rcnt.data(), 4, stream, false, pair_max));
         std::vector<uint64_t> read0s(world, 0);
         KCHECK(d->comm->allgather(read0, read0s.data()));
         origin.idx = ridx.as<u32>(); origin.n_seg = (uint32_t)world;
@@ -437,12 +438,13 @@ int global_rank(katome_dist_builder* d, int xphase, const u64* vals, uint64_t n,
     KCHECK(dev_iota(idx.as<u32>(), n, stream));
     KCHECK(dev_partition_range(vals, idx.as<u32>(), n, d_bounds.as<u64>(), (uint32_t)world, pv.as<u64>(), pidx.as<u32>(), counts.data(), stream));
     KCHECK_HIP(hipStreamSynchronize(stream));               // (bounds was read from a host vector)
-    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+    uint64_t pair_max = 0;
+    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data(), &pair_max));
     const uint64_t nR = sum(rcnt);
     if (nR >= (1ull << 32)) { set_error("more than 2^32 values to rank on one GPU"); return KATOME_E_UNSUPPORTED; }
     DevBuf rv(stream), pos(stream), ans(stream), back(stream);
     KCHECK(rv.alloc((nR + 1) * 8)); KCHECK(pos.alloc((nR + 1) * 4)); KCHECK(ans.alloc((nR + 1) * 8)); KCHECK(back.alloc((n + 1) * 8));
-    KCHECK(d->xchg(xphase, pv.p, counts.data(), rv.p, rcnt.data(), 8, stream));
+    KCHECK(d->xchg(xphase, pv.p, counts.data(), rv.p, rcnt.data(), 8, stream, false, pair_max));
     uint32_t bits = 1;
     while (bits < 64 && (vmax >> bits)) ++bits;
     KCHECK(dev_iota(pos.as<u32>(), nR, stream));
@@ -453,7 +455,7 @@ int global_rank(katome_dist_builder* d, int xphase, const u64* vals, uint64_t n,
     for (int p = 0; p < rank; ++p) base += all[p];
     if (nR) KLAUNCH(assign_rank_kernel, nR, stream, pos.as<u32>(), nR, base, ans.as<u64>());
     KCHECK_HIP(hipGetLastError());
-    KCHECK(d->xchg(xphase, ans.p, rcnt.data(), back.p, counts.data(), 8, stream));       // the mirrored route
+    KCHECK(d->xchg(xphase, ans.p, rcnt.data(), back.p, counts.data(), 8, stream, false, pair_max));       // the mirrored route
     if (n) KLAUNCH(scatter_u64_kernel, n, stream, back.as<u64>(), pidx.as<u32>(), n, out_rank);
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipStreamSynchronize(stream));
@@ -734,17 +736,18 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
         KCHECK(dev_partition(T.as<u64>(), origin.as<u32>(), E, nw, world, P.as<u64>(), porigin.as<u32>(), counts.data(), stream, 0, k - 2));
     }
     T.release(); origin.release();
-    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data()));
+    uint64_t pair_max = 0;
+    KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data(), &pair_max));
     const uint64_t nR = sum(rcnt);
     if (nR >= (1ull << 32)) { set_error("more than 2^32 target look-ups on one rank"); return KATOME_E_UNSUPPORTED; }
     DevBuf R(stream), rv(stream);
     KCHECK(R.alloc((nR + 1) * 8 * nw));
-    KCHECK(d->xchg(X_TARGETS, P.p, counts.data(), R.p, rcnt.data(), 8 * nw, stream));
+    KCHECK(d->xchg(X_TARGETS, P.p, counts.data(), R.p, rcnt.data(), 8 * nw, stream, false, pair_max));
     if (d->first_seen) {                                     // ... and tells it when it first touched the target (2 * seq + 1)
         KCHECK(tv.alloc((E + 1) * 8)); KCHECK(rv.alloc((nR + 1) * 8));
         if (E) KLAUNCH(target_value_kernel, E, stream, seq, porigin.as<u32>(), E, tv.as<u64>());
         KCHECK_HIP(hipGetLastError());
-        KCHECK(d->xchg(X_TARGETS, tv.p, counts.data(), rv.p, rcnt.data(), 8, stream));
+        KCHECK(d->xchg(X_TARGETS, tv.p, counts.data(), rv.p, rcnt.data(), 8, stream, false, pair_max));
         tv.release();
     }
     P.release();
@@ -814,7 +817,7 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     KCHECK(ans.alloc((nR + 1) * 8)); KCHECK(back.alloc((E + 1) * 8));
     if (nR) KLAUNCH(map_ids_kernel, nR, stream, local.as<u64>(), nR, id_map, base, ans.as<u64>());
     KCHECK_HIP(hipGetLastError());
-    KCHECK(d->xchg(X_IDS, ans.p, rcnt.data(), back.p, counts.data(), 8, stream));
+    KCHECK(d->xchg(X_IDS, ans.p, rcnt.data(), back.p, counts.data(), 8, stream, false, pair_max));
     KCHECK(d->edge_src.alloc((E + 1) * 8, stream)); KCHECK(d->edge_dst.alloc((E + 1) * 8, stream));
     if (E) {
         KLAUNCH(scatter_u64_kernel, E, stream, back.as<u64>(), porigin.as<u32>(), E, d->edge_dst.as<u64>());
@@ -824,7 +827,7 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     if (d->first_seen) {
         // for the stages that run on the sharded graph (dist_prune.hip): where every edge's target lives -- owner rank (the
         // segment its look-up travelled in) and the node's local index there (the owner's answer, unmapped)
-        KCHECK(d->xchg(X_IDS, local.p, rcnt.data(), back.p, counts.data(), 8, stream));
+        KCHECK(d->xchg(X_IDS, local.p, rcnt.data(), back.p, counts.data(), 8, stream, false, pair_max));
         KCHECK(d->edge_dlocal.alloc((E + 1) * 8, stream)); KCHECK(d->edge_drank.alloc((E + 1) * 8, stream));
         if (E) KLAUNCH(scatter_u64_kernel, E, stream, back.as<u64>(), porigin.as<u32>(), E, d->edge_dlocal.as<u64>());
         uint64_t off = 0;

@@ -285,7 +285,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 struct Routed {
     DevBuf a, b, pidx;
     std::vector<uint64_t> counts, rcnt;
-    uint64_t n = 0, n_sent = 0;
+    uint64_t n = 0, n_sent = 0, pair_max = 0;      // pair_max: the largest (rank -> peer) count of the whole exchange
     explicit Routed(hipStream_t s) : a(s), b(s), pidx(s) {}
 };
 struct Router {
@@ -310,15 +310,15 @@ struct Router {
             KCHECK(dev_partition_range(A, idx.as<u32>(), n, bounds.as<u64>(), (uint32_t)world, pa.as<u64>(), out.pidx.as<u32>(), out.counts.data(), stream));
             if (B) { KCHECK(pb.alloc((n + 1) * 8)); KCHECK(dev_gather_u64(B, out.pidx.as<u32>(), n, pb.as<u64>(), stream)); }
         }
-        KCHECK(d->comm->exchange_counts(out.counts.data(), out.rcnt.data()));
+        KCHECK(d->comm->exchange_counts(out.counts.data(), out.rcnt.data(), &out.pair_max));
         out.n = 0;
         for (uint64_t c : out.rcnt) out.n += c;
         KCHECK(out.a.alloc((out.n + 1) * 8));
-        KCHECK(d->xchg(X_PRUNE, pa.p, out.counts.data(), out.a.p, out.rcnt.data(), 8, stream));
+        KCHECK(d->xchg(X_PRUNE, pa.p, out.counts.data(), out.a.p, out.rcnt.data(), 8, stream, false, out.pair_max));
         if (B) {
             if (!n) KCHECK(pb.alloc(16));
             KCHECK(out.b.alloc((out.n + 1) * 8));
-            KCHECK(d->xchg(X_PRUNE, pb.p, out.counts.data(), out.b.p, out.rcnt.data(), 8, stream));
+            KCHECK(d->xchg(X_PRUNE, pb.p, out.counts.data(), out.b.p, out.rcnt.data(), 8, stream, false, out.pair_max));
         }
         KCHECK_HIP(hipStreamSynchronize(stream));
         return KATOME_OK;
@@ -327,7 +327,7 @@ struct Router {
     int reply(const Routed& r, const u64* ans, u64* out) {
         DevBuf back(stream);
         KCHECK(back.alloc((r.n_sent + 1) * 8));
-        KCHECK(d->xchg(X_PRUNE, ans, r.rcnt.data(), back.p, r.counts.data(), 8, stream));
+        KCHECK(d->xchg(X_PRUNE, ans, r.rcnt.data(), back.p, r.counts.data(), 8, stream, false, r.pair_max));
         if (r.n_sent) KLAUNCH(scatter_by_idx_kernel, r.n_sent, stream, back.as<u64>(), r.pidx.as<u32>(), r.n_sent, out);
         KCHECK_HIP(hipGetLastError());
         KCHECK_HIP(hipStreamSynchronize(stream));

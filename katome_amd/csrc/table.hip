@@ -636,13 +636,17 @@ __global__ __launch_bounds__(BLOCK) void tiles_to_records_kernel(const typename 
 // L2 / Infinity Cache; a sub-round's keys leave as oriented edges straight away (both strands, the remove_weak_edges
 // threshold), as one contiguous stretch behind a cursor.
 // ---------------------------------------------------------------------------------------------
-#ifndef KATOME_LC_SLOTS
-#define KATOME_LC_SLOTS 8192
+#ifndef KATOME_LC_PER
+#define KATOME_LC_PER 13
 #endif
-constexpr u32 LC_SLOTS = KATOME_LC_SLOTS;      // LDS table: 8 B key + 4 B count per slot (8192: 96 KiB, one workgroup of 1024 per CU)
-constexpr u32 LC_FILL = LC_SLOTS / 4096 * 2900;   // records a sub-round may hold at most on average (all new: load 0.71)
-constexpr u32 LC_THREADS = LC_SLOTS / 8;
-constexpr u32 LC_MAX_SUB = 5;                  // up to 32 sub-rounds
+constexpr u32 LC_THREADS = 1024;
+constexpr u32 LC_PER = KATOME_LC_PER;          // slots every thread reads out
+// LDS table: 8 B key + 4 B count per slot.  13312 slots = 156 KiB of the CU's 160: one workgroup of 1024 per CU either way, and
+// C3's groups of 22 k records go through in 3 sub-rounds instead of the 4 a table of 8192 needs (any number of sub-rounds:
+// a record's sub-round and its slot are two mulhi's of separate hash bits)
+constexpr u32 LC_SLOTS = LC_THREADS * LC_PER;
+constexpr u32 LC_FILL = LC_SLOTS / 4096.0 * 2900;   // records a sub-round may hold at most on average (all new: load 0.71)
+constexpr u32 LC_MAX_ROUNDS = 32;
 
 // index[g] = first record whose hash has top 16 bits >= g (records ordered by those bits), g = 0 .. 65536: one binary search
 // per group boundary (31 dependent reads each, 65537 of them) instead of a pass over all the records (3.4 ms at C3)
@@ -660,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __re
 
 template <bool RC>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index,
-                                                                u32 sub_bits, u32 k, u32 min_weight, u64* out_keys,
+                                                                u32 R, u32 k, u32 min_weight, u64* out_keys,
                                                                 u32* out_w, u64 out_cap, unsigned long long* cursor,
                                                                 unsigned long long* distinct, u32* err) {
     extern __shared__ unsigned long long lc_mem[];
@@ -669,7 +673,6 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
     __shared__ u32 wtot[LC_THREADS / 64];
     __shared__ unsigned long long base_sh;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u32 R = 1u << sub_bits;
     u32 my_distinct = 0;
     for (u32 g = blockIdx.x; g < 65536u; g += gridDim.x) {
         const u64 lo = index[g], hi = index[g + 1];
@@ -688,21 +691,21 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                     if (i >= hi) continue;
                     Key<1> key; key.w[0] = kv[u];
                     const u64 h = hash_key(key);
-                    if (sub_bits && ((h >> (48 - sub_bits)) & (R - 1)) != r) continue;
+                    if (R > 1 && (u32)((((h >> 32) & 0xFFFFull) * R) >> 16) != r) continue;      // (hash bits 32..47; the group is bits 48..63)
                     const unsigned long long want = key.w[0] | OCC;
-                    u32 s = (u32)(h >> 20) & (LC_SLOTS - 1);
+                    u32 s = (u32)(((h & 0xFFFFFFFFull) * LC_SLOTS) >> 32);                         // (bits 0..31)
                     u32 probes = 0;
                     for (; probes < LC_SLOTS; ++probes) {
                         const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
                         if (cur == 0ull || cur == want) { atomicAdd(&lcnt[s], wv[u]); break; }
-                        s = (s + 1) & (LC_SLOTS - 1);
+                        if (++s == LC_SLOTS) s = 0;
                     }
                     if (probes == LC_SLOTS) *err = 3;        // (cannot happen: a sub-round holds fewer records than slots)
                 }
             }
             __syncthreads();
             // read-out: every thread owns LC_SLOTS / LC_THREADS consecutive slots
-            constexpr u32 PER = LC_SLOTS / LC_THREADS;
+            constexpr u32 PER = LC_PER;
             Key<1> kk[PER]; u32 cc[PER], ne[PER]; u32 mine = 0;
 #pragma unroll
             for (u32 j = 0; j < PER; ++j) {
@@ -950,9 +953,8 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
                             DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
     *n_edges = 0; *n_distinct = 0;
     if (key_words_for_k(k) != 1) return KATOME_E_UNSUPPORTED;
-    u32 sub_bits = 0;
-    while (sub_bits <= LC_MAX_SUB && (n >> (16 + sub_bits)) > LC_FILL) ++sub_bits;
-    if (sub_bits > LC_MAX_SUB) return KATOME_E_UNSUPPORTED;
+    const u32 R = (u32)std::max<u64>(1, ((n >> 16) + LC_FILL - 1) / LC_FILL);          // sub-rounds: a group's share fits even if all new
+    if (R > LC_MAX_ROUNDS) return KATOME_E_UNSUPPORTED;
     const u64* ko = nullptr; const u32* wo = nullptr;
     {
         DevBuf kb(stream), wb(stream);
@@ -981,9 +983,9 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     }
     {
         KernelScope ks(K_LDS_COUNT, stream, n);
-        if (rc) hipLaunchKernelGGL((lds_count_kernel<true>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
+        if (rc) hipLaunchKernelGGL((lds_count_kernel<true>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), R, k, min_weight,
                                    edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
-        else    hipLaunchKernelGGL((lds_count_kernel<false>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), sub_bits, k, min_weight,
+        else    hipLaunchKernelGGL((lds_count_kernel<false>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), R, k, min_weight,
                                    edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
     }
     KCHECK_HIP(hipGetLastError());
