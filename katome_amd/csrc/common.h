@@ -156,6 +156,8 @@ int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, Dev
                    hipStream_t stream);
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream);
+int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
+                   const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream);
 int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipStream_t stream);
 int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t key_bits, const uint64_t* d_q, uint64_t nq,
              uint64_t* d_out, hipStream_t stream);

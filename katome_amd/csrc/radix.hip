@@ -418,6 +418,11 @@ __global__ __launch_bounds__(BLOCK) void run_sort_kernel(const u64* __restrict__
     }
 }
 
+// (A one-kernel pass -- digit offsets of all passes from one read of the keys, tile offsets by decoupled look-back over tiles
+// numbered in the order they start -- was built and measured in round 3 and removed again: profiles/r03_lookback.md.  The
+// look-back words must be read at agent scope, past the XCD's own L2, and every tile waits for that chain before it can write:
+// C3's four sort passes 53 + 10 + 3 ms -> 67 ms (75 ms with eight look-back loads in flight per digit), the two 9-bit hash
+// passes 23 + 5 + 1 -> 38 ms.)
 // passes over the top bits before the run sort takes over: the fewest with 2^(8 * passes) >= n
 static u32 top_passes_for(u64 n) {
     u32 t = 1;
@@ -571,6 +576,13 @@ static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u
     }
     *k_out = kin; *w_out = win;
     return KATOME_OK;
+}
+// one-word (k-mer, count) records ordered by the top 16 bits of the k-mer's hash, for the counting in LDS (table.hip): two
+// stable 8-bit passes.  The result is where *k_out / *w_out point (one of the two buffer pairs); *group_bits = 16.
+int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
+                   const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream) {
+    *group_bits = 16;
+    return region_order_t<1>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
 }
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream) {

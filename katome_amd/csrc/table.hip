@@ -636,37 +636,38 @@ __global__ __launch_bounds__(BLOCK) void tiles_to_records_kernel(const typename 
 // L2 / Infinity Cache; a sub-round's keys leave as oriented edges straight away (both strands, the remove_weak_edges
 // threshold), as one contiguous stretch behind a cursor.
 // ---------------------------------------------------------------------------------------------
-#ifndef KATOME_LC_PER
-#define KATOME_LC_PER 13
-#endif
 constexpr u32 LC_THREADS = 1024;
-constexpr u32 LC_PER = KATOME_LC_PER;          // slots every thread reads out
-// LDS table: 8 B key + 4 B count per slot.  13312 slots = 156 KiB of the CU's 160: one workgroup of 1024 per CU either way, and
-// C3's groups of 22 k records go through in 3 sub-rounds instead of the 4 a table of 8192 needs (any number of sub-rounds:
-// a record's sub-round and its slot are two mulhi's of separate hash bits)
-constexpr u32 LC_SLOTS = LC_THREADS * LC_PER;
-constexpr u32 LC_FILL = LC_SLOTS / 4096.0 * 2900;   // records a sub-round may hold at most on average (all new: load 0.71)
+// LDS table: 8 B key + 4 B count per slot, LC_THREADS x PER slots (every thread reads PER slots out).  PER = 13: 13312 slots =
+// 156 KiB of the CU's 160 (one workgroup of 1024 per CU either way): groups of 22 k records (2^16 groups at C3) go through in 3
+// sub-rounds instead of the 4 a table of 8192 needs.  PER = 8: groups of 5.5 k records (2^18 groups: the look-back passes of
+// radix.hip) fit an 8192-slot table in ONE round -- no re-read of the group, and less to clear and to read out per group.
+// Any number of sub-rounds: a record's sub-round and its slot are two mulhi's of separate hash bits.
+template <int PER> struct LcTable {
+    static constexpr u32 SLOTS = LC_THREADS * PER;
+    static constexpr u32 FILL = (u32)(SLOTS / 4096.0 * 2900);   // records a sub-round may hold at most on average (all new: load 0.71)
+};
 constexpr u32 LC_MAX_ROUNDS = 32;
 
-// index[g] = first record whose hash has top 16 bits >= g (records ordered by those bits), g = 0 .. 65536: one binary search
-// per group boundary (31 dependent reads each, 65537 of them) instead of a pass over all the records (3.4 ms at C3)
-__global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __restrict__ keys, u64 n, u64* __restrict__ index) {
-    for (u64 g = (u64)blockIdx.x * BLOCK + threadIdx.x; g <= 65536; g += (u64)gridDim.x * BLOCK) {
-        u64 lo = 0, hi = n;                                   // first i with (hash(keys[i]) >> 48) >= g
+// index[g] = first record whose hash has top `gbits` bits >= g (records ordered by those bits), g = 0 .. 2^gbits: one binary
+// search per group boundary (31 dependent reads each) instead of a pass over all the records (3.4 ms at C3)
+__global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __restrict__ keys, u64 n, u32 gbits, u64* __restrict__ index) {
+    for (u64 g = (u64)blockIdx.x * BLOCK + threadIdx.x; g <= (1ull << gbits); g += (u64)gridDim.x * BLOCK) {
+        u64 lo = 0, hi = n;                                   // first i with (hash(keys[i]) >> (64 - gbits)) >= g
         while (lo < hi) {
             const u64 mid = lo + ((hi - lo) >> 1);
             Key<1> a; a.w[0] = keys[mid];
-            if ((hash_key(a) >> 48) < g) lo = mid + 1; else hi = mid;
+            if ((hash_key(a) >> (64 - gbits)) < g) lo = mid + 1; else hi = mid;
         }
         index[g] = lo;
     }
 }
 
-template <bool RC>
-__global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index,
+template <bool RC, int PER>
+__global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
                                                                 u32 R, u32 k, u32 min_weight, u64* out_keys,
                                                                 u32* out_w, u64 out_cap, unsigned long long* cursor,
                                                                 unsigned long long* distinct, u32* err) {
+    constexpr u32 LC_SLOTS = LcTable<PER>::SLOTS;
     extern __shared__ unsigned long long lc_mem[];
     unsigned long long* lkey = lc_mem;                                   // [LC_SLOTS]
     u32* lcnt = reinterpret_cast<u32*>(lc_mem + LC_SLOTS);               // [LC_SLOTS]
@@ -674,7 +675,8 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
     __shared__ unsigned long long base_sh;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 my_distinct = 0;
-    for (u32 g = blockIdx.x; g < 65536u; g += gridDim.x) {
+    const u32 n_groups = 1u << gbits, sub_shift = 64 - gbits - 16;     // (the group is the hash's top gbits, the sub-round its next 16)
+    for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const u64 lo = index[g], hi = index[g + 1];
         if (lo == hi) continue;
         for (u32 r = 0; r < R; ++r) {
@@ -691,9 +693,9 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                     if (i >= hi) continue;
                     Key<1> key; key.w[0] = kv[u];
                     const u64 h = hash_key(key);
-                    if (R > 1 && (u32)((((h >> 32) & 0xFFFFull) * R) >> 16) != r) continue;      // (hash bits 32..47; the group is bits 48..63)
+                    if (R > 1 && (u32)((((h >> sub_shift) & 0xFFFFull) * R) >> 16) != r) continue;
                     const unsigned long long want = key.w[0] | OCC;
-                    u32 s = (u32)(((h & 0xFFFFFFFFull) * LC_SLOTS) >> 32);                         // (bits 0..31)
+                    u32 s = (u32)(((h & 0x3FFFFFFFull) * LC_SLOTS) >> 30);                         // (bits 0..29: below every sub-round bit)
                     u32 probes = 0;
                     for (; probes < LC_SLOTS; ++probes) {
                         const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
@@ -705,7 +707,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
             }
             __syncthreads();
             // read-out: every thread owns LC_SLOTS / LC_THREADS consecutive slots
-            constexpr u32 PER = LC_PER;
+
             Key<1> kk[PER]; u32 cc[PER], ne[PER]; u32 mine = 0;
 #pragma unroll
             for (u32 j = 0; j < PER; ++j) {
@@ -953,22 +955,28 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
                             DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
     *n_edges = 0; *n_distinct = 0;
     if (key_words_for_k(k) != 1) return KATOME_E_UNSUPPORTED;
-    const u32 R = (u32)std::max<u64>(1, ((n >> 16) + LC_FILL - 1) / LC_FILL);          // sub-rounds: a group's share fits even if all new
-    if (R > LC_MAX_ROUNDS) return KATOME_E_UNSUPPORTED;
+    if ((n >> 16) > (u64)LC_MAX_ROUNDS * LcTable<13>::FILL) return KATOME_E_UNSUPPORTED;
     const u64* ko = nullptr; const u32* wo = nullptr;
+    u32 gbits = 16;
     {
         DevBuf kb(stream), wb(stream);
         KCHECK(kb.alloc((n + 1) * 8)); KCHECK(wb.alloc((n + 1) * 4));
         // two passes: the first one's output goes to the scratch, the second one's lands in keys / weights again
-        KCHECK(dev_region_order(keys.as<u64>(), weights.as<u32>(), n, 1, 2, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, stream));
+        KCHECK(dev_hash_order(keys.as<u64>(), weights.as<u32>(), n, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, &gbits, stream));
     }
+    // the smaller table when a group fits it in one round (less to clear and to read out per group)
+    const u64 avg = n >> gbits;
+    const bool small = avg <= LcTable<8>::FILL;
+    const u32 fill = small ? LcTable<8>::FILL : LcTable<13>::FILL;
+    const u32 R = (u32)std::max<u64>(1, (avg + fill - 1) / fill);          // sub-rounds: a group's share fits even if all new
+    if (R > LC_MAX_ROUNDS) return KATOME_E_UNSUPPORTED;
     DevBuf index(stream), aux(stream);
-    KCHECK(index.alloc(65537 * 8));
+    KCHECK(index.alloc(((1ull << gbits) + 1) * 8));
     KCHECK(aux.alloc(64));
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
     {
         KernelScope ks(K_GROUP_INDEX, stream, n);
-        hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for(65537, BLOCK)), dim3(BLOCK), 0, stream, ko, n, index.as<u64>());
+        hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for((1ull << gbits) + 1, BLOCK)), dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
     }
     const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
     KCHECK(edge_key.alloc(out_cap * 8, stream));
@@ -976,18 +984,17 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     unsigned long long* cursor = aux.as<unsigned long long>();
     unsigned long long* distinct = cursor + 1;
     u32* err = reinterpret_cast<u32*>(cursor + 2);
-    const size_t lds = (size_t)LC_SLOTS * 12;
-    if (lds > (48u << 10)) {
-        KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    {
-        KernelScope ks(K_LDS_COUNT, stream, n);
-        if (rc) hipLaunchKernelGGL((lds_count_kernel<true>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), R, k, min_weight,
-                                   edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
-        else    hipLaunchKernelGGL((lds_count_kernel<false>), dim3(256u * (LC_SLOTS <= 4096 ? 3u : 1u)), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), R, k, min_weight,
-                                   edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);
-    }
+#define KATOME_LC_LAUNCH(RCV, PERV)                                                                                                     \
+    do {                                                                                                                              \
+        const size_t lds = (size_t)LcTable<PERV>::SLOTS * 12;                                                                         \
+        KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<RCV, PERV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        KernelScope ks(K_LDS_COUNT, stream, n);                                                                                       \
+        hipLaunchKernelGGL((lds_count_kernel<RCV, PERV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, R, k, \
+                           min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);                     \
+    } while (0)
+    if (small) { if (rc) KATOME_LC_LAUNCH(true, 8); else KATOME_LC_LAUNCH(false, 8); }
+    else       { if (rc) KATOME_LC_LAUNCH(true, 13); else KATOME_LC_LAUNCH(false, 13); }
+#undef KATOME_LC_LAUNCH
     KCHECK_HIP(hipGetLastError());
     uint64_t h[3] = {0, 0, 0};
     KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));

@@ -68,6 +68,26 @@ def test_radix_sort_with_values_is_stable(nw, bits):
     assert np.array_equal(dv.cpu().numpy().view(np.uint32), v[order])
 
 
+@pytest.mark.parametrize("nw,bits,n,dup", [(1, 62, 3_000_001, False), (1, 62, 2_200_000, True), (2, 126, 1_500_000, True), (1, 24, 1_100_000, True)])
+def test_radix_sort_of_millions_is_stable(nw, bits, n, dup):
+    """millions of keys (hundreds of workgroup tiles per pass, several offset chunks): sorted, and stable -- the values of
+    equal keys keep their order -- for spread-out keys (top passes + run sort) and for heavy duplication"""
+    from katome_amd import device as kd
+    rng = np.random.default_rng(n + bits)
+    a = _keys(rng, n, nw, bits)
+    if dup:
+        a[:, nw - 1] &= np.uint64(0xFFFFF)
+        if nw == 2:
+            a[:, 0] &= np.uint64(0x7)
+    v = np.arange(n, dtype=np.uint32)
+    d, dv = _to_dev(a), torch.from_numpy(v.view(np.int32).copy()).cuda()
+    kd.sort_keys(d, bits, nw, dv)
+    torch.cuda.synchronize()
+    order = np.lexsort((v,) + tuple(a[:, j] for j in range(nw - 1, -1, -1)))
+    assert np.array_equal(_from_dev(d, nw), a[order])
+    assert np.array_equal(dv.cpu().numpy().view(np.uint32), v[order])
+
+
 @pytest.mark.parametrize("nw", [1, 2])
 @pytest.mark.parametrize("n", [1, 2, 2047, 2048, 2049, 500000])
 def test_unique(nw, n):
