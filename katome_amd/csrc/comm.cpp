@@ -227,13 +227,14 @@ int make_rccl_comms_all(const int* devices, int n, katome_comm** out) {
 
 using namespace katome;
 
-int katome_comm::exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt, uint64_t* global_max) {
+int katome_comm::exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt, uint64_t* global_max, uint64_t* global_total) {
     const int w = world(), r = rank();
     std::vector<uint64_t> m((size_t)w * w, 0);                     // m[src][dst]; everybody fills its own row
     for (int p = 0; p < w; ++p) m[(size_t)r * w + p] = send_cnt[p];
     KCHECK(t->allreduce(m.data(), m.size(), OP_SUM));
     for (int p = 0; p < w; ++p) recv_cnt[p] = m[(size_t)p * w + r];
     if (global_max) { uint64_t mx = 0; for (uint64_t v : m) mx = std::max(mx, v); *global_max = mx; }
+    if (global_total) { uint64_t t = 0; for (uint64_t v : m) t += v; *global_total = t; }      // (records on the move anywhere)
     return KATOME_OK;
 }
 

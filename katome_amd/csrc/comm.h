@@ -59,7 +59,7 @@ struct katome_comm {
     // all-to-all of one u64 per peer
     // (global_max, optional: the largest single (rank -> peer) count of the whole matrix -- every rank sees all of it --, which
     // exchange() would otherwise agree on with a reduction of its own: pass it on as `known_max`)
-    int exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt, uint64_t* global_max = nullptr);
+    int exchange_counts(const uint64_t* send_cnt, uint64_t* recv_cnt, uint64_t* global_max = nullptr, uint64_t* global_total = nullptr);
     int allgather(uint64_t v, uint64_t* out);
     int allreduce(uint64_t* vals, size_t n, int op) { return t->allreduce(vals, n, op); }
     void use_stream(hipStream_t s) { t->work_stream = s; t->have_work_stream = true; }

@@ -279,6 +279,14 @@ __global__ __launch_bounds__(BLOCK) void gather_keys_by_kernel(const u64* __rest
     }
 }
 
+// two columns as one 16-byte record per element (one exchange instead of two), and back
+__global__ __launch_bounds__(BLOCK) void zip2_kernel(const u64* __restrict__ pa, const u64* __restrict__ B, const u32* __restrict__ pidx, u64 n, u64* __restrict__ out) {
+    WLOOP(i, n) if (i < n) { out[2 * i] = pa[i]; out[2 * i + 1] = B[pidx[i]]; }
+}
+__global__ __launch_bounds__(BLOCK) void unzip2_kernel(const u64* __restrict__ in, u64 n, u64* __restrict__ a, u64* __restrict__ b) {
+    WLOOP(i, n) if (i < n) { a[i] = in[2 * i]; b[i] = in[2 * i + 1]; }
+}
+
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // records with their destination rank in the top byte of column A [and a second column] -> their destinations
@@ -286,6 +294,7 @@ struct Routed {
     DevBuf a, b, pidx;
     std::vector<uint64_t> counts, rcnt;
     uint64_t n = 0, n_sent = 0, pair_max = 0;      // pair_max: the largest (rank -> peer) count of the whole exchange
+    uint64_t moved = 0;                            // records on the move between ANY two ranks in this exchange
     explicit Routed(hipStream_t s) : a(s), b(s), pidx(s) {}
 };
 struct Router {
@@ -303,22 +312,26 @@ struct Router {
     int send(const u64* A, const u64* B, uint64_t n, Routed& out) {
         const int world = d->world();
         out.counts.assign(world, 0); out.rcnt.assign(world, 0); out.n_sent = n;
-        DevBuf idx(stream), pa(stream), pb(stream);
+        DevBuf idx(stream), pa(stream), zipped(stream), landed(stream);
         KCHECK(idx.alloc((n + 1) * 4)); KCHECK(pa.alloc((n + 1) * 8)); KCHECK(out.pidx.alloc((n + 1) * 4));
         if (n) {
             KCHECK(dev_iota(idx.as<u32>(), n, stream));
             KCHECK(dev_partition_range(A, idx.as<u32>(), n, bounds.as<u64>(), (uint32_t)world, pa.as<u64>(), out.pidx.as<u32>(), out.counts.data(), stream));
-            if (B) { KCHECK(pb.alloc((n + 1) * 8)); KCHECK(dev_gather_u64(B, out.pidx.as<u32>(), n, pb.as<u64>(), stream)); }
         }
-        KCHECK(d->comm->exchange_counts(out.counts.data(), out.rcnt.data(), &out.pair_max));
+        KCHECK(d->comm->exchange_counts(out.counts.data(), out.rcnt.data(), &out.pair_max, &out.moved));
         out.n = 0;
         for (uint64_t c : out.rcnt) out.n += c;
         KCHECK(out.a.alloc((out.n + 1) * 8));
-        KCHECK(d->xchg(X_PRUNE, pa.p, out.counts.data(), out.a.p, out.rcnt.data(), 8, stream, false, out.pair_max));
-        if (B) {
-            if (!n) KCHECK(pb.alloc(16));
-            KCHECK(out.b.alloc((out.n + 1) * 8));
-            KCHECK(d->xchg(X_PRUNE, pb.p, out.counts.data(), out.b.p, out.rcnt.data(), 8, stream, false, out.pair_max));
+        if (B) KCHECK(out.b.alloc((out.n + 1) * 8));
+        if (out.moved == 0) return KATOME_OK;                          // nothing travels anywhere: no exchange at all
+        if (!B) {
+            KCHECK(d->xchg(X_PRUNE, pa.p, out.counts.data(), out.a.p, out.rcnt.data(), 8, stream, false, out.pair_max));
+        } else {                                                        // both columns in one exchange of 16-byte records
+            KCHECK(zipped.alloc((n + 1) * 16)); KCHECK(landed.alloc((out.n + 1) * 16));
+            if (n) KLAUNCH(zip2_kernel, n, stream, pa.as<u64>(), B, out.pidx.as<u32>(), n, zipped.as<u64>());
+            KCHECK(d->xchg(X_PRUNE, zipped.p, out.counts.data(), landed.p, out.rcnt.data(), 16, stream, false, out.pair_max));
+            if (out.n) KLAUNCH(unzip2_kernel, out.n, stream, landed.as<u64>(), out.n, out.a.as<u64>(), out.b.as<u64>());
+            KCHECK_HIP(hipGetLastError());
         }
         KCHECK_HIP(hipStreamSynchronize(stream));
         return KATOME_OK;
@@ -407,10 +420,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
         const u64 *wA = A.as<u64>(), *wB = B.as<u64>();
         Routed arrivals(stream);
         for (uint32_t step = 0;; ++step) {
-            uint64_t any = n_walk;
-            KCHECK(d->comm->allreduce(&any, 1, OP_MAX));
-            if (!any) break;
-            if (step >= two_k) { set_error("distributed pruning: a walk did not end within 2k steps"); return KATOME_E_DEVICE; }
+            if (step > two_k) { set_error("distributed pruning: a walk did not end within 2k steps"); return KATOME_E_DEVICE; }
             DevBuf oA(stream), oB(stream);
             KCHECK(oA.alloc((n_walk + 1) * 8)); KCHECK(oB.alloc((n_walk + 1) * 8));
             if (n_deadv + n_walk > deadv_cap) {                              // the verdicts collected on this rank so far + this step's
@@ -421,14 +431,19 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
                 const size_t bytes = bigger.bytes;
                 deadv.adopt(bigger.take(), bytes);
             }
-            KCHECK(reset_cursors());
-            if (n_walk) KLAUNCH(walk_step_kernel, n_walk, stream, wA, wB, n_walk, step ? 1u : 0u, two_k, indeg.as<u32>(), outdeg.as<u32>(), first_out.as<u32>(),
-                                drank, dlocal, oA.as<u64>(), oB.as<u64>(), cur, deadv.as<u64>() + n_deadv, cur + 1);
-            KCHECK_HIP(hipGetLastError());
-            KCHECK(read_cursors(h, 2));
+            h[0] = h[1] = 0;
+            if (n_walk) {
+                KCHECK(reset_cursors());
+                KLAUNCH(walk_step_kernel, n_walk, stream, wA, wB, n_walk, step ? 1u : 0u, two_k, indeg.as<u32>(), outdeg.as<u32>(), first_out.as<u32>(),
+                        drank, dlocal, oA.as<u64>(), oB.as<u64>(), cur, deadv.as<u64>() + n_deadv, cur + 1);
+                KCHECK_HIP(hipGetLastError());
+                KCHECK(read_cursors(h, 2));
+            }
             n_deadv += h[1];
+            // (the count matrix of the exchange tells every rank whether any walker moved anywhere: no agreement round of its own)
             KCHECK(router.send(oA.as<u64>(), oB.as<u64>(), h[0], arrivals));
             wA = arrivals.a.as<u64>(); wB = arrivals.b.as<u64>(); n_walk = arrivals.n;
+            if (arrivals.moved == 0) break;
         }
         st.dead_walks += n_deadv;
         // ---- the dead walks again, from their start vertices, to collect their edges -----------------------------------
@@ -439,18 +454,19 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             uint64_t n_m = m.n;
             Routed arrived(stream);
             for (uint32_t step = 0;; ++step) {
-                uint64_t any = n_m;
-                KCHECK(d->comm->allreduce(&any, 1, OP_MAX));
-                if (!any) break;
-                if (step >= two_k) { set_error("distributed pruning: a marking walk did not end within 2k steps"); return KATOME_E_DEVICE; }
+                if (step > two_k) { set_error("distributed pruning: a marking walk did not end within 2k steps"); return KATOME_E_DEVICE; }
                 DevBuf oM(stream);
                 KCHECK(oM.alloc((n_m + 1) * 8));
-                KCHECK(reset_cursors());
-                if (n_m) KLAUNCH(mark_step_kernel, n_m, stream, wM, n_m, first_out.as<u32>(), drank, dlocal, mult.as<u32>(), oM.as<u64>(), cur);
-                KCHECK_HIP(hipGetLastError());
-                KCHECK(read_cursors(h, 1));                       // (synchronises: the list just walked may be given up below)
+                h[0] = 0;
+                if (n_m) {
+                    KCHECK(reset_cursors());
+                    KLAUNCH(mark_step_kernel, n_m, stream, wM, n_m, first_out.as<u32>(), drank, dlocal, mult.as<u32>(), oM.as<u64>(), cur);
+                    KCHECK_HIP(hipGetLastError());
+                    KCHECK(read_cursors(h, 1));                   // (synchronises: the list just walked may be given up below)
+                }
                 KCHECK(router.send(oM.as<u64>(), nullptr, h[0], arrived));
                 wM = arrived.a.as<u64>(); n_m = arrived.n;
+                if (arrived.moved == 0) break;
             }
         }
         // ---- marked (position, count) pairs -> rank 0, which replays remove_paths' swap_removes --------------------------
