@@ -120,11 +120,14 @@ struct RcclTransport : Transport {
     ncclComm_t comm = nullptr;
     int device = 0;
     DevBuf red;                        // device staging for host reductions
+    uint64_t* pinned = nullptr;        // ... and their pinned host side (a pageable H2D / D2H copy costs a millisecond, this one microseconds)
+    size_t pinned_cap = 0;
     hipStream_t ctl = nullptr;         // ... on a stream of their own
     const char* kind() const override { return "rccl"; }
     ~RcclTransport() override {
         (void)hipSetDevice(device);
         red.release();
+        if (pinned) (void)hipHostFree(pinned);
         if (ctl) { dev_retire_stream(ctl); (void)hipStreamDestroy(ctl); }
         if (comm) (void)api->CommDestroy(comm);
     }
@@ -141,14 +144,23 @@ struct RcclTransport : Transport {
         return KATOME_OK;
     }
     int allreduce(uint64_t* vals, size_t n, int op) override {
-        if (n == 0) return KATOME_OK;
+        if (n == 0) return KATOME_OK;        // (a world of one goes through RCCL too: the one-GPU rehearsal of what N ranks do)
         KCHECK_HIP(hipSetDevice(device));
         hipStream_t s = have_work_stream ? work_stream : ctl;
         if (red.bytes < n * 8) KCHECK(red.alloc(std::max<size_t>(n * 8, 4096), ctl));
-        KCHECK_HIP(hipMemcpyAsync(red.p, vals, n * 8, hipMemcpyHostToDevice, s));
+        if (pinned_cap < n) {
+            if (pinned) (void)hipHostFree(pinned);
+            pinned = nullptr; pinned_cap = 0;
+            const size_t want = std::max<size_t>(n, 512);
+            KCHECK_HIP(hipHostMalloc((void**)&pinned, want * 8, hipHostMallocDefault));
+            pinned_cap = want;
+        }
+        memcpy(pinned, vals, n * 8);
+        KCHECK_HIP(hipMemcpyAsync(red.p, pinned, n * 8, hipMemcpyHostToDevice, s));
         KCHECK_NCCL(api, api->AllReduce(red.p, red.p, n, ncclUint64, op == OP_SUM ? ncclSum : op == OP_MAX ? ncclMax : ncclMin, comm, s));
-        KCHECK_HIP(hipMemcpyAsync(vals, red.p, n * 8, hipMemcpyDeviceToHost, s));
+        KCHECK_HIP(hipMemcpyAsync(pinned, red.p, n * 8, hipMemcpyDeviceToHost, s));
         KCHECK_HIP(hipStreamSynchronize(s));
+        memcpy(vals, pinned, n * 8);
         return KATOME_OK;
     }
 };

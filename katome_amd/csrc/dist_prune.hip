@@ -18,6 +18,7 @@
 // No gather: the graph stays sharded, and no index is narrower than 64 bits on the wire or in the replays, so a graph of
 // more than 2^32 edges (BASELINE config 5 in full: 1.1e10) is in range; a rank's own share stays below 2^32 edges.
 #include <chrono>
+#include <cstring>
 
 #include "dist_builder.h"
 
@@ -41,6 +42,31 @@ __device__ __forceinline__ u64 wave_append(bool have, unsigned long long* cursor
     base = __shfl(base, leader, 64);
     return base + __popcll(mask & (lane ? (~0ull >> (64 - lane)) : 0ull));
 }
+
+// The same for a whole workgroup and CA_ITEMS items per thread: ONE cursor atomic per 2048 items.  (A million waves adding to one
+// address take milliseconds -- same-address atomics serialise --, which is what the kernels that look at every edge or node
+// of the rank cost while they appended wave by wave: 4-8 ms each per pass, measured, for 0.3 ms of memory traffic.)
+// Every thread of the workgroup calls it, the same number of times; returns where this thread's first item goes.
+constexpr int CA_ITEMS = 8;
+__device__ __forceinline__ u64 block_append(u32 mine, unsigned long long* cursor) {
+    __shared__ u32 ca_wtot[BLOCK / 64];
+    __shared__ unsigned long long ca_base;
+    const u32 lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+    __syncthreads();                                         // (the previous call's readers are done with the shared words)
+    if (lane == 63) ca_wtot[wave] = incl;
+    __syncthreads();
+    u32 woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) { if (w < (int)wave) woff += ca_wtot[w]; total += ca_wtot[w]; }
+    if (threadIdx.x == 0) ca_base = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    return ca_base + woff + (incl - mine);
+}
+#define TLOOP(t0, n) for (u64 t0 = (u64)blockIdx.x * BLOCK * CA_ITEMS; t0 < (n); t0 += (u64)gridDim.x * BLOCK * CA_ITEMS)
+#define KLAUNCH_T(kernel, n, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid_for((n), BLOCK * CA_ITEMS, 256u * 16u)), dim3(BLOCK), 0, stream, __VA_ARGS__)
 
 // ---- set-up -----------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void run_start_kernel(const u64* __restrict__ lsrc, u64 E, u64 n_src, u64* __restrict__ start) {
@@ -131,17 +157,130 @@ __global__ __launch_bounds__(BLOCK) void mark_step_kernel(const u64* __restrict_
     }
 }
 
+// ---- walks on a REPLICATED successor table ------------------------------------------------------------------------------
+// 288 GB of HBM per MI355X: one 8-byte word per node of the WHOLE graph -- successor along the first out-edge, "has an
+// out-edge", in-degree saturated at 3, alive -- fits every rank (C3/C4: 12.6 GB; C5 in full: 88 GB), indexed by the node's
+// first-seen id, which never changes.  With it a walk is local (the one-GPU kernel's loop over a table), and a pass needs a
+// handful of collectives instead of two per walk step: the words that changed are all-gathered (O(what the pass removed)),
+// the marks of the dead walks travel to their edges' owners through a directory sharded by node id.
+constexpr u64 RW_SUCC = (1ull << 40) - 1, RW_HAS_OUT = 1ull << 40, RW_ALIVE = 1ull << 43;
+constexpr u32 RW_INDEG_SHIFT = 41;
+__global__ __launch_bounds__(BLOCK) void own_words_kernel(u64 N, u64 n_src, const u32* __restrict__ first_out, const u64* __restrict__ edst,
+                                                          const u32* __restrict__ indeg, const unsigned char* __restrict__ alive, u64* __restrict__ out) {
+    WLOOP(j, N) if (j < N) {
+        u64 w = 0;
+        if (alive[j]) {
+            const u32 fo = j < n_src ? first_out[j] : NONE32;
+            const u32 in = indeg[j] < 3u ? indeg[j] : 3u;
+            w = RW_ALIVE | ((u64)in << RW_INDEG_SHIFT) | (fo != NONE32 ? (RW_HAS_OUT | (edst[fo] & RW_SUCC)) : RW_SUCC);
+        }
+        out[j] = w;
+    }
+}
+// the words that differ from what the other ranks hold: {node id, word}
+__global__ __launch_bounds__(BLOCK) void delta_kernel(u64 N, const u64* __restrict__ now, u64* __restrict__ held, const u64* __restrict__ gid,
+                                                      u64* __restrict__ out, unsigned long long* cursor) {
+    TLOOP(t0, N) {
+        u64 w[CA_ITEMS]; u32 mine = 0, have = 0;
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) {
+            const u64 j = t0 + (u64)k * BLOCK + threadIdx.x;
+            if (j < N) { w[k] = now[j]; if (w[k] != held[j]) { have |= 1u << k; ++mine; } }
+        }
+        u64 at = block_append(mine, cursor);
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) if (have & (1u << k)) {
+            const u64 j = t0 + (u64)k * BLOCK + threadIdx.x;
+            out[2 * at] = gid[j]; out[2 * at + 1] = w[k]; held[j] = w[k]; ++at;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void apply_words_kernel(const u64* __restrict__ list, u64 n, u64* __restrict__ table) {
+    WLOOP(i, n) if (i < n) table[list[2 * i]] = list[2 * i + 1];
+}
+__global__ __launch_bounds__(BLOCK) void input_list_kernel(u64 N, const u32* __restrict__ indeg, const u32* __restrict__ outdeg,
+                                                           const unsigned char* __restrict__ alive, u32* __restrict__ out, unsigned long long* cursor) {
+    TLOOP(t0, N) {
+        u32 mine = 0, have = 0;
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) {
+            const u64 j = t0 + (u64)k * BLOCK + threadIdx.x;
+            if (j < N && alive[j] && indeg[j] == 0 && outdeg[j] > 0) { have |= 1u << k; ++mine; }      // Externals: Input (pruner.rs:181-183)
+        }
+        u64 at = block_append(mine, cursor);
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) if (have & (1u << k)) out[at++] = (u32)(t0 + (u64)k * BLOCK + threadIdx.x);
+    }
+}
+// check_dead_path (pruner.rs:229-257) from every listed vertex, on the replicated table: len[i] = edges of the dead path, 0 = not dead
+__global__ __launch_bounds__(BLOCK) void walk_table_kernel(const u32* __restrict__ list, u64 n, const u64* __restrict__ gid, const u64* __restrict__ W,
+                                                           u32 two_k, u32* __restrict__ len, unsigned long long* n_dead) {
+    u32 dead = 0;
+    WLOOP(i, n) if (i < n) {
+        u64 cur = gid[list[i]];
+        u32 steps = 0, L = 0;
+        for (;;) {
+            const u64 w = W[cur];
+            if (steps && ((w >> RW_INDEG_SHIFT) & 3u) >= 3u) { L = steps; break; }     // nth(2) of the incoming neighbours (253-255)
+            if (steps + 1 >= two_k) break;                                              // cnt >= 2K: kept (235-239)
+            if (!(w & RW_HAS_OUT)) { L = steps; break; }                                // no first_edge (248-251)
+            cur = w & RW_SUCC;
+            ++steps;
+        }
+        len[i] = L;
+        dead += L != 0;
+    }
+    if (dead) atomicAdd(n_dead, (unsigned long long)dead);
+}
+// the vertices a dead walk passes (their first out-edges are its edges), each addressed to the directory rank of its id
+__global__ __launch_bounds__(BLOCK) void walk_marks_kernel(const u32* __restrict__ list, u64 n, const u64* __restrict__ gid, const u64* __restrict__ W,
+                                                           const u32* __restrict__ len, const u64* __restrict__ offs, u64 per_rank, u64* __restrict__ out) {
+    WLOOP(i, n) if (i < n) {
+        const u32 L = len[i];
+        u64 cur = gid[list[i]], at = offs[i];
+        for (u32 s = 0; s < L; ++s) {
+            out[at + s] = ((cur / per_rank) << 56) | cur;
+            cur = W[cur] & RW_SUCC;
+        }
+    }
+}
+// directory: node id -> (owner rank << 56) | local index there
+__global__ __launch_bounds__(BLOCK) void dir_msg_kernel(u64 N, u64 my_rank, const u64* __restrict__ gid, u64 per_rank, u64* __restrict__ A, u64* __restrict__ B) {
+    WLOOP(j, N) if (j < N) { A[j] = ((gid[j] / per_rank) << 56) | gid[j]; B[j] = (my_rank << 56) | j; }
+}
+__global__ __launch_bounds__(BLOCK) void dir_fill_kernel(const u64* __restrict__ A, const u64* __restrict__ B, u64 n, u64 base, u64* __restrict__ dir) {
+    WLOOP(i, n) if (i < n) dir[(A[i] & LOW56) - base] = B[i];
+}
+__global__ __launch_bounds__(BLOCK) void dir_forward_kernel(const u64* __restrict__ marks, u64 n, u64 base, const u64* __restrict__ dir, u64* __restrict__ out) {
+    WLOOP(i, n) if (i < n) out[i] = dir[(marks[i] & LOW56) - base];
+}
+__global__ __launch_bounds__(BLOCK) void mark_nodes_kernel(const u64* __restrict__ msg, u64 n, const u32* __restrict__ first_out, u32* mult) {
+    WLOOP(i, n) if (i < n) atomicAdd(&mult[first_out[(u32)(msg[i] & LOW56)]], 1u);
+}
+
 // ---- marks, candidates, answers -----------------------------------------------------------------------------------------
 // (everything that goes to rank 0 carries rank 0 in the top byte: positions stay below 2^56)
 __global__ __launch_bounds__(BLOCK) void marks_kernel(const u32* __restrict__ mult, const u64* __restrict__ pos, u64 E, u64* __restrict__ out_pos,
                                                       u64* __restrict__ out_mult, unsigned long long* cursor, unsigned long long* total) {
-    u64 mine = 0;
-    WLOOP(e, E) {
-        const bool m = e < E && mult[e] != 0;
-        const u64 at = wave_append(m, cursor);
-        if (m) { out_pos[at] = pos[e]; out_mult[at] = mult[e]; mine += mult[e]; }
+    u64 sum = 0;
+    TLOOP(t0, E) {
+        u32 m[CA_ITEMS], mine = 0;
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) {
+            const u64 e = t0 + (u64)k * BLOCK + threadIdx.x;
+            m[k] = e < E ? mult[e] : 0u;
+            mine += m[k] != 0;
+        }
+        u64 at = block_append(mine, cursor);
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) if (m[k]) {
+            const u64 e = t0 + (u64)k * BLOCK + threadIdx.x;
+            out_pos[at] = pos[e]; out_mult[at] = m[k]; sum += m[k]; ++at;
+        }
     }
-    if (mine) atomicAdd(total, (unsigned long long)mine);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd(total, (unsigned long long)sum);
 }
 __global__ __launch_bounds__(BLOCK) void narrow_kernel(const u64* __restrict__ in, u64 n, u32* __restrict__ out) { WLOOP(i, n) if (i < n) out[i] = (u32)in[i]; }
 __global__ __launch_bounds__(BLOCK) void widen_kernel(const u32* __restrict__ in, u64 n, u64* __restrict__ out) { WLOOP(i, n) if (i < n) out[i] = in[i]; }
@@ -149,18 +288,30 @@ __global__ __launch_bounds__(BLOCK) void iota32_kernel(u32* __restrict__ out, u6
 // edges whose fate the replay decides: the marked ones and those in the tail [E_new, E) that disappears
 __global__ __launch_bounds__(BLOCK) void edge_cand_kernel(const u32* __restrict__ mult, const u64* __restrict__ pos, const unsigned char* __restrict__ alive,
                                                           u64 E, u64 E_new, u64* __restrict__ q, u32* __restrict__ who, unsigned long long* cursor) {
-    WLOOP(e, E) {
-        const bool c = e < E && alive[e] && (mult[e] != 0 || pos[e] >= E_new);
-        const u64 at = wave_append(c, cursor);
-        if (c) { q[at] = pos[e]; who[at] = (u32)e; }
+    TLOOP(t0, E) {
+        u64 p[CA_ITEMS]; u32 mine = 0, have = 0;
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) {
+            const u64 e = t0 + (u64)k * BLOCK + threadIdx.x;
+            if (e < E && alive[e]) { p[k] = pos[e]; if (mult[e] != 0 || p[k] >= E_new) { have |= 1u << k; ++mine; } }
+        }
+        u64 at = block_append(mine, cursor);
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) if (have & (1u << k)) { q[at] = p[k]; who[at] = (u32)(t0 + (u64)k * BLOCK + threadIdx.x); ++at; }
     }
 }
 __global__ __launch_bounds__(BLOCK) void node_cand_kernel(const u64* __restrict__ npos, const unsigned char* __restrict__ alive, u64 N, u64 N_new,
                                                           u64* __restrict__ q, u32* __restrict__ who, unsigned long long* cursor) {
-    WLOOP(j, N) {
-        const bool c = j < N && alive[j] && npos[j] >= N_new;
-        const u64 at = wave_append(c, cursor);
-        if (c) { q[at] = npos[j]; who[at] = (u32)j; }
+    TLOOP(t0, N) {
+        u64 p[CA_ITEMS]; u32 mine = 0, have = 0;
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) {
+            const u64 j = t0 + (u64)k * BLOCK + threadIdx.x;
+            if (j < N && alive[j]) { p[k] = npos[j]; if (p[k] >= N_new) { have |= 1u << k; ++mine; } }
+        }
+        u64 at = block_append(mine, cursor);
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) if (have & (1u << k)) { q[at] = p[k]; who[at] = (u32)(t0 + (u64)k * BLOCK + threadIdx.x); ++at; }
     }
 }
 // rank 0: answer[i] = table value at the query's place in the sorted key list, NONE64 if the query is not a key
@@ -251,10 +402,16 @@ __global__ __launch_bounds__(BLOCK) void clear_marks_kernel(const u32* __restric
 
 // ---- the result -------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(BLOCK) void alive_list_kernel(const unsigned char* __restrict__ alive, u64 n, u32* __restrict__ out, unsigned long long* cursor) {
-    WLOOP(i, n) {
-        const bool a = i < n && alive[i];
-        const u64 at = wave_append(a, cursor);
-        if (a) out[at] = (u32)i;
+    TLOOP(t0, n) {
+        u32 mine = 0, have = 0;
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) {
+            const u64 i = t0 + (u64)k * BLOCK + threadIdx.x;
+            if (i < n && alive[i]) { have |= 1u << k; ++mine; }
+        }
+        u64 at = block_append(mine, cursor);
+#pragma unroll
+        for (int k = 0; k < CA_ITEMS; ++k) if (have & (1u << k)) out[at++] = (u32)(t0 + (u64)k * BLOCK + threadIdx.x);
     }
 }
 __global__ __launch_bounds__(BLOCK) void npos_of_kernel(const u64* __restrict__ msg, u64 n, const u64* __restrict__ npos, u64* __restrict__ out) {
@@ -299,6 +456,7 @@ struct Routed {
 };
 struct Router {
     katome_dist_builder* d; hipStream_t stream; DevBuf bounds;
+    double t_part = 0, t_counts = 0, t_xchg = 0, t_gather = 0; uint64_t n_send = 0, n_reply = 0;      // host wall time per kind of step (KATOME_DIST_PRUNE_TRACE)
     Router(katome_dist_builder* d_, hipStream_t s) : d(d_), stream(s), bounds(s) {}
     int init() {
         const int world = d->world();
@@ -314,11 +472,15 @@ struct Router {
         out.counts.assign(world, 0); out.rcnt.assign(world, 0); out.n_sent = n;
         DevBuf idx(stream), pa(stream), zipped(stream), landed(stream);
         KCHECK(idx.alloc((n + 1) * 4)); KCHECK(pa.alloc((n + 1) * 8)); KCHECK(out.pidx.alloc((n + 1) * 4));
+        ++n_send;
+        double t0 = now_ms();
         if (n) {
             KCHECK(dev_iota(idx.as<u32>(), n, stream));
             KCHECK(dev_partition_range(A, idx.as<u32>(), n, bounds.as<u64>(), (uint32_t)world, pa.as<u64>(), out.pidx.as<u32>(), out.counts.data(), stream));
         }
+        t_part += now_ms() - t0; t0 = now_ms();
         KCHECK(d->comm->exchange_counts(out.counts.data(), out.rcnt.data(), &out.pair_max, &out.moved));
+        t_counts += now_ms() - t0; t0 = now_ms();
         out.n = 0;
         for (uint64_t c : out.rcnt) out.n += c;
         KCHECK(out.a.alloc((out.n + 1) * 8));
@@ -334,16 +496,46 @@ struct Router {
             KCHECK_HIP(hipGetLastError());
         }
         KCHECK_HIP(hipStreamSynchronize(stream));
+        t_xchg += now_ms() - t0;
+        return KATOME_OK;
+    }
+    // every rank's records (n_mine elements of `elem` bytes) to every rank, in rank order: the same send buffer for all peers
+    int allgather(const void* mine, uint64_t n_mine, size_t elem, DevBuf& out, uint64_t* total) {
+        const int world = d->world();
+        std::vector<uint64_t> all(world, 0);
+        KCHECK(d->comm->allgather(n_mine, all.data()));
+        uint64_t sum = 0, biggest = 0;
+        std::vector<uint64_t> roff(world, 0);
+        for (int p = 0; p < world; ++p) { roff[p] = sum; sum += all[p]; biggest = std::max(biggest, all[p]); }
+        *total = sum;
+        KCHECK(out.alloc((sum + 1) * elem));
+        if (sum == 0) return KATOME_OK;
+        const uint64_t chunk = std::max<uint64_t>(1, d->comm->max_message_bytes / elem);
+        std::vector<uint64_t> so(world), sc(world), ro(world), rc(world);
+        for (uint64_t done = 0; done < biggest; done += chunk) {
+            for (int p = 0; p < world; ++p) {
+                so[p] = std::min(n_mine, done); sc[p] = std::min(n_mine - so[p], chunk);
+                const uint64_t rb = std::min(all[p], done);
+                ro[p] = roff[p] + rb; rc[p] = std::min(all[p] - rb, chunk);
+            }
+            KCHECK(d->comm->t->alltoallv(mine, so.data(), sc.data(), out.p, ro.data(), rc.data(), elem, 1, stream));
+        }
+        katome::ExchangeStats& x = d->xstats[X_PRUNE];
+        x.calls += 1; x.bytes_out += n_mine * elem * (uint64_t)(world - 1);
+        KCHECK_HIP(hipStreamSynchronize(stream));
         return KATOME_OK;
     }
     // answers aligned with what `r` received travel back; out[i] = the answer to the i-th record of the sender's list
     int reply(const Routed& r, const u64* ans, u64* out) {
+        ++n_reply;
+        const double t0 = now_ms();
         DevBuf back(stream);
         KCHECK(back.alloc((r.n_sent + 1) * 8));
         KCHECK(d->xchg(X_PRUNE, ans, r.rcnt.data(), back.p, r.counts.data(), 8, stream, false, r.pair_max));
         if (r.n_sent) KLAUNCH(scatter_by_idx_kernel, r.n_sent, stream, back.as<u64>(), r.pidx.as<u32>(), r.n_sent, out);
         KCHECK_HIP(hipGetLastError());
         KCHECK_HIP(hipStreamSynchronize(stream));
+        t_xchg += now_ms() - t0;
         return KATOME_OK;
     }
 };
@@ -357,7 +549,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
     katome_builder* b = d->b;
     KCHECK_HIP(hipSetDevice(d->s.device));
     d->comm->use_stream(stream);
-    const int rank = d->rank();
+    const int rank = d->rank(), world = d->world();
     const uint32_t nw = d->nw, k = d->s.k, two_k = 2 * k;
     const uint64_t E = d->n_edges, N = d->n_nodes, n_src = d->n_src;
     const double t_begin = now_ms();
@@ -404,16 +596,108 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
         KCHECK_HIP(hipGetLastError());
     }
     uint64_t TE = d->total_edges, TN = d->total_nodes;
+    // The walks: on a replicated successor table when every rank has room for one word per node of the whole graph (the
+    // default), else walkers that hop from owner to owner (KATOME_DIST_PRUNE_WALKS=table|hop overrides; all ranks agree)
+    const uint64_t TN0 = d->total_nodes, per_rank = std::max<uint64_t>(1, (TN0 + world - 1) / world);
+    const u64* edst = d->edge_dst.as<u64>();                      // every edge's target as a first-seen node id (the pass installs new arrays at the end)
+    bool use_table = true;
+    {
+        size_t free_b = 0, total_b = 0;
+        KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+        free_b += dev_cached_bytes();
+        uint64_t ok = (TN0 + 1) * 8 + (N + 1) * 24 + per_rank * 8 + (4ull << 30) < free_b ? 1 : 0;
+        if (const char* e = getenv("KATOME_DIST_PRUNE_WALKS")) ok = strcmp(e, "hop") == 0 ? 0 : strcmp(e, "table") == 0 ? 1 : ok;
+        KCHECK(d->comm->allreduce(&ok, 1, OP_MIN));
+        use_table = ok != 0;
+    }
+    DevBuf w_table(stream), w_now(stream), w_held(stream), ngid0(stream), dir(stream);
+    if (use_table) {
+        KCHECK(w_table.alloc((TN0 + 1) * 8)); KCHECK(w_now.alloc((N + 1) * 8)); KCHECK(w_held.alloc((N + 1) * 8)); KCHECK(ngid0.alloc((N + 1) * 8));
+        KCHECK(dir.alloc((per_rank + 1) * 8));
+        KCHECK_HIP(hipMemsetAsync(w_table.p, 0, (TN0 + 1) * 8, stream));
+        KCHECK_HIP(hipMemsetAsync(w_held.p, 0, (N + 1) * 8, stream));             // (no live node's word is 0: the first pass sends them all)
+        if (N) KCHECK_HIP(hipMemcpyAsync(ngid0.p, d->node_gid.p, N * 8, hipMemcpyDeviceToDevice, stream));
+        // directory, sharded by node id: where each node lives
+        DevBuf da(stream), db(stream);
+        KCHECK(da.alloc((N + 1) * 8)); KCHECK(db.alloc((N + 1) * 8));
+        if (N) KLAUNCH(dir_msg_kernel, N, stream, N, (u64)rank, ngid0.as<u64>(), per_rank, da.as<u64>(), db.as<u64>());
+        Routed r(stream);
+        KCHECK(router.send(da.as<u64>(), db.as<u64>(), N, r));
+        if (r.n) KLAUNCH(dir_fill_kernel, r.n, stream, r.a.as<u64>(), r.b.as<u64>(), r.n, (u64)rank * per_rank, dir.as<u64>());
+        KCHECK_HIP(hipGetLastError());
+        KCHECK_HIP(hipStreamSynchronize(stream));
+    }
+    // positions (of edges and of nodes alike) fit this many bits: what the sorts and look-ups at rank 0 work on
+    uint32_t pos_bits = 1;
+    while (pos_bits < 64 && ((std::max(d->total_edges, d->total_nodes) + 1) >> pos_bits)) ++pos_bits;
+    static const bool trace = getenv("KATOME_DIST_PRUNE_TRACE") != nullptr;
+    double t_sec[24] = {0}, t_mark = now_ms();
+    auto lap = [&](int i) { if (trace) { (void)hipStreamSynchronize(stream); const double t = now_ms(); t_sec[i] += t - t_mark; t_mark = t; } };
     for (;;) {
         ++st.passes;
+        lap(7);
         if (n_src) KLAUNCH(first_out_kernel, n_src, stream, n_src, start.as<u64>(), age.as<u64>(), alive_e.as<unsigned char>(), first_out.as<u32>());
+        uint64_t h[4] = {0, 0, 0, 0};
+        lap(11);
+        if (use_table) {
+            // ---- the words of this rank's nodes that changed -> every rank's copy of the table -------------------------------
+            if (N) KLAUNCH(own_words_kernel, N, stream, N, n_src, first_out.as<u32>(), edst, indeg.as<u32>(), alive_n.as<unsigned char>(), w_now.as<u64>());
+            DevBuf delta(stream), all_delta(stream);
+            KCHECK(delta.alloc((N + 1) * 16));
+            KCHECK(reset_cursors());
+            if (N) KLAUNCH_T(delta_kernel, N, stream, N, w_now.as<u64>(), w_held.as<u64>(), ngid0.as<u64>(), delta.as<u64>(), cur);
+            KCHECK_HIP(hipGetLastError());
+            KCHECK(read_cursors(h, 1));
+            lap(12);
+            uint64_t n_delta = 0;
+            KCHECK(router.allgather(delta.p, h[0], 16, all_delta, &n_delta));
+            if (n_delta) KLAUNCH(apply_words_kernel, n_delta, stream, all_delta.as<u64>(), n_delta, w_table.as<u64>());
+            delta.release(); all_delta.release();
+            lap(13);
+            // ---- walks from every vertex without incoming edges: local --------------------------------------------------------
+            DevBuf inputs(stream), len(stream), offs(stream), marks(stream);
+            KCHECK(inputs.alloc((N + 1) * 4));
+            KCHECK(reset_cursors());
+            if (N) KLAUNCH_T(input_list_kernel, N, stream, N, indeg.as<u32>(), outdeg.as<u32>(), alive_n.as<unsigned char>(), inputs.as<u32>(), cur);
+            KCHECK_HIP(hipGetLastError());
+            KCHECK(read_cursors(h, 1));
+            const uint64_t n_in = h[0];
+            st.walks += n_in;
+            lap(14);
+            KCHECK(len.alloc((n_in + 1) * 4)); KCHECK(offs.alloc((n_in + 2) * 8));
+            KCHECK(reset_cursors());
+            if (n_in) KLAUNCH(walk_table_kernel, n_in, stream, inputs.as<u32>(), n_in, ngid0.as<u64>(), w_table.as<u64>(), two_k, len.as<u32>(), cur);
+            KCHECK_HIP(hipGetLastError());
+            KCHECK(read_cursors(h, 1));
+            st.dead_walks += h[0];
+            lap(15);
+            uint64_t n_marks = 0;
+            if (n_in) {
+                KCHECK(dev_scan_counts(len.as<u32>(), n_in, offs.as<u64>(), stream));
+                KCHECK_HIP(hipMemcpyAsync(&n_marks, offs.as<u64>() + n_in, 8, hipMemcpyDeviceToHost, stream));
+                KCHECK_HIP(hipStreamSynchronize(stream));
+            }
+            KCHECK(marks.alloc((n_marks + 1) * 8));
+            if (n_marks) KLAUNCH(walk_marks_kernel, n_in, stream, inputs.as<u32>(), n_in, ngid0.as<u64>(), w_table.as<u64>(), len.as<u32>(), offs.as<u64>(), per_rank, marks.as<u64>());
+            KCHECK_HIP(hipGetLastError());
+            lap(16);
+            // the marks -> the directory rank of each vertex -> its owner, where its first out-edge is counted
+            Routed at_dir(stream), at_owner(stream);
+            KCHECK(router.send(marks.as<u64>(), nullptr, n_marks, at_dir));
+            DevBuf fwd(stream);
+            KCHECK(fwd.alloc((at_dir.n + 1) * 8));
+            if (at_dir.n) KLAUNCH(dir_forward_kernel, at_dir.n, stream, at_dir.a.as<u64>(), at_dir.n, (u64)rank * per_rank, dir.as<u64>(), fwd.as<u64>());
+            KCHECK_HIP(hipGetLastError());
+            KCHECK(router.send(fwd.as<u64>(), nullptr, at_dir.n, at_owner));
+            if (at_owner.n) KLAUNCH(mark_nodes_kernel, at_owner.n, stream, at_owner.a.as<u64>(), at_owner.n, first_out.as<u32>(), mult.as<u32>());
+            KCHECK_HIP(hipGetLastError());
+        } else {
         // ---- walks from every vertex without incoming edges ------------------------------------------------------------
         DevBuf A(stream), B(stream), deadv(stream);
         KCHECK(A.alloc((N + 1) * 8)); KCHECK(B.alloc((N + 1) * 8));
         KCHECK(reset_cursors());
         if (N) KLAUNCH(input_kernel, N, stream, N, (u64)rank, indeg.as<u32>(), outdeg.as<u32>(), alive_n.as<unsigned char>(), A.as<u64>(), B.as<u64>(), cur);
         KCHECK_HIP(hipGetLastError());
-        uint64_t h[4] = {0, 0, 0, 0};
         KCHECK(read_cursors(h, 1));
         uint64_t n_walk = h[0], n_deadv = 0, deadv_cap = 0;
         st.walks += n_walk;
@@ -469,11 +753,13 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
                 if (arrived.moved == 0) break;
             }
         }
+        }
+        lap(0);
         // ---- marked (position, count) pairs -> rank 0, which replays remove_paths' swap_removes --------------------------
         DevBuf mp(stream), mm(stream);
         KCHECK(mp.alloc((E + 1) * 8)); KCHECK(mm.alloc((E + 1) * 8));
         KCHECK(reset_cursors());
-        if (E) KLAUNCH(marks_kernel, E, stream, mult.as<u32>(), pos.as<u64>(), E, mp.as<u64>(), mm.as<u64>(), cur, cur + 1);
+        if (E) KLAUNCH_T(marks_kernel, E, stream, mult.as<u32>(), pos.as<u64>(), E, mp.as<u64>(), mm.as<u64>(), cur, cur + 1);
         KCHECK_HIP(hipGetLastError());
         KCHECK(read_cursors(h, 2));
         const uint64_t u_local = h[0];
@@ -481,8 +767,10 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
         uint64_t u_total = u_local;
         KCHECK(d->comm->allreduce(&u_total, 1, OP_SUM));
         if (u_total == 0) break;                                            // "if to_remove.is_empty() ... Graph is pruned" (pruner.rs:69-72)
+        lap(8);
         Routed marks(stream);
         KCHECK(router.send(mp.as<u64>(), mm.as<u64>(), u_local, marks));   // (top byte 0: everything goes to rank 0)
+        lap(9);
         mp.release(); mm.release();
         // rank 0's tables for the questions that follow
         DevBuf victims(stream), to_e(stream), from_e(stream), vict_sorted(stream), vict_ord(stream), from_sorted(stream), from_idx(stream);
@@ -493,23 +781,25 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             DevBuf m32(stream);
             KCHECK(m32.alloc((u + 1) * 4));
             KLAUNCH(narrow_kernel, u, stream, marks.b.as<u64>(), u, m32.as<u32>());
-            KCHECK(dev_sort(marks.a.as<u64>(), m32.as<u32>(), u, 1, 64, stream));
+            KCHECK(dev_sort(marks.a.as<u64>(), m32.as<u32>(), u, 1, pos_bits, stream));
             KCHECK(dev_replay_edges64(marks.a.as<u64>(), m32.as<u32>(), u, TE, sc, victims, to_e, from_e, &m_removed, &E_new, &n_moves, &dups, stream));
+            lap(10);
             if (m_removed >= 0xFFFFFFFFull) { set_error("more than 2^32 edges removed in one pass"); return KATOME_E_UNSUPPORTED; }
             KCHECK(vict_sorted.alloc((m_removed + 1) * 8)); KCHECK(vict_ord.alloc((m_removed + 1) * 4));
             if (m_removed) {
                 KCHECK_HIP(hipMemcpyAsync(vict_sorted.p, victims.p, m_removed * 8, hipMemcpyDeviceToDevice, stream));
                 KLAUNCH(iota32_kernel, m_removed, stream, vict_ord.as<u32>(), m_removed);
-                KCHECK(dev_sort(vict_sorted.as<u64>(), vict_ord.as<u32>(), m_removed, 1, 64, stream));
+                KCHECK(dev_sort(vict_sorted.as<u64>(), vict_ord.as<u32>(), m_removed, 1, pos_bits, stream));
             }
             KCHECK(from_sorted.alloc((n_moves + 1) * 8)); KCHECK(from_idx.alloc((n_moves + 1) * 4));
             if (n_moves) {
                 KCHECK_HIP(hipMemcpyAsync(from_sorted.p, from_e.p, n_moves * 8, hipMemcpyDeviceToDevice, stream));
                 KLAUNCH(iota32_kernel, n_moves, stream, from_idx.as<u32>(), n_moves);
-                KCHECK(dev_sort(from_sorted.as<u64>(), from_idx.as<u32>(), n_moves, 1, 64, stream));
+                KCHECK(dev_sort(from_sorted.as<u64>(), from_idx.as<u32>(), n_moves, 1, pos_bits, stream));
             }
             KCHECK_HIP(hipGetLastError());
         }
+        lap(1);
         uint64_t agreed[3] = {rank == 0 ? TE - E_new : 0, rank == 0 ? dups : 0, 0};
         KCHECK(d->comm->allreduce(agreed, 2, OP_MAX));
         m_removed = agreed[0]; E_new = TE - m_removed;
@@ -518,7 +808,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
         DevBuf q(stream), who(stream), ans_ord(stream), ans_pos(stream);
         KCHECK(q.alloc((E + 1) * 8)); KCHECK(who.alloc((E + 1) * 4));
         KCHECK(reset_cursors());
-        if (E) KLAUNCH(edge_cand_kernel, E, stream, mult.as<u32>(), pos.as<u64>(), alive_e.as<unsigned char>(), E, E_new, q.as<u64>(), who.as<u32>(), cur);
+        if (E) KLAUNCH_T(edge_cand_kernel, E, stream, mult.as<u32>(), pos.as<u64>(), alive_e.as<unsigned char>(), E, E_new, q.as<u64>(), who.as<u32>(), cur);
         KCHECK_HIP(hipGetLastError());
         KCHECK(read_cursors(h, 1));
         const uint64_t n_q = h[0];
@@ -529,10 +819,10 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             DevBuf found(stream), a1(stream), a2(stream);
             KCHECK(found.alloc((asked.n + 1) * 8)); KCHECK(a1.alloc((asked.n + 1) * 8)); KCHECK(a2.alloc((asked.n + 1) * 8));
             if (asked.n) {                                                   // (rank 0 only)
-                if (m_removed) KCHECK(dev_rank(vict_sorted.as<u64>(), m_removed, 1, 64, asked.a.as<u64>(), asked.n, found.as<u64>(), stream));
+                if (m_removed) KCHECK(dev_rank(vict_sorted.as<u64>(), m_removed, 1, pos_bits, asked.a.as<u64>(), asked.n, found.as<u64>(), stream));
                 else KCHECK_HIP(hipMemsetAsync(found.p, 0xFF, asked.n * 8, stream));
                 KLAUNCH(answer_u32_kernel, asked.n, stream, found.as<u64>(), asked.n, vict_ord.as<u32>(), a1.as<u64>());
-                if (n_moves) KCHECK(dev_rank(from_sorted.as<u64>(), n_moves, 1, 64, asked.a.as<u64>(), asked.n, found.as<u64>(), stream));
+                if (n_moves) KCHECK(dev_rank(from_sorted.as<u64>(), n_moves, 1, pos_bits, asked.a.as<u64>(), asked.n, found.as<u64>(), stream));
                 else KCHECK_HIP(hipMemsetAsync(found.p, 0xFF, asked.n * 8, stream));
                 KLAUNCH(answer_to_kernel, asked.n, stream, found.as<u64>(), asked.n, from_idx.as<u32>(), to_e.as<u64>(), a2.as<u64>());
                 KCHECK_HIP(hipGetLastError());
@@ -541,6 +831,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             KCHECK(router.reply(asked, a2.as<u64>(), ans_pos.as<u64>()));
         }
         victims.release(); to_e.release(); from_e.release(); vict_sorted.release(); vict_ord.release(); from_sorted.release(); from_idx.release();
+        lap(2);
         // ---- apply: dead edges, their sources' degrees here, messages to their targets' owners ----------------------------
         DevBuf dead_e(stream), dead_t(stream), msgA(stream), msgB(stream);
         KCHECK(dead_e.alloc((n_q + 1) * 4)); KCHECK(dead_t.alloc((n_q + 1) * 4)); KCHECK(msgA.alloc((n_q + 1) * 8)); KCHECK(msgB.alloc((n_q + 1) * 8));
@@ -559,6 +850,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
         KCHECK_HIP(hipGetLastError());
         KCHECK_HIP(hipStreamSynchronize(stream));
         { uint64_t bar = 0; KCHECK(d->comm->allreduce(&bar, 1, OP_MAX)); }   // every rank has applied every loss before anyone decides who dies
+        lap(3);
         // ---- which endpoints go with which removal -> rank 0, which replays remove_single_node ------------------------------
         DevBuf X(stream), Y(stream);
         KCHECK(X.alloc((n_dead + losses.n + 1) * 8)); KCHECK(Y.alloc((n_dead + losses.n + 1) * 8));
@@ -589,10 +881,11 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             if (n_nmoves) {
                 KCHECK_HIP(hipMemcpyAsync(nfrom_sorted.p, from_n.p, n_nmoves * 8, hipMemcpyDeviceToDevice, stream));
                 KLAUNCH(iota32_kernel, n_nmoves, stream, nfrom_idx.as<u32>(), n_nmoves);
-                KCHECK(dev_sort(nfrom_sorted.as<u64>(), nfrom_idx.as<u32>(), n_nmoves, 1, 64, stream));
+                KCHECK(dev_sort(nfrom_sorted.as<u64>(), nfrom_idx.as<u32>(), n_nmoves, 1, pos_bits, stream));
             }
             KCHECK_HIP(hipGetLastError());
         }
+        lap(4);
         uint64_t removed_nodes = rank == 0 ? TN - N_new : 0;
         KCHECK(d->comm->allreduce(&removed_nodes, 1, OP_MAX));
         N_new = TN - removed_nodes;
@@ -601,7 +894,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             DevBuf nq(stream), nwho(stream), nans(stream);
             KCHECK(nq.alloc((N + 1) * 8)); KCHECK(nwho.alloc((N + 1) * 4));
             KCHECK(reset_cursors());
-            if (N) KLAUNCH(node_cand_kernel, N, stream, npos.as<u64>(), alive_n.as<unsigned char>(), N, N_new, nq.as<u64>(), nwho.as<u32>(), cur);
+            if (N) KLAUNCH_T(node_cand_kernel, N, stream, npos.as<u64>(), alive_n.as<unsigned char>(), N, N_new, nq.as<u64>(), nwho.as<u32>(), cur);
             KCHECK_HIP(hipGetLastError());
             KCHECK(read_cursors(h, 1));
             const uint64_t n_nq = h[0];
@@ -611,7 +904,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             DevBuf found(stream), a2(stream);
             KCHECK(found.alloc((asked.n + 1) * 8)); KCHECK(a2.alloc((asked.n + 1) * 8));
             if (asked.n) {
-                if (n_nmoves) KCHECK(dev_rank(nfrom_sorted.as<u64>(), n_nmoves, 1, 64, asked.a.as<u64>(), asked.n, found.as<u64>(), stream));
+                if (n_nmoves) KCHECK(dev_rank(nfrom_sorted.as<u64>(), n_nmoves, 1, pos_bits, asked.a.as<u64>(), asked.n, found.as<u64>(), stream));
                 else KCHECK_HIP(hipMemsetAsync(found.p, 0xFF, asked.n * 8, stream));
                 KLAUNCH(answer_to_kernel, asked.n, stream, found.as<u64>(), asked.n, nfrom_idx.as<u32>(), to_n.as<u64>(), a2.as<u64>());
                 KCHECK_HIP(hipGetLastError());
@@ -621,13 +914,22 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
             KCHECK_HIP(hipGetLastError());
         }
         TE = E_new; TN = N_new;
+        lap(5);
     }
+    if (trace)
+        fprintf(stderr, "[dist prune] rank %d router: %llu sends, %llu replies; host ms: partition %.1f, count rounds %.1f, exchanges %.1f\n", rank,
+                (unsigned long long)router.n_send, (unsigned long long)router.n_reply, router.t_part, router.t_counts, router.t_xchg);
+    if (trace)
+        fprintf(stderr, "[dist prune] rank %d: %llu passes; ms: walks+marks %.1f, marks->root+edge replay %.1f, edge questions %.1f, apply+losses %.1f, "
+                        "dies+node replay %.1f, node questions %.1f; of the second: marks kernel %.1f, send %.1f, sort+replay %.1f; walks: first_out %.1f, words+delta %.1f, allgather+apply %.1f, "
+                        "input list %.1f, walk %.1f, scan+marks %.1f, marks routed %.1f\n", rank, (unsigned long long)st.passes, t_sec[0], t_sec[1], t_sec[2], t_sec[3], t_sec[4], t_sec[5], t_sec[8], t_sec[9], t_sec[10],
+                t_sec[11], t_sec[12], t_sec[13], t_sec[14], t_sec[15], t_sec[16], t_sec[0]);
     // ---- the pruned graph, still sharded: survivors compacted, positions as indices, ages kept ---------------------------------
     DevBuf keep_e(stream), keep_n(stream);
     KCHECK(keep_e.alloc((E + 1) * 4)); KCHECK(keep_n.alloc((N + 1) * 4));
     KCHECK(reset_cursors());
-    if (E) KLAUNCH(alive_list_kernel, E, stream, alive_e.as<unsigned char>(), E, keep_e.as<u32>(), cur);
-    if (N) KLAUNCH(alive_list_kernel, N, stream, alive_n.as<unsigned char>(), N, keep_n.as<u32>(), cur + 1);
+    if (E) KLAUNCH_T(alive_list_kernel, E, stream, alive_e.as<unsigned char>(), E, keep_e.as<u32>(), cur);
+    if (N) KLAUNCH_T(alive_list_kernel, N, stream, alive_n.as<unsigned char>(), N, keep_n.as<u32>(), cur + 1);
     KCHECK_HIP(hipGetLastError());
     uint64_t hc[2] = {0, 0};
     KCHECK(read_cursors(hc, 2));

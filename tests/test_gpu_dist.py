@@ -74,20 +74,23 @@ def test_sharded_build_in_reference_order_equals_oracle(oracle, world, k, rc, n,
     _same_arrays(g, ref)
 
 
-@pytest.mark.parametrize("prune_route", ["sharded", "gather"])
+@pytest.mark.parametrize("prune_route", ["sharded", "sharded-hop", "gather"])
 @pytest.mark.parametrize("world,k,rc,n,L,genome,err", [(2, 63, True, 400, 150, 4000, 5e-4), (4, 63, True, 900, 150, 9000, 3e-4),
                                                        (8, 63, False, 600, 150, 4000, 5e-4), (2, 63, True, 400, 150, 4000, 5e-3),
                                                        (3, 31, True, 1500, 150, 9000, 1e-2), (2, 40, False, 800, 100, 5000, 2e-3)])
 def test_config5_shape_pruned_on_the_sharded_route(oracle, monkeypatch, world, k, rc, n, L, genome, err, prune_route):
     """BASELINE config 5's shape: k=63 (two-word keys, three-word tiles), reads sharded over the ranks, then the reference's
     first pruning -- Prunable::remove_dead_paths (pruner.rs:36-82), whose walks follow petgraph's adjacency and whose
-    swap_removes re-number by index.  "sharded": on the sharded graph itself (katome_dist_remove_dead_paths: walkers hop
-    between the owners, the index replays run on 64-bit positions; no gather, every rank writes its share of the result);
+    swap_removes re-number by index.  "sharded": on the sharded graph itself (katome_dist_remove_dead_paths: the walks run on
+    every rank's copy of the successor table, the index replays on 64-bit positions; no gather, every rank writes its share
+    of the result); "sharded-hop": the same with walkers that hop between the owners (what runs when the table does not fit);
     "gather": on the graph gathered to one rank (KATOME_DIST_PRUNE=gather).  Index for index against the oracle's literal
     petgraph, ages included."""
     from katome_amd.build import GpuGraph
     if prune_route == "gather":
         monkeypatch.setenv("KATOME_DIST_PRUNE", "gather")
+    if prune_route == "sharded-hop":
+        monkeypatch.setenv("KATOME_DIST_PRUNE_WALKS", "hop")
     ascii_reads, packed, skip = _reads(oracle, n, L, genome, err, 1)
     g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world,
                                         ranks_share_device=True, first_seen_order=True, remove_dead_paths=True)
