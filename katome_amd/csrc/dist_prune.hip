@@ -6,8 +6,12 @@
 // descending index, remove_single_node after every edge) is cut along what depends on what:
 //   * the WALKS follow first_edge(Outgoing) -- the live out-edge added last = largest first-seen index, which never changes
 //     (swap_remove re-labels edges, petgraph's lists keep their order) -- for fewer than 2k steps.  A node's out-edges, its
-//     degrees and its first out-edge are local to its owner, so a walker is a 16-byte record that hops from owner to owner:
-//     one all-to-all per step, <= 2k - 1 steps; dead walks are walked a second time to mark their edges (a count per edge);
+//     degrees and its first out-edge are local to its owner; what a walk reads of a node -- its successor, whether it has an
+//     out-edge, whether three or more edges come in -- is one word, and ONE WORD PER NODE OF THE WHOLE GRAPH fits every rank's
+//     288 GB (C5 in full: 88 GB): the table is replicated, the words a pass changes are all-gathered, and the walks are the
+//     one-GPU loop over a table.  Dead walks are walked a second time; every vertex they pass is a mark that goes to the
+//     vertex's owner through a directory sharded by node id.  (Without room for the table: 16-byte walkers that hop from
+//     owner to owner, one all-to-all per step, <= 2k - 1 steps.)
 //   * the two INDEX REPLAYS (which edge / node sits where after every swap_remove) only involve the marked indices and the
 //     tail positions that disappear -- O(what the pass removes), not O(graph).  They run on rank 0 with 64-bit positions
 //     (prune.hip's scan + pointer jumping, templated on the index width): the ranks send their marked (position, count)
