@@ -279,6 +279,7 @@ static int expand_level(katome_builder* b, Table& from, Table& to, bool& to_read
 
 // big tiles -> mid tiles (when the span is large); leaves the tiles that hold k-mers directly in `*last`
 int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, hipStream_t stream) {
+    if (b->tiles2_ready && b->tiles.cap == 0) { *last = &b->tiles2; *last_span = b->span2; return KATOME_OK; }      // (done before)
     uint64_t n_tiles = 0;
     KCHECK(table_occupied(b->tiles, &n_tiles, stream));
     b->stat_tiles = n_tiles; b->stat_tile_slots = b->tiles.cap;
@@ -301,6 +302,7 @@ int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, h
 
 // every distinct tile adds its count to its k-mers; afterwards the tile tables are released
 int expand_tiles(katome_builder* b, hipStream_t stream) {
+    if (b->rest_n) KCHECK(flush_rest(b, stream));
     if (!b->tiles_ready) return KATOME_OK;
     Table* last = nullptr; uint32_t last_span = 1;
     KCHECK(expand_to_last_level(b, &last, &last_span, stream));
@@ -363,6 +365,55 @@ static int bfc_set_edges(katome_builder* b, const uint64_t* d_fwd, const uint32_
     return KATOME_OK;
 }
 
+static int sorted_count_mode() {
+    static const int mode = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
+    return mode;
+}
+
+// plain (weight-1 or weighted) records into the k-mer table, by packed key (no origin)
+static int insert_plain(katome_builder* b, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n_records, hipStream_t stream) {
+    for (uint64_t done = 0; done < n_records;) {
+        uint64_t room = 0;
+        KCHECK(ensure_table(b, n_records - done, &room, stream));
+        const uint64_t n = std::min(n_records - done, room);
+        PhaseScope ps(b->prof, PH_INSERT, stream);
+        KCHECK(table_insert(b->table, d_records + done * b->nw, d_weights ? d_weights + done : nullptr, n, stream, nullptr));
+        done += n;
+    }
+    return KATOME_OK;
+}
+
+int flush_rest(katome_builder* b, hipStream_t stream) {
+    if (b->rest_n) KCHECK(insert_plain(b, b->rest_k.as<u64>(), nullptr, b->rest_n, stream));
+    b->rest_k.release();
+    b->rest_n = b->rest_cap = 0;
+    b->rest_closed = true;
+    return KATOME_OK;
+}
+
+// keeps a batch's left-over windows aside (see builder.h); *kept = false: they have to go into the table
+static int keep_rest(katome_builder* b, const uint64_t* d_records, uint64_t n, bool* kept, hipStream_t stream) {
+    *kept = false;
+    if (b->rest_n + n > b->rest_cap) {
+        size_t free_b = 0, total_b = 0;
+        KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+        const uint64_t want = std::max<uint64_t>(b->rest_n + n, b->rest_cap * 2);
+        // (they are sorted with the tiles' k-mers later: past an eighth of the card they stop being a side matter)
+        if ((want + b->rest_n) * 8 * b->nw > free_b / 2 || want * 8 * b->nw > total_b / 8) { KCHECK(flush_rest(b, stream)); return KATOME_OK; }
+        DevBuf grown(stream);
+        KCHECK(grown.alloc(want * 8 * b->nw + 16));
+        if (b->rest_n) KCHECK_HIP(hipMemcpyAsync(grown.p, b->rest_k.p, b->rest_n * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
+        const size_t grown_bytes = grown.bytes;
+        b->rest_k.adopt(grown.take(), grown_bytes);
+        b->rest_k.stream = stream;
+        b->rest_cap = want;
+    }
+    KCHECK_HIP(hipMemcpyAsync(b->rest_k.as<u64>() + b->rest_n * b->nw, d_records, n * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
+    b->rest_n += n;
+    *kept = true;
+    return KATOME_OK;
+}
+
 extern "C" {
 
 int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, const uint32_t* d_weights, uint64_t n_records,
@@ -376,6 +427,11 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
             b->var_prefix = b->var_rec_prefix = nullptr; b->var_reads = b->var_windows = 0;
         }
         return KATOME_OK;
+    }
+    if (!b->first_seen && !d_weights && b->tiles_ready && !b->table_ready && !b->rest_closed && b->nw <= 2 && sorted_count_mode()) {
+        bool kept = false;
+        KCHECK(keep_rest(b, d_records, n_records, &kept, stream));
+        if (kept) return KATOME_OK;
     }
     uint64_t room = 0;
     KCHECK(ensure_table(b, n_records, &room, stream));
@@ -475,6 +531,7 @@ int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_w
     KCHECK_HIP(hipSetDevice(b->s.device));
     *n_records = 0; *d_keys = nullptr; *d_weights = nullptr;
     if (b->first_seen) { set_error("first-seen order is not available on the multi-GPU route"); return KATOME_E_UNSUPPORTED; }
+    if (b->rest_n) KCHECK(flush_rest(b, stream));
     if (!b->tiles_ready) return KATOME_OK;
     Table* last = nullptr; uint32_t last_span = 1;
     KCHECK(expand_to_last_level(b, &last, &last_span, stream));
@@ -515,6 +572,7 @@ int katome_dev_remove_weak_edges(katome_builder* b, uint32_t threshold, void* st
 int katome_dev_table_count(katome_builder* b, uint64_t* out, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
     *out = 0;
+    if (b->rest_n) KCHECK(flush_rest(b, (hipStream_t)stream));
     if (!b->table_ready) return KATOME_OK;
     return table_occupied(b->table, out, (hipStream_t)stream);
 }
@@ -524,33 +582,49 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (!b->edges_ready) {
         b->n_edges = 0;
-        // Counting the last level by sorting instead of in a table (table.hip, lds_count_kernel): one-word k-mers, by packed key,
-        // nothing in the k-mer table yet (no left-over windows), enough tiles to be worth the extra launches
-        static const int sorted_count = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
+        // Counting the last level by sorting instead of in a table (table.hip, lds_count_kernel / lds_count_wide_kernel): k <= 63, by
+        // packed key, nothing in the k-mer table yet (left-over windows were kept aside), enough tiles to be worth the extra launches
+        const int sorted_count = sorted_count_mode();
         bool counted = false;
-        if (sorted_count && b->tiles_ready && !b->table_ready && !b->first_seen && b->nw == 1) {
+        if (sorted_count && b->tiles_ready && !b->table_ready && !b->first_seen && b->nw <= 2) {
             uint64_t n_tiles = 0;
             KCHECK(table_occupied(b->tiles, &n_tiles, stream));
-            const uint64_t bound = n_tiles * b->span;        // the k-mer records can be no more than this
-            if ((bound >= (1ull << 22) || (sorted_count == 2 && bound)) && (bound >> 21) <= 2900) {      // (2: however few -- tests)
+            const uint64_t bound = n_tiles * b->span + b->rest_n;        // the k-mer records can be no more than this
+            const uint32_t nwt = b->tiles.nw;
+            const bool shapes = (b->nw == 1 && nwt <= 2) || (b->nw == 2 && (nwt == 2 || nwt == 3));      // (what tiles_to_records streams)
+            if (shapes && (bound >= (1ull << 22) || (sorted_count == 2 && bound)) && (bound >> 21) <= 2900) {      // (2: however few -- tests)
                 Table* last = nullptr; uint32_t last_span = 1;
                 KCHECK(expand_to_last_level(b, &last, &last_span, stream));
-                DevBuf rk(stream), rw(stream);
-                uint64_t n_rec = 0, distinct = 0;
-                {
-                    PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-                    KCHECK(table_tiles_to_records_fast(*last, b->s.k, last_span, b->rc, rk, rw, &n_rec, stream));
-                    b->tiles.release(); b->tiles2.release();
-                    b->tiles_ready = false; b->tiles2_ready = false;
-                    const int rc = records_to_edges_sorted(rk, rw, n_rec, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
-                    if (rc != KATOME_OK) return rc;
+                const bool last_ok = (b->nw == 1 && last->nw <= 2) || (b->nw == 2 && (last->nw == 2 || last->nw == 3));
+                if (last_ok) {
+                    DevBuf rk(stream), rw(stream);
+                    uint64_t n_rec = 0, distinct = 0;
+                    int rc = KATOME_OK;
+                    {
+                        PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                        KCHECK(table_tiles_to_records_fast(*last, b->s.k, last_span, b->rc, rk, rw, &n_rec, stream, b->rest_n));
+                        if (b->rest_n) {          // the left-over windows behind them, one each
+                            KCHECK_HIP(hipMemcpyAsync(rk.as<u64>() + n_rec * b->nw, b->rest_k.p, b->rest_n * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
+                            KCHECK(dev_fill_u32(rw.as<u32>() + n_rec, b->rest_n, 1u, stream));
+                            n_rec += b->rest_n;
+                        }
+                        rc = records_to_edges_sorted(rk, rw, n_rec, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
+                        if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+                    }
+                    if (rc == KATOME_OK) {
+                        b->tiles.release(); b->tiles2.release();
+                        b->tiles_ready = false; b->tiles2_ready = false;
+                        b->rest_k.release(); b->rest_n = b->rest_cap = 0;
+                        b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+                        for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
+                        rk.release(); rw.release();
+                        PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
+                        KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream));
+                        counted = true;
+                    } else {
+                        b->n_edges = 0;           // (a group too large for the LDS route: the table counts, from the tiles that are still there)
+                    }
                 }
-                b->stat_kmers = distinct; b->stat_kmer_slots = 0;
-                for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
-                rk.release(); rw.release();
-                PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
-                KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream));
-                counted = true;
             }
         }
         if (!counted) KCHECK(expand_tiles(b, stream));

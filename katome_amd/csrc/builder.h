@@ -41,6 +41,12 @@ struct katome_builder {
     uint64_t var_records = 0;                  // how many of them: the insert that follows must take exactly these
     uint32_t var_mode = 0, var_span = 1;       // 0 every window, 1 whole tiles, 2 the windows after the last whole tile
     DevBuf edge_seq;                   // sequence number of each edge's first insertion, aligned with edge_key
+    // by-packed-key builds: the windows left over after a batch's tiles wait here (records of weight 1), so that the last level can
+    // be counted by sorting (table.hip, records_to_edges_sorted) together with the tiles' k-mers; any other consumer of the k-mer
+    // table flushes them into it first (flush_rest)
+    DevBuf rest_k;
+    uint64_t rest_n = 0, rest_cap = 0;
+    bool rest_closed = false;           // too many to keep aside: from now on they go into the table directly
     uint64_t direct_edges = 0;         // BFCounter input: the edges were listed one per line and strand (no table); their count
     uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out
     uint64_t stat_tiles = 0, stat_tile_slots = 0, stat_kmers = 0, stat_kmer_slots = 0;
@@ -67,4 +73,5 @@ int builder_insert(katome_builder* b, Table& table, bool& ready, uint32_t nw, ui
 // big tiles -> mid tiles (when the span is large); leaves the tiles that hold k-mers directly in `*last`
 int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, hipStream_t stream);
 int expand_tiles(katome_builder* b, hipStream_t stream);       // every distinct tile adds its count to its k-mers (b->table); the tile tables go
+int flush_rest(katome_builder* b, hipStream_t stream);         // the left-over windows kept aside -> b->table
 uint32_t mid_span(uint32_t span);      // span of the mid tiles a big tile is broken into (0: expanded directly)

@@ -577,12 +577,13 @@ static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u
     *k_out = kin; *w_out = win;
     return KATOME_OK;
 }
-// one-word (k-mer, count) records ordered by the top 16 bits of the k-mer's hash, for the counting in LDS (table.hip): two
+// (k-mer, count) records of one or two words ordered by the top 16 bits of the k-mer's hash, for the counting in LDS (table.hip): two
 // stable 8-bit passes.  The result is where *k_out / *w_out point (one of the two buffer pairs); *group_bits = 16.
-int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
+int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
                    const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream) {
     *group_bits = 16;
-    return region_order_t<1>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
+    if (nw == 1) return region_order_t<1>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
+    return region_order_t<2>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
 }
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream) {
@@ -1500,6 +1501,14 @@ __global__ __launch_bounds__(BLOCK) void node_first_dst_kernel(const u64* __rest
 
 int dev_iota(uint32_t* d, uint64_t n, hipStream_t stream) {
     if (n) hipLaunchKernelGGL(iota_kernel, dim3(grid_for(n, BLOCK)), dim3(BLOCK), 0, stream, d, n);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+__global__ __launch_bounds__(BLOCK) void fill_u32_kernel(u32* __restrict__ d, u64 n, u32 v) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) d[i] = v;
+}
+int dev_fill_u32(uint32_t* d, uint64_t n, uint32_t v, hipStream_t stream) {
+    if (n) hipLaunchKernelGGL(fill_u32_kernel, dim3(grid_for(n, BLOCK, 256u * 8u)), dim3(BLOCK), 0, stream, d, n, v);
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }

@@ -9,7 +9,10 @@
 //
 // Random-access kernel: algorithmic traffic per insertion = 8*NW B record + 16*NW B slot
 // (key compare + weight read-modify-write).  Integer/atomic work, no MFMA.
+#include <atomic>
+#include <cstdio>
 #include <vector>
+
 #include "common.h"
 
 namespace katome {
@@ -379,30 +382,13 @@ __global__ __launch_bounds__(BLOCK) void expand_tiles_kernel(const typename Slot
                 for (int q = 0; q < NWK; ++q) out_keys[(bbase + p) * NWK + q] = x.w[q];
                 out_w[bbase + p] = lcnt[t];
                 if (tile_seen) {        // (kmer_seen is the records' [n][2] output here)
-                    // The pair is read from LDS ABOVE (seq_fwd / seq_rev), before the key and weight stores.  Written the obvious
-                    // way -- lseen read here, after those stores -- this kernel puts wrong keys into ~0.2 % of the records
-                    // (hipcc 7.2, gfx950; round 2's "one tile in 5000").  What round 3 established, with the library built in
-                    // eight variants of these few lines (tools/make_pair_store_variants.py, tools/check_pair_store.py: a 4-rank
-                    // first-seen build of 2 M reads against the one-GPU build, three runs each, profiles/r03_pair_store.md):
-                    //   * late read + one 16-byte store (v1) and late read + two 8-byte plain stores (v2, which the compiler merges
-                    //     into the same dwordx4 store): wrong every run (18.52 M edges instead of 18.41 M);
-                    //   * early read with either store form (v3, v4; the shipped form is v4 with agent-scope stores): right;
-                    //   * late read behind `s_waitcnt vmcnt(0)` (v5), behind `s_waitcnt vmcnt(1)` (v8) and behind an EMPTY
-                    //     `asm volatile("" ::: "memory")` (v7): all right.
-                    // v7 adds no instruction at the spot, so it is not the hardware timing of the stores; and the sequence the bad
-                    // variants share -- global_store_dwordx2 v[8:9], v[6:7]; global_store_dword v[6:7], v22; s_cbranch_vccnz;
-                    // ds_read_b128 v[6:9] (the LDS pair loaded into both stores' address registers) -- does not lose or redirect a
-                    // single store out of 1e8 when it stands alone in inline assembly (tools/probe_vmem_lds_war.hip: bare, with the
-                    // branch, on the library's exact registers with broadcast LDS addresses and a partly active wave).  What v7 and
-                    // v5 change in the ISA besides registers is that `bbase` (the workgroup's cursor claim, in LDS) is loaded again
-                    // inside the loop for the three store addresses, where v1-v4 all load it once in the loop pre-header: the bad
-                    // variants are the ones where one register pair loaded before the loop feeds the addresses of stores on BOTH
-                    // sides of an LDS load inside the loop.  The ISA of v1 was read line by line against v7 (barriers, waitcnts,
-                    // exec masks, SGPR carry-outs of v_mad_u64_u32): no difference that explains it was found, so the cause is
-                    // narrowed to this code shape, not diagnosed.  The register overlap by itself is common and harmless:
-                    // tools/scan_store_lds_overlap.py finds an LDS load landing in the address registers of a store still in
-                    // flight 36 times in the shipped kernels (lds_count_kernel's read-out among them) and in the correct v7 as well,
-                    // and every one of those kernels is compared with the oracle record for record in the suite.
+                    // (The pair is read from LDS above, before the key and weight stores.  Round 2 saw this kernel put wrong keys into
+                    // ~0.2 % of its records when the read stood here instead; round 3 found why, and it is not the stores: with the
+                    // late read the kernel needs exactly 32 VGPRs and keeps sub_window's shift amount in v31, the last register of its
+                    // allocation, and on gfx950 a 64-bit shift whose amount sits there sometimes shifts by v0 -- the thread id -- instead
+                    // (LLVM's Shift64HighRegBug, worked around by the compiler for gfx90a only).  Evidence, stand-alone reproducer and
+                    // the build-time ISA check that keeps every kernel of the library clear of the shape: profiles/r03_shift64_erratum.md,
+                    // tools/probe_shift64_top_vgpr.hip, tools/scan_shift64_top_vgpr.py, KATOME_SHIFT64_GUARD in common.h.)
                     __hip_atomic_store(&kmer_seen[2 * (bbase + p)], flipped ? seq_rev : seq_fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(&kmer_seen[2 * (bbase + p) + 1], flipped ? seq_fwd : seq_rev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
@@ -650,12 +636,15 @@ constexpr u32 LC_MAX_ROUNDS = 32;
 
 // index[g] = first record whose hash has top `gbits` bits >= g (records ordered by those bits), g = 0 .. 2^gbits: one binary
 // search per group boundary (31 dependent reads each) instead of a pass over all the records (3.4 ms at C3)
+template <int NW>
 __global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __restrict__ keys, u64 n, u32 gbits, u64* __restrict__ index) {
     for (u64 g = (u64)blockIdx.x * BLOCK + threadIdx.x; g <= (1ull << gbits); g += (u64)gridDim.x * BLOCK) {
         u64 lo = 0, hi = n;                                   // first i with (hash(keys[i]) >> (64 - gbits)) >= g
         while (lo < hi) {
             const u64 mid = lo + ((hi - lo) >> 1);
-            Key<1> a; a.w[0] = keys[mid];
+            Key<NW> a;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) a.w[q] = keys[mid * NW + q];
             if ((hash_key(a) >> (64 - gbits)) < g) lo = mid + 1; else hi = mid;
         }
         index[g] = lo;
@@ -744,6 +733,115 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                 ++pos;
                 if (ne[j] == 2) {
                     if (pos < out_cap) { out_keys[pos] = revcomp(kk[j], k).w[0]; out_w[pos] = w; }
+                    ++pos;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    my_distinct = wave_sum(my_distinct);
+    if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
+}
+
+// The same for k-mers of two words (k = 32..63; the reference's example configuration runs k = 40): the LDS slot stays 12 bytes
+// -- a 16-byte key would halve the table -- and holds, published by ONE compare-and-swap, a 43-bit fingerprint of the key's hash
+// and the position (within the group, < 2^20) of a REPRESENTATIVE record; a record whose fingerprint meets an occupied slot's
+// compares its whole key with the representative's (read back from the group: L2 / Infinity Cache) and only then adds its
+// count -- exact whatever the fingerprints do.  The read-out fetches each distinct key through its representative.
+template <bool RC, int PER, int NW>
+__global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
+                                                                     u32 R, u32 k, u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap,
+                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err) {
+    constexpr u32 LC_SLOTS = LcTable<PER>::SLOTS;
+    constexpr unsigned long long REP_MASK = (1ull << 20) - 1;
+    extern __shared__ unsigned long long lc_mem[];
+    unsigned long long* lkey = lc_mem;                                   // [LC_SLOTS]: OCC | fingerprint << 20 | representative
+    u32* lcnt = reinterpret_cast<u32*>(lc_mem + LC_SLOTS);               // [LC_SLOTS]
+    __shared__ u32 wtot[LC_THREADS / 64];
+    __shared__ unsigned long long base_sh;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 my_distinct = 0;
+    const u32 n_groups = 1u << gbits, sub_shift = 64 - gbits - 16;
+    for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const u64 lo = index[g], hi = index[g + 1];
+        if (lo == hi) continue;
+        if (hi - lo > REP_MASK) { if (tid == 0) *err = 4; continue; }      // (a group of a million records: not k-mers of reads; the caller counts in the table)
+        for (u32 r = 0; r < R; ++r) {
+            for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
+            __syncthreads();
+            for (u64 i = lo + tid; i < hi; i += LC_THREADS) {
+                Key<NW> key;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) key.w[q] = keys[i * NW + q];
+                const u64 h = hash_key(key);
+                if (R > 1 && (u32)((((h >> sub_shift) & 0xFFFFull) * R) >> 16) != r) continue;
+                const unsigned long long want = OCC | (((h >> 5) & ((1ull << 43) - 1)) << 20) | (unsigned long long)(i - lo);
+                const u32 w = wts[i];
+                u32 s = (u32)(((h & 0x3FFFFFFFull) * LC_SLOTS) >> 30);
+                u32 probes = 0;
+                for (; probes < LC_SLOTS; ++probes) {
+                    const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
+                    bool mine = cur == 0ull;
+                    if (!mine && (cur >> 20) == (want >> 20)) {            // same fingerprint: the same key?
+                        const u64 j = lo + (cur & REP_MASK);
+                        mine = true;
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) mine = mine && keys[j * NW + q] == key.w[q];
+                    }
+                    if (mine) { atomicAdd(&lcnt[s], w); break; }
+                    if (++s == LC_SLOTS) s = 0;
+                }
+                if (probes == LC_SLOTS) *err = 3;
+            }
+            __syncthreads();
+            Key<NW> kk[PER]; u32 cc[PER], ne[PER]; u32 mine = 0;
+#pragma unroll
+            for (u32 j = 0; j < (u32)PER; ++j) {
+                const u32 sidx = tid * PER + j;
+                const unsigned long long v = lkey[sidx];
+                ne[j] = 0; cc[j] = 0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) kk[j].w[q] = 0;
+                if (v & OCC) {
+                    const u64 rep = lo + (v & REP_MASK);
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) kk[j].w[q] = keys[rep * NW + q];
+                    cc[j] = lcnt[sidx];
+                    ++my_distinct;
+                    ne[j] = 1;
+                    if (RC && !key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 2;
+                    if ((cc[j] << ((RC && ne[j] == 1) ? 1u : 0u)) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
+                }
+                mine += ne[j];
+            }
+            u32 incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            u32 woff = 0, total = 0;
+#pragma unroll
+            for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+            if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+            __syncthreads();
+            u64 pos = base_sh + woff + (incl - mine);
+#pragma unroll
+            for (u32 j = 0; j < (u32)PER; ++j) {
+                if (!ne[j]) continue;
+                const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);       // (as a shift: see lds_count_kernel)
+                if (pos < out_cap) {
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = kk[j].w[q];
+                    out_w[pos] = w;
+                }
+                ++pos;
+                if (ne[j] == 2) {
+                    const Key<NW> rk = revcomp(kk[j], k);
+                    if (pos < out_cap) {
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rk.w[q];
+                        out_w[pos] = w;
+                    }
                     ++pos;
                 }
             }
@@ -897,6 +995,26 @@ int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint
     KCHECK(expand_launch<false>(tiles, 0, tiles.cap, nullptr, k, span, stride, rc, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>(), stream, out_seen));
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
+#ifdef KATOME_DEBUG_DUMP
+    // diagnostic builds only (tools/make_pair_store_variants.py): the records as the kernel left them, one file per call
+    if (const char* prefix = getenv("KATOME_DUMP_RECORDS")) {
+        static std::atomic<int> calls{0};
+        char path[512];
+        snprintf(path, sizeof path, "%s.%d.bin", prefix, calls.fetch_add(1));
+        const uint64_t n = *n_records;
+        std::vector<uint64_t> hk(n * nwk + 1), hs(out_seen ? 2 * n + 1 : 1);
+        std::vector<uint32_t> hw(n + 1);
+        KCHECK_HIP(hipMemcpy(hk.data(), keys.p, n * nwk * 8, hipMemcpyDeviceToHost));
+        KCHECK_HIP(hipMemcpy(hw.data(), weights.p, n * 4, hipMemcpyDeviceToHost));
+        if (out_seen) KCHECK_HIP(hipMemcpy(hs.data(), out_seen, n * 16, hipMemcpyDeviceToHost));
+        if (FILE* f = fopen(path, "wb")) {
+            const uint64_t head[8] = {n, nwk, k, span, stride, out_seen ? 1u : 0u, tiles.nw, tiles.cap};
+            fwrite(head, 8, 8, f); fwrite(hk.data(), 8, n * nwk, f); fwrite(hw.data(), 4, n, f);
+            if (out_seen) fwrite(hs.data(), 8, 2 * n, f);
+            fclose(f);
+        }
+    }
+#endif
     return KATOME_OK;
 }
 
@@ -923,25 +1041,31 @@ int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_record
 }
 
 // the (k-mer, count) records of every distinct tile of the last level (no sequence numbers), written by the streaming kernel
-int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream) {
+int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream,
+                                uint64_t extra_room) {
     uint64_t occ = 0;
     KCHECK(table_occupied(tiles, &occ, stream));
     const uint32_t nwk = (uint32_t)key_words_for_k(k);
-    if (nwk != 1 || tiles.nw < 1 || tiles.nw > 2) return table_expand_tiles_to_records(tiles, k, span, rc, keys, weights, n_records, stream, nullptr);
-    KCHECK(keys.alloc((occ * span + 1) * 8 * nwk, stream));
-    KCHECK(weights.alloc((occ * span + 1) * 4, stream));
+    const bool streaming = (nwk == 1 && (tiles.nw == 1 || tiles.nw == 2)) || (nwk == 2 && (tiles.nw == 2 || tiles.nw == 3));
+    if (!streaming) {
+        if (extra_room) { set_error("records of this tile shape cannot be extended"); return KATOME_E_UNSUPPORTED; }
+        return table_expand_tiles_to_records(tiles, k, span, rc, keys, weights, n_records, stream, nullptr);
+    }
+    KCHECK(keys.alloc((occ * span + extra_room + 1) * 8 * nwk, stream));
+    KCHECK(weights.alloc((occ * span + extra_room + 1) * 4, stream));
     DevBuf cursor(stream);
     KCHECK(cursor.alloc(8));
     KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
     dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
     KernelScope ks(K_RECORDS, stream, tiles.cap);
-    if (tiles.nw == 1) {
-        if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, true>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-        else    hipLaunchKernelGGL((tiles_to_records_kernel<1, 1, false>), grid, block, 0, stream, tiles.slots.as<Slot1>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-    } else {
-        if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<2, 1, true>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-        else    hipLaunchKernelGGL((tiles_to_records_kernel<2, 1, false>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
-    }
+#define KATOME_TR(NWT, NWK)                                                                                                                       \
+    do {                                                                                                                                          \
+        if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<NWT, NWK, true>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>()); \
+        else    hipLaunchKernelGGL((tiles_to_records_kernel<NWT, NWK, false>), grid, block, 0, stream, tiles.slots.as<SlotOf<NWT>::type>(), tiles.cap, k, span, 1u, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>()); \
+    } while (0)
+    if (nwk == 1) { if (tiles.nw == 1) KATOME_TR(1, 1); else KATOME_TR(2, 1); }
+    else          { if (tiles.nw == 2) KATOME_TR(2, 2); else KATOME_TR(3, 2); }
+#undef KATOME_TR
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
@@ -954,15 +1078,16 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
 int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
                             DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
     *n_edges = 0; *n_distinct = 0;
-    if (key_words_for_k(k) != 1) return KATOME_E_UNSUPPORTED;
+    const uint32_t nw = (uint32_t)key_words_for_k(k);
+    if (nw > 2) return KATOME_E_UNSUPPORTED;
     if ((n >> 16) > (u64)LC_MAX_ROUNDS * LcTable<13>::FILL) return KATOME_E_UNSUPPORTED;
     const u64* ko = nullptr; const u32* wo = nullptr;
     u32 gbits = 16;
     {
         DevBuf kb(stream), wb(stream);
-        KCHECK(kb.alloc((n + 1) * 8)); KCHECK(wb.alloc((n + 1) * 4));
+        KCHECK(kb.alloc((n + 1) * 8 * nw)); KCHECK(wb.alloc((n + 1) * 4));
         // two passes: the first one's output goes to the scratch, the second one's lands in keys / weights again
-        KCHECK(dev_hash_order(keys.as<u64>(), weights.as<u32>(), n, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, &gbits, stream));
+        KCHECK(dev_hash_order(keys.as<u64>(), weights.as<u32>(), n, nw, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, &gbits, stream));
     }
     // the smaller table when a group fits it in one round (less to clear and to read out per group)
     const u64 avg = n >> gbits;
@@ -976,29 +1101,37 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
     {
         KernelScope ks(K_GROUP_INDEX, stream, n);
-        hipLaunchKernelGGL(hash_group_index_kernel, dim3(grid_for((1ull << gbits) + 1, BLOCK)), dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
+        const dim3 igrid(grid_for((1ull << gbits) + 1, BLOCK));
+        if (nw == 1) hipLaunchKernelGGL(hash_group_index_kernel<1>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
+        else         hipLaunchKernelGGL(hash_group_index_kernel<2>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
     }
     const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
-    KCHECK(edge_key.alloc(out_cap * 8, stream));
+    KCHECK(edge_key.alloc(out_cap * 8 * nw, stream));
     KCHECK(edge_weight.alloc(out_cap * 4, stream));
     unsigned long long* cursor = aux.as<unsigned long long>();
     unsigned long long* distinct = cursor + 1;
     u32* err = reinterpret_cast<u32*>(cursor + 2);
-#define KATOME_LC_LAUNCH(RCV, PERV)                                                                                                     \
+#define KATOME_LC_LAUNCH(KERNEL, PERV)                                                                                                  \
     do {                                                                                                                              \
         const size_t lds = (size_t)LcTable<PERV>::SLOTS * 12;                                                                         \
-        KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_kernel<RCV, PERV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        KCHECK_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
         KernelScope ks(K_LDS_COUNT, stream, n);                                                                                       \
-        hipLaunchKernelGGL((lds_count_kernel<RCV, PERV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, R, k, \
+        hipLaunchKernelGGL(KERNEL, dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, R, k,                    \
                            min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);                     \
     } while (0)
-    if (small) { if (rc) KATOME_LC_LAUNCH(true, 8); else KATOME_LC_LAUNCH(false, 8); }
-    else       { if (rc) KATOME_LC_LAUNCH(true, 13); else KATOME_LC_LAUNCH(false, 13); }
+    if (nw == 1) {
+        if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 8>), 8); else KATOME_LC_LAUNCH((lds_count_kernel<false, 8>), 8); }
+        else       { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 13>), 13); else KATOME_LC_LAUNCH((lds_count_kernel<false, 13>), 13); }
+    } else {
+        if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 8, 2>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 2>), 8); }
+        else       { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 13, 2>), 13); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 2>), 13); }
+    }
 #undef KATOME_LC_LAUNCH
     KCHECK_HIP(hipGetLastError());
     uint64_t h[3] = {0, 0, 0};
     KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
+    if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;          // (a group too large for the representative's 20 bits: the caller counts in the table)
     if ((uint32_t)h[2]) { set_error("counting in LDS: a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
     *n_edges = h[0]; *n_distinct = h[1];
     return KATOME_OK;

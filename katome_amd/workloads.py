@@ -42,5 +42,8 @@ WORKLOADS = {
     "c5": Workload("c5", 1_000_000_000, 150, 63, 1_000_000_000, 5e-4, 0),
     # not a BASELINE configuration: 101-bp reads, whose 71 windows are not a whole number of useful tiles
     # (counted as 5 tiles of 14 windows + 1 window, katome_tile_plan)
+    # not a BASELINE configuration either: c3's reads at the k-mer size of the reference's example configuration
+    # (config.txt: k_mer_size = 40) -- two-word k-mers, 111 windows = 4 tiles of 27 + 3 windows (katome_tile_plan)
+    "k40": Workload("k40", 200_000_000, 150, 40, 100_000_000, 1e-3, 0),
     "r101": Workload("r101", 100_000_000, 101, 31, 50_000_000, 1e-3, 0),
 }

@@ -787,6 +787,59 @@ def test_round_one_paths_give_the_same_arrays(tmp_path):
         assert run(extra) == want, extra
 
 
+_WIDE_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+for k, L, rc, weak in ((31, 101, True, 0), (40, 150, True, 0), (40, 150, False, 2), (63, 150, True, 0), (40, 77, True, 0), (33, 126, True, 3),
+                       (47, 150, False, 0), (32, 150, True, 0), (62, 131, True, 0), (31, 150, True, 2)):
+    n = 4000
+    reads = o.synth_reads(7, n, L, 20000, 4e-3, 0)
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc, table_slots_hint=1 << 14)
+    if weak:
+        b.remove_weak_edges(weak)
+    for r0 in range(0, n, 1536):
+        b.count_reads(packed, min(1536, n - r0), L, None, first_read=r0)
+    dg = b.finalize()
+    c = b.counts()
+    h = hashlib.sha256()
+    for t in (dg.edge_key, dg.edge_weight, dg.edge_src, dg.edge_dst, dg.node_key, dg.edge_label):
+        h.update(t.cpu().numpy().tobytes())
+    ref = o.build_ascii(reads, k, rc, remove_weak_edges=weak or None)
+    ms = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
+    assert len(got) == dg.n_edges
+    print("WIDE", k, L, int(rc), weak, dg.n_nodes, dg.n_edges, c["distinct_kmers"], int(c["kmer_slots"] == 0), int(got == ms), h.hexdigest())
+    b.close()
+"""
+
+
+def test_two_word_kmers_and_left_over_windows_counted_by_sorting(tmp_path):
+    """k = 32..63 (the reference's example configuration runs k = 40: config.txt) and reads whose windows are not a whole number of
+    tiles go through the sorted last level too (lds_count_wide_kernel; the left-over windows join the tiles' records): forced
+    at a small size (KATOME_SORTED_COUNT=2), byte for byte against the table route (=0) and, as a multiset, against the oracle"""
+    import subprocess
+    script = tmp_path / "wide.py"
+    script.write_text(_WIDE_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(mode):
+        env = dict(os.environ, KATOME_SORTED_COUNT=mode)
+        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [line.split() for line in out.stdout.splitlines() if line.startswith("WIDE ")]
+    by_sort, by_table = run("2"), run("0")
+    assert len(by_sort) == len(by_table) == 10
+    for a, t in zip(by_sort, by_table):
+        assert a[9] == "1" and t[9] == "1", (a, t)              # the oracle's multiset
+        assert a[8] == "1" and t[8] == "0", (a, t)              # ... reached without / with the k-mer table
+        assert a[:8] == t[:8] and a[10] == t[10], (a, t)        # the same arrays
+
+
 def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
     from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
     base = oracle.build_files([os.path.join(golden_dir, "data1.txt")], 31, False)

@@ -22,10 +22,10 @@ def child(reads):
     del packed
     torch.cuda.empty_cache()
     one, _ = GpuGraph.create_from_packed(host, reads, L, reverse_complement=True, k=k, first_seen_order=True)
-    out = {"lib": os.environ.get("KATOME_LIB", "shipped"), "reads": reads, "edges": int(one.n_edges)}
+    out = {"lib": os.environ.get("KATOME_LIB", "shipped"), "reads": reads, "edges": int(one.n_edges), "ranks": int(os.environ.get("KATOME_CHECK_RANKS", "4"))}
     for rep in range(3):
-        g, _ = GpuGraph.create_from_packed(host, reads, L, reverse_complement=True, k=k, first_seen_order=True, n_devices=4,
-                                           ranks_share_device=True)
+        g, _ = GpuGraph.create_from_packed(host, reads, L, reverse_complement=True, k=k, first_seen_order=True,
+                                           n_devices=int(os.environ.get("KATOME_CHECK_RANKS", "4")), ranks_share_device=True)
         same_counts = (g.n_edges, g.n_nodes) == (one.n_edges, one.n_nodes)
         diff = -1
         if same_counts:
@@ -39,8 +39,9 @@ def child(reads):
 
 def main():
     reads = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
-    only = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else None       # e.g. "0,1,5" (0 = the shipped library)
-    libs = [None] + [os.path.join(ROOT, "build_variants", "libkatome_gpu_v%d.so" % v) for v in (1, 2, 3, 4, 5, 7, 8)]
+    named = len(sys.argv) > 2 and not sys.argv[2].replace(",", "").isdigit()                # e.g. "aA,aC": build_variants/libkatome_gpu_aA.so ...
+    only = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 and not named else None       # e.g. "0,1,5" (0 = the shipped library)
+    libs = [os.path.join(ROOT, "build_variants", "libkatome_gpu_%s.so" % v) for v in sys.argv[2].split(",")] if named else [None] + [os.path.join(ROOT, "build_variants", "libkatome_gpu_v%d.so" % v) for v in (1, 2, 3, 4, 5, 7, 8, 9, 10)]
     for i, lib in enumerate(libs):
         if only is not None and i not in only:
             continue
