@@ -471,7 +471,9 @@ def main():
                         "emit_edges": "emit_edges_kernel", "sort_edges": "radix sort (edges)",
                         "node_set": "src_count/src_write_kernel + dst_seg_kernel + dst_merge_kernel (+ missing_rank_kernel)", "rank": "bucket_index + rank_kernel",
                         "labels": "labels_kernel"}
-        if sorted_last_level:
+        if sorted_last_level and args.first_seen_order:
+            kernel_names["expand_tiles"] = "seen_records_kernel + 2 x radix pass (HashTaggedDigit) + hash_group_index_kernel + lds_count_seen_kernel (no k-mer table; the edges leave with their sequence numbers)"
+        elif sorted_last_level:
             kernel_names["expand_tiles"] = "tiles_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_kernel (no k-mer table; the edges are written here)"
         kernels = {}                      # phases of the build (one or several launches each)
         kernel_launches = {}              # single kernels timed launch by launch inside the phases (library: KernelScope)
@@ -513,13 +515,17 @@ def main():
                 last_slots, last_tiles, last_span, last_nw = ((cnt["mid_tile_slots"], cnt["distinct_mid_tiles"], ms2, _katome_lib().katome_tile_words(wl.k, ms2)) if ms2
                                                               else (cnt["tile_slots"], cnt["distinct_tiles"], span, nwt))
                 n_rec = last_tiles * last_span
-                kalg.update({"radix_scatter_kernel<HashDigit>": 2 * 12, "radix_hist_kernel<HashDigit>": 8,
-                             "tiles_to_records_kernel": 16 * last_nw + 12.0 * n_rec / last_slots, "hash_group_index_kernel": 8,
-                             "lds_count_kernel": 12 + 12.0 * n_edges / n_rec})
-                kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<1, true, HashDigit<1> >",
-                               "radix_hist_kernel<HashDigit>": "void radix_hist_kernel<1, HashDigit<1> >",
-                               "tiles_to_records_kernel": "void tiles_to_records_kernel<%d, 1, %s>" % (last_nw, rcs),
-                               "hash_group_index_kernel": "hash_group_index_kernel", "lds_count_kernel": "void lds_count_kernel<%s>" % rcs})
+                # (the group index is 2^16 + 1 binary searches of ~31 reads each, not a pass over the records)
+                per = 8 if (n_rec >> 16) <= 5800 else 13           # table.hip, records_to_edges_sorted: the smaller LDS table when a group fits it
+                kalg.update({"radix_scatter_kernel<HashDigit>": 2 * pair, "radix_hist_kernel<HashDigit>": 8 * nw,
+                             "tiles_to_records_kernel": 16 * last_nw + float(pair) * n_rec / last_slots,
+                             "hash_group_index_kernel": 65537.0 * (31 * 8 * nw + 8) / max(n_rec, 1),
+                             "lds_count_kernel": pair + float(pair) * n_edges / n_rec})
+                kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nw, nw),
+                               "radix_hist_kernel<HashDigit>": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nw, nw),
+                               "tiles_to_records_kernel": "void tiles_to_records_kernel<%d, %d, %s>" % (last_nw, nw, rcs),
+                               "hash_group_index_kernel": "void hash_group_index_kernel<%d, %d>" % (nw, nw),
+                               "lds_count_kernel": ("void lds_count_kernel<%s, %d>" % (rcs, per)) if nw == 1 else ("void lds_count_wide_kernel<%s, %d, %d>" % (rcs, per, nw))})
         for name, ph in phases.items():
             if not name.startswith("k:"):
                 continue
@@ -544,9 +550,9 @@ def main():
                                     ("void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw), passes, True),
                                     ("radix_chunk_kernel", passes, True)]}
             label = kernel_names.get(name, name)
-            if sorted_last_level:          # (the phase is five kernels: records, two partition passes with their histograms, index, counting)
+            if sorted_last_level and "tiles_to_records_kernel" in kexact:     # (the phase is five kernels: records, two partition passes with their histograms, index, counting)
                 parts["expand_tiles"] = [(kexact["tiles_to_records_kernel"], 1, True), (kexact["radix_scatter_kernel<HashDigit>"], 2, True),
-                                         (kexact["radix_hist_kernel<HashDigit>"], 2, True), ("hash_group_index_kernel", 1, True),
+                                         (kexact["radix_hist_kernel<HashDigit>"], 2, True), (kexact["hash_group_index_kernel"], 1, True),
                                          (kexact["lds_count_kernel"], 1, False)]
             single = name not in parts
             parts = parts.get(name, [(exact.get(name, name), 1, name == "extract")])

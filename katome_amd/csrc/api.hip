@@ -627,12 +627,41 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 }
             }
         }
-        if (!counted) KCHECK(expand_tiles(b, stream));
-        if (!counted && b->table_ready) {
-            KCHECK(table_occupied(b->table, &b->stat_kmers, stream));
-            b->stat_kmer_slots = b->table.cap;
-            DevBuf raw_w(stream), raw_seq(stream);
-            {
+        // The same for a first-seen-order build (table.hip, lds_count_seen_kernel): reads of one length whose windows are whole tiles
+        // (nothing in the k-mer table), so that a record's two sequence numbers pack into one word
+        DevBuf raw_w(stream), raw_seq(stream);
+        bool counted_seen = false;
+        if (sorted_count && b->first_seen && b->tiles_ready && !b->table_ready && b->nw <= 2 && !b->var_seq_base && !b->var_prefix && !b->direct_edges &&
+            b->seen_read_len >= b->s.k) {
+            uint64_t n_tiles = 0;
+            KCHECK(table_occupied(b->tiles, &n_tiles, stream));
+            const uint64_t bound = n_tiles * b->span;
+            if (bound >= (1ull << 22) || (sorted_count == 2 && bound)) {       // (the last level's own size is checked where its records are made)
+                Table* last = nullptr; uint32_t last_span = 1;
+                KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+                uint64_t distinct = 0;
+                int rc = KATOME_OK;
+                {
+                    PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                    rc = tiles_to_edges_sorted_seen(*last, b->s.k, last_span, b->rc, 2ull * (b->seen_read_len - b->s.k + 1), b->edge_key, raw_seq, &b->n_edges,
+                                                    &distinct, stream);
+                    if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+                }
+                if (rc == KATOME_OK) {
+                    b->tiles.release(); b->tiles2.release();
+                    b->tiles_ready = false; b->tiles2_ready = false;
+                    b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+                    counted_seen = true;
+                } else {
+                    b->n_edges = 0;               // (numbers that do not pack, or a group too large: the table counts, from the tiles that are still there)
+                }
+            }
+        }
+        if (!counted && !counted_seen) KCHECK(expand_tiles(b, stream));
+        if (!counted && (b->table_ready || counted_seen)) {
+            if (!counted_seen) {
+                KCHECK(table_occupied(b->table, &b->stat_kmers, stream));
+                b->stat_kmer_slots = b->table.cap;
                 PhaseScope ps(b->prof, PH_EMIT_EDGES, stream);
                 // (first-seen order: the threshold is applied after the numbering, as the reference's retain passes do)
                 if (b->first_seen) KCHECK(table_emit_edges(b->table, b->s.k, b->rc, 0, b->edge_key, raw_w, &b->n_edges, stream, &raw_seq));

@@ -161,6 +161,8 @@ int dev_partition_range(const uint64_t* d_vals, const uint32_t* idx_in, uint64_t
                         uint64_t* d_out, uint32_t* idx_out, uint64_t* h_counts, hipStream_t stream);
 int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src, uint64_t* n_src,
                    hipStream_t stream);
+int dev_hash_order_tagged(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nwk, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
+                          const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream);
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream);
 int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
@@ -291,6 +293,11 @@ int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool 
 // (extra_room: records the caller will append behind them -- the windows left over after the tiles)
 int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream,
                                 uint64_t extra_room = 0);
+// first-seen builds, last level counted by sorting: the tiles' k-mers as (k-mer, packed sequence numbers) records, counted and
+// numbered in LDS; edge_key (unsorted) and seq_weight ([n][2]: {sequence number, weight}) come out as table_emit_edges leaves them.
+// seq_per_read: sequence numbers a read takes (2 x windows); E_UNSUPPORTED when the packing does not fit (the caller counts in the table)
+int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc, uint64_t seq_per_read, DevBuf& edge_key, DevBuf& seq_weight,
+                               uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream);
 int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
                             DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream);
 int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, DevBuf* seen_pairs = nullptr);

@@ -70,6 +70,18 @@ template <int NW> struct HashDigit {
     __device__ __forceinline__ u32 operator()(const Key<NW>& k) const { return (u32)(hash_key(k) >> shift) & (RADIX - 1); }
 };
 
+// the same digit for records that carry one more word behind the k-mer (first-seen builds: the packed sequence numbers travel as
+// the record's last word; only the k-mer's NW - 1 words are hashed)
+template <int NW> struct HashTaggedDigit {
+    u32 shift;
+    __device__ __forceinline__ u32 operator()(const Key<NW>& k) const {
+        Key<NW - 1> c;
+#pragma unroll
+        for (int q = 0; q < NW - 1; ++q) c.w[q] = k.w[q];
+        return (u32)(hash_key(c) >> shift) & (RADIX - 1);
+    }
+};
+
 template <int NW> __device__ __forceinline__ Key<NW> load_key(const u64* p, u64 i) {
     Key<NW> k;
     if (NW == 1) { k.w[0] = p[i]; }
@@ -269,6 +281,7 @@ struct PassBuffers {
 // which per-kernel timer (common.h K_*) a pass with this digit reports to
 template <class Digit> struct DigitTimers { static constexpr int HIST = K_SORT_HIST, SCATTER = K_SORT_SCATTER; };
 template <int NW> struct DigitTimers<HashDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
+template <int NW> struct DigitTimers<HashTaggedDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
 template <int NW> struct DigitTimers<OwnerDigit<NW>> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 template <> struct DigitTimers<RangeDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 
@@ -584,6 +597,29 @@ int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint3
     *group_bits = 16;
     if (nw == 1) return region_order_t<1>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
     return region_order_t<2>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
+}
+// records of nwk + 1 words (k-mer, tag) with their counts, ordered by the top 16 bits of the K-MER's hash (two stable passes)
+template <int NW>
+static int tagged_order_t(const u64* d_in, const u32* w_in, u64 n, u64* ka, u64* kb, u32* wa, u32* wb, const u64** k_out, const u32** w_out, hipStream_t stream) {
+    PassBuffers pb;
+    KCHECK(pb.init(n, NW, stream));
+    const u64* kin = d_in; const u32* win = w_in;
+    u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
+    for (int p = 0; p < 2; ++p) {
+        HashTaggedDigit<NW> dg{(u32)(64 - 8 * (2 - p))};
+        KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
+        kin = kdst[p & 1]; win = wdst[p & 1];
+    }
+    *k_out = kin; *w_out = win;
+    return KATOME_OK;
+}
+int dev_hash_order_tagged(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nwk, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
+                          const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream) {
+    *group_bits = 16;
+    if (nwk == 1) return tagged_order_t<2>(d_in, w_in, n, ka, kb, wa, wb, k_out, w_out, stream);
+    if (nwk == 2) return tagged_order_t<3>(d_in, w_in, n, ka, kb, wa, wb, k_out, w_out, stream);
+    set_error("tagged records: k-mers of one or two words");
+    return KATOME_E_UNSUPPORTED;
 }
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream) {

@@ -636,7 +636,8 @@ constexpr u32 LC_MAX_ROUNDS = 32;
 
 // index[g] = first record whose hash has top `gbits` bits >= g (records ordered by those bits), g = 0 .. 2^gbits: one binary
 // search per group boundary (31 dependent reads each) instead of a pass over all the records (3.4 ms at C3)
-template <int NW>
+// (STRIDE: words per record -- first-seen builds carry one more word behind the k-mer's NW)
+template <int NW, int STRIDE = NW>
 __global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __restrict__ keys, u64 n, u32 gbits, u64* __restrict__ index) {
     for (u64 g = (u64)blockIdx.x * BLOCK + threadIdx.x; g <= (1ull << gbits); g += (u64)gridDim.x * BLOCK) {
         u64 lo = 0, hi = n;                                   // first i with (hash(keys[i]) >> (64 - gbits)) >= g
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __re
             const u64 mid = lo + ((hi - lo) >> 1);
             Key<NW> a;
 #pragma unroll
-            for (int q = 0; q < NW; ++q) a.w[q] = keys[mid * NW + q];
+            for (int q = 0; q < NW; ++q) a.w[q] = keys[mid * STRIDE + q];
             if ((hash_key(a) >> (64 - gbits)) < g) lo = mid + 1; else hi = mid;
         }
         index[g] = lo;
@@ -841,6 +842,215 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
 #pragma unroll
                         for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rk.w[q];
                         out_w[pos] = w;
+                    }
+                    ++pos;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    my_distinct = wave_sum(my_distinct);
+    if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
+}
+
+// ---- first-seen builds: the last level counted by sorting ------------------------------------------------------------------------
+// A k-mer record of such a build has two sequence numbers: the first insertion of the stored (canonical) k-mer and the first
+// insertion of its reverse complement (pt_graph.rs:282-308 adds a read's forward windows, then those of its reverse complement).
+// Both fall into the range of ONE read -- the first read that holds the k-mer on either strand --, so with reads of a fixed length
+// (S sequence numbers each) the pair packs into one word: read << 32 | offset of the one << 16 | offset of the other.  The records
+// (k-mer, packed pair) + count go through the same two hash passes as the headline build's (the k-mer's words are hashed, the
+// tag rides along) and are counted in LDS, where the two numbers are lowered by 64-bit atomicMin's of read << 16 | offset.
+constexpr unsigned long long SEEN_NONE = ~0ull;
+__device__ __forceinline__ unsigned long long seen_pack(u64 read, u32 a, u32 b) { return read << 32 | (unsigned long long)a << 16 | b; }
+
+// every distinct tile of the last level -> its `span` k-mers as records of NWK + 1 words + the tile's count (tiles_to_records_kernel's
+// shape: 2048 slots per trip).  read = fwd / seq_per_read as a multiplication by `magic` = floor(2^64 / seq_per_read) + 1: exact for
+// numbers below 2^64 / seq_per_read, which 2^32 reads of < 2^16 numbers each stay under.
+template <int NWT, int NWK, bool RC>
+__global__ __launch_bounds__(BLOCK) void seen_records_kernel(const typename SlotOf<NWT>::type* __restrict__ tiles, const u64* __restrict__ tile_seen, u64 tile_cap,
+                                                              u32 k, u32 span, u64 seq_per_read, u64 magic, u64* __restrict__ out, u32* __restrict__ out_w,
+                                                              u64* cursor, u32* err) {
+    extern __shared__ u64 sr_mem[];
+    u64* lkey = sr_mem;                                               // [BLOCK * TR_ITEMS * NWT]
+    u64* lread = lkey + BLOCK * TR_ITEMS * NWT;                       // [BLOCK * TR_ITEMS]
+    u32* loff = reinterpret_cast<u32*>(lread + BLOCK * TR_ITEMS);     // [BLOCK * TR_ITEMS * 2]
+    u32* lcnt = loff + BLOCK * TR_ITEMS * 2;                          // [BLOCK * TR_ITEMS]
+    __shared__ u32 wtot[BLOCK / 64];
+    __shared__ u64 bbase;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const u64 trip = (u64)BLOCK * TR_ITEMS;
+    for (u64 t0 = (u64)blockIdx.x * trip; t0 < tile_cap; t0 += (u64)gridDim.x * trip) {
+        Key<NWT> tk[TR_ITEMS]; u32 tc[TR_ITEMS]; u64 fwd[TR_ITEMS], rev[TR_ITEMS]; bool have[TR_ITEMS]; u32 mine = 0;
+#pragma unroll
+        for (u32 j = 0; j < TR_ITEMS; ++j) {
+            const u64 i = t0 + (u64)j * BLOCK + tid;
+            have[j] = false; tc[j] = 0; fwd[j] = rev[j] = 0;
+            if (i < tile_cap) {
+                typename SlotOf<NWT>::type sl = tiles[i];
+                have[j] = slot_key(sl, tk[j]);
+                tc[j] = sl.count;
+                if (have[j]) { fwd[j] = tile_seen[2 * i]; if (RC) rev[j] = tile_seen[2 * i + 1]; }
+            }
+            mine += have[j];
+        }
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (u32 w = 0; w < BLOCK / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+        u32 at = woff + (incl - mine);
+#pragma unroll
+        for (u32 j = 0; j < TR_ITEMS; ++j) {
+            if (!have[j]) continue;
+#pragma unroll
+            for (int q = 0; q < NWT; ++q) lkey[at * NWT + q] = tk[j].w[q];
+            lcnt[at] = tc[j];
+            const u64 read = __umul64hi(fwd[j], magic);
+            const u64 a = fwd[j] - read * seq_per_read, b = RC ? rev[j] - read * seq_per_read : 0;        // (no reverse complements: one number)
+            if (read >> 32 || a >= seq_per_read || a + span > 0xFFFFu || (RC && (rev[j] < read * seq_per_read || b > 0xFFFFu))) *err = 5;   // (does not pack)
+            lread[at] = read; loff[2 * at] = (u32)a; loff[2 * at + 1] = (u32)b;
+            ++at;
+        }
+        if (tid == 0 && total) bbase = atomicAdd((unsigned long long*)cursor, (unsigned long long)total * span);
+        __syncthreads();
+        const u32 pairs = total * span;
+        const u64 base = bbase;
+        for (u32 p = tid; p < pairs; p += BLOCK) {
+            const u32 t = p / span, o = p - t * span;
+            Key<NWT> tile;
+#pragma unroll
+            for (int q = 0; q < NWT; ++q) tile.w[q] = lkey[t * NWT + q];
+            Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, 1, o);
+            bool flipped = false;
+            if (RC) x = canonical_flip(x, k, flipped);
+            // window o of the tile went in at fwd + o; the tile's reverse complement holds its reverse complement as window span-1-o
+            const u32 a = loff[2 * t] + o, b = loff[2 * t + 1] + (span - 1 - o);
+            const u64 rec = (base + p) * (NWK + 1);
+#pragma unroll
+            for (int q = 0; q < NWK; ++q) out[rec + q] = x.w[q];
+            out[rec + NWK] = seen_pack(lread[t], flipped ? b : a, flipped ? a : b);
+            out_w[base + p] = lcnt[t];
+        }
+        __syncthreads();
+    }
+}
+
+// counts the records of each hash group in an LDS table and lowers the two sequence numbers; writes every distinct k-mer as one or
+// two edges {key} + {sequence number, weight}.  The slot's first word is the k-mer itself when it has one word (lds_count_kernel's
+// slot) and fingerprint | representative record when it has two (lds_count_wide_kernel's: the full keys are compared in the group).
+constexpr int LCS_PER = 5;                                        // 5120 slots of 28 bytes = 140 KiB
+template <bool RC, int NWK>
+__global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* recs, const u32* wts, const u64* __restrict__ index, u32 gbits, u32 R, u32 k,
+                                                                     u64 seq_per_read, u64* out_keys, u64* out_pairs, u64 out_cap,
+                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err) {
+    constexpr u32 SLOTS = LC_THREADS * LCS_PER;
+    constexpr int STRIDE = NWK + 1;
+    constexpr unsigned long long REP_MASK = (1ull << 20) - 1;
+    extern __shared__ unsigned long long lcs_mem[];
+    unsigned long long* lkey = lcs_mem;                                  // [SLOTS]: OCC | key, or OCC | fingerprint << 20 | representative
+    unsigned long long* lA = lcs_mem + SLOTS;                            // [SLOTS]: read << 16 | offset, stored orientation
+    unsigned long long* lB = lcs_mem + 2 * SLOTS;                        // [SLOTS]: ... reverse complement
+    u32* lcnt = reinterpret_cast<u32*>(lcs_mem + 3 * SLOTS);             // [SLOTS]
+    __shared__ u32 wtot[LC_THREADS / 64];
+    __shared__ unsigned long long base_sh;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 my_distinct = 0;
+    const u32 n_groups = 1u << gbits, sub_shift = 64 - gbits - 16;
+    for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
+        const u64 lo = index[g], hi = index[g + 1];
+        if (lo == hi) continue;
+        if (NWK > 1 && hi - lo > REP_MASK) { if (tid == 0) *err = 4; continue; }
+        for (u32 r = 0; r < R; ++r) {
+            for (u32 i = tid; i < SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lA[i] = SEEN_NONE; lB[i] = SEEN_NONE; lcnt[i] = 0u; }
+            __syncthreads();
+            for (u64 i = lo + tid; i < hi; i += LC_THREADS) {
+                Key<NWK> key;
+#pragma unroll
+                for (int q = 0; q < NWK; ++q) key.w[q] = recs[i * STRIDE + q];
+                const u64 h = hash_key(key);
+                if (R > 1 && (u32)((((h >> sub_shift) & 0xFFFFull) * R) >> 16) != r) continue;
+                const unsigned long long tag = recs[i * STRIDE + NWK];
+                const unsigned long long want = NWK == 1 ? (OCC | key.w[0]) : (OCC | (((h >> 5) & ((1ull << 43) - 1)) << 20) | (unsigned long long)(i - lo));
+                const u32 w = wts[i];
+                u32 s = (u32)(((h & 0x3FFFFFFFull) * SLOTS) >> 30);
+                u32 probes = 0;
+                for (; probes < SLOTS; ++probes) {
+                    const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
+                    bool mine = cur == 0ull || (NWK == 1 && cur == want);
+                    if (NWK > 1 && !mine && (cur >> 20) == (want >> 20)) {
+                        const u64 j = lo + (cur & REP_MASK);
+                        mine = true;
+#pragma unroll
+                        for (int q = 0; q < NWK; ++q) mine = mine && recs[j * STRIDE + q] == key.w[q];
+                    }
+                    if (mine) {
+                        atomicAdd(&lcnt[s], w);
+                        atomicMin(&lA[s], (tag >> 32) << 16 | ((tag >> 16) & 0xFFFFull));
+                        if (RC) atomicMin(&lB[s], (tag >> 32) << 16 | (tag & 0xFFFFull));
+                        break;
+                    }
+                    if (++s == SLOTS) s = 0;
+                }
+                if (probes == SLOTS) *err = 3;
+            }
+            __syncthreads();
+            Key<NWK> kk[LCS_PER]; u32 ne[LCS_PER]; u32 mine = 0;
+#pragma unroll
+            for (u32 j = 0; j < (u32)LCS_PER; ++j) {
+                const unsigned long long v = lkey[tid * LCS_PER + j];
+                ne[j] = 0;
+#pragma unroll
+                for (int q = 0; q < NWK; ++q) kk[j].w[q] = 0;
+                if (v & OCC) {
+                    ++my_distinct;
+                    if (NWK == 1) kk[j].w[0] = v & KEYBITS;
+                    else {
+                        const u64 rep = lo + (v & REP_MASK);
+#pragma unroll
+                        for (int q = 0; q < NWK; ++q) kk[j].w[q] = recs[rep * STRIDE + q];
+                    }
+                    ne[j] = (RC && !key_eq(revcomp(kk[j], k), kk[j])) ? 2 : 1;
+                }
+                mine += ne[j];
+            }
+            u32 incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            u32 woff = 0, total = 0;
+#pragma unroll
+            for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+            if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+            __syncthreads();
+            u64 pos = base_sh + woff + (incl - mine);
+#pragma unroll
+            for (u32 j = 0; j < (u32)LCS_PER; ++j) {
+                if (!ne[j]) continue;
+                const u32 sidx = tid * LCS_PER + j;
+                const unsigned long long a = lA[sidx], b = lB[sidx];
+                const u64 seq_a = (a >> 16) * seq_per_read + (a & 0xFFFFull), seq_b = (b >> 16) * seq_per_read + (b & 0xFFFFull);
+                const u32 c = lcnt[sidx];
+                if (ne[j] == 2) {
+                    if (pos + 1 < out_cap) {
+                        const Key<NWK> rk = revcomp(kk[j], k);
+#pragma unroll
+                        for (int q = 0; q < NWK; ++q) { out_keys[pos * NWK + q] = kk[j].w[q]; out_keys[(pos + 1) * NWK + q] = rk.w[q]; }
+                        out_pairs[2 * pos] = seq_a; out_pairs[2 * pos + 1] = c;
+                        out_pairs[2 * pos + 2] = seq_b; out_pairs[2 * pos + 3] = c;
+                    }
+                    pos += 2;
+                } else {
+                    // one edge: no reverse complements in this build, or a k-mer that is its own (added twice per window: both numbers
+                    // are insertions of this edge)
+                    if (pos < out_cap) {
+#pragma unroll
+                        for (int q = 0; q < NWK; ++q) out_keys[pos * NWK + q] = kk[j].w[q];
+                        out_pairs[2 * pos] = RC ? (seq_a < seq_b ? seq_a : seq_b) : seq_a;
+                        out_pairs[2 * pos + 1] = RC ? (u64)(c << 1) : (u64)c;
                     }
                     ++pos;
                 }
@@ -1069,6 +1279,91 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc, uint64_t seq_per_read, DevBuf& edge_key, DevBuf& seq_weight,
+                               uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
+    *n_edges = 0; *n_distinct = 0;
+    const uint32_t nwk = (uint32_t)key_words_for_k(k), stride = nwk + 1;
+    const bool shapes = tiles.track_seen && ((nwk == 1 && tiles.nw <= 2) || (nwk == 2 && (tiles.nw == 2 || tiles.nw == 3)));
+    if (!shapes || seq_per_read == 0 || seq_per_read > 0xFFFFu) return KATOME_E_UNSUPPORTED;
+    uint64_t occ = 0;
+    KCHECK(table_occupied(tiles, &occ, stream));
+    const u64 bound = occ * span;
+    constexpr u32 FILL = (u32)(LC_THREADS * LCS_PER / 4096.0 * 2900);
+    if (bound >= (1ull << 32) || (bound >> 16) > (u64)LC_MAX_ROUNDS * FILL) return KATOME_E_UNSUPPORTED;
+    DevBuf recs(stream), wts(stream), aux(stream);
+    KCHECK(recs.alloc((bound + 1) * 8 * stride));
+    KCHECK(wts.alloc((bound + 1) * 4));
+    KCHECK(aux.alloc(64));
+    KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+    unsigned long long* cursor = aux.as<unsigned long long>();
+    unsigned long long* distinct = cursor + 1;
+    u32* err = reinterpret_cast<u32*>(cursor + 2);
+    u64* rec_cursor = reinterpret_cast<u64*>(cursor + 3);
+    {
+        KernelScope ks(K_RECORDS, stream, tiles.cap);
+        const dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
+        const u64 magic = ~0ull / seq_per_read + 1;
+#define KATOME_SR(NWT, NWK)                                                                                                              \
+        do {                                                                                                                             \
+            const size_t lds = (size_t)BLOCK * TR_ITEMS * (8 * NWT + 8 + 8 + 4);                                                         \
+            if (rc) { KCHECK_HIP(hipFuncSetAttribute((const void*)seen_records_kernel<NWT, NWK, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                      hipLaunchKernelGGL((seen_records_kernel<NWT, NWK, true>), grid, block, lds, stream, tiles.slots.as<SlotOf<NWT>::type>(), tiles.seen.as<u64>(), tiles.cap, k, span, seq_per_read, magic, recs.as<u64>(), wts.as<u32>(), rec_cursor, err); } \
+            else    { KCHECK_HIP(hipFuncSetAttribute((const void*)seen_records_kernel<NWT, NWK, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                      hipLaunchKernelGGL((seen_records_kernel<NWT, NWK, false>), grid, block, lds, stream, tiles.slots.as<SlotOf<NWT>::type>(), tiles.seen.as<u64>(), tiles.cap, k, span, seq_per_read, magic, recs.as<u64>(), wts.as<u32>(), rec_cursor, err); } \
+        } while (0)
+        if (nwk == 1) { if (tiles.nw == 1) KATOME_SR(1, 1); else KATOME_SR(2, 1); }
+        else          { if (tiles.nw == 2) KATOME_SR(2, 2); else KATOME_SR(3, 2); }
+#undef KATOME_SR
+        KCHECK_HIP(hipGetLastError());
+    }
+    uint64_t h[4] = {0, 0, 0, 0};
+    KCHECK_HIP(hipMemcpyAsync(h, aux.p, 32, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    if ((uint32_t)h[2]) return KATOME_E_UNSUPPORTED;                 // (sequence numbers that do not pack)
+    const u64 n = h[3];
+    if (n == 0) { KCHECK(edge_key.alloc(16, stream)); KCHECK(seq_weight.alloc(16, stream)); return KATOME_OK; }
+    const u64* ko = nullptr; const u32* wo = nullptr;
+    u32 gbits = 16;
+    DevBuf kb(stream), wb(stream);
+    KCHECK(kb.alloc((n + 1) * 8 * stride)); KCHECK(wb.alloc((n + 1) * 4));
+    KCHECK(dev_hash_order_tagged(recs.as<u64>(), wts.as<u32>(), n, nwk, kb.as<u64>(), recs.as<u64>(), wb.as<u32>(), wts.as<u32>(), &ko, &wo, &gbits, stream));
+    kb.release(); wb.release();                                      // (two passes: the result is back in recs / wts)
+    const u64 avg = n >> gbits;
+    const u32 R = (u32)std::max<u64>(1, (avg + FILL - 1) / FILL);
+    if (R > LC_MAX_ROUNDS) return KATOME_E_UNSUPPORTED;
+    DevBuf index(stream);
+    KCHECK(index.alloc(((1ull << gbits) + 1) * 8));
+    {
+        KernelScope ks(K_GROUP_INDEX, stream, n);
+        const dim3 igrid(grid_for((1ull << gbits) + 1, BLOCK));
+        if (nwk == 1) hipLaunchKernelGGL((hash_group_index_kernel<1, 2>), igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
+        else          hipLaunchKernelGGL((hash_group_index_kernel<2, 3>), igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
+    }
+    const uint64_t out_cap = (rc ? 2 : 1) * n + 2;
+    KCHECK(edge_key.alloc(out_cap * 8 * nwk, stream));
+    KCHECK(seq_weight.alloc(out_cap * 16, stream));
+    {
+        const size_t lds = (size_t)LC_THREADS * LCS_PER * 28;
+        KernelScope ks(K_LDS_COUNT, stream, n);
+#define KATOME_LCS(RCV, NWKV)                                                                                                            \
+        do {                                                                                                                             \
+            KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_seen_kernel<RCV, NWKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((lds_count_seen_kernel<RCV, NWKV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, R, k, \
+                               seq_per_read, edge_key.as<u64>(), seq_weight.as<u64>(), out_cap, cursor, distinct, err);                  \
+        } while (0)
+        if (nwk == 1) { if (rc) KATOME_LCS(true, 1); else KATOME_LCS(false, 1); }
+        else          { if (rc) KATOME_LCS(true, 2); else KATOME_LCS(false, 2); }
+#undef KATOME_LCS
+        KCHECK_HIP(hipGetLastError());
+    }
+    KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;
+    if ((uint32_t)h[2]) { set_error("counting in LDS (first-seen order): a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
+    *n_edges = h[0]; *n_distinct = h[1];
     return KATOME_OK;
 }
 
