@@ -633,6 +633,13 @@ template <int PER> struct LcTable {
     static constexpr u32 FILL = (u32)(SLOTS / 4096.0 * 2900);   // records a sub-round may hold at most on average (all new: load 0.71)
 };
 constexpr u32 LC_MAX_ROUNDS = 32;
+constexpr u32 LC_PROBE_LIMIT = 128;                    // the optimistic attempt's patience with a full table
+// share of a group's records assumed distinct when the sub-rounds of the first attempt are chosen (KATOME_LC_OPTIMISM; 1 = never
+// try with fewer than the guaranteed number)
+static double lc_optimism() {
+    static const double v = getenv("KATOME_LC_OPTIMISM") ? std::min(1.0, std::max(0.05, atof(getenv("KATOME_LC_OPTIMISM")))) : 0.75;
+    return v;
+}
 
 // index[g] = first record whose hash has top `gbits` bits >= g (records ordered by those bits), g = 0 .. 2^gbits: one binary
 // search per group boundary (31 dependent reads each) instead of a pass over all the records (3.4 ms at C3)
@@ -656,7 +663,7 @@ template <bool RC, int PER>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
                                                                 u32 R, u32 k, u32 min_weight, u64* out_keys,
                                                                 u32* out_w, u64 out_cap, unsigned long long* cursor,
-                                                                unsigned long long* distinct, u32* err) {
+                                                                unsigned long long* distinct, u32* err, u32 probe_limit) {
     constexpr u32 LC_SLOTS = LcTable<PER>::SLOTS;
     extern __shared__ unsigned long long lc_mem[];
     unsigned long long* lkey = lc_mem;                                   // [LC_SLOTS]
@@ -687,12 +694,14 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                     const unsigned long long want = key.w[0] | OCC;
                     u32 s = (u32)(((h & 0x3FFFFFFFull) * LC_SLOTS) >> 30);                         // (bits 0..29: below every sub-round bit)
                     u32 probes = 0;
-                    for (; probes < LC_SLOTS; ++probes) {
+                    for (; probes < probe_limit; ++probes) {
                         const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
                         if (cur == 0ull || cur == want) { atomicAdd(&lcnt[s], wv[u]); break; }
                         if (++s == LC_SLOTS) s = 0;
                     }
-                    if (probes == LC_SLOTS) *err = 3;        // (cannot happen: a sub-round holds fewer records than slots)
+                    // (with the guaranteed number of sub-rounds this cannot happen: a sub-round holds fewer records than slots; the
+                    // optimistic first attempt -- records_to_edges_sorted -- gives up here and the host counts again)
+                    if (probes == probe_limit) *err = 3;
                 }
             }
             __syncthreads();
@@ -752,7 +761,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
 template <bool RC, int PER, int NW>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
                                                                      u32 R, u32 k, u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap,
-                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err) {
+                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err, u32 probe_limit) {
     constexpr u32 LC_SLOTS = LcTable<PER>::SLOTS;
     constexpr unsigned long long REP_MASK = (1ull << 20) - 1;
     extern __shared__ unsigned long long lc_mem[];
@@ -770,17 +779,33 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
         for (u32 r = 0; r < R; ++r) {
             for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
             __syncthreads();
-            for (u64 i = lo + tid; i < hi; i += LC_THREADS) {
-                Key<NW> key;
+            constexpr u32 LU = 4;                            // records in flight per thread
+            for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
+              Key<NW> kv[LU]; u32 wv[LU];
 #pragma unroll
-                for (int q = 0; q < NW; ++q) key.w[q] = keys[i * NW + q];
+              for (u32 u = 0; u < LU; ++u) {
+                  const u64 i = i0 + (u64)u * LC_THREADS;
+                  wv[u] = 0;
+#pragma unroll
+                  for (int q = 0; q < NW; ++q) kv[u].w[q] = 0;
+                  if (i < hi) {
+#pragma unroll
+                      for (int q = 0; q < NW; ++q) kv[u].w[q] = keys[i * NW + q];
+                      wv[u] = wts[i];
+                  }
+              }
+#pragma unroll
+              for (u32 u = 0; u < LU; ++u) {
+                const u64 i = i0 + (u64)u * LC_THREADS;
+                if (i >= hi) continue;
+                const Key<NW> key = kv[u];
                 const u64 h = hash_key(key);
                 if (R > 1 && (u32)((((h >> sub_shift) & 0xFFFFull) * R) >> 16) != r) continue;
                 const unsigned long long want = OCC | (((h >> 5) & ((1ull << 43) - 1)) << 20) | (unsigned long long)(i - lo);
-                const u32 w = wts[i];
+                const u32 w = wv[u];
                 u32 s = (u32)(((h & 0x3FFFFFFFull) * LC_SLOTS) >> 30);
                 u32 probes = 0;
-                for (; probes < LC_SLOTS; ++probes) {
+                for (; probes < probe_limit; ++probes) {
                     const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
                     bool mine = cur == 0ull;
                     if (!mine && (cur >> 20) == (want >> 20)) {            // same fingerprint: the same key?
@@ -792,7 +817,8 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                     if (mine) { atomicAdd(&lcnt[s], w); break; }
                     if (++s == LC_SLOTS) s = 0;
                 }
-                if (probes == LC_SLOTS) *err = 3;
+                if (probes == probe_limit) *err = 3;
+              }
             }
             __syncthreads();
             Key<NW> kk[PER]; u32 cc[PER], ne[PER]; u32 mine = 0;
@@ -945,7 +971,7 @@ constexpr int LCS_PER = 5;                                        // 5120 slots 
 template <bool RC, int NWK>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* recs, const u32* wts, const u64* __restrict__ index, u32 gbits, u32 R, u32 k,
                                                                      u64 seq_per_read, u64* out_keys, u64* out_pairs, u64 out_cap,
-                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err) {
+                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err, u32 probe_limit) {
     constexpr u32 SLOTS = LC_THREADS * LCS_PER;
     constexpr int STRIDE = NWK + 1;
     constexpr unsigned long long REP_MASK = (1ull << 20) - 1;
@@ -966,18 +992,34 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
         for (u32 r = 0; r < R; ++r) {
             for (u32 i = tid; i < SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lA[i] = SEEN_NONE; lB[i] = SEEN_NONE; lcnt[i] = 0u; }
             __syncthreads();
-            for (u64 i = lo + tid; i < hi; i += LC_THREADS) {
-                Key<NWK> key;
+            constexpr u32 LU = 4;                            // records in flight per thread (the group is re-read from L2 / Infinity Cache)
+            for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
+              Key<NWK> kv[LU]; unsigned long long tv[LU]; u32 wv[LU];
 #pragma unroll
-                for (int q = 0; q < NWK; ++q) key.w[q] = recs[i * STRIDE + q];
+              for (u32 u = 0; u < LU; ++u) {
+                  const u64 i = i0 + (u64)u * LC_THREADS;
+                  tv[u] = 0; wv[u] = 0;
+#pragma unroll
+                  for (int q = 0; q < NWK; ++q) kv[u].w[q] = 0;
+                  if (i < hi) {
+#pragma unroll
+                      for (int q = 0; q < NWK; ++q) kv[u].w[q] = recs[i * STRIDE + q];
+                      tv[u] = recs[i * STRIDE + NWK]; wv[u] = wts[i];
+                  }
+              }
+#pragma unroll
+              for (u32 u = 0; u < LU; ++u) {
+                const u64 i = i0 + (u64)u * LC_THREADS;
+                if (i >= hi) continue;
+                const Key<NWK> key = kv[u];
                 const u64 h = hash_key(key);
                 if (R > 1 && (u32)((((h >> sub_shift) & 0xFFFFull) * R) >> 16) != r) continue;
-                const unsigned long long tag = recs[i * STRIDE + NWK];
+                const unsigned long long tag = tv[u];
                 const unsigned long long want = NWK == 1 ? (OCC | key.w[0]) : (OCC | (((h >> 5) & ((1ull << 43) - 1)) << 20) | (unsigned long long)(i - lo));
-                const u32 w = wts[i];
+                const u32 w = wv[u];
                 u32 s = (u32)(((h & 0x3FFFFFFFull) * SLOTS) >> 30);
                 u32 probes = 0;
-                for (; probes < SLOTS; ++probes) {
+                for (; probes < probe_limit; ++probes) {
                     const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
                     bool mine = cur == 0ull || (NWK == 1 && cur == want);
                     if (NWK > 1 && !mine && (cur >> 20) == (want >> 20)) {
@@ -994,7 +1036,8 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
                     }
                     if (++s == SLOTS) s = 0;
                 }
-                if (probes == SLOTS) *err = 3;
+                if (probes == probe_limit) *err = 3;
+              }
             }
             __syncthreads();
             Key<NWK> kk[LCS_PER]; u32 ne[LCS_PER]; u32 mine = 0;
@@ -1345,22 +1388,28 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
     const uint64_t out_cap = (rc ? 2 : 1) * n + 2;
     KCHECK(edge_key.alloc(out_cap * 8 * nwk, stream));
     KCHECK(seq_weight.alloc(out_cap * 16, stream));
-    {
+    auto count = [&](u32 rounds, u32 probe_limit) -> int {
+        KCHECK_HIP(hipMemsetAsync(aux.p, 0, 24, stream));
         const size_t lds = (size_t)LC_THREADS * LCS_PER * 28;
         KernelScope ks(K_LDS_COUNT, stream, n);
 #define KATOME_LCS(RCV, NWKV)                                                                                                            \
         do {                                                                                                                             \
             KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_seen_kernel<RCV, NWKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((lds_count_seen_kernel<RCV, NWKV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, R, k, \
-                               seq_per_read, edge_key.as<u64>(), seq_weight.as<u64>(), out_cap, cursor, distinct, err);                  \
+            hipLaunchKernelGGL((lds_count_seen_kernel<RCV, NWKV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, rounds, k, \
+                               seq_per_read, edge_key.as<u64>(), seq_weight.as<u64>(), out_cap, cursor, distinct, err, probe_limit);     \
         } while (0)
         if (nwk == 1) { if (rc) KATOME_LCS(true, 1); else KATOME_LCS(false, 1); }
         else          { if (rc) KATOME_LCS(true, 2); else KATOME_LCS(false, 2); }
 #undef KATOME_LCS
         KCHECK_HIP(hipGetLastError());
-    }
-    KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
-    KCHECK_HIP(hipStreamSynchronize(stream));
+        KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        return KATOME_OK;
+    };
+    // first with fewer sub-rounds than would hold a group of distinct records (lc_optimism): records of reads repeat
+    const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / FILL));
+    if (R_try < R) { KCHECK(count(R_try, LC_PROBE_LIMIT)); if ((uint32_t)h[2] == 3) KCHECK(count(R, LC_THREADS * LCS_PER)); }
+    else KCHECK(count(R, LC_THREADS * LCS_PER));
     if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;
     if ((uint32_t)h[2]) { set_error("counting in LDS (first-seen order): a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
     *n_edges = h[0]; *n_distinct = h[1];
@@ -1393,7 +1442,6 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     DevBuf index(stream), aux(stream);
     KCHECK(index.alloc(((1ull << gbits) + 1) * 8));
     KCHECK(aux.alloc(64));
-    KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
     {
         KernelScope ks(K_GROUP_INDEX, stream, n);
         const dim3 igrid(grid_for((1ull << gbits) + 1, BLOCK));
@@ -1406,26 +1454,37 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     unsigned long long* cursor = aux.as<unsigned long long>();
     unsigned long long* distinct = cursor + 1;
     u32* err = reinterpret_cast<u32*>(cursor + 2);
-#define KATOME_LC_LAUNCH(KERNEL, PERV)                                                                                                  \
-    do {                                                                                                                              \
-        const size_t lds = (size_t)LcTable<PERV>::SLOTS * 12;                                                                         \
-        KCHECK_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                   \
-        KernelScope ks(K_LDS_COUNT, stream, n);                                                                                       \
-        hipLaunchKernelGGL(KERNEL, dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, R, k,                    \
-                           min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err);                     \
-    } while (0)
-    if (nw == 1) {
-        if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 8>), 8); else KATOME_LC_LAUNCH((lds_count_kernel<false, 8>), 8); }
-        else       { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 13>), 13); else KATOME_LC_LAUNCH((lds_count_kernel<false, 13>), 13); }
-    } else {
-        if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 8, 2>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 2>), 8); }
-        else       { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 13, 2>), 13); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 2>), 13); }
-    }
-#undef KATOME_LC_LAUNCH
-    KCHECK_HIP(hipGetLastError());
     uint64_t h[3] = {0, 0, 0};
-    KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
-    KCHECK_HIP(hipStreamSynchronize(stream));
+    auto count = [&](u32 rounds, u32 probe_limit) -> int {
+        KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+#define KATOME_LC_LAUNCH(KERNEL, PERV)                                                                                                  \
+        do {                                                                                                                          \
+            const size_t lds = (size_t)LcTable<PERV>::SLOTS * 12;                                                                     \
+            KCHECK_HIP(hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));               \
+            KernelScope ks(K_LDS_COUNT, stream, n);                                                                                   \
+            hipLaunchKernelGGL(KERNEL, dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, rounds, k,           \
+                               min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err,                  \
+                               std::min<u32>(probe_limit, LcTable<PERV>::SLOTS));                                                      \
+        } while (0)
+        if (nw == 1) {
+            if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 8>), 8); else KATOME_LC_LAUNCH((lds_count_kernel<false, 8>), 8); }
+            else       { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 13>), 13); else KATOME_LC_LAUNCH((lds_count_kernel<false, 13>), 13); }
+        } else {
+            if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 8, 2>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 2>), 8); }
+            else       { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 13, 2>), 13); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 2>), 13); }
+        }
+#undef KATOME_LC_LAUNCH
+        KCHECK_HIP(hipGetLastError());
+        KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        return KATOME_OK;
+    };
+    // First with fewer sub-rounds than would hold a group of DISTINCT records: the k-mers of reads repeat (C3: 1.8 records per
+    // k-mer at this level), so the table is half empty at the guaranteed number.  An attempt that fills its table gives up after
+    // LC_PROBE_LIMIT probes (err 3, nothing it wrote is used) and the guaranteed number runs.
+    const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / fill));
+    if (R_try < R) { KCHECK(count(R_try, LC_PROBE_LIMIT)); if ((uint32_t)h[2] == 3) KCHECK(count(R, ~0u)); }
+    else KCHECK(count(R, ~0u));
     if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;          // (a group too large for the representative's 20 bits: the caller counts in the table)
     if ((uint32_t)h[2]) { set_error("counting in LDS: a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
     *n_edges = h[0]; *n_distinct = h[1];

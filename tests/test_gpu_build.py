@@ -840,6 +840,53 @@ def test_two_word_kmers_and_left_over_windows_counted_by_sorting(tmp_path):
         assert a[:8] == t[:8] and a[10] == t[10], (a, t)        # the same arrays
 
 
+_OPTIMISM_SCRIPT = r"""
+import sys, hashlib, torch
+sys.path.insert(0, sys.argv[1])
+from katome_amd import device as kd
+from katome_amd.workloads import WORKLOADS
+first_seen = sys.argv[2] == "1"
+w = WORKLOADS["c3"].scaled(100_000_000)
+packed, skip = kd.synth_reads(0, w.reads, w.read_len, w.genome_len, w.err_rate, w.n_inject_percent, device=0)
+b = kd.Builder(w.k, True, first_seen_order=first_seen, table_slots_hint=int(1.8 * w.expected_distinct_canonical()))
+step = 1 << 24
+for r0 in range(0, w.reads, step):
+    b.count_reads(packed, min(step, w.reads - r0), w.read_len, None, first_read=r0)
+del packed
+dg = b.finalize()
+c = b.counts()
+h = hashlib.sha256()
+for t in (dg.edge_key, dg.edge_weight, dg.edge_src, dg.edge_dst):
+    h.update(t.cpu().numpy().tobytes())
+print("OPT", dg.n_nodes, dg.n_edges, c["distinct_kmers"], int(c["kmer_slots"] == 0), h.hexdigest())
+"""
+
+
+@pytest.mark.parametrize("first_seen", [False, True])
+def test_optimistic_sub_rounds_fall_back_to_the_guaranteed_number(tmp_path, first_seen):
+    """the sorted last level first tries fewer sub-rounds than a group of distinct records needs (table.hip, lc_optimism); an
+    attempt that fills its LDS table gives up and the guaranteed number runs.  Half of C3 (groups of 11 k records): with
+    KATOME_LC_OPTIMISM=0.05 the first attempt is one round and must fail over; =1 never tries; the default tries and succeeds --
+    the same arrays all three times"""
+    _need_whole_gpu(80)
+    import subprocess
+    script = tmp_path / "opt.py"
+    script.write_text(_OPTIMISM_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = set()
+    for optimism in ("0.05", "1", None):
+        env = dict(os.environ)
+        env.pop("KATOME_LC_OPTIMISM", None)
+        if optimism:
+            env["KATOME_LC_OPTIMISM"] = optimism
+        out = subprocess.run([sys.executable, str(script), root, "1" if first_seen else "0"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("OPT ")][-1].split()
+        assert line[4] == "1", line                       # counted by sorting, no k-mer table
+        seen.add(tuple(line))
+    assert len(seen) == 1, seen
+
+
 def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
     from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
     base = oracle.build_files([os.path.join(golden_dir, "data1.txt")], 31, False)
