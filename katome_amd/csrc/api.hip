@@ -383,10 +383,30 @@ static int insert_plain(katome_builder* b, const uint64_t* d_records, const uint
     return KATOME_OK;
 }
 
+// how many valid records wait in b->rest_k (the device cursor; b->rest_n counts what was handed over, skipped reads included)
+static int rest_valid(katome_builder* b, uint64_t* n, hipStream_t stream) {
+    *n = 0;
+    if (!b->rest_n || !b->rest_count.p) return KATOME_OK;
+    KCHECK_HIP(hipMemcpyAsync(n, b->rest_count.p, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+static void rest_reset(katome_builder* b) { b->rest_k.release(); b->rest_count.release(); b->rest_n = b->rest_cap = 0; }
+
 int flush_rest(katome_builder* b, hipStream_t stream) {
-    if (b->rest_n) KCHECK(insert_plain(b, b->rest_k.as<u64>(), nullptr, b->rest_n, stream));
-    b->rest_k.release();
-    b->rest_n = b->rest_cap = 0;
+    uint64_t n_valid = 0;
+    KCHECK(rest_valid(b, &n_valid, stream));
+    if (n_valid && b->first_seen) {            // tagged records: back into keys + their two sequence numbers for the table
+        DevBuf keys(stream), pairs(stream);
+        KCHECK(keys.alloc(n_valid * 8 * b->nw + 16)); KCHECK(pairs.alloc(n_valid * 16 + 16));
+        KCHECK(table_tagged_to_pairs(b->rest_k.as<u64>(), n_valid, b->nw, 2ull * (b->seen_read_len - b->s.k + 1), keys.as<u64>(), pairs.as<u64>(), stream));
+        SeenOrigin origin;
+        origin.pairs = pairs.as<u64>(); origin.rc = b->rc;
+        KCHECK(builder_insert(b, b->table, b->table_ready, b->nw, b->s.table_slots_hint, keys.as<u64>(), nullptr, n_valid, &origin, PH_INSERT, stream));
+    } else if (n_valid) {
+        KCHECK(insert_plain(b, b->rest_k.as<u64>(), nullptr, n_valid, stream));
+    }
+    rest_reset(b);
     b->rest_closed = true;
     return KATOME_OK;
 }
@@ -394,21 +414,24 @@ int flush_rest(katome_builder* b, hipStream_t stream) {
 // keeps a batch's left-over windows aside (see builder.h); *kept = false: they have to go into the table
 static int keep_rest(katome_builder* b, const uint64_t* d_records, uint64_t n, bool* kept, hipStream_t stream) {
     *kept = false;
+    const uint32_t words = b->nw + (b->first_seen ? 1 : 0);          // (first-seen order: tagged records)
     if (b->rest_n + n > b->rest_cap) {
         size_t free_b = 0, total_b = 0;
         KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
         const uint64_t want = std::max<uint64_t>(b->rest_n + n, b->rest_cap * 2);
         // (they are sorted with the tiles' k-mers later: past an eighth of the card they stop being a side matter)
-        if ((want + b->rest_n) * 8 * b->nw > free_b / 2 || want * 8 * b->nw > total_b / 8) { KCHECK(flush_rest(b, stream)); return KATOME_OK; }
+        if ((want + b->rest_n) * 8 * words > free_b / 2 || want * 8 * words > total_b / 8) { KCHECK(flush_rest(b, stream)); return KATOME_OK; }
         DevBuf grown(stream);
-        KCHECK(grown.alloc(want * 8 * b->nw + 16));
-        if (b->rest_n) KCHECK_HIP(hipMemcpyAsync(grown.p, b->rest_k.p, b->rest_n * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
+        KCHECK(grown.alloc(want * 8 * words + 16));
+        if (b->rest_n) KCHECK_HIP(hipMemcpyAsync(grown.p, b->rest_k.p, b->rest_n * 8 * words, hipMemcpyDeviceToDevice, stream));
         const size_t grown_bytes = grown.bytes;
         b->rest_k.adopt(grown.take(), grown_bytes);
         b->rest_k.stream = stream;
         b->rest_cap = want;
     }
-    KCHECK_HIP(hipMemcpyAsync(b->rest_k.as<u64>() + b->rest_n * b->nw, d_records, n * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
+    if (!b->rest_count.p) { KCHECK(b->rest_count.alloc(8, stream)); KCHECK_HIP(hipMemsetAsync(b->rest_count.p, 0, 8, stream)); }
+    KCHECK(table_keep_rest(d_records, n, b->nw, b->first_seen, b->last_batch_read0, b->rem_per_read, b->rem_win0,
+                           b->first_seen ? 2u * (b->seen_read_len - b->s.k + 1) : 0u, b->rest_k.as<u64>(), b->rest_count.as<u64>(), stream));
     b->rest_n += n;
     *kept = true;
     return KATOME_OK;
@@ -432,6 +455,14 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
         bool kept = false;
         KCHECK(keep_rest(b, d_records, n_records, &kept, stream));
         if (kept) return KATOME_OK;
+    }
+    // first-seen order, reads of one length: the windows after the batch's tiles wait as tagged records (table.hip, seen_pack)
+    if (b->first_seen && b->rem_pending && !d_weights && !b->var_prefix && !b->var_seq_base && b->tiles_ready && !b->table_ready && !b->rest_closed &&
+        b->nw <= 2 && sorted_count_mode() && b->seen_read_len >= b->s.k && 2ull * (b->seen_read_len - b->s.k + 1) <= 0xFFFFu &&
+        b->last_batch_read0 + b->last_batch_reads < (1ull << 32) && n_records == b->last_batch_reads * b->rem_per_read) {
+        bool kept = false;
+        KCHECK(keep_rest(b, d_records, n_records, &kept, stream));
+        if (kept) { b->rem_pending = false; return KATOME_OK; }
     }
     uint64_t room = 0;
     KCHECK(ensure_table(b, n_records, &room, stream));
@@ -602,11 +633,13 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     int rc = KATOME_OK;
                     {
                         PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-                        KCHECK(table_tiles_to_records_fast(*last, b->s.k, last_span, b->rc, rk, rw, &n_rec, stream, b->rest_n));
-                        if (b->rest_n) {          // the left-over windows behind them, one each
-                            KCHECK_HIP(hipMemcpyAsync(rk.as<u64>() + n_rec * b->nw, b->rest_k.p, b->rest_n * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
-                            KCHECK(dev_fill_u32(rw.as<u32>() + n_rec, b->rest_n, 1u, stream));
-                            n_rec += b->rest_n;
+                        uint64_t n_rest = 0;
+                        KCHECK(rest_valid(b, &n_rest, stream));
+                        KCHECK(table_tiles_to_records_fast(*last, b->s.k, last_span, b->rc, rk, rw, &n_rec, stream, n_rest));
+                        if (n_rest) {             // the left-over windows behind them, one each
+                            KCHECK_HIP(hipMemcpyAsync(rk.as<u64>() + n_rec * b->nw, b->rest_k.p, n_rest * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
+                            KCHECK(dev_fill_u32(rw.as<u32>() + n_rec, n_rest, 1u, stream));
+                            n_rec += n_rest;
                         }
                         rc = records_to_edges_sorted(rk, rw, n_rec, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
                         if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
@@ -614,7 +647,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     if (rc == KATOME_OK) {
                         b->tiles.release(); b->tiles2.release();
                         b->tiles_ready = false; b->tiles2_ready = false;
-                        b->rest_k.release(); b->rest_n = b->rest_cap = 0;
+                        rest_reset(b);
                         b->stat_kmers = distinct; b->stat_kmer_slots = 0;
                         for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
                         rk.release(); rw.release();
@@ -643,13 +676,16 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 int rc = KATOME_OK;
                 {
                     PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                    uint64_t n_rest = 0;
+                    KCHECK(rest_valid(b, &n_rest, stream));
                     rc = tiles_to_edges_sorted_seen(*last, b->s.k, last_span, b->rc, 2ull * (b->seen_read_len - b->s.k + 1), b->edge_key, raw_seq, &b->n_edges,
-                                                    &distinct, stream);
+                                                    &distinct, stream, n_rest ? b->rest_k.as<u64>() : nullptr, n_rest);
                     if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
                 }
                 if (rc == KATOME_OK) {
                     b->tiles.release(); b->tiles2.release();
                     b->tiles_ready = false; b->tiles2_ready = false;
+                    rest_reset(b);
                     b->stat_kmers = distinct; b->stat_kmer_slots = 0;
                     counted_seen = true;
                 } else {

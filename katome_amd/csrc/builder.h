@@ -44,8 +44,8 @@ struct katome_builder {
     // by-packed-key builds: the windows left over after a batch's tiles wait here (records of weight 1), so that the last level can
     // be counted by sorting (table.hip, records_to_edges_sorted) together with the tiles' k-mers; any other consumer of the k-mer
     // table flushes them into it first (flush_rest)
-    DevBuf rest_k;
-    uint64_t rest_n = 0, rest_cap = 0;
+    DevBuf rest_k, rest_count;          // rest_count: device cursor -- how many of them are valid records (reads with N leave invalid ones)
+    uint64_t rest_n = 0, rest_cap = 0;  // rest_n: records handed over so far (an upper bound of the cursor)
     bool rest_closed = false;           // too many to keep aside: from now on they go into the table directly
     uint64_t direct_edges = 0;         // BFCounter input: the edges were listed one per line and strand (no table); their count
     uint32_t prune_weight = 0;      // Clean::remove_weak_edges threshold applied when the edges are read out

@@ -296,8 +296,13 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
 // first-seen builds, last level counted by sorting: the tiles' k-mers as (k-mer, packed sequence numbers) records, counted and
 // numbered in LDS; edge_key (unsorted) and seq_weight ([n][2]: {sequence number, weight}) come out as table_emit_edges leaves them.
 // seq_per_read: sequence numbers a read takes (2 x windows); E_UNSUPPORTED when the packing does not fit (the caller counts in the table)
+// (d_extra / n_extra: tagged records to count with them -- the windows left over after the tiles, table_rest_to_tagged)
 int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc, uint64_t seq_per_read, DevBuf& edge_key, DevBuf& seq_weight,
-                               uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream);
+                               uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, const uint64_t* d_extra = nullptr, uint64_t n_extra = 0);
+// appends the valid records of d_rec behind *d_cursor in d_out (tagged: as records of nw + 1 words, see seen_pack in table.hip)
+int table_keep_rest(const uint64_t* d_rec, uint64_t n, uint32_t nw, bool tagged, uint64_t read0, uint32_t per_read, uint32_t win0, uint32_t seq_per_read,
+                    uint64_t* d_out, uint64_t* d_cursor, hipStream_t stream);
+int table_tagged_to_pairs(const uint64_t* d_tagged, uint64_t n, uint32_t nw, uint64_t seq_per_read, uint64_t* d_keys, uint64_t* d_pairs, hipStream_t stream);
 int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
                             DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream);
 int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, DevBuf* seen_pairs = nullptr);

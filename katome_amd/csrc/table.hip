@@ -889,6 +889,61 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
 constexpr unsigned long long SEEN_NONE = ~0ull;
 __device__ __forceinline__ unsigned long long seen_pack(u64 read, u32 a, u32 b) { return read << 32 | (unsigned long long)a << 16 | b; }
 
+// The windows left over after a batch's tiles, kept aside for the sorted last level: the valid ones (a skipped read's records are
+// all-ones) are appended behind a device cursor, one atomic per workgroup and trip.  TAGGED (first-seen order): plain k-mer records
+// that carry RC_MARK when the stored orientation is the reverse complement's become tagged records -- record i is window
+// win0 + i % per_read of read read0 + i / per_read.
+template <int NW, bool TAGGED>
+__global__ __launch_bounds__(BLOCK) void keep_rest_kernel(const u64* __restrict__ rec, u64 n, u64 read0, u32 per_read, u32 win0, u32 seq_per_read,
+                                                           u64* __restrict__ out, unsigned long long* cursor) {
+    constexpr int WORDS = NW + (TAGGED ? 1 : 0);
+    __shared__ u32 wtot[BLOCK / 64];
+    __shared__ unsigned long long base_sh;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < n; i0 += (u64)gridDim.x * BLOCK) {
+        const u64 i = i0 + tid;
+        Key<NW> key = key_invalid<NW>();
+        if (i < n) {
+#pragma unroll
+            for (int q = 0; q < NW; ++q) key.w[q] = rec[i * NW + q];
+        }
+        const bool valid = key_valid(key);
+        const u64 m = __ballot(valid);
+        const u32 before = __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
+        if (lane == 0) wtot[wave] = __popcll(m);
+        __syncthreads();
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (u32 w = 0; w < BLOCK / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+        if (tid == 0 && total) base_sh = atomicAdd(cursor, (unsigned long long)total);
+        __syncthreads();
+        if (valid) {
+            const u64 at = (base_sh + woff + before) * WORDS;
+            const bool flipped = TAGGED && (key.w[0] & RC_MARK) != 0;
+            if (TAGGED) key.w[0] &= ~RC_MARK;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) out[at + q] = key.w[q];
+            if (TAGGED) {
+                const u64 read = read0 + i / per_read;
+                const u32 w = win0 + (u32)(i % per_read), fwd = w, rev = seq_per_read - 1 - w;      // (insert_kernel's P and Q within the read)
+                out[at + NW] = seen_pack(read, flipped ? rev : fwd, flipped ? fwd : rev);
+            }
+        }
+        __syncthreads();
+    }
+}
+// ... and back into (key, {first insertion of the stored orientation, of its reverse complement}) for the k-mer table
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void tagged_to_pairs_kernel(const u64* __restrict__ tagged, u64 n, u64 seq_per_read, u64* __restrict__ keys,
+                                                                 u64* __restrict__ pairs) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+#pragma unroll
+        for (int q = 0; q < NW; ++q) keys[i * NW + q] = tagged[i * (NW + 1) + q];
+        const u64 tag = tagged[i * (NW + 1) + NW], base = (tag >> 32) * seq_per_read;
+        pairs[2 * i] = base + ((tag >> 16) & 0xFFFFull); pairs[2 * i + 1] = base + (tag & 0xFFFFull);
+    }
+}
+
 // every distinct tile of the last level -> its `span` k-mers as records of NWK + 1 words + the tile's count (tiles_to_records_kernel's
 // shape: 2048 slots per trip).  read = fwd / seq_per_read as a multiplication by `magic` = floor(2^64 / seq_per_read) + 1: exact for
 // numbers below 2^64 / seq_per_read, which 2^32 reads of < 2^16 numbers each stay under.
@@ -1325,15 +1380,37 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
     return KATOME_OK;
 }
 
+int table_keep_rest(const uint64_t* d_rec, uint64_t n, uint32_t nw, bool tagged, uint64_t read0, uint32_t per_read, uint32_t win0, uint32_t seq_per_read,
+                    uint64_t* d_out, uint64_t* d_cursor, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    const dim3 grid(grid_for(n, BLOCK, 256u * 16u)), block(BLOCK);
+    unsigned long long* cur = reinterpret_cast<unsigned long long*>(d_cursor);
+    if (!per_read) per_read = 1;
+#define KATOME_KR(NWV, TAG) hipLaunchKernelGGL((keep_rest_kernel<NWV, TAG>), grid, block, 0, stream, d_rec, n, read0, per_read, win0, seq_per_read, d_out, cur)
+    if (nw == 1) { if (tagged) KATOME_KR(1, true); else KATOME_KR(1, false); }
+    else         { if (tagged) KATOME_KR(2, true); else KATOME_KR(2, false); }
+#undef KATOME_KR
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+int table_tagged_to_pairs(const uint64_t* d_tagged, uint64_t n, uint32_t nw, uint64_t seq_per_read, uint64_t* d_keys, uint64_t* d_pairs, hipStream_t stream) {
+    if (n == 0) return KATOME_OK;
+    const dim3 grid(grid_for(n, BLOCK, 256u * 16u)), block(BLOCK);
+    if (nw == 1) hipLaunchKernelGGL(tagged_to_pairs_kernel<1>, grid, block, 0, stream, d_tagged, n, seq_per_read, d_keys, d_pairs);
+    else         hipLaunchKernelGGL(tagged_to_pairs_kernel<2>, grid, block, 0, stream, d_tagged, n, seq_per_read, d_keys, d_pairs);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
 int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc, uint64_t seq_per_read, DevBuf& edge_key, DevBuf& seq_weight,
-                               uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
+                               uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, const uint64_t* d_extra, uint64_t n_extra) {
     *n_edges = 0; *n_distinct = 0;
     const uint32_t nwk = (uint32_t)key_words_for_k(k), stride = nwk + 1;
     const bool shapes = tiles.track_seen && ((nwk == 1 && tiles.nw <= 2) || (nwk == 2 && (tiles.nw == 2 || tiles.nw == 3)));
     if (!shapes || seq_per_read == 0 || seq_per_read > 0xFFFFu) return KATOME_E_UNSUPPORTED;
     uint64_t occ = 0;
     KCHECK(table_occupied(tiles, &occ, stream));
-    const u64 bound = occ * span;
+    const u64 bound = occ * span + n_extra;
     constexpr u32 FILL = (u32)(LC_THREADS * LCS_PER / 4096.0 * 2900);
     if (bound >= (1ull << 32) || (bound >> 16) > (u64)LC_MAX_ROUNDS * FILL) return KATOME_E_UNSUPPORTED;
     DevBuf recs(stream), wts(stream), aux(stream);
@@ -1366,7 +1443,12 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
     KCHECK_HIP(hipMemcpyAsync(h, aux.p, 32, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
     if ((uint32_t)h[2]) return KATOME_E_UNSUPPORTED;                 // (sequence numbers that do not pack)
-    const u64 n = h[3];
+    u64 n = h[3];
+    if (n_extra) {                                                   // the left-over windows behind them, one each
+        KCHECK_HIP(hipMemcpyAsync(recs.as<u64>() + n * stride, d_extra, n_extra * 8 * stride, hipMemcpyDeviceToDevice, stream));
+        KCHECK(dev_fill_u32(wts.as<u32>() + n, n_extra, 1u, stream));
+        n += n_extra;
+    }
     if (n == 0) { KCHECK(edge_key.alloc(16, stream)); KCHECK(seq_weight.alloc(16, stream)); return KATOME_OK; }
     const u64* ko = nullptr; const u32* wo = nullptr;
     u32 gbits = 16;

@@ -793,35 +793,49 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
 from helpers import pack_reads_ascii
 from oracle import oracle as o
 from katome_amd import device as kd
-for k, L, rc, weak in ((31, 101, True, 0), (40, 150, True, 0), (40, 150, False, 2), (63, 150, True, 0), (40, 77, True, 0), (33, 126, True, 3),
-                       (47, 150, False, 0), (32, 150, True, 0), (62, 131, True, 0), (31, 150, True, 2)):
+for k, L, rc, weak, first_seen in ((31, 101, True, 0, False), (40, 150, True, 0, False), (40, 150, False, 2, False), (63, 150, True, 0, False), (40, 77, True, 0, False),
+                                   (33, 126, True, 3, False), (47, 150, False, 0, False), (32, 150, True, 0, False), (62, 131, True, 0, False), (31, 150, True, 2, False),
+                                   # the reference's numbering: whole tiles (31/150), left-over windows (31/101, 40/150), two-word k-mers, one strand
+                                   (31, 150, True, 0, True), (31, 101, True, 0, True), (40, 150, True, 0, True), (63, 150, True, 0, True), (40, 150, False, 0, True),
+                                   (16, 50, True, 0, True)):
     n = 4000
-    reads = o.synth_reads(7, n, L, 20000, 4e-3, 0)
-    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
-    b = kd.Builder(k, rc, table_slots_hint=1 << 14)
+    reads = o.synth_reads(7, n, L, 20000, 4e-3, 2)              # 2 % of the reads carry an N: skipped (builder.rs:155-158), their records invalid
+    has_n = (reads == ord("N")).any(axis=1)
+    clean = reads.copy()
+    clean[clean == ord("N")] = ord("A")
+    packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+    skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+    b = kd.Builder(k, rc, first_seen_order=first_seen, table_slots_hint=1 << 14)
     if weak:
         b.remove_weak_edges(weak)
     for r0 in range(0, n, 1536):
-        b.count_reads(packed, min(1536, n - r0), L, None, first_read=r0)
+        b.count_reads(packed, min(1536, n - r0), L, skip, first_read=r0)
     dg = b.finalize()
     c = b.counts()
     h = hashlib.sha256()
     for t in (dg.edge_key, dg.edge_weight, dg.edge_src, dg.edge_dst, dg.node_key, dg.edge_label):
         h.update(t.cpu().numpy().tobytes())
     ref = o.build_ascii(reads, k, rc, remove_weak_edges=weak or None)
-    ms = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
     lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
-    got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
-    assert len(got) == dg.n_edges
-    print("WIDE", k, L, int(rc), weak, dg.n_nodes, dg.n_edges, c["distinct_kmers"], int(c["kmer_slots"] == 0), int(got == ms), h.hexdigest())
+    if first_seen:            # array for array: petgraph's own numbering
+        same = (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges) and np.array_equal(lab, ref.edge_label) and \
+            np.array_equal(dg.edge_weight.cpu().numpy(), ref.edge_weight) and np.array_equal(dg.edge_src.cpu().numpy(), ref.edge_src) and \
+            np.array_equal(dg.edge_dst.cpu().numpy(), ref.edge_dst)
+    else:
+        ms = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
+        got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
+        same = len(got) == dg.n_edges and got == ms
+    print("WIDE", k, L, int(rc), weak, int(first_seen), dg.n_nodes, dg.n_edges, c["distinct_kmers"], int(c["kmer_slots"] == 0), int(same), h.hexdigest())
     b.close()
 """
 
 
 def test_two_word_kmers_and_left_over_windows_counted_by_sorting(tmp_path):
-    """k = 32..63 (the reference's example configuration runs k = 40: config.txt) and reads whose windows are not a whole number of
-    tiles go through the sorted last level too (lds_count_wide_kernel; the left-over windows join the tiles' records): forced
-    at a small size (KATOME_SORTED_COUNT=2), byte for byte against the table route (=0) and, as a multiset, against the oracle"""
+    """k = 32..63 (the reference's example configuration runs k = 40: config.txt), reads whose windows are not a whole number of
+    tiles (the left-over windows join the tiles' records; reads with N leave invalid ones) and first-seen-order builds (records
+    tagged with their packed sequence numbers) go through the sorted last level too: forced at a small size
+    (KATOME_SORTED_COUNT=2), byte for byte against the table route (=0) and against the oracle -- as a multiset, and array for
+    array where the build keeps the reference's numbering"""
     import subprocess
     script = tmp_path / "wide.py"
     script.write_text(_WIDE_SCRIPT)
@@ -833,11 +847,11 @@ def test_two_word_kmers_and_left_over_windows_counted_by_sorting(tmp_path):
         assert out.returncode == 0, out.stderr[-2000:]
         return [line.split() for line in out.stdout.splitlines() if line.startswith("WIDE ")]
     by_sort, by_table = run("2"), run("0")
-    assert len(by_sort) == len(by_table) == 10
+    assert len(by_sort) == len(by_table) == 16
     for a, t in zip(by_sort, by_table):
-        assert a[9] == "1" and t[9] == "1", (a, t)              # the oracle's multiset
-        assert a[8] == "1" and t[8] == "0", (a, t)              # ... reached without / with the k-mer table
-        assert a[:8] == t[:8] and a[10] == t[10], (a, t)        # the same arrays
+        assert a[10] == "1" and t[10] == "1", (a, t)            # the oracle's graph (first-seen order: array for array)
+        assert a[9] == "1" and t[9] == "0", (a, t)              # ... reached without / with the k-mer table
+        assert a[:9] == t[:9] and a[11] == t[11], (a, t)        # the same arrays
 
 
 _OPTIMISM_SCRIPT = r"""
