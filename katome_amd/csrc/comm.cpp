@@ -258,13 +258,14 @@ int katome_comm::allgather(uint64_t v, uint64_t* out) {
 }
 
 int katome_comm::exchange(const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, int on_device,
-                          hipStream_t stream, bool one_round, uint64_t known_max) {
+                          hipStream_t stream, bool one_round, uint64_t known_max, const uint64_t* send_off) {
     const int w = world();
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint64_t> so(w, 0), ro(w, 0);
     uint64_t biggest = 0, out_b = 0, in_b = 0;
     for (int p = 0; p < w; ++p) {
         if (p) { so[p] = so[p - 1] + send_cnt[p - 1]; ro[p] = ro[p - 1] + recv_cnt[p - 1]; }
+        if (send_off) so[p] = send_off[p];
         biggest = std::max(biggest, std::max(send_cnt[p], recv_cnt[p]));
         if (p != rank()) { out_b += send_cnt[p] * elem_bytes; in_b += recv_cnt[p] * elem_bytes; stats.max_pair_bytes = std::max<uint64_t>(stats.max_pair_bytes, send_cnt[p] * elem_bytes); }
     }

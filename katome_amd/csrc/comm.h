@@ -67,8 +67,9 @@ struct katome_comm {
     // (recv_cnt from exchange_counts).  Splits into rounds when a pair's message exceeds max_message_bytes.
     // one_round: the caller knows that no pair's message exceeds max_message_bytes on any rank (no agreement needed)
     static constexpr uint64_t MAX_UNKNOWN = ~0ull;
+    // send_off (optional): where each peer's records start in `send`, in elements (they need not be adjacent)
     int exchange(const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, int on_device,
-                 hipStream_t stream, bool one_round = false, uint64_t known_max = MAX_UNKNOWN);
+                 hipStream_t stream, bool one_round = false, uint64_t known_max = MAX_UNKNOWN, const uint64_t* send_off = nullptr);
 };
 
 namespace katome {

@@ -161,6 +161,8 @@ int dev_partition_range(const uint64_t* d_vals, const uint32_t* idx_in, uint64_t
                         uint64_t* d_out, uint32_t* idx_out, uint64_t* h_counts, hipStream_t stream);
 int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src, uint64_t* n_src,
                    hipStream_t stream);
+int dev_hash_order_core(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t core_shift, uint32_t core_bases, uint64_t* ka, uint64_t* kb,
+                        uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream);
 int dev_hash_order_tagged(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nwk, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
                           const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream);
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
@@ -303,8 +305,15 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
 int table_keep_rest(const uint64_t* d_rec, uint64_t n, uint32_t nw, bool tagged, uint64_t read0, uint32_t per_read, uint32_t win0, uint32_t seq_per_read,
                     uint64_t* d_out, uint64_t* d_cursor, hipStream_t stream);
 int table_tagged_to_pairs(const uint64_t* d_tagged, uint64_t n, uint32_t nw, uint64_t seq_per_read, uint64_t* d_keys, uint64_t* d_pairs, hipStream_t stream);
+// A rank's own distinct k-mers on their way to their owners (sharded build): with an OwnerSplit the records are grouped by the hash
+// of their CORE instead of the whole k-mer's, and every group's keys are written into its owner's stretch of the output -- base[p],
+// count[p] on return --, so that no partition pass is needed before the exchange.  One-word k-mers, one record per k-mer (rc = false).
+struct OwnerSplit {
+    uint32_t n_parts = 0, core_shift = 0, core_bases = 0;
+    uint64_t base[KATOME_MAX_RANKS] = {0}, count[KATOME_MAX_RANKS] = {0};
+};
 int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
-                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream);
+                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, OwnerSplit* split = nullptr);
 int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, DevBuf* seen_pairs = nullptr);
 int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint32_t stride, bool rc, DevBuf& keys, DevBuf& weights,
                                    uint64_t* n_records, hipStream_t stream, DevBuf* seen = nullptr);

@@ -305,6 +305,66 @@ int route_weighted(katome_dist_builder* d, int xphase, const DevBuf& keys, const
     return rc;
 }
 
+// The same exchange for records that already lie grouped by owner (records_to_edges_sorted with an OwnerSplit: owner p's records
+// are keys[base[p] .. base[p] + count[p])): no partition pass; a round sends every owner the next stretch of its records.  The
+// collectives are route_weighted's -- one agreement on the number of rounds, then counts + keys + weights per round --, so ranks
+// that took different routes to their records still meet.
+int route_owned(katome_dist_builder* d, int xphase, const DevBuf& keys, const DevBuf& weights, const OwnerSplit& sp, uint32_t nwr, hipStream_t stream,
+                Collected& collect, uint64_t n_rec) {
+    const int world = d->world();
+    const uint64_t chunk = std::max<uint64_t>(1, d->comm->max_message_bytes / 4 / (8 * nwr));
+    uint64_t ns = 0;
+    for (int p = 0; p < world; ++p) ns = std::max(ns, (sp.count[p] + chunk - 1) / chunk);
+    KCHECK(d->comm->allreduce(&ns, 1, OP_MAX));
+    if (ns == 0) return KATOME_OK;
+    if (!d->xstream) KCHECK_HIP(hipStreamCreateWithFlags(&d->xstream, hipStreamNonBlocking));
+    hipStream_t X = d->xstream;
+    struct Slot {
+        DevBuf rk, rw;
+        std::vector<uint64_t> counts, offs, rcnt;
+        uint64_t nR = 0;
+        hipEvent_t arrived = nullptr;
+        explicit Slot(hipStream_t s) : rk(s), rw(s) {}
+        ~Slot() { if (arrived) (void)hipEventDestroy(arrived); }
+    };
+    Slot slot[2] = {Slot(stream), Slot(stream)};
+    hipEvent_t ready = nullptr;
+    KCHECK_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    for (auto& sl : slot) KCHECK_HIP(hipEventCreateWithFlags(&sl.arrived, hipEventDisableTiming));
+    d->comm->use_stream(X);
+    static const bool tight = getenv("KATOME_SORTED_COUNT") && atoi(getenv("KATOME_SORTED_COUNT")) == 2;
+    auto take_slice = [&](Slot& sl) -> int {
+        KCHECK_HIP(hipStreamWaitEvent(stream, sl.arrived, 0));
+        trace_words("kmers received: keys", d->rank(), sl.rk.p, sl.nR * nwr, stream);
+        trace_words("kmers received: weights", d->rank(), sl.rw.p, sl.nR / 2, stream);
+        if (sl.nR) KCHECK(collect.append(sl.rk.p, sl.rw.p, sl.nR, nwr, tight ? 0 : n_rec + n_rec / 8 + (1u << 20), stream));
+        return KATOME_OK;
+    };
+    int rc = KATOME_OK;
+    if (hipEventRecord(ready, stream) != hipSuccess || hipStreamWaitEvent(X, ready, 0) != hipSuccess) { set_error("event failed"); rc = KATOME_E_DEVICE; }
+    for (uint64_t j = 0; j < ns && rc == KATOME_OK; ++j) {
+        Slot& sl = slot[j & 1];
+        sl.counts.assign(world, 0); sl.offs.assign(world, 0); sl.rcnt.assign(world, 0);
+        for (int p = 0; p < world; ++p) {
+            const uint64_t done = std::min(sp.count[p], j * chunk);
+            sl.counts[p] = std::min(sp.count[p] - done, chunk); sl.offs[p] = sp.base[p] + done;
+        }
+        if ((rc = d->comm->exchange_counts(sl.counts.data(), sl.rcnt.data()))) break;
+        sl.nR = sum(sl.rcnt);
+        if ((rc = sl.rk.alloc(std::max<uint64_t>(sl.nR, 1) * 8 * nwr)) || (rc = sl.rw.alloc(std::max<uint64_t>(sl.nR, 1) * 4))) break;
+        if ((rc = d->xchg(xphase, keys.p, sl.counts.data(), sl.rk.p, sl.rcnt.data(), 8 * nwr, X, true, katome_comm::MAX_UNKNOWN, sl.offs.data()))) break;
+        if ((rc = d->xchg(xphase, weights.p, sl.counts.data(), sl.rw.p, sl.rcnt.data(), 4, X, true, katome_comm::MAX_UNKNOWN, sl.offs.data()))) break;
+        if (hipEventRecord(sl.arrived, X) != hipSuccess) { set_error("event record failed"); rc = KATOME_E_DEVICE; break; }
+        if (j > 0) rc = take_slice(slot[(j - 1) & 1]);
+    }
+    if (rc == KATOME_OK) rc = take_slice(slot[(ns - 1) & 1]);
+    (void)hipStreamSynchronize(X);
+    (void)hipStreamSynchronize(stream);
+    (void)hipEventDestroy(ready);
+    d->comm->use_stream(stream);
+    return rc;
+}
+
 // may the k-mer records that arrive be kept and counted by sorting (katome_dev_edges' rule: one-word k-mers by packed key,
 // nothing in the k-mer table yet)?
 bool may_collect(const katome_dist_builder* d) {
@@ -686,6 +746,8 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
         // add them up in a fresh table
         DevBuf keys(stream), weights(stream), pairs(stream);
         uint64_t n_rec = 0;
+        OwnerSplit split;
+        bool split_used = false;
         static const int sorted_count = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
         if (b->tiles_ready && may_collect(d)) {
             // the rank's own distinct k-mers by sorting (as katome_dev_edges does, but one record per canonical k-mer: no strands yet)
@@ -701,7 +763,11 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
                 KCHECK(table_tiles_to_records_fast(*last, k, last_span, d->rc, rk, rw, &n_win, stream));
                 b->tiles.release(); b->tiles2.release();
                 b->tiles_ready = false; b->tiles2_ready = false;
-                KCHECK(records_to_edges_sorted(rk, rw, n_win, k, false, 0, keys, weights, &n_rec, &distinct, stream));
+                // (grouped by the hash that names the owner, every group's keys written into its owner's stretch: no partition pass
+                // before the exchange; KATOME_DIST_OWNER_SPLIT=0: by the whole k-mer's hash, then route_weighted's partition)
+                static const bool owner_split = !getenv("KATOME_DIST_OWNER_SPLIT") || atoi(getenv("KATOME_DIST_OWNER_SPLIT")) != 0;
+                if (owner_split) { split.n_parts = (uint32_t)world; split.core_shift = 2; split.core_bases = k - 2; split_used = true; }
+                KCHECK(records_to_edges_sorted(rk, rw, n_win, k, false, 0, keys, weights, &n_rec, &distinct, stream, split_used ? &split : nullptr));
             }
         }
         if (b->tiles_ready) KCHECK(expand_tiles(b, stream));
@@ -714,7 +780,8 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
             fprintf(stderr, "[dist] rank %d of %d: %llu distinct k-mers of its own reads to route\n", rank, world, (unsigned long long)n_rec);
         if (may_collect(d)) {
             Collected got(stream);
-            KCHECK(route_weighted(d, X_KMERS, keys, weights, pairs, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream, &got));
+            if (split_used) KCHECK(route_owned(d, X_KMERS, keys, weights, split, nw, stream, got, n_rec));
+            else KCHECK(route_weighted(d, X_KMERS, keys, weights, pairs, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream, &got));
             keys.release(); weights.release();
             KCHECK(count_collected(d, got, stream));
         } else KCHECK(route_weighted(d, X_KMERS, keys, weights, pairs, n_rec, nw, 2, k - 2, b->table, b->table_ready, b->s.table_slots_hint, PH_INSERT, stream));

@@ -42,12 +42,12 @@ struct katome_dist_builder {
     struct XEvent { int phase; hipEvent_t a, b; };
     std::vector<XEvent> xevents;
     int xchg(int phase, const void* send, const uint64_t* send_cnt, void* recv, const uint64_t* recv_cnt, size_t elem_bytes, hipStream_t stream,
-             bool one_round = false, uint64_t known_max = katome_comm::MAX_UNKNOWN) {
+             bool one_round = false, uint64_t known_max = katome_comm::MAX_UNKNOWN, const uint64_t* send_off = nullptr) {
         const katome::ExchangeStats before = comm->stats;
         hipEvent_t ea = nullptr, eb = nullptr;
         const bool timed = b->prof.on && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
         if (timed) (void)hipEventRecord(ea, stream);
-        const int rc = comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream, one_round, known_max);
+        const int rc = comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream, one_round, known_max, send_off);
         if (timed) { (void)hipEventRecord(eb, stream); xevents.push_back({phase, ea, eb}); }
         if (rc != KATOME_OK) return rc;
         katome::ExchangeStats& x = xstats[phase];

@@ -193,9 +193,17 @@ template <int NW> KD Key<NW> canonical_flip(const Key<NW>& a, u32 k, bool& flipp
 // of its keys (eight ranks: the mid-tile table, sized for what arrives, ran 8 x over its load limit in that stretch and an
 // insert of 1.6 M records took 2 s).  A second mix makes the owner independent of the slot.
 template <int NW> KD u64 whole_key_owner(const Key<NW>& a, u64 n) { return hash_to_range(mix64(hash_key(a) ^ 0x5851F42D4C957F2Dull), n); }
-template <int NW> KD u64 core_owner(const Key<NW>& a, u32 shift, u32 core, u64 n) {
+// hash of a record's core (the `core` bases `shift` bits above its low end, either strand); the record's owner is a function of
+// the top CORE_GROUP_BITS of it only, so that records ordered by those bits are ordered by owner as well (a rank's own distinct
+// k-mers leave its LDS count already grouped by owner: table.hip, records_to_edges_sorted with an OwnerSplit)
+constexpr u32 CORE_GROUP_BITS = 16;
+template <int NW> KD u64 core_hash(const Key<NW>& a, u32 shift, u32 core) {
     const Key<NW> m = key_low_bits(key_shr(a, shift), 2 * core);
-    return hash_to_range(hash_key(canonical(m, core)), n);
+    return hash_key(canonical(m, core));
+}
+KD u64 core_group_owner(u64 group, u64 n) { return (group * n) >> CORE_GROUP_BITS; }          // group = top CORE_GROUP_BITS of core_hash
+template <int NW> KD u64 core_owner(const Key<NW>& a, u32 shift, u32 core, u64 n) {
+    return core_group_owner(core_hash(a, shift, core) >> (64 - CORE_GROUP_BITS), n);
 }
 
 template <int NW> KD Key<NW> source_node(const Key<NW>& kmer) { return key_shr(kmer, 2); }

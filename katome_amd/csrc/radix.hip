@@ -82,6 +82,13 @@ template <int NW> struct HashTaggedDigit {
     }
 };
 
+// ... and for a rank's own distinct k-mers on their way to their owners: the digit comes from the hash of the k-mer's CORE, whose
+// top bits name the owner (kmer_bits.h core_owner), so that the groups of the LDS count are grouped by owner as well
+template <int NW> struct CoreHashDigit {
+    u32 shift, core_shift, core_bases;
+    __device__ __forceinline__ u32 operator()(const Key<NW>& k) const { return (u32)(core_hash(k, core_shift, core_bases) >> shift) & (RADIX - 1); }
+};
+
 template <int NW> __device__ __forceinline__ Key<NW> load_key(const u64* p, u64 i) {
     Key<NW> k;
     if (NW == 1) { k.w[0] = p[i]; }
@@ -282,6 +289,7 @@ struct PassBuffers {
 template <class Digit> struct DigitTimers { static constexpr int HIST = K_SORT_HIST, SCATTER = K_SORT_SCATTER; };
 template <int NW> struct DigitTimers<HashDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
 template <int NW> struct DigitTimers<HashTaggedDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
+template <int NW> struct DigitTimers<CoreHashDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
 template <int NW> struct DigitTimers<OwnerDigit<NW>> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 template <> struct DigitTimers<RangeDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 
@@ -608,6 +616,22 @@ static int tagged_order_t(const u64* d_in, const u32* w_in, u64 n, u64* ka, u64*
     for (int p = 0; p < 2; ++p) {
         HashTaggedDigit<NW> dg{(u32)(64 - 8 * (2 - p))};
         KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
+        kin = kdst[p & 1]; win = wdst[p & 1];
+    }
+    *k_out = kin; *w_out = win;
+    return KATOME_OK;
+}
+// one-word (k-mer, count) records ordered by the top 16 bits of the hash of their core (see CoreHashDigit)
+int dev_hash_order_core(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t core_shift, uint32_t core_bases, uint64_t* ka, uint64_t* kb,
+                        uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream) {
+    *group_bits = CORE_GROUP_BITS;
+    PassBuffers pb;
+    KCHECK(pb.init(n, 1, stream));
+    const u64* kin = d_in; const u32* win = w_in;
+    u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
+    for (int p = 0; p < 2; ++p) {
+        CoreHashDigit<1> dg{(u32)(64 - 8 * (2 - p)), core_shift, core_bases};
+        KCHECK((radix_pass<1, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
         kin = kdst[p & 1]; win = wdst[p & 1];
     }
     *k_out = kin; *w_out = win;

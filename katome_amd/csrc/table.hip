@@ -663,7 +663,8 @@ template <bool RC, int PER>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
                                                                 u32 R, u32 k, u32 min_weight, u64* out_keys,
                                                                 u32* out_w, u64 out_cap, unsigned long long* cursor,
-                                                                unsigned long long* distinct, u32* err, u32 probe_limit) {
+                                                                unsigned long long* distinct, u32* err, u32 probe_limit,
+                                                                unsigned long long* owner_cursor, u32 n_owners) {
     constexpr u32 LC_SLOTS = LcTable<PER>::SLOTS;
     extern __shared__ unsigned long long lc_mem[];
     unsigned long long* lkey = lc_mem;                                   // [LC_SLOTS]
@@ -730,7 +731,9 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
             u32 woff = 0, total = 0;
 #pragma unroll
             for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
-            if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+            // (owner_cursor: the group's keys go to the stretch of the rank that owns them -- groups are cut by the core's hash then)
+            if (tid == 0) base_sh = !total ? 0ull : owner_cursor ? atomicAdd(&owner_cursor[core_group_owner(g, n_owners)], (unsigned long long)total)
+                                                               : atomicAdd(cursor, (unsigned long long)total);
             __syncthreads();
             u64 pos = base_sh + woff + (incl - mine);
 #pragma unroll
@@ -753,6 +756,29 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
     if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
 }
 
+// group boundaries when the records are ordered by the hash of their core (dev_hash_order_core), and the owners' first positions:
+// owner p's groups are [ceil(p * 2^gbits / n), ceil((p + 1) * 2^gbits / n))
+__global__ __launch_bounds__(BLOCK) void core_group_index_kernel(const u64* __restrict__ keys, u64 n, u32 gbits, u32 core_shift, u32 core_bases,
+                                                                 u64* __restrict__ index) {
+    for (u64 g = (u64)blockIdx.x * BLOCK + threadIdx.x; g <= (1ull << gbits); g += (u64)gridDim.x * BLOCK) {
+        u64 lo = 0, hi = n;
+        while (lo < hi) {
+            const u64 mid = lo + ((hi - lo) >> 1);
+            Key<1> a; a.w[0] = keys[mid];
+            if ((core_hash(a, core_shift, core_bases) >> (64 - gbits)) < g) lo = mid + 1; else hi = mid;
+        }
+        index[g] = lo;
+    }
+}
+__global__ void owner_bases_kernel(const u64* __restrict__ index, u32 gbits, u32 n_owners, unsigned long long* owner_cursor, u64* bases) {
+    const u32 p = threadIdx.x;
+    if (p > n_owners) return;
+    const u64 g0 = (((u64)p << gbits) + n_owners - 1) / n_owners;          // first group whose owner is p (p == n_owners: one past the end)
+    const u64 at = index[g0 < (1ull << gbits) ? g0 : (1ull << gbits)];
+    bases[p] = at;
+    if (p < n_owners) owner_cursor[p] = at;
+}
+
 // The same for k-mers of two words (k = 32..63; the reference's example configuration runs k = 40): the LDS slot stays 12 bytes
 // -- a 16-byte key would halve the table -- and holds, published by ONE compare-and-swap, a 43-bit fingerprint of the key's hash
 // and the position (within the group, < 2^20) of a REPRESENTATIVE record; a record whose fingerprint meets an occupied slot's
@@ -761,7 +787,8 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
 template <bool RC, int PER, int NW>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
                                                                      u32 R, u32 k, u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap,
-                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err, u32 probe_limit) {
+                                                                     unsigned long long* cursor, unsigned long long* distinct, u32* err, u32 probe_limit,
+                                                                     unsigned long long* /*owner_cursor: one-word k-mers only*/, u32 /*n_owners*/) {
     constexpr u32 LC_SLOTS = LcTable<PER>::SLOTS;
     constexpr unsigned long long REP_MASK = (1ull << 20) - 1;
     extern __shared__ unsigned long long lc_mem[];
@@ -1502,10 +1529,13 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
 // by sorting instead of in a table (see lds_count_kernel).  keys/weights: the records (consumed).  KATOME_E_UNSUPPORTED when
 // the input is out of the kernel's range (the caller counts in the table instead).
 int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
-                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
+                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, OwnerSplit* split) {
     *n_edges = 0; *n_distinct = 0;
     const uint32_t nw = (uint32_t)key_words_for_k(k);
     if (nw > 2) return KATOME_E_UNSUPPORTED;
+    if (split && (nw != 1 || rc || min_weight || split->n_parts == 0 || split->n_parts > (uint32_t)KATOME_MAX_RANKS)) {
+        set_error("records by owner: one-word k-mers, one record per k-mer"); return KATOME_E_ARG;
+    }
     if ((n >> 16) > (u64)LC_MAX_ROUNDS * LcTable<13>::FILL) return KATOME_E_UNSUPPORTED;
     const u64* ko = nullptr; const u32* wo = nullptr;
     u32 gbits = 16;
@@ -1513,7 +1543,9 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         DevBuf kb(stream), wb(stream);
         KCHECK(kb.alloc((n + 1) * 8 * nw)); KCHECK(wb.alloc((n + 1) * 4));
         // two passes: the first one's output goes to the scratch, the second one's lands in keys / weights again
-        KCHECK(dev_hash_order(keys.as<u64>(), weights.as<u32>(), n, nw, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, &gbits, stream));
+        if (split) KCHECK(dev_hash_order_core(keys.as<u64>(), weights.as<u32>(), n, split->core_shift, split->core_bases, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(),
+                                              weights.as<u32>(), &ko, &wo, &gbits, stream));
+        else KCHECK(dev_hash_order(keys.as<u64>(), weights.as<u32>(), n, nw, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, &gbits, stream));
     }
     // the smaller table when a group fits it in one round (less to clear and to read out per group)
     const u64 avg = n >> gbits;
@@ -1527,7 +1559,8 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     {
         KernelScope ks(K_GROUP_INDEX, stream, n);
         const dim3 igrid(grid_for((1ull << gbits) + 1, BLOCK));
-        if (nw == 1) hipLaunchKernelGGL(hash_group_index_kernel<1>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
+        if (split)   hipLaunchKernelGGL(core_group_index_kernel, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, split->core_shift, split->core_bases, index.as<u64>());
+        else if (nw == 1) hipLaunchKernelGGL(hash_group_index_kernel<1>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
         else         hipLaunchKernelGGL(hash_group_index_kernel<2>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
     }
     const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
@@ -1537,8 +1570,19 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     unsigned long long* distinct = cursor + 1;
     u32* err = reinterpret_cast<u32*>(cursor + 2);
     uint64_t h[3] = {0, 0, 0};
+    // (with a split: the owners' cursors, started at the owners' first records -- a group's keys are no more than its records --, and
+    // those starts themselves, n_parts + 1 of them)
+    DevBuf owners(stream);
+    unsigned long long* owner_cursor = nullptr;
+    u64* owner_base = nullptr;
+    if (split) {
+        KCHECK(owners.alloc((2 * KATOME_MAX_RANKS + 2) * 8));
+        owner_cursor = owners.as<unsigned long long>(); owner_base = owners.as<u64>() + KATOME_MAX_RANKS + 1;
+    }
+    const u32 n_owners = split ? split->n_parts : 0;
     auto count = [&](u32 rounds, u32 probe_limit) -> int {
         KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+        if (split) hipLaunchKernelGGL(owner_bases_kernel, dim3(1), dim3(64), 0, stream, index.as<u64>(), gbits, n_owners, owner_cursor, owner_base);
 #define KATOME_LC_LAUNCH(KERNEL, PERV)                                                                                                  \
         do {                                                                                                                          \
             const size_t lds = (size_t)LcTable<PERV>::SLOTS * 12;                                                                     \
@@ -1546,7 +1590,7 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
             KernelScope ks(K_LDS_COUNT, stream, n);                                                                                   \
             hipLaunchKernelGGL(KERNEL, dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, rounds, k,           \
                                min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err,                  \
-                               std::min<u32>(probe_limit, LcTable<PERV>::SLOTS));                                                      \
+                               std::min<u32>(probe_limit, LcTable<PERV>::SLOTS), owner_cursor, n_owners);                              \
         } while (0)
         if (nw == 1) {
             if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 8>), 8); else KATOME_LC_LAUNCH((lds_count_kernel<false, 8>), 8); }
@@ -1570,6 +1614,18 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;          // (a group too large for the representative's 20 bits: the caller counts in the table)
     if ((uint32_t)h[2]) { set_error("counting in LDS: a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
     *n_edges = h[0]; *n_distinct = h[1];
+    if (split) {
+        uint64_t hb[2 * KATOME_MAX_RANKS + 2];
+        KCHECK_HIP(hipMemcpyAsync(hb, owners.p, sizeof hb, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        uint64_t total = 0;
+        for (uint32_t p = 0; p < n_owners; ++p) {
+            split->base[p] = hb[KATOME_MAX_RANKS + 1 + p];
+            split->count[p] = hb[p] - split->base[p];
+            total += split->count[p];
+        }
+        *n_edges = total;             // (the records: scattered over the owners' stretches of edge_key / edge_weight)
+    }
     return KATOME_OK;
 }
 

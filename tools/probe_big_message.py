@@ -29,4 +29,20 @@ for gib in [float(x) for x in sys.argv[1:]] or [0.5, 1.5, 2.5, 3.8, 6.0]:
         bad = int((dst != src).sum().item()) if st == 0 else -1
         print("%.1f GiB, message limit %s: status %d, received %d, mismatching words %d" % (gib, "1 GiB" if limit == 1 << 30 else "none", st, rc[0], bad),
               flush=True)
+        if bad > 0:       # WHERE are they, and what do they hold?  (round 3: is it the probe's aliasing or RCCL's?)
+            wrong = (dst != src)
+            idx = torch.nonzero(wrong).flatten()
+            first, last = int(idx[0]), int(idx[-1])
+            edges = torch.nonzero(wrong[1:] != wrong[:-1]).flatten() + 1            # where right/wrong changes
+            runs = [0] + [int(e) for e in edges[:16].tolist()]
+            zeros = int((dst[wrong] == 0).sum().item())
+            print("      first wrong word %d (byte offset %.3f GiB), last %d; right/wrong changes at words %s%s; wrong words that are still 0 (never written): %d of %d"
+                  % (first, first * 8 / 2**30, last, runs[1:], " ..." if len(edges) > 16 else "", zeros, bad), flush=True)
+            # do the wrong words hold the source's data from another offset?
+            j = first
+            v = int(dst[j].item())
+            if v != 0:
+                k = (v - 12345) // 2654435761 if (v - 12345) % 2654435761 == 0 else None
+                print("      dst[%d] = src[%s]" % (j, k), flush=True)
+            del wrong, idx, edges
 L.katome_comm_destroy(comm)
