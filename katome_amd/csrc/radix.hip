@@ -439,6 +439,102 @@ __global__ __launch_bounds__(BLOCK) void run_sort_kernel(const u64* __restrict__
     }
 }
 
+// The same placement without LDS: where the keys are spread out a run is a few records, so a wave takes a stretch of records with
+// RW_REACH more on either side and every lane finds its run among its neighbours' keys by wave shuffles -- no staging, no
+// round trips to LDS whose results decide whether there is another one.  A run that leaves the shuffled window (or the wave's
+// stretch) is walked in global memory by the lanes it concerns (rare: a window of 2 * RW_REACH + 1 records of equal top bits);
+// one longer than RW_LONGEST raises `overflow` like the staged kernel.
+constexpr u32 RW_REACH = 7, RW_OWN = 64 - 2 * RW_REACH, RW_LONGEST = 1u << 12;
+template <int NW> __device__ __forceinline__ Key<NW> shfl_key_up(const Key<NW>& k, u32 s) {
+    Key<NW> r;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) r.w[q] = __shfl_up(k.w[q], s, 64);
+    return r;
+}
+template <int NW> __device__ __forceinline__ Key<NW> shfl_key_down(const Key<NW>& k, u32 s) {
+    Key<NW> r;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) r.w[q] = __shfl_down(k.w[q], s, 64);
+    return r;
+}
+template <int NW, bool HAS_VAL>
+__global__ __launch_bounds__(BLOCK) void run_sort_wave_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in, u64 n, u32 low,
+                                                               u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ overflow) {
+    const u32 lane = threadIdx.x & 63;
+    const u64 wave = ((u64)blockIdx.x * BLOCK + threadIdx.x) >> 6, n_waves = ((u64)gridDim.x * BLOCK) >> 6;
+    const u64 n_chunks = (n + RW_OWN - 1) / RW_OWN;
+    // (the next stretch's loads are issued before this one is worked on)
+    auto fetch = [&](u64 c, Key<NW>& key, u32& val) {
+        const long long j = (long long)(c * RW_OWN) - (long long)RW_REACH + (long long)lane;
+        const bool there = c < n_chunks && j >= 0 && (u64)j < n;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) key.w[q] = 0;
+        val = 0;
+        if (there) key = load_key<NW>(keys_in, (u64)j);
+        if (HAS_VAL && there && lane >= RW_REACH && lane < RW_REACH + RW_OWN) val = vals_in[j];
+    };
+    Key<NW> key_next; u32 val_next;
+    fetch(wave, key_next, val_next);
+    for (u64 c = wave; c < n_chunks; c += n_waves) {
+        const long long j = (long long)(c * RW_OWN) - (long long)RW_REACH + (long long)lane;         // the record this lane looks at
+        const bool there = j >= 0 && (u64)j < n;
+        const bool own = there && lane >= RW_REACH && lane < RW_REACH + RW_OWN;
+        const Key<NW> key = key_next;
+        const u32 val = val_next;
+        fetch(c + n_waves, key_next, val_next);
+        const Key<NW> top = key_shr(key, low);
+        // to the left: records of the run with a key <= this one come first; to the right: only strictly smaller keys
+        u32 left = 0, before = 0;
+        bool open = there, more_left = false, more_right = false;
+#pragma unroll
+        for (u32 s = 1; s <= RW_REACH; ++s) {
+            const Key<NW> x = shfl_key_up<NW>(key, s);
+            const bool has = lane >= s && j - (long long)s >= 0;
+            const bool same = open && has && key_eq(key_shr(x, low), top);
+            left += same ? 1u : 0u;
+            before += (same && !key_lt(key, x)) ? 1u : 0u;
+            open = same;
+        }
+        more_left = open && j - (long long)RW_REACH > 0;              // the window ended inside the run
+        open = there;
+#pragma unroll
+        for (u32 s = 1; s <= RW_REACH; ++s) {
+            const Key<NW> x = shfl_key_down<NW>(key, s);
+            const bool has = lane + s < 64 && (u64)j + s < n;
+            const bool same = open && has && key_eq(key_shr(x, low), top);
+            before += (same && key_lt(x, key)) ? 1u : 0u;
+            open = same;
+        }
+        more_right = open && (u64)j + RW_REACH + 1 < n;
+        if (own && (more_left || more_right)) {       // a long run: the rest of it from global memory
+            u64 a = (u64)j - left, b = (u64)j + 1;
+            u32 steps = 0;
+            if (more_left) {
+                while (a > 0 && steps < RW_LONGEST) {
+                    const Key<NW> x = load_key<NW>(keys_in, a - 1);
+                    if (!key_eq(key_shr(x, low), top)) break;
+                    before += key_lt(key, x) ? 0u : 1u; ++left; --a; ++steps;
+                }
+            }
+            // (the right side is counted afresh: the window's share of it is in `before` already only for the first RW_REACH records)
+            if (more_right) {
+                b = (u64)j + RW_REACH + 1;
+                while (b < n && steps < RW_LONGEST) {
+                    const Key<NW> x = load_key<NW>(keys_in, b);
+                    if (!key_eq(key_shr(x, low), top)) break;
+                    before += key_lt(x, key) ? 1u : 0u; ++b; ++steps;
+                }
+            }
+            if (steps >= RW_LONGEST) { *overflow = 1; before = left; }       // (the result is discarded; the store stays in bounds)
+        }
+        if (own) {
+            const u64 out = (u64)j - left + before;
+            store_key<NW>(keys_out, out, key);
+            if (HAS_VAL) vals_out[out] = val;
+        }
+    }
+}
+
 // (A one-kernel pass -- digit offsets of all passes from one read of the keys, tile offsets by decoupled look-back over tiles
 // numbered in the order they start -- was built and measured in round 3 and removed again: profiles/r03_lookback.md.  The
 // look-back words must be read at agent scope, past the XCD's own L2, and every tile waits for that chain before it can write:
@@ -483,9 +579,14 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
         const size_t lds = (size_t)(RUN_TILE + 2 * RUN_HALO) * NW * 8;
         if (lds > (64u << 10)) KCHECK_HIP(hipFuncSetAttribute((const void*)run_sort_kernel<NW, HAS_VAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {
+            static const int by_waves = getenv("KATOME_RUN_SORT") ? atoi(getenv("KATOME_RUN_SORT")) : 2;      // 1: the staged kernel (A/B)
             KernelScope ks(K_RUN_SORT, stream, n);
-            hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
-                               kout, vout, overflow.as<u32>());
+            if (by_waves == 2)
+                hipLaunchKernelGGL((run_sort_wave_kernel<NW, HAS_VAL>), dim3(grid_for(n, (BLOCK / 64) * RW_OWN * 4, 256u * 32u)), dim3(BLOCK), 0, stream, kin, vin, n,
+                                   low, kout, vout, overflow.as<u32>());
+            else
+                hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
+                                   kout, vout, overflow.as<u32>());
         }
         KCHECK_HIP(hipGetLastError());
         u32 h = 0;

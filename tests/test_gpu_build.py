@@ -783,7 +783,8 @@ def test_round_one_paths_give_the_same_arrays(tmp_path):
     assert len(want) == 2
     # (KATOME_SORTED_COUNT=2: the last level counted by sorting however small the input -- by default only from 4 M records on)
     for extra in ({"KATOME_DST_RANK": "1"}, {"KATOME_SORT_NODES": "1"}, {"KATOME_FULL_SORT": "1"},
-                  {"KATOME_DST_RANK": "1", "KATOME_SORT_NODES": "1"}, {"KATOME_SORTED_COUNT": "2"}, {"KATOME_SORTED_COUNT": "0"}):
+                  {"KATOME_DST_RANK": "1", "KATOME_SORT_NODES": "1"}, {"KATOME_SORTED_COUNT": "2"}, {"KATOME_SORTED_COUNT": "0"},
+                  {"KATOME_RUN_SORT": "1"}):        # (the run sort staged in LDS instead of by wave shuffles)
         assert run(extra) == want, extra
 
 

@@ -301,9 +301,10 @@ def test_synth_reads_match_cpu_definition(oracle, L, npct):
 @pytest.mark.parametrize("nw,bits", [(1, 62), (2, 126), (2, 80), (2, 100)])
 @pytest.mark.parametrize("shape", ["shared_top_bits", "short_runs", "runs_across_tiles", "runs_near_the_halo", "runs_past_the_halo"])
 def test_sort_by_top_bits_and_run_sort(nw, bits, shape):
-    """dev_sort only runs the passes over the top 8 * ceil(log2(n) / 8) bits and lets run_sort_kernel place every record
-    inside the run that shares them (radix.hip); a run longer than the staged halo (512 records either side) makes the
-    whole sort fall back to all passes; equal keys keep their input order either way"""
+    """dev_sort only runs the passes over the top 8 * ceil(log2(n) / 8) bits and lets the run sort place every record
+    inside the run that shares them (radix.hip): run_sort_wave_kernel finds a run of up to 15 records by wave shuffles, walks a
+    longer one in global memory and gives up past 4096 records -- the whole sort then falls back to all passes (the staged
+    kernel, KATOME_RUN_SORT=1, gives up past its halo of 512 records either side); equal keys keep their input order either way"""
     from katome_amd import device as kd
     rng = np.random.default_rng(nw * 100 + bits + len(shape))
     n = 300001
