@@ -633,7 +633,14 @@ template <int PER> struct LcTable {
     static constexpr u32 FILL = (u32)(SLOTS / 4096.0 * 2900);   // records a sub-round may hold at most on average (all new: load 0.71)
 };
 constexpr u32 LC_MAX_ROUNDS = 32;
-constexpr u32 LC_PROBE_LIMIT = 128;                    // the optimistic attempt's patience with a full table
+// the optimistic attempt's patience with a full table (KATOME_LC_PROBE_LIMIT: tests make the first attempt fail with it)
+static u32 lc_probe_limit() {
+    static const u32 v = getenv("KATOME_LC_PROBE_LIMIT") ? (u32)std::max(1, atoi(getenv("KATOME_LC_PROBE_LIMIT"))) : 128u;
+    return v;
+}
+static void lc_trace(const char* what, u32 tried, u32 guaranteed) {
+    if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] %s: the attempt with %u sub-rounds filled a table; counting again with %u\n", what, tried, guaranteed);
+}
 // share of a group's records assumed distinct when the sub-rounds of the first attempt are chosen (KATOME_LC_OPTIMISM; 1 = never
 // try with fewer than the guaranteed number)
 static double lc_optimism() {
@@ -1517,7 +1524,7 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
     };
     // first with fewer sub-rounds than would hold a group of distinct records (lc_optimism): records of reads repeat
     const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / FILL));
-    if (R_try < R) { KCHECK(count(R_try, LC_PROBE_LIMIT)); if ((uint32_t)h[2] == 3) KCHECK(count(R, LC_THREADS * LCS_PER)); }
+    if (R_try < R) { KCHECK(count(R_try, lc_probe_limit())); if ((uint32_t)h[2] == 3) { lc_trace("first-seen order", R_try, R); KCHECK(count(R, LC_THREADS * LCS_PER)); } }
     else KCHECK(count(R, LC_THREADS * LCS_PER));
     if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;
     if ((uint32_t)h[2]) { set_error("counting in LDS (first-seen order): a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
@@ -1607,9 +1614,9 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     };
     // First with fewer sub-rounds than would hold a group of DISTINCT records: the k-mers of reads repeat (C3: 1.8 records per
     // k-mer at this level), so the table is half empty at the guaranteed number.  An attempt that fills its table gives up after
-    // LC_PROBE_LIMIT probes (err 3, nothing it wrote is used) and the guaranteed number runs.
+    // lc_probe_limit() = 128 probes (err 3, nothing it wrote is used) and the guaranteed number runs.
     const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / fill));
-    if (R_try < R) { KCHECK(count(R_try, LC_PROBE_LIMIT)); if ((uint32_t)h[2] == 3) KCHECK(count(R, ~0u)); }
+    if (R_try < R) { KCHECK(count(R_try, lc_probe_limit())); if ((uint32_t)h[2] == 3) { lc_trace("packed key", R_try, R); KCHECK(count(R, ~0u)); } }
     else KCHECK(count(R, ~0u));
     if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;          // (a group too large for the representative's 20 bits: the caller counts in the table)
     if ((uint32_t)h[2]) { set_error("counting in LDS: a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
