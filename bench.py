@@ -509,7 +509,8 @@ def main():
                          "dst_merge_kernel": 8 * nw + 8 + 8 * nw * n_nodes / max(n_edges, 1)})
             kexact.update({"radix_scatter_kernel<RadixDigit>": exact["sort_edges"],
                            "radix_hist_kernel<RadixDigit>": "void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw),
-                           "run_sort_kernel": "void run_sort_kernel<%d, true>" % nw, "dst_merge_kernel": "void dst_merge_kernel<%d, false>" % nw})
+                           "run_sort_kernel": ("void run_sort_kernel<%d, true>" if os.environ.get("KATOME_RUN_SORT") == "1" else "void run_sort_wave_kernel<%d, true>") % nw,
+                           "dst_merge_kernel": "void dst_merge_kernel<%d, false>" % nw})
             if sorted_last_level:
                 ms2 = cnt.get("mid_span", 0)
                 last_slots, last_tiles, last_span, last_nw = ((cnt["mid_tile_slots"], cnt["distinct_mid_tiles"], ms2, _katome_lib().katome_tile_words(wl.k, ms2)) if ms2

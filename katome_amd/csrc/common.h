@@ -83,14 +83,16 @@ struct DevBuf {
 enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
              PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_SHRINK,
              K_SORT_SCATTER, K_SORT_HIST, K_RUN_SORT, K_HASH_SCATTER, K_HASH_HIST, K_OWNER_SCATTER, K_OWNER_HIST, K_PASS_OFFSETS,
-             K_RECORDS, K_GROUP_INDEX, K_LDS_COUNT, K_SRC_IDS, K_DST_MERGE, K_EXPAND, PH_COUNT };
+             K_RECORDS, K_GROUP_INDEX, K_LDS_COUNT, K_SRC_IDS, K_DST_MERGE, K_EXPAND, K_SORT_SCATTER_KEYS, K_RUN_SORT_KEYS, PH_COUNT };
 static const char* const PHASE_NAMES[PH_COUNT] = {
     "extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set", "rank", "labels", "insert_tiles", "expand_tiles",
     "expand_mid_tiles", "first_seen_order", "remove_dead_paths", "shrink",
     "k:radix_scatter_kernel<RadixDigit>", "k:radix_hist_kernel<RadixDigit>", "k:run_sort_kernel", "k:radix_scatter_kernel<HashDigit>",
     "k:radix_hist_kernel<HashDigit>", "k:radix_scatter_kernel<OwnerDigit>", "k:radix_hist_kernel<OwnerDigit>", "k:radix_chunk+offsets",
     "k:tiles_to_records_kernel", "k:hash_group_index_kernel", "k:lds_count_kernel", "k:src_count+src_write", "k:dst_merge_kernel",
-    "k:expand_tiles_kernel"};
+    "k:expand_tiles_kernel",
+    // (the keys-only instantiations -- the small sort of the nodes without out-edges -- are kernels of their own in a trace)
+    "k:radix_scatter_kernel<RadixDigit> (keys only)", "k:run_sort_kernel (keys only)"};
 struct Profiler {
     bool on = false;
     struct Ev { int phase; hipEvent_t a, b; uint64_t work; };      // work: elements the launch processed (K_* entries)

@@ -311,7 +311,7 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
         KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     {
-        KernelScope ks(DigitTimers<Digit>::SCATTER, stream, n);
+        KernelScope ks((!HAS_VAL && DigitTimers<Digit>::SCATTER == K_SORT_SCATTER) ? (int)K_SORT_SCATTER_KEYS : (int)DigitTimers<Digit>::SCATTER, stream, n);
         hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
                            pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks);
     }
@@ -580,7 +580,7 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
         if (lds > (64u << 10)) KCHECK_HIP(hipFuncSetAttribute((const void*)run_sort_kernel<NW, HAS_VAL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         {
             static const int by_waves = getenv("KATOME_RUN_SORT") ? atoi(getenv("KATOME_RUN_SORT")) : 2;      // 1: the staged kernel (A/B)
-            KernelScope ks(K_RUN_SORT, stream, n);
+            KernelScope ks(HAS_VAL ? K_RUN_SORT : K_RUN_SORT_KEYS, stream, n);
             if (by_waves == 2)
                 hipLaunchKernelGGL((run_sort_wave_kernel<NW, HAS_VAL>), dim3(grid_for(n, (BLOCK / 64) * RW_OWN * 4, 256u * 32u)), dim3(BLOCK), 0, stream, kin, vin, n,
                                    low, kout, vout, overflow.as<u32>());
