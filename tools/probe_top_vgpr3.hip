@@ -1,0 +1,86 @@
+// Third probe for the gfx950 erratum of profiles/r03_shift64_erratum.md: WHICH instructions misread a 32-bit operand held in the last
+// VGPR of the allocation?  The 64-bit shifts do (tools/probe_shift64_top_vgpr.hip).  Here: other instructions that mix 32- and
+// 64-bit operands or take a VGPR "amount", each with that operand in v31 of a 32-register allocation, under the same occupancy
+// (2048 workgroups of 256).  The result of every instruction is compared with what the compiler's own code gives for the same
+// inputs held elsewhere.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+typedef uint32_t u32;
+typedef unsigned long long u64;
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+// BODY: inline assembly that puts `amt` into v31 and produces a 64-bit `got` from (x, amt); WANT: the same in C
+#define PROBE(NAME, BODY, WANT)                                                                                              \
+    __global__ __launch_bounds__(256) void NAME(u32* count, u32* as_v0, u32 outer) {                                        \
+        __shared__ u64 lds[256];                                                                                             \
+        const u32 tid = threadIdx.x;                                                                                         \
+        asm volatile("v_mov_b32 v31, 0" ::: "v31");                                                                          \
+        u32 wrong = 0, v0like = 0;                                                                                           \
+        for (u32 it = 0; it < outer; ++it) {                                                                                 \
+            lds[tid] = 0x9E3779B97F4A7C15ull * (tid + 1 + it);                                                               \
+            __syncthreads();                                                                                                 \
+            for (u32 trip = 0; trip < 2; ++trip) {                                                                           \
+                const u64 x = lds[(tid * 5 + trip) & 255] | 1ull << 62;                                                      \
+                const u32 amt = 1 + ((tid * 7 + it + trip) % 10);                                                            \
+                u64 got;                                                                                                     \
+                BODY;                                                                                                        \
+                const u64 want = WANT(x, amt);                                                                               \
+                if (got != want) { ++wrong; if (got == WANT(x, tid)) ++v0like; }                                             \
+            }                                                                                                                \
+            __syncthreads();                                                                                                 \
+        }                                                                                                                    \
+        if (wrong) { atomicAdd(count, wrong); atomicAdd(as_v0, v0like); }                                                    \
+    }
+
+#define W_LSHR64(x, a) ((x) >> ((a) & 63))
+#define W_MAD_A(x, a) ((u64)(u32)(a) * (u64)(u32)(x) + (x))
+#define W_MULHI(x, a) ((u64)(((u64)(u32)(a) * (u64)(u32)(x)) >> 32))
+#define W_LSHL32(x, a) ((u64)((u32)(x) << ((a) & 31)))
+#define W_BFE(x, a) ((u64)(((u32)(x) >> ((a) & 31)) & 0xFFu))
+#define W_ALIGN(x, a) ((u64)(u32)((((u64)(u32)((x) >> 32) << 32) | (u32)(x)) >> ((a) & 31)))
+#define W_ADD64(x, a) ((x) + (u64)(a))
+
+PROBE(p_lshrrev_b64, asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_lshrrev_b64 %0, v31, %1" : "=v"(got) : "v"(x), "v"(amt) : "v31"), W_LSHR64)
+PROBE(p_mad_u64_u32_src0, asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_mad_u64_u32 %0, vcc, v31, %3, %1" : "=v"(got) : "v"(x), "v"(amt), "v"((u32)x) : "v31", "vcc"), W_MAD_A)
+PROBE(p_mad_u64_u32_src1, asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_mad_u64_u32 %0, vcc, %3, v31, %1" : "=v"(got) : "v"(x), "v"(amt), "v"((u32)x) : "v31", "vcc"), W_MAD_A)
+PROBE(p_mul_hi_u32, { u32 g32; asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_mul_hi_u32 %0, v31, %1" : "=v"(g32) : "v"((u32)x), "v"(amt) : "v31"); got = g32; }, W_MULHI)
+PROBE(p_lshlrev_b32, { u32 g32; asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_lshlrev_b32 %0, v31, %1" : "=v"(g32) : "v"((u32)x), "v"(amt) : "v31"); got = g32; }, W_LSHL32)
+PROBE(p_bfe_u32, { u32 g32; asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_bfe_u32 %0, %1, v31, 8" : "=v"(g32) : "v"((u32)x), "v"(amt) : "v31"); got = g32; }, W_BFE)
+PROBE(p_alignbit_b32, { u32 g32; asm volatile("v_mov_b32 v31, %3\n\ts_nop 1\n\tv_alignbit_b32 %0, %1, %2, v31" : "=v"(g32) : "v"((u32)(x >> 32)), "v"((u32)x), "v"(amt) : "v31"); got = g32; }, W_ALIGN)
+// a 64-bit source whose HIGH half is the last register: v[30:31] (the pair is inside the allocation)
+PROBE(p_lshl_add_u64_pair_30_31, asm volatile("v_mov_b32 v30, %2\n\tv_mov_b32 v31, 0\n\ts_nop 1\n\tv_lshl_add_u64 %0, v[30:31], 0, %1" : "=v"(got) : "v"(x), "v"(amt) : "v30", "v31"), W_ADD64)
+
+typedef void (*kernel_t)(u32*, u32*, u32);
+
+int main(int argc, char** argv) {
+    const int launches = argc > 1 ? atoi(argv[1]) : 10;
+    const u32 outer = argc > 2 ? (u32)atoi(argv[2]) : 200;
+    u32* d = nullptr;
+    CHECK(hipMalloc(&d, 8));
+    struct { const char* name; kernel_t k; } kernels[] = {
+        {"v_lshrrev_b64   amount in v31 (the known case)", p_lshrrev_b64}, {"v_mad_u64_u32   src0 (32-bit) in v31", p_mad_u64_u32_src0},
+        {"v_mad_u64_u32   src1 (32-bit) in v31", p_mad_u64_u32_src1},     {"v_mul_hi_u32    src0 in v31", p_mul_hi_u32},
+        {"v_lshlrev_b32   amount in v31", p_lshlrev_b32},                  {"v_bfe_u32       offset in v31", p_bfe_u32},
+        {"v_alignbit_b32  amount in v31", p_alignbit_b32},                 {"v_lshl_add_u64  64-bit source in v[30:31]", p_lshl_add_u64_pair_30_31}};
+    for (auto& kn : kernels) {
+        hipFuncAttributes fa;
+        CHECK(hipFuncGetAttributes(&fa, (const void*)kn.k));
+        unsigned long long wrong = 0, v0like = 0;
+        for (int l = 0; l < launches; ++l) {
+            CHECK(hipMemset(d, 0, 8));
+            hipLaunchKernelGGL(kn.k, dim3(2048), dim3(256), 0, 0, d, d + 1, outer);
+            CHECK(hipGetLastError()); CHECK(hipDeviceSynchronize());
+            u32 h[2];
+            CHECK(hipMemcpy(h, d, 8, hipMemcpyDeviceToHost));
+            wrong += h[0]; v0like += h[1];
+        }
+        printf("%-48s numRegs %3d: %.3g results, wrong %llu (as if the operand were thread id: %llu)\n", kn.name, fa.numRegs,
+               (double)launches * 2048 * 256 * outer * 2, wrong, v0like);
+        fflush(stdout);
+    }
+    return 0;
+}

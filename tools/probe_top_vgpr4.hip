@@ -1,0 +1,105 @@
+// Fourth probe (see probe_top_vgpr3.hip): WHAT amount does a v_lshrrev_b64 use when it misreads an amount held in the last VGPR?
+// Every wrong result is matched against the value shifted by every amount 0..63 and the pairs (named amount, used amount) are
+// counted, with the thread id's low six bits beside them.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+typedef uint32_t u32;
+typedef unsigned long long u64;
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(2); } } while (0)
+
+// hist[named][used] (64 x 65; used 64 = none fits); lanehist[used == lane ? 1 : 0]
+template <int VARIANT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(32))) void probe(u32* hist, u32* lanehit, u32 outer, u64* cursor) {
+    __shared__ u64 lds[256];
+    __shared__ u64 base;
+    const u32 tid = threadIdx.x;
+    asm volatile("v_mov_b32 v31, 0" ::: "v31");
+    for (u32 it = 0; it < outer; ++it) {
+        lds[tid] = 0x9E3779B97F4A7C15ull * (tid + 1 + it);
+        __syncthreads();
+        if (VARIANT == 7 || VARIANT == 8) {       // one wave reaches a second barrier late: it waits for a returning global atomic
+            if (tid == 0) base = atomicAdd(cursor, 256ull);
+            __syncthreads();
+        }
+        const u64 x = (lds[(tid * 5) & 255] + (VARIANT == 8 ? (base & 1) : 0)) | 1ull << 63;
+        const u32 amt = 1 + ((tid * 7 + it) % 10);
+        u64 got;
+        // (every variant keeps the allocation at 32 registers: the neighbouring shifts write v[28:29], named as clobbers)
+        if (VARIANT == 0)        // five wait states on either side
+            asm volatile("v_mov_b32 v31, %2\n\ts_nop 4\n\tv_lshrrev_b64 %0, v31, %1\n\ts_nop 4" : "=v"(got) : "v"(x), "v"(amt) : "v31");
+        else if (VARIANT == 1)   // the amount written right before the shift
+            asm volatile("v_mov_b32 v31, %2\n\tv_lshrrev_b64 %0, v31, %1\n\ts_nop 4" : "=v"(got) : "v"(x), "v"(amt) : "v31");
+        else if (VARIANT == 2)   // two wait states before, none after (what follows is the compiler's code)
+            asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_lshrrev_b64 %0, v31, %1" : "=v"(got) : "v"(x), "v"(amt) : "v31");
+        else if (VARIANT == 3 || VARIANT == 4) {
+            // another 64-bit shift right behind (3) / right before (4) it, amount 33 / 44 in an ordinary register; every register of the
+            // sequence is named so that the allocation stays at 32
+            const u32 xl = (u32)x, xh = (u32)(x >> 32), a2 = VARIANT == 3 ? 33u : 44u;
+            u32 gl, gh, ol, oh;
+            if (VARIANT == 3)
+                asm volatile("v_mov_b32 v28, %4\n\tv_mov_b32 v29, %5\n\tv_mov_b32 v30, %7\n\tv_mov_b32 v31, %6\n\ts_nop 4\n\t"
+                             "v_lshrrev_b64 v[24:25], v31, v[28:29]\n\tv_lshrrev_b64 v[26:27], v30, v[28:29]\n\ts_nop 4\n\t"
+                             "v_mov_b32 %0, v24\n\tv_mov_b32 %1, v25\n\tv_mov_b32 %2, v26\n\tv_mov_b32 %3, v27"
+                             : "=&v"(gl), "=&v"(gh), "=&v"(ol), "=&v"(oh) : "v"(xl), "v"(xh), "v"(amt), "v"(a2) : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
+            else
+                asm volatile("v_mov_b32 v28, %4\n\tv_mov_b32 v29, %5\n\tv_mov_b32 v30, %7\n\tv_mov_b32 v31, %6\n\ts_nop 4\n\t"
+                             "v_lshrrev_b64 v[26:27], v30, v[28:29]\n\tv_lshrrev_b64 v[24:25], v31, v[28:29]\n\ts_nop 4\n\t"
+                             "v_mov_b32 %0, v24\n\tv_mov_b32 %1, v25\n\tv_mov_b32 %2, v26\n\tv_mov_b32 %3, v27"
+                             : "=&v"(gl), "=&v"(gh), "=&v"(ol), "=&v"(oh) : "v"(xl), "v"(xh), "v"(amt), "v"(a2) : "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31");
+            got = (u64)gh << 32 | gl;
+            if (((u64)oh << 32 | ol) != x >> a2) atomicAdd(&lanehit[2], 1u);
+        }
+        else if (VARIANT == 5)   // an ordinary VALU instruction that reads v0 right behind it
+            asm volatile("v_mov_b32 v31, %2\n\ts_nop 4\n\tv_lshrrev_b64 %0, v31, %1\n\tv_add_u32 v28, v0, v0\n\ts_nop 4" : "=&v"(got) : "v"(x), "v"(amt) : "v31", "v28");
+        else if (VARIANT == 7 || VARIANT == 8)   // as variant 2, behind the late barrier
+            asm volatile("v_mov_b32 v31, %2\n\ts_nop 1\n\tv_lshrrev_b64 %0, v31, %1" : "=v"(got) : "v"(x), "v"(amt) : "v31");
+        else                     // an LDS read in flight across it
+            asm volatile("v_mov_b32 v31, %2\n\tds_read_b64 v[28:29], %3\n\ts_nop 4\n\tv_lshrrev_b64 %0, v31, %1\n\ts_nop 4\n\ts_waitcnt lgkmcnt(0)" : "=&v"(got) : "v"(x), "v"(amt), "v"((tid * 8) & 2047) : "v31", "v28", "v29");
+        if (got != x >> amt) {
+            u32 used = 64;
+            for (u32 s = 0; s < 64; ++s) if (got == x >> s) { used = s; break; }
+            atomicAdd(&hist[amt * 65 + used], 1u);
+            atomicAdd(&lanehit[used == (tid & 63) ? 1 : 0], 1u);
+        }
+        __syncthreads();
+    }
+}
+
+int main(int argc, char** argv) {
+    const u32 outer = argc > 1 ? (u32)atoi(argv[1]) : 400;
+    u32* d = nullptr;
+    CHECK(hipMalloc(&d, (64 * 65 + 4) * 4));
+    u64* cursor = nullptr;
+    CHECK(hipMalloc(&cursor, 8)); CHECK(hipMemset(cursor, 0, 8));
+    const char* names[9] = {"s_nop 4 | shift by v31 | s_nop 4", "v_mov v31 | shift by v31 | s_nop 4", "s_nop 1 | shift by v31 | (compiler's code)",
+                            "s_nop 4 | shift by v31 | shift by 33 | s_nop 4", "s_nop 4 | shift by 44 | shift by v31 | s_nop 4",
+                            "s_nop 4 | shift by v31 | v_add_u32 reading v0 | s_nop 4", "ds_read in flight | shift by v31",
+                            "late barrier (global atomic) | s_nop 1 | shift by v31", "the same, the atomic's result used"};
+    for (int v = 0; v < 9; ++v) {
+        CHECK(hipMemset(d, 0, (64 * 65 + 4) * 4));
+        for (int l = 0; l < 10; ++l) {
+            switch (v) {
+                case 0: hipLaunchKernelGGL(probe<0>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                case 1: hipLaunchKernelGGL(probe<1>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                case 2: hipLaunchKernelGGL(probe<2>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                case 3: hipLaunchKernelGGL(probe<3>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                case 4: hipLaunchKernelGGL(probe<4>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                case 5: hipLaunchKernelGGL(probe<5>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                case 6: hipLaunchKernelGGL(probe<6>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                case 7: hipLaunchKernelGGL(probe<7>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+                default: hipLaunchKernelGGL(probe<8>, dim3(2048), dim3(256), 0, 0, d, d + 64 * 65, outer, cursor); break;
+            }
+            CHECK(hipGetLastError()); CHECK(hipDeviceSynchronize());
+        }
+        std::vector<u32> h(64 * 65 + 4);
+        CHECK(hipMemcpy(h.data(), d, h.size() * 4, hipMemcpyDeviceToHost));
+        unsigned long long wrong = 0, none = 0, by33 = 0, by44 = 0;
+        for (u32 a = 0; a < 64; ++a) for (u32 s = 0; s <= 64; ++s) { wrong += h[a * 65 + s]; if (s == 64) none += h[a * 65 + s]; if (s == 33) by33 += h[a * 65 + s]; if (s == 44) by44 += h[a * 65 + s]; }
+        printf("%-58s: %.3g shifts, wrong %llu: used amount == thread id & 63: %u, another amount: %u (of them 33: %llu, 44: %llu, no shift of the value at all: %llu); the neighbouring shift wrong: %u\n",
+               names[v], 10.0 * 2048 * 256 * outer, wrong, h[64 * 65 + 1], h[64 * 65], by33, by44, none, h[64 * 65 + 2]);
+    }
+    return 0;
+}
