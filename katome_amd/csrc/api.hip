@@ -52,9 +52,20 @@ void katome_builder_destroy(katome_builder* b) {
     delete b;
 }
 
+// first-seen order numbers window i of read r as r * 2W + i: every fixed-length batch of a build must have the same length
+// (reads of several lengths go through katome_dev_extract_var*, which numbers by window prefix sums)
+static int check_seen_len(katome_builder* b, uint32_t read_len) {
+    if (b->first_seen && b->reads_inserted && b->seen_read_len && b->seen_read_len != read_len) {
+        set_error("first-seen order: fixed-length batches of %u and %u bases in one build (use the variable-length entry points)", b->seen_read_len, read_len);
+        return KATOME_E_ARG;
+    }
+    return KATOME_OK;
+}
+
 int katome_dev_extract_fixed(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len,
                              const uint8_t* d_skip, uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
+    KCHECK(check_seen_len(b, read_len));
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     b->seen_read_len = read_len;
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, 1,
@@ -108,6 +119,7 @@ int katome_dev_extract_tiles(katome_builder* b, const uint8_t* d_packed, uint64_
                              const uint8_t* d_skip, uint64_t* d_records, void* stream) {
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (span < 1 || b->s.k + span - 1 > 95) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    KCHECK(check_seen_len(b, read_len));
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     b->seen_read_len = read_len;
     return launch_extract_fixed(b->s.k, b->rc, d_packed, n_reads, read_len, d_skip, d_records, (hipStream_t)stream, span,
@@ -120,6 +132,7 @@ int katome_dev_extract_remainder(katome_builder* b, const uint8_t* d_packed, uin
     if (span < 1 || read_len < b->s.k) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
     const uint32_t W = read_len - b->s.k + 1, first = (W / span) * span, rest = W - first;
     if (rest == 0) return KATOME_OK;
+    KCHECK(check_seen_len(b, read_len));
     PhaseScope ps(b->prof, PH_EXTRACT, (hipStream_t)stream);
     b->seen_read_len = read_len;
     b->rem_pending = true; b->rem_win0 = first; b->rem_per_read = rest;

@@ -913,6 +913,21 @@ def test_optimistic_sub_rounds_fall_back_to_the_guaranteed_number(tmp_path, firs
     assert len(seen) == 1, seen
 
 
+def test_first_seen_order_refuses_fixed_batches_of_two_lengths(oracle):
+    """window i of read r is number r * 2W + i in the reference's order: a second fixed-length batch with another W would number
+    past the first one's reads -- an error, not a graph (reads of several lengths have their own entry points)"""
+    from katome_amd import device as kd
+    from katome_amd.build import KatomePanic
+    reads = oracle.synth_reads(3, 64, 100, 5000, 0.0, 0)
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    shorter = torch.from_numpy(pack_reads_ascii(reads[:, :90]).reshape(-1).copy()).cuda()
+    b = kd.Builder(31, True, first_seen_order=True)
+    b.count_reads(packed, 64, 100, None, first_read=0)
+    with pytest.raises(KatomePanic, match="fixed-length batches of 100 and 90"):
+        b.count_reads(shorter, 64, 90, None, first_read=0)
+    b.close()
+
+
 def test_first_seen_order_bfcounter(oracle, golden_dir, tmp_path):
     from katome_amd.build import GpuGraph, InputFileType, set_global_k_sizes
     base = oracle.build_files([os.path.join(golden_dir, "data1.txt")], 31, False)
