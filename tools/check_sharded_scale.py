@@ -28,15 +28,28 @@ M = np.uint64(0x9E3779B97F4A7C15)
 
 
 def digest(g):
-    key = g.edge_key.reshape(-1)
+    nw = 1 if k <= 31 else 2
+    keys = g.edge_key.reshape(-1, nw)
+    key = keys[:, 0] if nw == 1 else (keys[:, 0] * np.uint64(0xD6E8FEB86659FD93)) ^ keys[:, 1]         # (two words folded into one for the checksums)
     h = (key * M) ^ (key >> np.uint64(29))
     s = int((h * g.edge_weight.astype(np.uint64)).sum(dtype=np.uint64))
     x = int(np.bitwise_xor.reduce(h + g.edge_weight.astype(np.uint64)))
-    nk = g.node_key.reshape(-1)
-    ns = int(((nk * M) ^ (nk >> np.uint64(31))).sum(dtype=np.uint64))
-    mask = np.uint64((1 << (2 * (k - 1))) - 1)
-    ok_src = bool((nk[g.edge_src.astype(np.int64)] == (key >> np.uint64(2))).all())
-    ok_dst = bool((nk[g.edge_dst.astype(np.int64)] == (key & mask)).all())
+    nk = g.node_key.reshape(-1, nw)
+    nf = nk.reshape(-1)
+    ns = int(((nf * M) ^ (nf >> np.uint64(31))).sum(dtype=np.uint64))
+    src, dst = g.edge_src.astype(np.int64), g.edge_dst.astype(np.int64)
+    if nw == 1:
+        mask = np.uint64((1 << (2 * (k - 1))) - 1)
+        ok_src = bool((nk[src, 0] == (keys[:, 0] >> np.uint64(2))).all())
+        ok_dst = bool((nk[dst, 0] == (keys[:, 0] & mask)).all())
+    else:                         # 128-bit keys: source = key >> 2, target = low 2(k-1) bits
+        hi, lo = keys[:, 0], keys[:, 1]
+        s_hi, s_lo = hi >> np.uint64(2), (lo >> np.uint64(2)) | (hi << np.uint64(62))
+        bits = 2 * (k - 1)
+        t_hi = hi & np.uint64((1 << (bits - 64)) - 1) if bits > 64 else np.zeros_like(hi)
+        t_lo = lo if bits >= 64 else lo & np.uint64((1 << bits) - 1)
+        ok_src = bool(((nk[src, 0] == s_hi) & (nk[src, 1] == s_lo)).all())
+        ok_dst = bool(((nk[dst, 0] == t_hi) & (nk[dst, 1] == t_lo)).all())
     return (g.n_nodes, g.n_edges, s, x, ns, int(g.edge_weight.sum(dtype=np.uint64))), ok_src and ok_dst
 
 
