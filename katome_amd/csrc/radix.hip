@@ -163,7 +163,7 @@ template <int NW, bool HAS_VAL, class Digit>
 __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                u64 n, Digit dg, const u32* __restrict__ rel,
                                                                const u64* __restrict__ chunk_off, u64* __restrict__ keys_out,
-                                                               u32* __restrict__ vals_out, u32 chunk_blocks) {
+                                                               u32* __restrict__ vals_out, u32 chunk_blocks, u32 xcd_tiles) {
     constexpr int SORT_ITEMS = SortTile<NW>::ITEMS, SORT_TILE = SortTile<NW>::KEYS;
     extern __shared__ u64 smem[];
     u64* skeys = smem;                                            // [SORT_TILE * NW]; reused for the values afterwards
@@ -173,7 +173,13 @@ __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel
     __shared__ u32 wsum[BLOCK / 64];
 
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const u64 base = (u64)blockIdx.x * SORT_TILE;
+    // Workgroups are dealt out round-robin over the 8 XCDs, each with an L2 of its own; tiles that follow each other write
+    // stretches that follow each other in every digit's run.  With xcd_tiles (tiles per XCD) > 0 workgroup i takes tile
+    // (i % 8) * xcd_tiles + i / 8, so that an XCD works through consecutive tiles and the halves of a cache line two tiles share
+    // meet in ONE L2 instead of being written back from two.
+    const u64 bid = xcd_tiles ? (u64)(blockIdx.x & 7u) * xcd_tiles + (blockIdx.x >> 3) : (u64)blockIdx.x;
+    const u64 base = bid * SORT_TILE;
+    if (base >= n) return;                                  // (the grid is rounded up to 8 x xcd_tiles)
     const u32 cnt = (u32)((n - base) < (u64)SORT_TILE ? (n - base) : (u64)SORT_TILE);
     for (u32 i = tid; i < (BLOCK / 64) * RADIX; i += BLOCK) (&whist[0][0])[i] = 0;
     __syncthreads();
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) if (w < (int)wave) woff += wsum[w];
         dstart[d] = woff + incl - run;
-        gbase[d] = chunk_off[(u64)(blockIdx.x / chunk_blocks) * RADIX + d] + rel[(u64)blockIdx.x * RADIX + d];
+        gbase[d] = chunk_off[(bid / chunk_blocks) * RADIX + d] + rel[bid * RADIX + d];
     }
     __syncthreads();
 
@@ -311,9 +317,11 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
         KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     {
+        static const bool xcd_aware = !getenv("KATOME_XCD_TILES") || atoi(getenv("KATOME_XCD_TILES")) != 0;       // (0: workgroup i takes tile i)
+        const u32 xcd_tiles = xcd_aware && pb.nblocks >= 64 ? (u32)((pb.nblocks + 7) / 8) : 0u;
         KernelScope ks((!HAS_VAL && DigitTimers<Digit>::SCATTER == K_SORT_SCATTER) ? (int)K_SORT_SCATTER_KEYS : (int)DigitTimers<Digit>::SCATTER, stream, n);
-        hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3((unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
-                           pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks);
+        hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3(xcd_tiles ? xcd_tiles * 8u : (unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
+                           pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks, xcd_tiles);
     }
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
@@ -461,8 +469,12 @@ template <int NW, bool HAS_VAL>
 __global__ __launch_bounds__(BLOCK) void run_sort_wave_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in, u64 n, u32 low,
                                                                u64* __restrict__ keys_out, u32* __restrict__ vals_out, u32* __restrict__ overflow) {
     const u32 lane = threadIdx.x & 63;
-    const u64 wave = ((u64)blockIdx.x * BLOCK + threadIdx.x) >> 6, n_waves = ((u64)gridDim.x * BLOCK) >> 6;
     const u64 n_chunks = (n + RW_OWN - 1) / RW_OWN;
+    // every XCD (workgroup index mod 8) works through its own eighth of the stretches: neighbouring stretches share cache lines,
+    // which then meet in one L2 (see radix_scatter_kernel); the grid is a multiple of 8 workgroups
+    const u64 per_xcd = (n_chunks + 7) / 8, xcd = blockIdx.x & 7u;
+    const u64 wave = ((u64)(blockIdx.x >> 3) * BLOCK + threadIdx.x) >> 6, n_waves = ((u64)(gridDim.x >> 3) * BLOCK) >> 6;
+    const u64 c_end = (xcd + 1) * per_xcd < n_chunks ? (xcd + 1) * per_xcd : n_chunks;
     // (the next stretch's loads are issued before this one is worked on)
     auto fetch = [&](u64 c, Key<NW>& key, u32& val) {
         const long long j = (long long)(c * RW_OWN) - (long long)RW_REACH + (long long)lane;
@@ -474,14 +486,14 @@ __global__ __launch_bounds__(BLOCK) void run_sort_wave_kernel(const u64* __restr
         if (HAS_VAL && there && lane >= RW_REACH && lane < RW_REACH + RW_OWN) val = vals_in[j];
     };
     Key<NW> key_next; u32 val_next;
-    fetch(wave, key_next, val_next);
-    for (u64 c = wave; c < n_chunks; c += n_waves) {
+    fetch(xcd * per_xcd + wave < c_end ? xcd * per_xcd + wave : n_chunks, key_next, val_next);
+    for (u64 c = xcd * per_xcd + wave; c < c_end; c += n_waves) {
         const long long j = (long long)(c * RW_OWN) - (long long)RW_REACH + (long long)lane;         // the record this lane looks at
         const bool there = j >= 0 && (u64)j < n;
         const bool own = there && lane >= RW_REACH && lane < RW_REACH + RW_OWN;
         const Key<NW> key = key_next;
         const u32 val = val_next;
-        fetch(c + n_waves, key_next, val_next);
+        fetch(c + n_waves < c_end ? c + n_waves : n_chunks, key_next, val_next);
         const Key<NW> top = key_shr(key, low);
         // to the left: records of the run with a key <= this one come first; to the right: only strictly smaller keys
         u32 left = 0, before = 0;
@@ -582,7 +594,7 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
             static const int by_waves = getenv("KATOME_RUN_SORT") ? atoi(getenv("KATOME_RUN_SORT")) : 2;      // 1: the staged kernel (A/B)
             KernelScope ks(HAS_VAL ? K_RUN_SORT : K_RUN_SORT_KEYS, stream, n);
             if (by_waves == 2)
-                hipLaunchKernelGGL((run_sort_wave_kernel<NW, HAS_VAL>), dim3(grid_for(n, (BLOCK / 64) * RW_OWN * 4, 256u * 32u)), dim3(BLOCK), 0, stream, kin, vin, n,
+                hipLaunchKernelGGL((run_sort_wave_kernel<NW, HAS_VAL>), dim3((grid_for(n, (BLOCK / 64) * RW_OWN * 4, 256u * 32u) + 7u) & ~7u), dim3(BLOCK), 0, stream, kin, vin, n,
                                    low, kout, vout, overflow.as<u32>());
             else
                 hipLaunchKernelGGL((run_sort_kernel<NW, HAS_VAL>), dim3(grid_for(n, RUN_TILE, 256u * 16u)), dim3(BLOCK), lds, stream, kin, vin, n, low,
