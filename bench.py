@@ -443,6 +443,14 @@ def main():
                     cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * (span // ms2) * 16 * nwm)
                 alg["expand_tiles"] = lambda launches, reads: steps * (
                     cnt["mid_tile_slots"] * 16 * nwm + cnt["distinct_mid_tiles"] * ms2 * 16 * nw)
+                if not cnt["mid_tile_slots"] and cnt["tile_slots"]:
+                    # the mid tiles were counted by sorting (api.hip, KATOME_SORTED_TILES): one scan of the big-tile table, a record
+                    # written per sub-tile, two partition passes (histogram reads the keys, scatter reads and writes the records),
+                    # the group index, the counting pass, and one list entry written per distinct mid tile
+                    pair_m = 8 * nwm + 4
+                    alg["expand_mid_tiles"] = lambda launches, reads: steps * (
+                        cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * (span // ms2) * (pair_m + 2 * (8 * nwm + 2 * pair_m) + 8 + pair_m)
+                        + cnt["distinct_mid_tiles"] * pair_m)
             else:
                 alg["expand_tiles"] = lambda launches, reads: steps * (cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * span * 16 * nw)
             sorted_last_level = bool(cnt.get("distinct_kmers")) and not cnt.get("kmer_slots")
@@ -453,8 +461,8 @@ def main():
                 last_slots, last_tiles, last_span, last_nw = ((cnt["mid_tile_slots"], cnt["distinct_mid_tiles"], ms2, nwm) if ms2
                                                               else (cnt["tile_slots"], cnt["distinct_tiles"], span, nwt))
                 n_rec = last_tiles * last_span
-                alg["expand_tiles"] = lambda launches, reads: steps * (last_slots * 16 * last_nw + n_rec * (12 + 2 * (8 + 12 + 12) + 8 + 12)
-                                                                       + n_edges * 12)
+                last_read = last_slots * 16 * last_nw if last_slots else last_tiles * (8 * last_nw + 4)      # (a table scanned, or a compact list)
+                alg["expand_tiles"] = lambda launches, reads: steps * (last_read + n_rec * (12 + 2 * (8 + 12 + 12) + 8 + 12) + n_edges * 12)
             # dev_sort: passes over the top log2(n)+9 bits (all of them if that saves fewer than four), each reading and writing
             # every (key, weight) pair once, then one more read + write by the run sort
             sort_passes[0] = _sort_passes(2 * wl.k, n_edges)
@@ -475,6 +483,13 @@ def main():
             kernel_names["expand_tiles"] = "seen_records_kernel + 2 x radix pass (HashTaggedDigit) + hash_group_index_kernel + lds_count_seen_kernel (no k-mer table; the edges leave with their sequence numbers)"
         elif sorted_last_level:
             kernel_names["expand_tiles"] = "tiles_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_kernel (no k-mer table; the edges are written here)"
+            if cnt.get("mid_span") and not cnt.get("mid_tile_slots"):
+                kernel_names["expand_tiles"] = kernel_names["expand_tiles"].replace("tiles_to_records_kernel", "list_to_records_kernel")
+                if cnt.get("tile_slots"):
+                    kernel_names["expand_mid_tiles"] = "tiles_to_records_kernel (big tiles -> mid-tile records) + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no mid-tile table; a compact list of (mid tile, count) is written)"
+                else:
+                    kernel_names["insert_tiles"] = "tile records kept aside per batch + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no tile table)"
+                    kernel_names["expand_mid_tiles"] = "list_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no mid-tile table)"
         kernels = {}                      # phases of the build (one or several launches each)
         kernel_launches = {}              # single kernels timed launch by launch inside the phases (library: KernelScope)
         reads_per_rank_step = wl.reads / world
@@ -516,24 +531,39 @@ def main():
                 last_slots, last_tiles, last_span, last_nw = ((cnt["mid_tile_slots"], cnt["distinct_mid_tiles"], ms2, _katome_lib().katome_tile_words(wl.k, ms2)) if ms2
                                                               else (cnt["tile_slots"], cnt["distinct_tiles"], span, nwt))
                 n_rec = last_tiles * last_span
+                sorted_tiles = not last_slots            # the tile levels were counted by sorting too: no tile tables, the records are cut out of compact lists
                 # (the group index is 2^16 + 1 binary searches of ~31 reads each, not a pass over the records)
                 per = 8 if (n_rec >> 16) <= 5800 else 13           # table.hip, records_to_edges_sorted: the smaller LDS table when a group fits it
                 kalg.update({"radix_scatter_kernel<HashDigit>": 2 * pair, "radix_hist_kernel<HashDigit>": 8 * nw,
-                             "tiles_to_records_kernel": 16 * last_nw + float(pair) * n_rec / last_slots,
+                             "tiles_to_records_kernel": (16 * last_nw + float(pair) * n_rec / last_slots) if last_slots else (8 * last_nw + 4 + pair * last_span),
                              "hash_group_index_kernel": 65537.0 * (31 * 8 * nw + 8) / max(n_rec, 1),
                              "lds_count_kernel": pair + float(pair) * n_edges / n_rec})
                 kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nw, nw),
                                "radix_hist_kernel<HashDigit>": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nw, nw),
-                               "tiles_to_records_kernel": "void tiles_to_records_kernel<%d, %d, %s>" % (last_nw, nw, rcs),
+                               "tiles_to_records_kernel": ("void list_to_records_kernel<%d, %d, %s>" if sorted_tiles else "void tiles_to_records_kernel<%d, %d, %s>") % (last_nw, nw, rcs),
                                "hash_group_index_kernel": "void hash_group_index_kernel<%d, %d>" % (nw, nw),
                                "lds_count_kernel": ("void lds_count_kernel<%s, %d>" % (rcs, per)) if nw == 1 else ("void lds_count_wide_kernel<%s, %d, %d>" % (rcs, per, nw))})
+            if sorted_last_level and cnt.get("mid_span") and not cnt.get("mid_tile_slots") and cnt.get("tile_slots"):
+                # the mid tiles counted by sorting: the same kernels on the big tiles' sub-tile records (two-word keys, 20 bytes)
+                ms2 = cnt["mid_span"]
+                nwm = _katome_lib().katome_tile_words(wl.k, ms2)
+                pair_m = 8 * nwm + 4
+                n_mid = cnt["distinct_tiles"] * (span // ms2)
+                per_m = 8 if (n_mid >> 16) <= 5800 else 13
+                kalg.update({"radix_scatter_kernel<HashDigit> (tile records)": 2 * pair_m, "radix_hist_kernel<HashDigit> (tile records)": 8 * nwm,
+                             "tiles_to_records_kernel (tile records)": 16 * nwt + float(pair_m) * n_mid / cnt["tile_slots"],
+                             "lds_count_kernel (tile records)": pair_m + float(pair_m) * cnt["distinct_mid_tiles"] / max(n_mid, 1)})
+                kexact.update({"radix_scatter_kernel<HashDigit> (tile records)": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nwm, nwm),
+                               "radix_hist_kernel<HashDigit> (tile records)": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nwm, nwm),
+                               "tiles_to_records_kernel (tile records)": "void tiles_to_records_kernel<%d, %d, %s>" % (nwt, nwm, rcs),
+                               "lds_count_kernel (tile records)": ("void lds_count_kernel<false, %d>" % per_m) if nwm == 1 else ("void lds_count_wide_kernel<false, %d, %d>" % (per_m, nwm))})
         for name, ph in phases.items():
             if not name.startswith("k:"):
                 continue
             kn = name[2:]
             entry = {"launches_per_step": ph["launches"] / args.steps, "avg_ms": ph["avg_ms"], "ms_per_step": ph["total_ms"] / args.steps,
                      "elements_per_step": ph["work"] / args.steps}
-            if kn in kalg and ph["work"]:
+            if kalg.get(kn) and ph["work"]:
                 # launches of one kernel may differ in size (the edge sort's passes and the small sort of the nodes without out-edges):
                 # the rate is all their bytes over all their time; "per launch" figures are the averages
                 total_bytes = kalg[kn] * ph["work"]
@@ -555,6 +585,11 @@ def main():
                 parts["expand_tiles"] = [(kexact["tiles_to_records_kernel"], 1, True), (kexact["radix_scatter_kernel<HashDigit>"], 2, True),
                                          (kexact["radix_hist_kernel<HashDigit>"], 2, True), (kexact["hash_group_index_kernel"], 1, True),
                                          (kexact["lds_count_kernel"], 1, False)]
+            if "lds_count_kernel (tile records)" in kexact:          # (the mid tiles counted by sorting: the same five kernels)
+                t_ = " (tile records)"
+                parts["expand_mid_tiles"] = [(kexact["tiles_to_records_kernel" + t_], 1, True), (kexact["radix_scatter_kernel<HashDigit>" + t_], 2, True),
+                                             (kexact["radix_hist_kernel<HashDigit>" + t_], 2, True), (kexact["hash_group_index_kernel"].replace("<1, 1>", "<2, 2>"), 1, True),
+                                             (kexact["lds_count_kernel" + t_], 1, False)]
             single = name not in parts
             parts = parts.get(name, [(exact.get(name, name), 1, name == "extract")])
             t = pmc_traffic(parts, cfg_now) if not use_dist else None
@@ -566,7 +601,7 @@ def main():
 
         def roof_kernel(kn):
             e = kernel_launches[kn]
-            streaming = kn != "lds_count_kernel"
+            streaming = not kn.startswith("lds_count_kernel")
             t = pmc_traffic([(kexact[kn], 1, streaming)], cfg_now) if kn in kexact and not use_dist else None
             return {"kernel": kexact.get(kn, kn).replace("void ", ""), "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": e["frac_of_hbm_peak"], "traffic": t["bytes_per_launch"] if t else None, "traffic_detail": t,
@@ -575,6 +610,9 @@ def main():
                     "timed": "HIP events around every launch of this kernel on the build's stream (library KernelScope)"}
         # `roofline` = the ONE kernel the step spends most time in: a kernel timed launch by launch, or a phase that is one kernel
         multi = {"sort_edges", "node_set"} | ({"expand_tiles"} if sorted_last_level else set())
+        mid_sorted = "lds_count_kernel (tile records)" in kexact
+        if mid_sorted:
+            multi.add("expand_mid_tiles")
         cands = [("k", kn, e["ms_per_step"]) for kn, e in kernel_launches.items() if "alg_bytes_per_launch" in e]
         cands += [("p", n, e["ms_per_step"]) for n, e in kernels.items() if e.get("alg_bytes_per_launch", 0) > 0 and n not in multi]
         kind, dom_name, _ = max(cands, key=lambda c: c[2])
@@ -583,12 +621,14 @@ def main():
         # whatever the footprint): say so next to the byte figures the contract asks for
         upserts = {"insert_tiles": reads_per_rank_step * (tiles if span > 1 else 0),
                    "expand_mid_tiles": cnt.get("distinct_tiles", 0) * ((span // cnt["mid_span"]) if cnt.get("mid_span") else 0)} if cnt else {}
+        if mid_sorted:
+            upserts.pop("expand_mid_tiles", None)
         if kind == "p" and upserts.get(dom_name):
             rate = upserts[dom_name] / (kernels[dom_name]["ms_per_step"] * 1e-3)
             roofline.update({"limiter": "device-scope atomics (one upsert = a compare-and-swap or an add on a random slot)", "upserts_per_step": upserts[dom_name],
                              "upserts_per_s": rate, "atomic_wall_per_s": 2.5e10, "frac_of_atomic_wall": rate / 2.5e10})
         # the largest kernel that IS bound by bytes, for comparison with earlier rounds (round 2's `roofline` was this kernel)
-        stream_cands = [c for c in cands if c[0] == "k" and c[1] not in ("lds_count_kernel",)]
+        stream_cands = [c for c in cands if c[0] == "k" and not c[1].startswith("lds_count_kernel")]
         roofline_streaming = roof_kernel(max(stream_cands, key=lambda c: c[2])[1]) if stream_cands else None
         dom = max((n for n in kernels if kernels[n].get("alg_bytes_per_launch", 0) > 0), key=lambda n: kernels[n]["ms_per_step"])
         roof = roof_phase

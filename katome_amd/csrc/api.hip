@@ -315,6 +315,7 @@ int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, h
 
 // every distinct tile adds its count to its k-mers; afterwards the tile tables are released
 int expand_tiles(katome_builder* b, hipStream_t stream) {
+    if (b->tile_recs_n) KCHECK(flush_tile_recs(b, stream));
     if (b->rest_n) KCHECK(flush_rest(b, stream));
     if (!b->tiles_ready) return KATOME_OK;
     Table* last = nullptr; uint32_t last_span = 1;
@@ -424,6 +425,68 @@ int flush_rest(katome_builder* b, hipStream_t stream) {
     return KATOME_OK;
 }
 
+// KATOME_SORTED_TILES: 1 (default) the mid tiles are counted by sorting, out of the big-tile table; 0 both tile levels in tables;
+// 2 the big tiles by sorting as well (their records kept aside per batch) -- slower at C3, kept for measurements and tests
+static int sorted_tiles_mode() {
+    static const int mode = getenv("KATOME_SORTED_TILES") ? atoi(getenv("KATOME_SORTED_TILES")) : 1;
+    return mode;
+}
+
+// the tile records kept aside (builder.h) go into the tile table after all: another consumer wants the table, or the sorted
+// counting of the tiles gave up
+static int tile_recs_valid(katome_builder* b, uint64_t* n, hipStream_t stream) {
+    *n = 0;
+    if (!b->tile_recs_n || !b->tile_recs_count.p) return KATOME_OK;
+    KCHECK_HIP(hipMemcpyAsync(n, b->tile_recs_count.p, 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+int flush_tile_recs(katome_builder* b, hipStream_t stream) {
+    if (b->tile_recs_n) {
+        const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + b->span - 1);
+        uint64_t n = 0;
+        KCHECK(tile_recs_valid(b, &n, stream));
+        b->tile_recs_n = 0;
+        for (uint64_t done = 0; done < n;) {
+            uint64_t room = 0;
+            KCHECK(ensure_table(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 4, n - done, &room, stream));
+            const uint64_t m = std::min(n - done, room);
+            PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+            KCHECK(table_insert(b->tiles, b->tile_recs.as<u64>() + done * nwt, nullptr, m, stream, nullptr));
+            done += m;
+        }
+    }
+    b->tile_recs.release(); b->tile_recs_count.release();
+    b->tile_recs_n = b->tile_recs_cap = 0;
+    b->tile_recs_closed = true;
+    return KATOME_OK;
+}
+
+// a batch's tiles kept aside as records; *kept = false: they go into the tile table
+static int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uint32_t nwt, bool* kept, hipStream_t stream) {
+    *kept = false;
+    if (b->tile_recs_n + n > b->tile_recs_cap) {
+        size_t free_b = 0, total_b = 0;
+        KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+        // room for sixteen batches like this one to begin with (a build is a dozen batches), doubled when that was too little
+        const uint64_t want = std::max<uint64_t>(b->tile_recs_cap ? b->tile_recs_cap * 2 : n * 16, b->tile_recs_n + n);
+        // (the counting needs the records twice more -- the passes' scratch and the next level)
+        if (want * 8 * nwt * 3 > free_b + b->tile_recs_cap * 8 * nwt || want * 8 * nwt > total_b / 6) { KCHECK(flush_tile_recs(b, stream)); return KATOME_OK; }
+        DevBuf grown(stream);
+        KCHECK(grown.alloc(want * 8 * nwt + 16));
+        if (b->tile_recs_n) KCHECK_HIP(hipMemcpyAsync(grown.p, b->tile_recs.p, b->tile_recs_n * 8 * nwt, hipMemcpyDeviceToDevice, stream));
+        const size_t grown_bytes = grown.bytes;
+        b->tile_recs.adopt(grown.take(), grown_bytes);
+        b->tile_recs.stream = stream;
+        b->tile_recs_cap = want;
+    }
+    if (!b->tile_recs_count.p) { KCHECK(b->tile_recs_count.alloc(8, stream)); KCHECK_HIP(hipMemsetAsync(b->tile_recs_count.p, 0, 8, stream)); }
+    KCHECK(table_keep_rest(d_records, n, nwt, false, 0, 1, 0, 0, b->tile_recs.as<u64>(), b->tile_recs_count.as<u64>(), stream));      // (the valid ones, behind the cursor)
+    b->tile_recs_n += n;
+    *kept = true;
+    return KATOME_OK;
+}
+
 // keeps a batch's left-over windows aside (see builder.h); *kept = false: they have to go into the table
 static int keep_rest(katome_builder* b, const uint64_t* d_records, uint64_t n, bool* kept, hipStream_t stream) {
     *kept = false;
@@ -464,7 +527,7 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
         }
         return KATOME_OK;
     }
-    if (!b->first_seen && !d_weights && b->tiles_ready && !b->table_ready && !b->rest_closed && b->nw <= 2 && sorted_count_mode()) {
+    if (!b->first_seen && !d_weights && (b->tiles_ready || b->tile_recs_n) && !b->table_ready && !b->rest_closed && b->nw <= 2 && sorted_count_mode()) {
         bool kept = false;
         KCHECK(keep_rest(b, d_records, n_records, &kept, stream));
         if (kept) return KATOME_OK;
@@ -540,6 +603,12 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     if (n_records == 0) return KATOME_OK;
     b->span = span;
     const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
+    if (!b->first_seen && nwt == 2 && b->nw == 1 && !b->tiles_ready && !b->table_ready && !b->tile_recs_closed && sorted_count_mode() && sorted_tiles_mode() == 2) {
+        bool kept = false;
+        PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+        KCHECK(keep_tile_recs(b, d_records, n_records, nwt, &kept, stream));
+        if (kept) return KATOME_OK;
+    }
     SeenOrigin origin;
     const bool var_tiles = b->first_seen && b->var_prefix != nullptr;
     if (var_tiles) {
@@ -575,6 +644,7 @@ int katome_dev_expand_tiles(katome_builder* b, uint64_t** d_keys, uint32_t** d_w
     KCHECK_HIP(hipSetDevice(b->s.device));
     *n_records = 0; *d_keys = nullptr; *d_weights = nullptr;
     if (b->first_seen) { set_error("first-seen order is not available on the multi-GPU route"); return KATOME_E_UNSUPPORTED; }
+    if (b->tile_recs_n) KCHECK(flush_tile_recs(b, stream));
     if (b->rest_n) KCHECK(flush_rest(b, stream));
     if (!b->tiles_ready) return KATOME_OK;
     Table* last = nullptr; uint32_t last_span = 1;
@@ -630,7 +700,77 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
         // packed key, nothing in the k-mer table yet (left-over windows were kept aside), enough tiles to be worth the extra launches
         const int sorted_count = sorted_count_mode();
         bool counted = false;
-        if (sorted_count && b->tiles_ready && !b->table_ready && !b->first_seen && b->nw <= 2) {
+        // ... and the tile levels above it the same way when the tiles were kept as records (katome_dev_insert_tiles): every level is
+        // "records -> two hash passes -> counted in LDS -> a compact list of distinct keys with their counts", the next level's
+        // records are cut out of that list (table.hip, list_to_records_kernel)
+        if (b->tile_recs_n && (b->table_ready || (b->tile_recs_n * b->span < (1ull << 22) && sorted_count != 2)))
+            KCHECK(flush_tile_recs(b, stream));      // (k-mers in the table already, or too few tiles to be worth it)
+        if (b->tile_recs_n) {
+            const uint32_t k = b->s.k, span = b->span, tile_bases = k + span - 1;
+            b->span2 = mid_span(span);
+            DevBuf t1k(stream), t1w(stream);
+            uint64_t n1 = 0, d1 = 0;
+            int rc;
+            {
+                PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+                TileLevelScope tl;
+                DevBuf ones(stream);
+                uint64_t n = 0;
+                KCHECK(tile_recs_valid(b, &n, stream));
+                if (n == 0) rc = KATOME_E_UNSUPPORTED;       // (every read was skipped: nothing to count)
+                else {
+                    KCHECK(ones.alloc((n + 1) * 4));
+                    KCHECK(dev_fill_u32(ones.as<u32>(), n, 1u, stream));
+                    rc = records_to_edges_sorted(b->tile_recs, ones, n, tile_bases, false, 0, t1k, t1w, &n1, &d1, stream);
+                }
+                if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+            }
+            if (rc == KATOME_E_UNSUPPORTED) {
+                KCHECK(flush_tile_recs(b, stream));          // (the records are all still there, in another order: into the table with them)
+            } else {
+                b->tile_recs.release(); b->tile_recs_count.release(); b->tile_recs_n = b->tile_recs_cap = 0;
+                b->stat_tiles = n1; b->stat_tile_slots = 0; b->stat_tiles2 = 0; b->stat_tile2_slots = 0;
+                const uint64_t* lk = t1k.as<u64>(); const uint32_t* lw = t1w.as<u32>();
+                uint64_t n_last = n1; uint32_t last_bases = tile_bases, last_span = span;
+                DevBuf t2k(stream), t2w(stream);
+                if (b->span2 && n1) {
+                    const uint32_t kk2 = k + b->span2 - 1, n_sub = span / b->span2;
+                    PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
+                    TileLevelScope tl;
+                    DevBuf mk(stream), mw(stream);
+                    uint64_t n_mid = 0, n2 = 0, d2 = 0;
+                    KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream));
+                    t1k.release(); t1w.release();
+                    rc = records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream);
+                    if (rc != KATOME_OK) { if (rc == KATOME_E_UNSUPPORTED) set_error("mid tiles: a hash group too large to count by sorting (KATOME_SORTED_TILES=0 counts in tables)"); return rc; }
+                    b->stat_tiles2 = n2;
+                    lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
+                }
+                DevBuf rk(stream), rw(stream);
+                uint64_t n_rec = 0, distinct = 0;
+                {
+                    PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                    uint64_t n_rest = 0;
+                    KCHECK(rest_valid(b, &n_rest, stream));
+                    KCHECK(table_list_to_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, rk, rw, &n_rec, stream, n_rest));
+                    t1k.release(); t1w.release(); t2k.release(); t2w.release();
+                    if (n_rest) {
+                        KCHECK_HIP(hipMemcpyAsync(rk.as<u64>() + n_rec * b->nw, b->rest_k.p, n_rest * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
+                        KCHECK(dev_fill_u32(rw.as<u32>() + n_rec, n_rest, 1u, stream));
+                        n_rec += n_rest;
+                    }
+                    rest_reset(b);
+                    rc = records_to_edges_sorted(rk, rw, n_rec, k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
+                    if (rc != KATOME_OK) { if (rc == KATOME_E_UNSUPPORTED) set_error("k-mers: a hash group too large to count by sorting (KATOME_SORTED_TILES=0 counts in tables)"); return rc; }
+                }
+                b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+                rk.release(); rw.release();
+                PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
+                KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * k, stream));
+                counted = true;
+            }
+        }
+        if (!counted && sorted_count && b->tiles_ready && !b->table_ready && !b->first_seen && b->nw <= 2) {
             uint64_t n_tiles = 0;
             KCHECK(table_occupied(b->tiles, &n_tiles, stream));
             const uint64_t bound = n_tiles * b->span + b->rest_n;        // the k-mer records can be no more than this
@@ -638,8 +778,33 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             const bool shapes = (b->nw == 1 && nwt <= 2) || (b->nw == 2 && (nwt == 2 || nwt == 3));      // (what tiles_to_records streams)
             if (shapes && (bound >= (1ull << 22) || (sorted_count == 2 && bound)) && (bound >> 21) <= 2900) {      // (2: however few -- tests)
                 Table* last = nullptr; uint32_t last_span = 1;
-                KCHECK(expand_to_last_level(b, &last, &last_span, stream));
-                const bool last_ok = (b->nw == 1 && last->nw <= 2) || (b->nw == 2 && (last->nw == 2 || last->nw == 3));
+                // The mid tiles are counted by sorting as well (KATOME_SORTED_TILES, default on): the big tiles' sub-tiles leave the
+                // tile table as records, two hash passes, counted in LDS into a compact list of (mid tile, count), and the k-mer
+                // records are cut out of that list -- no mid-tile table, no 7e8 128-bit upserts (C3: 45 -> 32 ms for the level).
+                // The big tiles stay in their table: their records are 20 bytes each, 8e8 of them, and sorting those costs more
+                // than the upserts do (C3: 68 against 42 ms, KATOME_SORTED_TILES=2).
+                DevBuf t2k(stream), t2w(stream);
+                uint64_t n_mid_list = 0;
+                bool mid_sorted = false;
+                const uint32_t sp2 = mid_span(b->span);
+                if (sorted_tiles_mode() && nwt == 2 && b->nw == 1 && sp2 && !b->tiles2_ready && b->tiles.cap && n_tiles) {
+                    const uint32_t kk2 = b->s.k + sp2 - 1, n_sub = b->span / sp2;
+                    PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
+                    TileLevelScope tl;
+                    DevBuf mk(stream), mw(stream);
+                    uint64_t n_mid = 0, d2 = 0;
+                    KCHECK(table_expand_tiles_to_subtiles(b->tiles, kk2, n_sub, sp2, b->rc, mk, mw, &n_mid, stream, nullptr));
+                    int rc2 = n_mid ? records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n_mid_list, &d2, stream) : KATOME_E_UNSUPPORTED;
+                    if (rc2 != KATOME_OK && rc2 != KATOME_E_UNSUPPORTED) return rc2;
+                    if (rc2 == KATOME_OK) {
+                        mid_sorted = true;           // (the big-tile table stays until the k-mers are counted: the table route's way back)
+                        b->stat_tiles = n_tiles; b->stat_tile_slots = b->tiles.cap;
+                        b->span2 = sp2; b->stat_tiles2 = n_mid_list; b->stat_tile2_slots = 0;
+                        last_span = sp2;
+                    } else { t2k.release(); t2w.release(); }
+                }
+                if (!mid_sorted) KCHECK(expand_to_last_level(b, &last, &last_span, stream));
+                const bool last_ok = mid_sorted || (b->nw == 1 && last->nw <= 2) || (b->nw == 2 && (last->nw == 2 || last->nw == 3));
                 if (last_ok) {
                     DevBuf rk(stream), rw(stream);
                     uint64_t n_rec = 0, distinct = 0;
@@ -648,6 +813,10 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                         PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
                         uint64_t n_rest = 0;
                         KCHECK(rest_valid(b, &n_rest, stream));
+                        if (mid_sorted) {
+                            KCHECK(table_list_to_records(t2k.as<u64>(), t2w.as<u32>(), n_mid_list, b->s.k + sp2 - 1, b->s.k, sp2, 1, b->rc, rk, rw, &n_rec, stream, n_rest));
+                            t2k.release(); t2w.release();
+                        } else
                         KCHECK(table_tiles_to_records_fast(*last, b->s.k, last_span, b->rc, rk, rw, &n_rec, stream, n_rest));
                         if (n_rest) {             // the left-over windows behind them, one each
                             KCHECK_HIP(hipMemcpyAsync(rk.as<u64>() + n_rec * b->nw, b->rest_k.p, n_rest * 8 * b->nw, hipMemcpyDeviceToDevice, stream));

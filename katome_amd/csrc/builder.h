@@ -44,6 +44,11 @@ struct katome_builder {
     // by-packed-key builds: the windows left over after a batch's tiles wait here (records of weight 1), so that the last level can
     // be counted by sorting (table.hip, records_to_edges_sorted) together with the tiles' k-mers; any other consumer of the k-mer
     // table flushes them into it first (flush_rest)
+    // by-packed-key builds with two-word tiles and one-word k-mers: the tiles themselves are kept as records too and counted by
+    // sorting when the edges are asked for (api.hip, count_tiles_sorted) -- no tile table, no device-scope atomics at any level
+    DevBuf tile_recs, tile_recs_count;  // tile_recs_count: device cursor -- the valid ones among them (a skipped read's tiles are all-ones)
+    uint64_t tile_recs_n = 0, tile_recs_cap = 0;      // tile_recs_n: records handed over (an upper bound of the cursor)
+    bool tile_recs_closed = false;
     DevBuf rest_k, rest_count;          // rest_count: device cursor -- how many of them are valid records (reads with N leave invalid ones)
     uint64_t rest_n = 0, rest_cap = 0;  // rest_n: records handed over so far (an upper bound of the cursor)
     bool rest_closed = false;           // too many to keep aside: from now on they go into the table directly
@@ -73,5 +78,6 @@ int builder_insert(katome_builder* b, Table& table, bool& ready, uint32_t nw, ui
 // big tiles -> mid tiles (when the span is large); leaves the tiles that hold k-mers directly in `*last`
 int expand_to_last_level(katome_builder* b, Table** last, uint32_t* last_span, hipStream_t stream);
 int expand_tiles(katome_builder* b, hipStream_t stream);       // every distinct tile adds its count to its k-mers (b->table); the tile tables go
-int flush_rest(katome_builder* b, hipStream_t stream);         // the left-over windows kept aside -> b->table
+int flush_rest(katome_builder* b, hipStream_t stream);
+int flush_tile_recs(katome_builder* b, hipStream_t stream);    // the tile records kept aside -> b->tiles         // the left-over windows kept aside -> b->table
 uint32_t mid_span(uint32_t span);      // span of the mid tiles a big tile is broken into (0: expanded directly)

@@ -83,7 +83,8 @@ struct DevBuf {
 enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGES, PH_NODE_SET, PH_RANK, PH_LABELS,
              PH_INSERT_TILES, PH_EXPAND_TILES, PH_EXPAND_MID, PH_FIRST_SEEN, PH_DEAD_PATHS, PH_SHRINK,
              K_SORT_SCATTER, K_SORT_HIST, K_RUN_SORT, K_HASH_SCATTER, K_HASH_HIST, K_OWNER_SCATTER, K_OWNER_HIST, K_PASS_OFFSETS,
-             K_RECORDS, K_GROUP_INDEX, K_LDS_COUNT, K_SRC_IDS, K_DST_MERGE, K_EXPAND, K_SORT_SCATTER_KEYS, K_RUN_SORT_KEYS, PH_COUNT };
+             K_RECORDS, K_GROUP_INDEX, K_LDS_COUNT, K_SRC_IDS, K_DST_MERGE, K_EXPAND, K_SORT_SCATTER_KEYS, K_RUN_SORT_KEYS,
+             K_TILE_HASH_SCATTER, K_TILE_HASH_HIST, K_TILE_RECORDS, K_TILE_GROUP_INDEX, K_TILE_LDS_COUNT, PH_COUNT };
 static const char* const PHASE_NAMES[PH_COUNT] = {
     "extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set", "rank", "labels", "insert_tiles", "expand_tiles",
     "expand_mid_tiles", "first_seen_order", "remove_dead_paths", "shrink",
@@ -92,7 +93,10 @@ static const char* const PHASE_NAMES[PH_COUNT] = {
     "k:tiles_to_records_kernel", "k:hash_group_index_kernel", "k:lds_count_kernel", "k:src_count+src_write", "k:dst_merge_kernel",
     "k:expand_tiles_kernel",
     // (the keys-only instantiations -- the small sort of the nodes without out-edges -- are kernels of their own in a trace)
-    "k:radix_scatter_kernel<RadixDigit> (keys only)", "k:run_sort_kernel (keys only)"};
+    "k:radix_scatter_kernel<RadixDigit> (keys only)", "k:run_sort_kernel (keys only)",
+    // (the same kernels counting a TILE level by sorting -- other record sizes, so timed apart: TileLevelScope)
+    "k:radix_scatter_kernel<HashDigit> (tile records)", "k:radix_hist_kernel<HashDigit> (tile records)", "k:tiles_to_records_kernel (tile records)",
+    "k:hash_group_index_kernel (tile records)", "k:lds_count_kernel (tile records)"};
 struct Profiler {
     bool on = false;
     struct Ev { int phase; hipEvent_t a, b; uint64_t work; };      // work: elements the launch processed (K_* entries)
@@ -109,10 +113,29 @@ struct PhaseScope {
     }
     ~PhaseScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b, 0}); current_profiler() = outer; } }
 };
+// while one of these is alive on the thread, the record/count kernels report to the K_TILE_* timers: a tile level counted by
+// sorting runs the last level's kernels on records of another size, and a timer prices ONE record size
+inline bool& counting_tile_level() { static thread_local bool on = false; return on; }
+struct TileLevelScope {
+    bool outer;
+    TileLevelScope() : outer(counting_tile_level()) { counting_tile_level() = true; }
+    ~TileLevelScope() { counting_tile_level() = outer; }
+};
+inline int tile_level_timer(int ph) {
+    if (!counting_tile_level()) return ph;
+    switch (ph) {
+        case K_HASH_SCATTER: return K_TILE_HASH_SCATTER;
+        case K_HASH_HIST:    return K_TILE_HASH_HIST;
+        case K_RECORDS:      return K_TILE_RECORDS;
+        case K_GROUP_INDEX:  return K_TILE_GROUP_INDEX;
+        case K_LDS_COUNT:    return K_TILE_LDS_COUNT;
+        default:             return ph;
+    }
+}
 // one kernel launch (or a couple of tiny ones) inside a phase; a no-op unless a profiling PhaseScope is open on this thread
 struct KernelScope {
     Profiler* p; hipStream_t s; hipEvent_t a = nullptr, b = nullptr; int phase; uint64_t work;
-    KernelScope(int ph, hipStream_t st, uint64_t elements = 0) : p(current_profiler()), s(st), phase(ph), work(elements) {
+    KernelScope(int ph, hipStream_t st, uint64_t elements = 0) : p(current_profiler()), s(st), phase(tile_level_timer(ph)), work(elements) {
         if (p && hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) (void)hipEventRecord(a, s); else p = nullptr;
     }
     ~KernelScope() { if (p) { (void)hipEventRecord(b, s); p->evs.push_back({phase, a, b, work}); } }
@@ -294,6 +317,8 @@ int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmer
 // (seen: when the tile table tracks first-seen order, the records' two sequence numbers, [n][2])
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
                                   uint64_t* n_records, hipStream_t stream, DevBuf* seen = nullptr);
+int table_list_to_records(const uint64_t* d_tiles, const uint32_t* d_counts, uint64_t n_tiles, uint32_t tile_bases, uint32_t k, uint32_t span, uint32_t stride, bool rc,
+                          DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room = 0);
 // (extra_room: records the caller will append behind them -- the windows left over after the tiles)
 int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream,
                                 uint64_t extra_room = 0);

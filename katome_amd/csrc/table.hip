@@ -614,6 +614,26 @@ __global__ __launch_bounds__(BLOCK) void tiles_to_records_kernel(const typename 
     }
 }
 
+// a compact list of distinct tiles with their counts (what the sorted counting of a level leaves) -> the (sub-window, count) records
+// of the next level: record p is sub-window p % span of tile p / span; consecutive lanes write consecutive records
+template <int NWT, int NWK, bool RC>
+__global__ __launch_bounds__(BLOCK) void list_to_records_kernel(const u64* __restrict__ tiles, const u32* __restrict__ counts, u64 n_tiles, u32 k, u32 span,
+                                                                 u32 stride, u64* __restrict__ out_keys, u32* __restrict__ out_w) {
+    const u64 n = n_tiles * span;
+    for (u64 p = (u64)blockIdx.x * BLOCK + threadIdx.x; p < n; p += (u64)gridDim.x * BLOCK) {
+        const u64 t = p / span;
+        const u32 o = (u32)(p - t * span);
+        Key<NWT> tile;
+#pragma unroll
+        for (int q = 0; q < NWT; ++q) tile.w[q] = tiles[t * NWT + q];
+        Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, stride, o);
+        if (RC) x = canonical(x, k);
+#pragma unroll
+        for (int q = 0; q < NWK; ++q) out_keys[p * NWK + q] = x.w[q];
+        out_w[p] = counts[t];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The last level without device-scope atomics.  The (k-mer, count) records of the distinct tiles are ordered by the top 16
 // bits of their hash (two stable 8-bit passes of radix.hip, HashDigit), which cuts them into 65536 groups; a workgroup takes a
@@ -1330,6 +1350,7 @@ int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint
         // two-word tiles into two-word sub-tiles without sequence numbers (C3's 60-mers into 36-mers on the sharded route): the
         // compacting kernel of the last level, 3.0 -> 0.6 ms for an eighth of C3
         dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
+        KernelScope ks(K_RECORDS, stream, tiles.cap);
         if (rc) hipLaunchKernelGGL((tiles_to_records_kernel<2, 2, true>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, stride, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
         else    hipLaunchKernelGGL((tiles_to_records_kernel<2, 2, false>), grid, block, 0, stream, tiles.slots.as<Slot2>(), tiles.cap, k, span, stride, keys.as<u64>(), weights.as<u32>(), cursor.as<u64>());
         KCHECK_HIP(hipGetLastError());
@@ -1379,6 +1400,30 @@ int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_record
     KCHECK_HIP(hipGetLastError());
     KCHECK_HIP(hipMemcpyAsync(n_records, cursor.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
+    return KATOME_OK;
+}
+
+// the (sub-window, count) records of a compact list of distinct tiles (list_to_records_kernel); extra_room: see below
+int table_list_to_records(const uint64_t* d_tiles, const uint32_t* d_counts, uint64_t n_tiles, uint32_t tile_bases, uint32_t k, uint32_t span, uint32_t stride, bool rc,
+                          DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room) {
+    const uint32_t nwt = (uint32_t)key_words_for_k(tile_bases), nwk = (uint32_t)key_words_for_k(k);
+    *n_records = n_tiles * span;
+    KCHECK(keys.alloc((*n_records + extra_room + 1) * 8 * nwk, stream));
+    KCHECK(weights.alloc((*n_records + extra_room + 1) * 4, stream));
+    if (*n_records == 0) return KATOME_OK;
+    const dim3 grid(grid_for(*n_records, BLOCK, 256u * 32u)), block(BLOCK);
+    KernelScope ks(K_RECORDS, stream, n_tiles);
+#define KATOME_LR(NWT, NWK)                                                                                                             \
+    do {                                                                                                                              \
+        if (rc) hipLaunchKernelGGL((list_to_records_kernel<NWT, NWK, true>), grid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>()); \
+        else    hipLaunchKernelGGL((list_to_records_kernel<NWT, NWK, false>), grid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>()); \
+    } while (0)
+    if (nwt == 2 && nwk == 2) KATOME_LR(2, 2);
+    else if (nwt == 2 && nwk == 1) KATOME_LR(2, 1);
+    else if (nwt == 1 && nwk == 1) KATOME_LR(1, 1);
+    else { set_error("records of a tile list: tiles of %u words into windows of %u", nwt, nwk); return KATOME_E_UNSUPPORTED; }
+#undef KATOME_LR
+    KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
 
