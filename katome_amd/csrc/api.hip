@@ -270,6 +270,10 @@ int builder_insert(katome_builder* b, Table& table, bool& ready, uint32_t nw, ui
 // span of the mid tiles a big tile is broken into: the divisor of `span` in 2..8 closest to 6; 0 = expand directly
 uint32_t mid_span(uint32_t span) {
     if (span <= 16 || getenv("KATOME_ONE_LEVEL_TILES")) return 0;
+    if (const char* e = getenv("KATOME_MID_SPAN")) {         // experiments: any divisor of the span
+        const uint32_t s = (uint32_t)atoi(e);
+        if (s >= 2 && s < span && span % s == 0) return s;
+    }
     static const uint32_t pref[] = {6, 5, 7, 4, 8, 3, 2};
     for (uint32_t s : pref) if (span % s == 0) return s;
     return 0;

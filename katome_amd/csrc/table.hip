@@ -947,36 +947,51 @@ __device__ __forceinline__ unsigned long long seen_pack(u64 read, u32 a, u32 b) 
 // all-ones) are appended behind a device cursor, one atomic per workgroup and trip.  TAGGED (first-seen order): plain k-mer records
 // that carry RC_MARK when the stored orientation is the reverse complement's become tagged records -- record i is window
 // win0 + i % per_read of read read0 + i / per_read.
+constexpr int KR_ITEMS = 8;            // records per thread and trip: one atomic on the cursor per 2048 records (one per 256 made a batch of
+                                       // 5e7 records wait 3 ms for its 2e5 turns at that one address)
 template <int NW, bool TAGGED>
 __global__ __launch_bounds__(BLOCK) void keep_rest_kernel(const u64* __restrict__ rec, u64 n, u64 read0, u32 per_read, u32 win0, u32 seq_per_read,
                                                            u64* __restrict__ out, unsigned long long* cursor) {
     constexpr int WORDS = NW + (TAGGED ? 1 : 0);
-    __shared__ u32 wtot[BLOCK / 64];
+    constexpr u32 TILE = BLOCK * KR_ITEMS;
+    __shared__ u32 wtot[KR_ITEMS][BLOCK / 64];       // valid records of row j in wave w; then their offset inside the workgroup's claim
     __shared__ unsigned long long base_sh;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (u64 i0 = (u64)blockIdx.x * BLOCK; i0 < n; i0 += (u64)gridDim.x * BLOCK) {
-        const u64 i = i0 + tid;
-        Key<NW> key = key_invalid<NW>();
-        if (i < n) {
+    const u64 lt_mask = lane ? (~0ull >> (64 - lane)) : 0ull;
+    for (u64 t0 = (u64)blockIdx.x * TILE; t0 < n; t0 += (u64)gridDim.x * TILE) {
+        Key<NW> key[KR_ITEMS];
+        u32 before[KR_ITEMS];
 #pragma unroll
-            for (int q = 0; q < NW; ++q) key.w[q] = rec[i * NW + q];
+        for (int j = 0; j < KR_ITEMS; ++j) {
+            const u64 i = t0 + (u64)j * BLOCK + tid;
+            key[j] = key_invalid<NW>();
+            if (i < n) {
+#pragma unroll
+                for (int q = 0; q < NW; ++q) key[j].w[q] = rec[i * NW + q];
+            }
+            const u64 m = __ballot(key_valid(key[j]));
+            before[j] = __popcll(m & lt_mask);
+            if (lane == 0) wtot[j][wave] = __popcll(m);
         }
-        const bool valid = key_valid(key);
-        const u64 m = __ballot(valid);
-        const u32 before = __popcll(m & (lane ? (~0ull >> (64 - lane)) : 0ull));
-        if (lane == 0) wtot[wave] = __popcll(m);
         __syncthreads();
-        u32 woff = 0, total = 0;
+        if (tid == 0) {
+            u32 run = 0;
 #pragma unroll
-        for (u32 w = 0; w < BLOCK / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
-        if (tid == 0 && total) base_sh = atomicAdd(cursor, (unsigned long long)total);
+            for (int j = 0; j < KR_ITEMS; ++j)
+#pragma unroll
+                for (u32 w = 0; w < BLOCK / 64; ++w) { const u32 c = wtot[j][w]; wtot[j][w] = run; run += c; }
+            base_sh = run ? atomicAdd(cursor, (unsigned long long)run) : 0ull;
+        }
         __syncthreads();
-        if (valid) {
-            const u64 at = (base_sh + woff + before) * WORDS;
-            const bool flipped = TAGGED && (key.w[0] & RC_MARK) != 0;
-            if (TAGGED) key.w[0] &= ~RC_MARK;
 #pragma unroll
-            for (int q = 0; q < NW; ++q) out[at + q] = key.w[q];
+        for (int j = 0; j < KR_ITEMS; ++j) {
+            if (!key_valid(key[j])) continue;
+            const u64 i = t0 + (u64)j * BLOCK + tid;
+            const u64 at = (base_sh + wtot[j][wave] + before[j]) * WORDS;
+            const bool flipped = TAGGED && (key[j].w[0] & RC_MARK) != 0;
+            if (TAGGED) key[j].w[0] &= ~RC_MARK;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) out[at + q] = key[j].w[q];
             if (TAGGED) {
                 const u64 read = read0 + i / per_read;
                 const u32 w = win0 + (u32)(i % per_read), fwd = w, rev = seq_per_read - 1 - w;      // (insert_kernel's P and Q within the read)
@@ -1462,7 +1477,7 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
 int table_keep_rest(const uint64_t* d_rec, uint64_t n, uint32_t nw, bool tagged, uint64_t read0, uint32_t per_read, uint32_t win0, uint32_t seq_per_read,
                     uint64_t* d_out, uint64_t* d_cursor, hipStream_t stream) {
     if (n == 0) return KATOME_OK;
-    const dim3 grid(grid_for(n, BLOCK, 256u * 16u)), block(BLOCK);
+    const dim3 grid(grid_for(n, BLOCK * KR_ITEMS, 256u * 8u)), block(BLOCK);
     unsigned long long* cur = reinterpret_cast<unsigned long long*>(d_cursor);
     if (!per_read) per_read = 1;
 #define KATOME_KR(NWV, TAG) hipLaunchKernelGGL((keep_rest_kernel<NWV, TAG>), grid, block, 0, stream, d_rec, n, read0, per_read, win0, seq_per_read, d_out, cur)
