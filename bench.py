@@ -443,7 +443,16 @@ def main():
                     cnt["tile_slots"] * 16 * nwt + cnt["distinct_tiles"] * (span // ms2) * 16 * nwm)
                 alg["expand_tiles"] = lambda launches, reads: steps * (
                     cnt["mid_tile_slots"] * 16 * nwm + cnt["distinct_mid_tiles"] * ms2 * 16 * nw)
-                if not cnt["mid_tile_slots"] and cnt["tile_slots"]:
+                if not cnt["mid_tile_slots"] and not cnt["tile_slots"]:
+                    # all three levels by sorting: a batch's tile records copied behind those kept so far (read + write), then two
+                    # partition passes, the group index and the counting pass over all of them, one list entry per distinct tile;
+                    # the mid level the same, its records cut out of that list
+                    pair_t, pair_m = 8 * nwt + 4, 8 * nwm + 4
+                    alg["insert_tiles"] = lambda launches, reads: reads * tiles * (16 * nwt + 4 + 2 * (8 * nwt + 2 * pair_t) + 8 + pair_t) + steps * cnt["distinct_tiles"] * pair_t
+                    alg["expand_mid_tiles"] = lambda launches, reads: steps * (
+                        cnt["distinct_tiles"] * pair_t + cnt["distinct_tiles"] * (span // ms2) * (pair_m + 2 * (8 * nwm + 2 * pair_m) + 8 + pair_m)
+                        + cnt["distinct_mid_tiles"] * pair_m)
+                elif not cnt["mid_tile_slots"] and cnt["tile_slots"]:
                     # the mid tiles were counted by sorting (api.hip, KATOME_SORTED_TILES): one scan of the big-tile table, a record
                     # written per sub-tile, two partition passes (histogram reads the keys, scatter reads and writes the records),
                     # the group index, the counting pass, and one list entry written per distinct mid tile
@@ -543,19 +552,23 @@ def main():
                                "tiles_to_records_kernel": ("void list_to_records_kernel<%d, %d, %s>" if sorted_tiles else "void tiles_to_records_kernel<%d, %d, %s>") % (last_nw, nw, rcs),
                                "hash_group_index_kernel": "void hash_group_index_kernel<%d, %d>" % (nw, nw),
                                "lds_count_kernel": ("void lds_count_kernel<%s, %d>" % (rcs, per)) if nw == 1 else ("void lds_count_wide_kernel<%s, %d, %d>" % (rcs, per, nw))})
-            if sorted_last_level and cnt.get("mid_span") and not cnt.get("mid_tile_slots") and cnt.get("tile_slots"):
-                # the mid tiles counted by sorting: the same kernels on the big tiles' sub-tile records (two-word keys, 20 bytes)
+            if sorted_last_level and cnt.get("mid_span") and not cnt.get("mid_tile_slots") and nwt == _katome_lib().katome_tile_words(wl.k, cnt["mid_span"]):
+                # the tile levels counted by sorting: the same kernels on tile records (two-word keys, 20 bytes) -- the mid tiles'
+                # (cut out of the big-tile table, or out of the list of big tiles) and, without a tile table, the big tiles' as well
                 ms2 = cnt["mid_span"]
                 nwm = _katome_lib().katome_tile_words(wl.k, ms2)
                 pair_m = 8 * nwm + 4
                 n_mid = cnt["distinct_tiles"] * (span // ms2)
                 per_m = 8 if (n_mid >> 16) <= 5800 else 13
+                n_big = 0 if cnt["tile_slots"] else reads_per_rank_step * tiles          # (tile records kept aside: counted here too)
+                n_all, d_all = n_mid + n_big, cnt["distinct_mid_tiles"] + (cnt["distinct_tiles"] if n_big else 0)
                 kalg.update({"radix_scatter_kernel<HashDigit> (tile records)": 2 * pair_m, "radix_hist_kernel<HashDigit> (tile records)": 8 * nwm,
-                             "tiles_to_records_kernel (tile records)": 16 * nwt + float(pair_m) * n_mid / cnt["tile_slots"],
-                             "lds_count_kernel (tile records)": pair_m + float(pair_m) * cnt["distinct_mid_tiles"] / max(n_mid, 1)})
+                             "tiles_to_records_kernel (tile records)": (16 * nwt + float(pair_m) * n_mid / cnt["tile_slots"]) if cnt["tile_slots"]
+                             else pair_m + pair_m * (span // ms2),
+                             "lds_count_kernel (tile records)": pair_m + float(pair_m) * d_all / max(n_all, 1)})
                 kexact.update({"radix_scatter_kernel<HashDigit> (tile records)": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nwm, nwm),
                                "radix_hist_kernel<HashDigit> (tile records)": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nwm, nwm),
-                               "tiles_to_records_kernel (tile records)": "void tiles_to_records_kernel<%d, %d, %s>" % (nwt, nwm, rcs),
+                               "tiles_to_records_kernel (tile records)": ("void tiles_to_records_kernel<%d, %d, %s>" if cnt["tile_slots"] else "void list_to_records_kernel<%d, %d, %s>") % (nwt, nwm, rcs),
                                "lds_count_kernel (tile records)": ("void lds_count_kernel<false, %d>" % per_m) if nwm == 1 else ("void lds_count_wide_kernel<false, %d, %d>" % (per_m, nwm))})
         for name, ph in phases.items():
             if not name.startswith("k:"):
@@ -613,6 +626,9 @@ def main():
         mid_sorted = "lds_count_kernel (tile records)" in kexact
         if mid_sorted:
             multi.add("expand_mid_tiles")
+        big_sorted = bool(cnt) and span > 1 and sorted_last_level and not cnt.get("tile_slots")
+        if big_sorted:
+            multi.add("insert_tiles")
         cands = [("k", kn, e["ms_per_step"]) for kn, e in kernel_launches.items() if "alg_bytes_per_launch" in e]
         cands += [("p", n, e["ms_per_step"]) for n, e in kernels.items() if e.get("alg_bytes_per_launch", 0) > 0 and n not in multi]
         kind, dom_name, _ = max(cands, key=lambda c: c[2])
@@ -623,6 +639,8 @@ def main():
                    "expand_mid_tiles": cnt.get("distinct_tiles", 0) * ((span // cnt["mid_span"]) if cnt.get("mid_span") else 0)} if cnt else {}
         if mid_sorted:
             upserts.pop("expand_mid_tiles", None)
+        if big_sorted:
+            upserts.pop("insert_tiles", None)
         if kind == "p" and upserts.get(dom_name):
             rate = upserts[dom_name] / (kernels[dom_name]["ms_per_step"] * 1e-3)
             roofline.update({"limiter": "device-scope atomics (one upsert = a compare-and-swap or an add on a random slot)", "upserts_per_step": upserts[dom_name],

@@ -429,10 +429,11 @@ int flush_rest(katome_builder* b, hipStream_t stream) {
     return KATOME_OK;
 }
 
-// KATOME_SORTED_TILES: 1 (default) the mid tiles are counted by sorting, out of the big-tile table; 0 both tile levels in tables;
-// 2 the big tiles by sorting as well (their records kept aside per batch) -- slower at C3, kept for measurements and tests
+// KATOME_SORTED_TILES: 2 (default) both tile levels are counted by sorting -- the big tiles' records are kept aside batch by batch
+// (two-word tiles, by packed key; anything else takes the table) --, 1 the big tiles in their table and only the mid tiles by
+// sorting, out of that table; 0 both tile levels in tables.  C3: 222 / 232 / 257 ms per build.
 static int sorted_tiles_mode() {
-    static const int mode = getenv("KATOME_SORTED_TILES") ? atoi(getenv("KATOME_SORTED_TILES")) : 1;
+    static const int mode = getenv("KATOME_SORTED_TILES") ? atoi(getenv("KATOME_SORTED_TILES")) : 2;
     return mode;
 }
 
@@ -472,10 +473,18 @@ static int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t
     if (b->tile_recs_n + n > b->tile_recs_cap) {
         size_t free_b = 0, total_b = 0;
         KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
+        uint64_t pool[3] = {0, 0, 0};
+        dev_cache_stats(b->s.device, pool);
+        free_b += pool[1];                         // (what the caching allocator holds idle is as good as free)
         // room for sixteen batches like this one to begin with (a build is a dozen batches), doubled when that was too little
         const uint64_t want = std::max<uint64_t>(b->tile_recs_cap ? b->tile_recs_cap * 2 : n * 16, b->tile_recs_n + n);
         // (the counting needs the records twice more -- the passes' scratch and the next level)
-        if (want * 8 * nwt * 3 > free_b + b->tile_recs_cap * 8 * nwt || want * 8 * nwt > total_b / 6) { KCHECK(flush_tile_recs(b, stream)); return KATOME_OK; }
+        // (KATOME_TILE_RECS_LIMIT: no more records than this are kept aside -- tests; by default a sixth of the card's memory)
+        static const uint64_t limit = getenv("KATOME_TILE_RECS_LIMIT") ? strtoull(getenv("KATOME_TILE_RECS_LIMIT"), nullptr, 10) : ~0ull;
+        if (b->tile_recs_n + n > limit || want * 8 * nwt * 3 > free_b + b->tile_recs_cap * 8 * nwt || want * 8 * nwt > total_b / 6) {
+            KCHECK(flush_tile_recs(b, stream));
+            return KATOME_OK;
+        }
         DevBuf grown(stream);
         KCHECK(grown.alloc(want * 8 * nwt + 16));
         if (b->tile_recs_n) KCHECK_HIP(hipMemcpyAsync(grown.p, b->tile_recs.p, b->tile_recs_n * 8 * nwt, hipMemcpyDeviceToDevice, stream));
@@ -602,7 +611,7 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     hipStream_t stream = (hipStream_t)stream_;
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
-    if (span < 2 || b->s.k + span - 1 > 95 || (b->tiles_ready && span != b->span)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    if (span < 2 || b->s.k + span - 1 > 95 || ((b->tiles_ready || b->tile_recs_n) && span != b->span)) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
     if (b->first_seen && b->var_prefix && b->s.k + span - 1 > 95) { set_error("variable-length reads: tiles of at most 95 bases"); return KATOME_E_ARG; }
     if (n_records == 0) return KATOME_OK;
     b->span = span;

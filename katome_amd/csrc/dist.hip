@@ -585,6 +585,7 @@ int katome_dist_create(const katome_settings* s, katome_comm* comm, katome_dist_
     katome_dist_builder* d = new (std::nothrow) katome_dist_builder();
     if (!d) { katome_builder_destroy(b); set_error("out of host memory"); return KATOME_E_OOM; }
     d->s = *s; d->comm = comm; d->b = b; d->nw = b->nw; d->rc = b->rc; d->first_seen = b->first_seen;
+    b->tile_recs_closed = true;                   // (the sharded routes read the tile TABLE; tiles are never kept aside as records here)
     d->local_first = comm->world() <= 2;
     if (const char* e = getenv("KATOME_DIST_ROUTE")) d->local_first = strcmp(e, "local") == 0 ? true : strcmp(e, "tiles") == 0 ? false : d->local_first;
     *out = d;

@@ -784,8 +784,68 @@ def test_round_one_paths_give_the_same_arrays(tmp_path):
     # (KATOME_SORTED_COUNT=2: the last level counted by sorting however small the input -- by default only from 4 M records on)
     for extra in ({"KATOME_DST_RANK": "1"}, {"KATOME_SORT_NODES": "1"}, {"KATOME_FULL_SORT": "1"},
                   {"KATOME_DST_RANK": "1", "KATOME_SORT_NODES": "1"}, {"KATOME_SORTED_COUNT": "2"}, {"KATOME_SORTED_COUNT": "0"},
-                  {"KATOME_RUN_SORT": "1"}):        # (the run sort staged in LDS instead of by wave shuffles)
+                  {"KATOME_RUN_SORT": "1"},         # (the run sort staged in LDS instead of by wave shuffles)
+                  # the tile levels: all three by sorting (the default from 4 M records on), the big tiles in their table, both in tables
+                  {"KATOME_SORTED_COUNT": "2", "KATOME_SORTED_TILES": "1"}, {"KATOME_SORTED_COUNT": "2", "KATOME_SORTED_TILES": "0"},
+                  {"KATOME_SORTED_COUNT": "2", "KATOME_MID_SPAN": "10"}):
         assert run(extra) == want, extra
+
+
+_KEPT_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+n, L, k = 6000, 150, 31
+reads = o.synth_reads(11, n, L, 25000, 4e-3, 3)
+has_n = (reads == ord("N")).any(axis=1)
+clean = reads.copy()
+clean[clean == ord("N")] = ord("A")
+packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+ref = o.build_ascii(reads, k, True)
+want = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
+for batch, plain in ((100, False), (100, True), (6000, False)):
+    b = kd.Builder(k, True, table_slots_hint=1 << 14)
+    for i, r0 in enumerate(range(0, n, batch)):
+        if plain and i % 7 == 3:     # a batch counted window by window in between: its records wait with the tiles' (left-over windows do the same)
+            b.insert(b.extract_fixed(packed, min(batch, n - r0), L, skip, first_read=r0))
+        else:
+            b.count_reads(packed, min(batch, n - r0), L, skip, first_read=r0)
+    dg = b.finalize()
+    c = b.counts()
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
+    print("KEPT", batch, int(plain), dg.n_edges, int(len(got) == dg.n_edges and got == want), c["tile_slots"], c["kmer_slots"])
+    b.close()
+"""
+
+
+def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
+    """the big tiles of a build by packed key are kept aside as records and counted by sorting (api.hip keep_tile_recs): sixty
+    batches (room for sixteen to begin with, doubled when that is too little), reads with N in them (their records are dropped),
+    batches counted window by window in between -- and, in a second process, a limit on what may be kept that is reached half-way
+    (the records kept so far go into the tile table, later batches too) -- against the oracle"""
+    import subprocess
+    script = tmp_path / "kept.py"
+    script.write_text(_KEPT_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for limit in (None, "9000"):
+        env = dict(os.environ, KATOME_SORTED_COUNT="2")
+        if limit:
+            env["KATOME_TILE_RECS_LIMIT"] = limit
+        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        rows = [line.split() for line in out.stdout.splitlines() if line.startswith("KEPT ")]
+        assert len(rows) == 3
+        for r in rows:
+            assert r[4] == "1", (limit, r)
+        assert rows[0][3] == rows[1][3] == rows[2][3]
+        if limit:
+            assert rows[0][5] != "0" and rows[2][5] != "0"     # the tile table took over (6000 reads are 24000 tiles)
+        else:
+            assert rows[0][5] == "0" and rows[2][5] == "0"     # no tile table: counted by sorting
 
 
 _WIDE_SCRIPT = r"""
