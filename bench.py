@@ -448,7 +448,8 @@ def main():
                     # partition passes, the group index and the counting pass over all of them, one list entry per distinct tile;
                     # the mid level the same, its records cut out of that list
                     pair_t, pair_m = 8 * nwt + 4, 8 * nwm + 4
-                    alg["insert_tiles"] = lambda launches, reads: reads * tiles * (16 * nwt + 4 + 2 * (8 * nwt + 2 * pair_t) + 8 + pair_t) + steps * cnt["distinct_tiles"] * pair_t
+                    # (the big tiles' records carry no counts: 8 * nwt bytes each through the passes)
+                    alg["insert_tiles"] = lambda launches, reads: reads * tiles * (16 * nwt + 2 * (8 * nwt + 2 * 8 * nwt) + 8 + 8 * nwt) + steps * cnt["distinct_tiles"] * pair_t
                     alg["expand_mid_tiles"] = lambda launches, reads: steps * (
                         cnt["distinct_tiles"] * pair_t + cnt["distinct_tiles"] * (span // ms2) * (pair_m + 2 * (8 * nwm + 2 * pair_m) + 8 + pair_m)
                         + cnt["distinct_mid_tiles"] * pair_m)
@@ -562,10 +563,12 @@ def main():
                 per_m = 8 if (n_mid >> 16) <= 5800 else 13
                 n_big = 0 if cnt["tile_slots"] else reads_per_rank_step * tiles          # (tile records kept aside: counted here too)
                 n_all, d_all = n_mid + n_big, cnt["distinct_mid_tiles"] + (cnt["distinct_tiles"] if n_big else 0)
-                kalg.update({"radix_scatter_kernel<HashDigit> (tile records)": 2 * pair_m, "radix_hist_kernel<HashDigit> (tile records)": 8 * nwm,
+                # (the big tiles' records carry no counts -- one each --, so their passes move the 16-byte keys only)
+                rec_big = 8 * nwt
+                kalg.update({"radix_scatter_kernel<HashDigit> (tile records)": 2.0 * (pair_m * n_mid + rec_big * n_big) / max(n_all, 1), "radix_hist_kernel<HashDigit> (tile records)": 8 * nwm,
                              "tiles_to_records_kernel (tile records)": (16 * nwt + float(pair_m) * n_mid / cnt["tile_slots"]) if cnt["tile_slots"]
                              else pair_m + pair_m * (span // ms2),
-                             "lds_count_kernel (tile records)": pair_m + float(pair_m) * d_all / max(n_all, 1)})
+                             "lds_count_kernel (tile records)": (float(pair_m) * n_mid + rec_big * n_big + float(pair_m) * d_all) / max(n_all, 1)})
                 kexact.update({"radix_scatter_kernel<HashDigit> (tile records)": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nwm, nwm),
                                "radix_hist_kernel<HashDigit> (tile records)": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nwm, nwm),
                                "tiles_to_records_kernel (tile records)": ("void tiles_to_records_kernel<%d, %d, %s>" if cnt["tile_slots"] else "void list_to_records_kernel<%d, %d, %s>") % (nwt, nwm, rcs),

@@ -432,6 +432,11 @@ int flush_rest(katome_builder* b, hipStream_t stream) {
 // KATOME_SORTED_TILES: 2 (default) both tile levels are counted by sorting -- the big tiles' records are kept aside batch by batch
 // (two-word tiles, by packed key; anything else takes the table) --, 1 the big tiles in their table and only the mid tiles by
 // sorting, out of that table; 0 both tile levels in tables.  C3: 222 / 232 / 257 ms per build.
+// KATOME_SORTED_FAIL=mid|last: that level's counting by sorting reports a group too large -- tests of the way back into the tables
+static bool sorted_fail(const char* level) {
+    static const char* at = getenv("KATOME_SORTED_FAIL");
+    return at && !strcmp(at, level);
+}
 static int sorted_tiles_mode() {
     static const int mode = getenv("KATOME_SORTED_TILES") ? atoi(getenv("KATOME_SORTED_TILES")) : 2;
     return mode;
@@ -732,8 +737,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 KCHECK(tile_recs_valid(b, &n, stream));
                 if (n == 0) rc = KATOME_E_UNSUPPORTED;       // (every read was skipped: nothing to count)
                 else {
-                    KCHECK(ones.alloc((n + 1) * 4));
-                    KCHECK(dev_fill_u32(ones.as<u32>(), n, 1u, stream));
+                    // (`ones` stays empty: records without weights count once each, and the passes move 16 bytes a record, not 20)
                     rc = records_to_edges_sorted(b->tile_recs, ones, n, tile_bases, false, 0, t1k, t1w, &n1, &d1, stream);
                 }
                 if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
@@ -742,10 +746,12 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 KCHECK(flush_tile_recs(b, stream));          // (the records are all still there, in another order: into the table with them)
             } else {
                 b->tile_recs.release(); b->tile_recs_count.release(); b->tile_recs_n = b->tile_recs_cap = 0;
+                b->tile_recs_closed = true;
                 b->stat_tiles = n1; b->stat_tile_slots = 0; b->stat_tiles2 = 0; b->stat_tile2_slots = 0;
                 const uint64_t* lk = t1k.as<u64>(); const uint32_t* lw = t1w.as<u32>();
                 uint64_t n_last = n1; uint32_t last_bases = tile_bases, last_span = span;
                 DevBuf t2k(stream), t2w(stream);
+                rc = KATOME_OK;
                 if (b->span2 && n1) {
                     const uint32_t kk2 = k + b->span2 - 1, n_sub = span / b->span2;
                     PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
@@ -753,34 +759,51 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     DevBuf mk(stream), mw(stream);
                     uint64_t n_mid = 0, n2 = 0, d2 = 0;
                     KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream));
-                    t1k.release(); t1w.release();
-                    rc = records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream);
-                    if (rc != KATOME_OK) { if (rc == KATOME_E_UNSUPPORTED) set_error("mid tiles: a hash group too large to count by sorting (KATOME_SORTED_TILES=0 counts in tables)"); return rc; }
-                    b->stat_tiles2 = n2;
-                    lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
+                    rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED : records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream);
+                    if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+                    if (rc == KATOME_OK) {
+                        b->stat_tiles2 = n2;
+                        lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
+                    }
                 }
-                DevBuf rk(stream), rw(stream);
-                uint64_t n_rec = 0, distinct = 0;
-                {
+                uint64_t distinct = 0;
+                if (rc == KATOME_OK) {
                     PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-                    uint64_t n_rest = 0;
+                    DevBuf rk(stream), rw(stream);
+                    uint64_t n_rec = 0, n_rest = 0;
                     KCHECK(rest_valid(b, &n_rest, stream));
                     KCHECK(table_list_to_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, rk, rw, &n_rec, stream, n_rest));
-                    t1k.release(); t1w.release(); t2k.release(); t2w.release();
+                    t2k.release(); t2w.release();
                     if (n_rest) {
                         KCHECK_HIP(hipMemcpyAsync(rk.as<u64>() + n_rec * b->nw, b->rest_k.p, n_rest * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
                         KCHECK(dev_fill_u32(rw.as<u32>() + n_rec, n_rest, 1u, stream));
                         n_rec += n_rest;
                     }
-                    rest_reset(b);
-                    rc = records_to_edges_sorted(rk, rw, n_rec, k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
-                    if (rc != KATOME_OK) { if (rc == KATOME_E_UNSUPPORTED) set_error("k-mers: a hash group too large to count by sorting (KATOME_SORTED_TILES=0 counts in tables)"); return rc; }
+                    rc = sorted_fail("last") ? KATOME_E_UNSUPPORTED
+                        : records_to_edges_sorted(rk, rw, n_rec, k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
+                    if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
                 }
-                b->stat_kmers = distinct; b->stat_kmer_slots = 0;
-                rk.release(); rw.release();
-                PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
-                KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * k, stream));
-                counted = true;
+                if (rc == KATOME_OK) {
+                    t1k.release(); t1w.release();
+                    rest_reset(b);
+                    b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+                    PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
+                    KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * k, stream));
+                    counted = true;
+                } else {
+                    // a level below gave up (a hash group too large for the LDS route): the distinct big tiles go into the tile table
+                    // with their counts, and the build goes on from there as if they had been counted in it
+                    b->n_edges = 0;
+                    t2k.release(); t2w.release();
+                    for (uint64_t done = 0; done < n1;) {
+                        uint64_t room = 0;
+                        KCHECK(ensure_table(b, b->tiles, b->tiles_ready, (uint32_t)key_words_for_k(tile_bases), b->s.table_slots_hint / 4, n1 - done, &room, stream));
+                        const uint64_t m = std::min(n1 - done, room);
+                        PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+                        KCHECK(table_insert(b->tiles, t1k.as<u64>() + done * key_words_for_k(tile_bases), t1w.as<u32>() + done, m, stream, nullptr));
+                        done += m;
+                    }
+                }
             }
         }
         if (!counted && sorted_count && b->tiles_ready && !b->table_ready && !b->first_seen && b->nw <= 2) {
@@ -807,7 +830,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     DevBuf mk(stream), mw(stream);
                     uint64_t n_mid = 0, d2 = 0;
                     KCHECK(table_expand_tiles_to_subtiles(b->tiles, kk2, n_sub, sp2, b->rc, mk, mw, &n_mid, stream, nullptr));
-                    int rc2 = n_mid ? records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n_mid_list, &d2, stream) : KATOME_E_UNSUPPORTED;
+                    int rc2 = (n_mid && !sorted_fail("mid")) ? records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n_mid_list, &d2, stream) : KATOME_E_UNSUPPORTED;
                     if (rc2 != KATOME_OK && rc2 != KATOME_E_UNSUPPORTED) return rc2;
                     if (rc2 == KATOME_OK) {
                         mid_sorted = true;           // (the big-tile table stays until the k-mers are counted: the table route's way back)
@@ -836,7 +859,8 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                             KCHECK(dev_fill_u32(rw.as<u32>() + n_rec, n_rest, 1u, stream));
                             n_rec += n_rest;
                         }
-                        rc = records_to_edges_sorted(rk, rw, n_rec, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
+                        rc = sorted_fail("last") ? KATOME_E_UNSUPPORTED
+                            : records_to_edges_sorted(rk, rw, n_rec, b->s.k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
                         if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
                     }
                     if (rc == KATOME_OK) {

@@ -845,7 +845,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                   if (i < hi) {
 #pragma unroll
                       for (int q = 0; q < NW; ++q) kv[u].w[q] = keys[i * NW + q];
-                      wv[u] = wts[i];
+                      wv[u] = wts ? wts[i] : 1u;         // (no weights: every record counts once -- a level's records straight from the reads)
                   }
               }
 #pragma unroll
@@ -1606,9 +1606,13 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     if ((n >> 16) > (u64)LC_MAX_ROUNDS * LcTable<13>::FILL) return KATOME_E_UNSUPPORTED;
     const u64* ko = nullptr; const u32* wo = nullptr;
     u32 gbits = 16;
+    // (weights not allocated: every record counts once; the passes move keys only.  Two-word keys: lds_count_wide_kernel)
+    const bool unit = weights.p == nullptr;
+    if (unit && (nw != 2 || split)) { set_error("records without weights: two-word keys"); return KATOME_E_ARG; }
     {
         DevBuf kb(stream), wb(stream);
-        KCHECK(kb.alloc((n + 1) * 8 * nw)); KCHECK(wb.alloc((n + 1) * 4));
+        KCHECK(kb.alloc((n + 1) * 8 * nw));
+        if (!unit) KCHECK(wb.alloc((n + 1) * 4));
         // two passes: the first one's output goes to the scratch, the second one's lands in keys / weights again
         if (split) KCHECK(dev_hash_order_core(keys.as<u64>(), weights.as<u32>(), n, split->core_shift, split->core_bases, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(),
                                               weights.as<u32>(), &ko, &wo, &gbits, stream));

@@ -825,15 +825,18 @@ for batch, plain in ((100, False), (100, True), (6000, False)):
 def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
     """the big tiles of a build by packed key are kept aside as records and counted by sorting (api.hip keep_tile_recs): sixty
     batches (room for sixteen to begin with, doubled when that is too little), reads with N in them (their records are dropped),
-    batches counted window by window in between -- and, in a second process, a limit on what may be kept that is reached half-way
-    (the records kept so far go into the tile table, later batches too) -- against the oracle"""
+    batches counted window by window in between -- and, in processes of their own, a limit on what may be kept that is reached
+    half-way (the records kept so far go into the tile table, later batches too) and a level below that gives up (the distinct big
+    tiles go into the tile table with their counts) -- against the oracle"""
     import subprocess
     script = tmp_path / "kept.py"
     script.write_text(_KEPT_SCRIPT)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for limit in (None, "9000"):
+    for limit in (None, "9000", "mid", "last"):
         env = dict(os.environ, KATOME_SORTED_COUNT="2")
-        if limit:
+        if limit in ("mid", "last"):          # that level gives up: the distinct big tiles go into the tile table with their counts
+            env["KATOME_SORTED_FAIL"] = limit
+        elif limit:
             env["KATOME_TILE_RECS_LIMIT"] = limit
         out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
