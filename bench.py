@@ -606,6 +606,12 @@ def main():
                 parts["expand_mid_tiles"] = [(kexact["tiles_to_records_kernel" + t_], 1, True), (kexact["radix_scatter_kernel<HashDigit>" + t_], 2, True),
                                              (kexact["radix_hist_kernel<HashDigit>" + t_], 2, True), (kexact["hash_group_index_kernel"].replace("<1, 1>", "<2, 2>"), 1, True),
                                              (kexact["lds_count_kernel" + t_], 1, False)]
+                if not cnt.get("tile_slots"):      # (... and the big tiles: their records copied batch by batch, keys-only passes)
+                    n_batches = -(-int(reads_per_rank_step) // int(batch_reads))
+                    parts["insert_tiles"] = [("void keep_rest_kernel<%d, false>" % nwt, n_batches, True),
+                                             (kexact["radix_scatter_kernel<HashDigit>" + t_].replace(", true,", ", false,"), 2, True),
+                                             (kexact["radix_hist_kernel<HashDigit>" + t_], 2, True), (kexact["hash_group_index_kernel"].replace("<1, 1>", "<2, 2>"), 1, True),
+                                             (kexact["lds_count_kernel" + t_], 1, False)]
             single = name not in parts
             parts = parts.get(name, [(exact.get(name, name), 1, name == "extract")])
             t = pmc_traffic(parts, cfg_now) if not use_dist else None
@@ -671,6 +677,9 @@ def main():
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
             "roofline": roofline, "roofline_streaming": roofline_streaming, "roofline_phase": roof_phase(dom), "roofline_extract": roof_phase("extract"),
+            # the three counting levels (big tiles, mid tiles, k-mers), each a phase of several kernels: bytes of the phase / its time,
+            # and the HBM traffic of its kernels from the committed PMC passes
+            "roofline_levels": [roof_phase(n) for n in ("insert_tiles", "expand_mid_tiles", "expand_tiles") if kernels.get(n, {}).get("alg_bytes_per_launch", 0) > 0],
             "kernels": kernels, "kernel_launches": kernel_launches, "counts": cnt, "source_id": source_id(),
         }
         if args.prune:
