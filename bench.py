@@ -615,10 +615,17 @@ def main():
             single = name not in parts
             parts = parts.get(name, [(exact.get(name, name), 1, name == "extract")])
             t = pmc_traffic(parts, cfg_now) if not use_dist else None
+            lps = kernels[name]["launches_per_step"]
+            # (a phase timed once per batch and once at the end -- the big tiles kept aside, then counted -- has its kernels listed
+            # per STEP above: its traffic per "launch" is the step's over the step's launches, as its algorithmic bytes are)
+            per_step = name == "insert_tiles" and name in multi
+            traffic = (t["bytes_per_launch"] / (lps if per_step else 1)) if t else None
             return {"kernel": exact[name].replace("void ", "") if (single and name in exact) else None, "kernels": label, "phase": name, "bound": "hbm",
                     "achieved": kernels[name]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": kernels[name]["frac_of_hbm_peak"], "traffic": t["bytes_per_launch"] if t else None,
+                    "frac": kernels[name]["frac_of_hbm_peak"], "traffic": traffic,
                     "traffic_detail": t, "alg_bytes_per_launch": kernels[name]["alg_bytes_per_launch"],
+                    "launches_per_step": lps, "alg_bytes_per_step": kernels[name]["alg_bytes_per_launch"] * lps,
+                    "traffic_per_step": traffic * lps if traffic is not None else None,
                     "avg_launch_ms": kernels[name]["avg_ms"], "ms_per_step": kernels[name]["ms_per_step"]}
 
         def roof_kernel(kn):
