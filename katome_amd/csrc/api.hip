@@ -383,7 +383,7 @@ static int bfc_set_edges(katome_builder* b, const uint64_t* d_fwd, const uint32_
     return KATOME_OK;
 }
 
-static int sorted_count_mode() {
+int sorted_count_mode() {
     static const int mode = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
     return mode;
 }
@@ -433,18 +433,18 @@ int flush_rest(katome_builder* b, hipStream_t stream) {
 // (two-word tiles, by packed key; anything else takes the table) --, 1 the big tiles in their table and only the mid tiles by
 // sorting, out of that table; 0 both tile levels in tables.  C3: 222 / 232 / 257 ms per build.
 // KATOME_SORTED_FAIL=mid|last: that level's counting by sorting reports a group too large -- tests of the way back into the tables
-static bool sorted_fail(const char* level) {
+bool sorted_fail(const char* level) {
     static const char* at = getenv("KATOME_SORTED_FAIL");
     return at && !strcmp(at, level);
 }
-static int sorted_tiles_mode() {
+int sorted_tiles_mode() {
     static const int mode = getenv("KATOME_SORTED_TILES") ? atoi(getenv("KATOME_SORTED_TILES")) : 2;
     return mode;
 }
 
 // the tile records kept aside (builder.h) go into the tile table after all: another consumer wants the table, or the sorted
 // counting of the tiles gave up
-static int tile_recs_valid(katome_builder* b, uint64_t* n, hipStream_t stream) {
+int tile_recs_valid(katome_builder* b, uint64_t* n, hipStream_t stream) {
     *n = 0;
     if (!b->tile_recs_n || !b->tile_recs_count.p) return KATOME_OK;
     KCHECK_HIP(hipMemcpyAsync(n, b->tile_recs_count.p, 8, hipMemcpyDeviceToHost, stream));
@@ -473,7 +473,7 @@ int flush_tile_recs(katome_builder* b, hipStream_t stream) {
 }
 
 // a batch's tiles kept aside as records; *kept = false: they go into the tile table
-static int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uint32_t nwt, bool* kept, hipStream_t stream) {
+int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uint32_t nwt, bool* kept, hipStream_t stream) {
     *kept = false;
     if (b->tile_recs_n + n > b->tile_recs_cap) {
         size_t free_b = 0, total_b = 0;
@@ -503,6 +503,62 @@ static int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t
     b->tile_recs_n += n;
     *kept = true;
     return KATOME_OK;
+}
+
+// The tile records kept aside -> the (k-mer, count) records of the last tile level, every level counted by sorting (DESIGN.md
+// section 4): records -> two hash passes -> counted in LDS -> a compact list of distinct tiles with their counts; the next level's
+// records are cut out of that list.  KATOME_OK: keys / weights hold *n_records records (room for extra_room more behind them) and
+// the tile records are gone.  KATOME_E_UNSUPPORTED: a level could not be counted this way (or there is nothing to count) -- the
+// tile records, or the distinct big tiles with their counts, are in the tile table instead and the caller goes on in tables.
+int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, uint64_t* n_records, uint64_t extra_room, hipStream_t stream) {
+    *n_records = 0;
+    const uint32_t k = b->s.k, span = b->span, tile_bases = k + span - 1, nwt = (uint32_t)key_words_for_k(tile_bases);
+    b->span2 = mid_span(span);
+    DevBuf t1k(stream), t1w(stream);
+    uint64_t n1 = 0, d1 = 0;
+    int rc;
+    {
+        PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+        TileLevelScope tl;
+        DevBuf ones(stream);          // (stays empty: records without weights count once each, and the passes move 16 bytes a record, not 20)
+        uint64_t n = 0;
+        KCHECK(tile_recs_valid(b, &n, stream));
+        rc = n ? records_to_edges_sorted(b->tile_recs, ones, n, tile_bases, false, 0, t1k, t1w, &n1, &d1, stream)
+               : KATOME_E_UNSUPPORTED;                          // (every read was skipped: nothing to count)
+        if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+    }
+    if (rc == KATOME_E_UNSUPPORTED) {
+        KCHECK(flush_tile_recs(b, stream));          // (the records are all still there, in another order: into the table with them)
+        return KATOME_E_UNSUPPORTED;
+    }
+    b->tile_recs.release(); b->tile_recs_count.release(); b->tile_recs_n = b->tile_recs_cap = 0;
+    b->tile_recs_closed = true;
+    b->stat_tiles = n1; b->stat_tile_slots = 0; b->stat_tiles2 = 0; b->stat_tile2_slots = 0;
+    const uint64_t* lk = t1k.as<u64>(); const uint32_t* lw = t1w.as<u32>();
+    uint64_t n_last = n1; uint32_t last_bases = tile_bases, last_span = span;
+    DevBuf t2k(stream), t2w(stream);
+    if (b->span2 && n1) {
+        const uint32_t kk2 = k + b->span2 - 1, n_sub = span / b->span2;
+        PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
+        TileLevelScope tl;
+        DevBuf mk(stream), mw(stream);
+        uint64_t n_mid = 0, n2 = 0, d2 = 0;
+        KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream));
+        rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED : records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream);
+        if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+        if (rc == KATOME_E_UNSUPPORTED) {
+            // the mid tiles cannot be counted this way: the distinct big tiles go into the tile table with their counts, and the build
+            // goes on from there as if they had been counted in it
+            mk.release(); mw.release(); t2k.release(); t2w.release();
+            KCHECK(builder_insert(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 4, t1k.as<u64>(), t1w.as<u32>(), n1, nullptr, PH_INSERT_TILES, stream));
+            return KATOME_E_UNSUPPORTED;
+        }
+        b->stat_tiles2 = n2;
+        lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
+        t1k.release(); t1w.release();
+    }
+    PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+    return table_list_to_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, keys, weights, n_records, stream, extra_room);
 }
 
 // keeps a batch's left-over windows aside (see builder.h); *kept = false: they have to go into the table
@@ -724,85 +780,36 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
         if (b->tile_recs_n && (b->table_ready || (b->tile_recs_n * b->span < (1ull << 22) && sorted_count != 2)))
             KCHECK(flush_tile_recs(b, stream));      // (k-mers in the table already, or too few tiles to be worth it)
         if (b->tile_recs_n) {
-            const uint32_t k = b->s.k, span = b->span, tile_bases = k + span - 1;
-            b->span2 = mid_span(span);
-            DevBuf t1k(stream), t1w(stream);
-            uint64_t n1 = 0, d1 = 0;
-            int rc;
-            {
-                PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
-                TileLevelScope tl;
-                DevBuf ones(stream);
-                uint64_t n = 0;
-                KCHECK(tile_recs_valid(b, &n, stream));
-                if (n == 0) rc = KATOME_E_UNSUPPORTED;       // (every read was skipped: nothing to count)
-                else {
-                    // (`ones` stays empty: records without weights count once each, and the passes move 16 bytes a record, not 20)
-                    rc = records_to_edges_sorted(b->tile_recs, ones, n, tile_bases, false, 0, t1k, t1w, &n1, &d1, stream);
-                }
-                if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
-            }
-            if (rc == KATOME_E_UNSUPPORTED) {
-                KCHECK(flush_tile_recs(b, stream));          // (the records are all still there, in another order: into the table with them)
-            } else {
-                b->tile_recs.release(); b->tile_recs_count.release(); b->tile_recs_n = b->tile_recs_cap = 0;
-                b->tile_recs_closed = true;
-                b->stat_tiles = n1; b->stat_tile_slots = 0; b->stat_tiles2 = 0; b->stat_tile2_slots = 0;
-                const uint64_t* lk = t1k.as<u64>(); const uint32_t* lw = t1w.as<u32>();
-                uint64_t n_last = n1; uint32_t last_bases = tile_bases, last_span = span;
-                DevBuf t2k(stream), t2w(stream);
-                rc = KATOME_OK;
-                if (b->span2 && n1) {
-                    const uint32_t kk2 = k + b->span2 - 1, n_sub = span / b->span2;
-                    PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
-                    TileLevelScope tl;
-                    DevBuf mk(stream), mw(stream);
-                    uint64_t n_mid = 0, n2 = 0, d2 = 0;
-                    KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream));
-                    rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED : records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream);
-                    if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
-                    if (rc == KATOME_OK) {
-                        b->stat_tiles2 = n2;
-                        lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
-                    }
-                }
-                uint64_t distinct = 0;
-                if (rc == KATOME_OK) {
+            const uint32_t k = b->s.k;
+            DevBuf rk(stream), rw(stream);
+            uint64_t n_rec = 0, n_rest = 0, distinct = 0;
+            KCHECK(rest_valid(b, &n_rest, stream));
+            int rc = tile_recs_to_kmer_records(b, rk, rw, &n_rec, n_rest, stream);
+            if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+            if (rc == KATOME_OK) {         // (otherwise the tiles are in their table now, and the blocks below take it from there)
+                {
                     PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-                    DevBuf rk(stream), rw(stream);
-                    uint64_t n_rec = 0, n_rest = 0;
-                    KCHECK(rest_valid(b, &n_rest, stream));
-                    KCHECK(table_list_to_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, rk, rw, &n_rec, stream, n_rest));
-                    t2k.release(); t2w.release();
                     if (n_rest) {
                         KCHECK_HIP(hipMemcpyAsync(rk.as<u64>() + n_rec * b->nw, b->rest_k.p, n_rest * 8 * b->nw, hipMemcpyDeviceToDevice, stream));
                         KCHECK(dev_fill_u32(rw.as<u32>() + n_rec, n_rest, 1u, stream));
                         n_rec += n_rest;
                     }
+                    rest_reset(b);
                     rc = sorted_fail("last") ? KATOME_E_UNSUPPORTED
                         : records_to_edges_sorted(rk, rw, n_rec, k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
                     if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
                 }
                 if (rc == KATOME_OK) {
-                    t1k.release(); t1w.release();
-                    rest_reset(b);
                     b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+                    rk.release(); rw.release();
                     PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
                     KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * k, stream));
                     counted = true;
                 } else {
-                    // a level below gave up (a hash group too large for the LDS route): the distinct big tiles go into the tile table
-                    // with their counts, and the build goes on from there as if they had been counted in it
+                    // the k-mers cannot be counted this way (a hash group beyond the LDS route): their records, counts and all, go
+                    // into the k-mer table and the edges are read out of it
                     b->n_edges = 0;
-                    t2k.release(); t2w.release();
-                    for (uint64_t done = 0; done < n1;) {
-                        uint64_t room = 0;
-                        KCHECK(ensure_table(b, b->tiles, b->tiles_ready, (uint32_t)key_words_for_k(tile_bases), b->s.table_slots_hint / 4, n1 - done, &room, stream));
-                        const uint64_t m = std::min(n1 - done, room);
-                        PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
-                        KCHECK(table_insert(b->tiles, t1k.as<u64>() + done * key_words_for_k(tile_bases), t1w.as<u32>() + done, m, stream, nullptr));
-                        done += m;
-                    }
+                    KCHECK(builder_insert(b, b->table, b->table_ready, b->nw, b->s.table_slots_hint, rk.as<u64>(), rw.as<u32>(), n_rec, nullptr, PH_INSERT, stream));
                 }
             }
         }

@@ -409,6 +409,8 @@ int expand_and_route_kmers(katome_dist_builder* d, uint32_t span, hipStream_t st
     // tiles are routed to owners of their own and counted there, like the big tiles before them.
     const uint32_t span2 = mid_span(span);
     const bool route_mid = span2 != 0 && (world > 1 || getenv("KATOME_ROUTE_MID_TILES"));
+    DevBuf keys(stream), weights(stream), seen(stream);         // the k-mer records this rank sends on
+    uint64_t n_rec = 0;
     if (route_mid) {
         const uint32_t kk2 = k + span2 - 1, n_sub = span / span2, nw2 = (uint32_t)key_words_for_k(kk2);
         DevBuf mk(stream), mw(stream), ms(stream);
@@ -426,12 +428,12 @@ int expand_and_route_kmers(katome_dist_builder* d, uint32_t span, hipStream_t st
         // (a rank receives about what it sends, and about half of that is distinct; the table grows if it is not.  Twice the
         // slots doubled the time of the scan that expands them)
         const uint64_t mid_hint = std::max<uint64_t>(n_mid, 1u << 16);
+        // (Counting what arrives here by sorting, as one GPU counts its tile levels, was measured at an eighth of C3 per rank: 5.9 + 6.2 ms
+        // against the tables' 5.3 + 6.0 -- the sorted levels' fixed costs, a few host round trips each, eat their gain at 10^8 records.)
         KCHECK(route_weighted(d, X_MID_TILES, mk, mw, ms, n_mid, nw2, 0, 0, b->tiles2, b->tiles2_ready, mid_hint, PH_EXPAND_MID, stream));
         b->tiles_ready = b->tiles2_ready;                    // (what is left to expand, if anything arrived)
         if (b->tiles2_ready) { KCHECK(table_occupied(b->tiles2, &b->stat_tiles2, stream)); b->stat_tile2_slots = b->tiles2.cap; }
     }
-    DevBuf keys(stream), weights(stream), seen(stream);
-    uint64_t n_rec = 0;
     if (b->tiles_ready) {
         Table* last = &b->tiles2; uint32_t last_span = span2;
         if (!route_mid) {
@@ -585,7 +587,6 @@ int katome_dist_create(const katome_settings* s, katome_comm* comm, katome_dist_
     katome_dist_builder* d = new (std::nothrow) katome_dist_builder();
     if (!d) { katome_builder_destroy(b); set_error("out of host memory"); return KATOME_E_OOM; }
     d->s = *s; d->comm = comm; d->b = b; d->nw = b->nw; d->rc = b->rc; d->first_seen = b->first_seen;
-    b->tile_recs_closed = true;                   // (the sharded routes read the tile TABLE; tiles are never kept aside as records here)
     d->local_first = comm->world() <= 2;
     if (const char* e = getenv("KATOME_DIST_ROUTE")) d->local_first = strcmp(e, "local") == 0 ? true : strcmp(e, "tiles") == 0 ? false : d->local_first;
     *out = d;
@@ -657,6 +658,13 @@ int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint6
             origin.per_read = per_read; origin.span = tiled ? d->span : 1; origin.win0 = 0;
             if (tiled) {
                 b->span = d->span;
+                // (one GPU's rule: two-word tiles of one-word k-mers by packed key wait as records and are counted by sorting at the end)
+                bool kept = false;
+                if (!d->first_seen && d->nwt == 2 && nw == 1 && !b->tiles_ready && !b->tile_recs_closed && sorted_count_mode() && sorted_tiles_mode() == 2) {
+                    PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+                    KCHECK(keep_tile_recs(b, recbuf.as<u64>(), nr * per_read, d->nwt, &kept, stream));
+                }
+                if (!kept)
                 KCHECK(builder_insert(b, b->tiles, b->tiles_ready, d->nwt, b->s.table_slots_hint / 4, recbuf.as<u64>(), nullptr, nr * per_read,
                                       d->first_seen ? &origin : nullptr, PH_INSERT_TILES, stream));
             } else {
@@ -750,6 +758,28 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
         OwnerSplit split;
         bool split_used = false;
         static const int sorted_count = getenv("KATOME_SORTED_COUNT") ? atoi(getenv("KATOME_SORTED_COUNT")) : 1;
+        // (owner split: grouped by the hash that names the owner, every group's keys written into its owner's stretch: no partition pass
+        // before the exchange; KATOME_DIST_OWNER_SPLIT=0: by the whole k-mer's hash, then route_weighted's partition)
+        static const bool owner_split_on = !getenv("KATOME_DIST_OWNER_SPLIT") || atoi(getenv("KATOME_DIST_OWNER_SPLIT")) != 0;
+        if (b->tile_recs_n && (!may_collect(d) || (b->tile_recs_n * b->span < (1ull << 22) && sorted_count != 2))) KCHECK(flush_tile_recs(b, stream));
+        if (b->tile_recs_n) {
+            // the tiles kept as records: every level by sorting, down to this rank's distinct k-mers
+            DevBuf rk(stream), rw(stream);
+            uint64_t n_win = 0, distinct = 0;
+            int rc = tile_recs_to_kmer_records(b, rk, rw, &n_win, 0, stream);
+            if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+            if (rc == KATOME_OK) {
+                PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                if (owner_split_on) { split.n_parts = (uint32_t)world; split.core_shift = 2; split.core_bases = k - 2; split_used = true; }
+                rc = sorted_fail("last") ? KATOME_E_UNSUPPORTED
+                    : records_to_edges_sorted(rk, rw, n_win, k, false, 0, keys, weights, &n_rec, &distinct, stream, split_used ? &split : nullptr);
+                if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+                if (rc == KATOME_E_UNSUPPORTED) {          // (beyond the LDS route: the records, counts and all, into the k-mer table)
+                    split_used = false; n_rec = 0;
+                    KCHECK(builder_insert(b, b->table, b->table_ready, nw, b->s.table_slots_hint, rk.as<u64>(), rw.as<u32>(), n_win, nullptr, PH_INSERT, stream));
+                }
+            }
+        }
         if (b->tiles_ready && may_collect(d)) {
             // the rank's own distinct k-mers by sorting (as katome_dev_edges does, but one record per canonical k-mer: no strands yet)
             uint64_t n_tiles = 0;
@@ -764,10 +794,7 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
                 KCHECK(table_tiles_to_records_fast(*last, k, last_span, d->rc, rk, rw, &n_win, stream));
                 b->tiles.release(); b->tiles2.release();
                 b->tiles_ready = false; b->tiles2_ready = false;
-                // (grouped by the hash that names the owner, every group's keys written into its owner's stretch: no partition pass
-                // before the exchange; KATOME_DIST_OWNER_SPLIT=0: by the whole k-mer's hash, then route_weighted's partition)
-                static const bool owner_split = !getenv("KATOME_DIST_OWNER_SPLIT") || atoi(getenv("KATOME_DIST_OWNER_SPLIT")) != 0;
-                if (owner_split) { split.n_parts = (uint32_t)world; split.core_shift = 2; split.core_bases = k - 2; split_used = true; }
+                if (owner_split_on) { split.n_parts = (uint32_t)world; split.core_shift = 2; split.core_bases = k - 2; split_used = true; }
                 KCHECK(records_to_edges_sorted(rk, rw, n_win, k, false, 0, keys, weights, &n_rec, &distinct, stream, split_used ? &split : nullptr));
             }
         }

@@ -845,7 +845,9 @@ def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
         for r in rows:
             assert r[4] == "1", (limit, r)
         assert rows[0][3] == rows[1][3] == rows[2][3]
-        if limit:
+        if limit == "last":
+            assert rows[0][6] != "0" and rows[2][6] != "0"     # the k-mer records went into the k-mer table, counts and all
+        elif limit:
             assert rows[0][5] != "0" and rows[2][5] != "0"     # the tile table took over (6000 reads are 24000 tiles)
         else:
             assert rows[0][5] == "0" and rows[2][5] == "0"     # no tile table: counted by sorting
