@@ -491,7 +491,10 @@ int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uin
             return KATOME_OK;
         }
         DevBuf grown(stream);
-        KCHECK(grown.alloc(want * 8 * nwt + 16));
+        if (grown.alloc(want * 8 * nwt + 16) != KATOME_OK) {          // (no room after all: the table takes over)
+            KCHECK(flush_tile_recs(b, stream));
+            return KATOME_OK;
+        }
         if (b->tile_recs_n) KCHECK_HIP(hipMemcpyAsync(grown.p, b->tile_recs.p, b->tile_recs_n * 8 * nwt, hipMemcpyDeviceToDevice, stream));
         const size_t grown_bytes = grown.bytes;
         b->tile_recs.adopt(grown.take(), grown_bytes);
