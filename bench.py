@@ -136,8 +136,12 @@ def one_build_single(wl, packed, skip, recbuf, batch_reads, timer, first_seen=Fa
         for r0 in range(0, wl.reads, batch_reads):
             nr = min(batch_reads, wl.reads - r0)
             if span > 1:      # tiled counting: tiles of `span` windows, expanded before the edges are read out (+ left-over windows)
-                rec = b.extract_tiles(packed, nr, wl.read_len, span, skip, out=recbuf, first_read=r0)
-                b.insert_tiles(rec, span)
+                # (extraction + the tile level's insertion in one call: the records are made where the builder keeps them;
+                # KATOME_BENCH_TWO_CALLS=1: extract into a buffer of the caller's, then insert -- the earlier boundary)
+                if os.environ.get("KATOME_BENCH_TWO_CALLS") == "1":
+                    b.insert_tiles(b.extract_tiles(packed, nr, wl.read_len, span, skip, out=recbuf, first_read=r0), span)
+                else:
+                    b.count_tiles(packed, nr, wl.read_len, span, skip, first_read=r0)
                 if rest:
                     b.insert(b.extract_remainder(packed, nr, wl.read_len, span, skip, out=recbuf, first_read=r0))
             else:
@@ -449,7 +453,9 @@ def main():
                     # the mid level the same, its records cut out of that list
                     pair_t, pair_m = 8 * nwt + 4, 8 * nwm + 4
                     # (the big tiles' records carry no counts: 8 * nwt bytes each through the passes)
-                    alg["insert_tiles"] = lambda launches, reads: reads * tiles * (16 * nwt + 2 * (8 * nwt + 2 * 8 * nwt) + 8 + 8 * nwt) + steps * cnt["distinct_tiles"] * pair_t
+                    # (... and are written where they are kept by the extraction: no copy, unless reads are skipped)
+                    copy_b = 16 * nwt if (os.environ.get("KATOME_BENCH_TWO_CALLS") == "1" or skip_arg is not None) else 0
+                    alg["insert_tiles"] = lambda launches, reads: reads * tiles * (copy_b + 2 * (8 * nwt + 2 * 8 * nwt) + 8 + 8 * nwt) + steps * cnt["distinct_tiles"] * pair_t
                     alg["expand_mid_tiles"] = lambda launches, reads: steps * (
                         cnt["distinct_tiles"] * pair_t + cnt["distinct_tiles"] * (span // ms2) * (pair_m + 2 * (8 * nwm + 2 * pair_m) + 8 + pair_m)
                         + cnt["distinct_mid_tiles"] * pair_m)
@@ -608,7 +614,8 @@ def main():
                                              (kexact["lds_count_kernel" + t_], 1, False)]
                 if not cnt.get("tile_slots"):      # (... and the big tiles: their records copied batch by batch, keys-only passes)
                     n_batches = -(-int(reads_per_rank_step) // int(batch_reads))
-                    parts["insert_tiles"] = [("void keep_rest_kernel<%d, false>" % nwt, n_batches, True),
+                    two_calls = os.environ.get("KATOME_BENCH_TWO_CALLS") == "1" or skip_arg is not None
+                    parts["insert_tiles"] = ([("void keep_rest_kernel<%d, false>" % nwt, n_batches, True)] if two_calls else []) + [
                                              (kexact["radix_scatter_kernel<HashDigit>" + t_].replace(", true,", ", false,"), 2, True),
                                              (kexact["radix_hist_kernel<HashDigit>" + t_], 2, True), (kexact["hash_group_index_kernel"].replace("<1, 1>", "<2, 2>"), 1, True),
                                              (kexact["lds_count_kernel" + t_], 1, False)]

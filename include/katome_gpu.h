@@ -284,6 +284,13 @@ int katome_dev_extract_tiles(katome_builder *b, const uint8_t *d_packed, uint64_
                              uint32_t span, const uint8_t *d_skip, uint64_t *d_records, void *stream);
 int katome_dev_insert_tiles(katome_builder *b, const uint64_t *d_records, uint64_t n_records, uint32_t span,
                             void *stream);
+/* katome_dev_extract_tiles + katome_dev_insert_tiles in one call, without a record buffer of the caller's: one batch of reads
+ * of one length counted as tiles (add_read_fastaq's windows, pt_graph.rs:277-315, `span` at a time).  When the builder keeps tile
+ * records aside to count them by sorting (by packed key, tiles of two words) and no read is skipped (d_skip == NULL), the records
+ * are written where they are kept.  The windows behind a read's last whole tile still go through
+ * katome_dev_extract_remainder + katome_dev_insert.                                                        */
+int katome_dev_count_tiles(katome_builder *b, const uint8_t *d_packed, uint64_t n_reads, uint32_t read_len,
+                           uint32_t span, const uint8_t *d_skip, void *stream);
 int katome_dev_expand_tiles(katome_builder *b, uint64_t **d_keys, uint32_t **d_weights, uint64_t *n_records,
                             void *stream);
 

@@ -123,6 +123,7 @@ SYMBOLS = {
     "katome_dev_extract_remainder": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp]),
     "katome_dev_extract_tiles": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp, _vp]),
     "katome_dev_insert_tiles": (_i, [_vp, _vp, _u64, _u32, _vp]),
+    "katome_dev_count_tiles": (_i, [_vp, _vp, _u64, _u32, _u32, _vp, _vp]),
     "katome_dev_expand_tiles": (_i, [_vp, C.POINTER(_vp), C.POINTER(_vp), u64p, _vp]),
     "katome_dev_finalize": (_i, [_vp, C.POINTER(DevGraph), _vp]),
     "katome_shrink_files": (_i, [C.POINTER(Settings), _pp, _sz, C.POINTER(C.POINTER(Contigs))]),

@@ -446,6 +446,7 @@ int sorted_tiles_mode() {
 // counting of the tiles gave up
 int tile_recs_valid(katome_builder* b, uint64_t* n, hipStream_t stream) {
     *n = 0;
+    if (b->tile_recs_exact) { *n = b->tile_recs_n; return KATOME_OK; }       // (every record kept so far was valid: nothing to ask the device)
     if (!b->tile_recs_n || !b->tile_recs_count.p) return KATOME_OK;
     KCHECK_HIP(hipMemcpyAsync(n, b->tile_recs_count.p, 8, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));
@@ -468,13 +469,15 @@ int flush_tile_recs(katome_builder* b, hipStream_t stream) {
     }
     b->tile_recs.release(); b->tile_recs_count.release();
     b->tile_recs_n = b->tile_recs_cap = 0;
+    b->tile_recs_exact = false;
     b->tile_recs_closed = true;
     return KATOME_OK;
 }
 
-// a batch's tiles kept aside as records; *kept = false: they go into the tile table
-int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uint32_t nwt, bool* kept, hipStream_t stream) {
-    *kept = false;
+// room for n more tile records behind those kept aside; *ok = false: no room (or over the limit) -- what was kept has gone into the
+// tile table and later batches follow it there
+static int reserve_tile_recs(katome_builder* b, uint64_t n, uint32_t nwt, bool* ok, hipStream_t stream) {
+    *ok = false;
     if (b->tile_recs_n + n > b->tile_recs_cap) {
         size_t free_b = 0, total_b = 0;
         KCHECK_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -501,7 +504,25 @@ int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uin
         b->tile_recs.stream = stream;
         b->tile_recs_cap = want;
     }
-    if (!b->tile_recs_count.p) { KCHECK(b->tile_recs_count.alloc(8, stream)); KCHECK_HIP(hipMemsetAsync(b->tile_recs_count.p, 0, 8, stream)); }
+    if (b->tile_recs_n == 0) b->tile_recs_exact = true;          // (nothing kept yet: the host knows the count until a batch with holes comes)
+    *ok = true;
+    return KATOME_OK;
+}
+
+// a batch's tiles kept aside as records; *kept = false: they go into the tile table
+int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uint32_t nwt, bool* kept, hipStream_t stream) {
+    *kept = false;
+    bool ok = false;
+    KCHECK(reserve_tile_recs(b, n, nwt, &ok, stream));
+    if (!ok) return KATOME_OK;
+    if (!b->tile_recs_count.p) KCHECK(b->tile_recs_count.alloc(8, stream));
+    if (b->tile_recs_exact) {
+        // from here on only the device knows how many of the records handed over were valid: its cursor starts at what the host knew
+        const uint64_t start = b->tile_recs_n;
+        KCHECK_HIP(hipMemcpyAsync(b->tile_recs_count.p, &start, 8, hipMemcpyHostToDevice, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        b->tile_recs_exact = false;
+    }
     KCHECK(table_keep_rest(d_records, n, nwt, false, 0, 1, 0, 0, b->tile_recs.as<u64>(), b->tile_recs_count.as<u64>(), stream));      // (the valid ones, behind the cursor)
     b->tile_recs_n += n;
     *kept = true;
@@ -535,6 +556,7 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
         return KATOME_E_UNSUPPORTED;
     }
     b->tile_recs.release(); b->tile_recs_count.release(); b->tile_recs_n = b->tile_recs_cap = 0;
+    b->tile_recs_exact = false;
     b->tile_recs_closed = true;
     b->stat_tiles = n1; b->stat_tile_slots = 0; b->stat_tiles2 = 0; b->stat_tile2_slots = 0;
     const uint64_t* lk = t1k.as<u64>(); const uint32_t* lw = t1w.as<u32>();
@@ -671,6 +693,43 @@ int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_r
     return katome_dev_insert_weighted(b, d_records, nullptr, n_records, stream);
 }
 
+// may this builder keep a batch's tile records aside and count them by sorting at the end?
+static bool keeps_tile_recs(const katome_builder* b, uint32_t nwt) {
+    return !b->first_seen && nwt == 2 && b->nw == 1 && !b->tiles_ready && !b->table_ready && !b->tile_recs_closed && sorted_count_mode() &&
+           sorted_tiles_mode() == 2;
+}
+
+int katome_dev_count_tiles(katome_builder* b, const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len, uint32_t span,
+                           const uint8_t* d_skip, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!b || (!d_packed && n_reads)) { set_error("null argument"); return KATOME_E_ARG; }
+    KCHECK_HIP(hipSetDevice(b->s.device));
+    if (b->edges_ready) { set_error("builder already finalized"); return KATOME_E_ARG; }
+    if (read_len < b->s.k || span < 2 || b->s.k + span - 1 > 95) { set_error("bad tile span %u", span); return KATOME_E_ARG; }
+    const uint32_t per_read = (read_len - b->s.k + 1) / span, nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
+    const uint64_t n = n_reads * per_read;
+    if (n == 0) return KATOME_OK;
+    // No read skipped and every record kept so far valid: the records are made where they are kept -- no buffer in between, no copy
+    // (C3: 12.8 GB not read and not written again per build).  Otherwise: into a scratch of the builder's, then as
+    // katome_dev_insert_tiles does.
+    if (!d_skip && keeps_tile_recs(b, nwt) && (b->tile_recs_n == 0 || (b->tile_recs_exact && span == b->span))) {
+        bool ok = false;
+        {
+            PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+            KCHECK(reserve_tile_recs(b, n, nwt, &ok, stream));
+        }
+        if (ok && b->tile_recs_exact) {
+            KCHECK(katome_dev_extract_tiles(b, d_packed, n_reads, read_len, span, nullptr, b->tile_recs.as<u64>() + b->tile_recs_n * nwt, stream));
+            b->span = span;
+            b->tile_recs_n += n;
+            return KATOME_OK;
+        }
+    }
+    KCHECK(b->tile_scratch.alloc(n * 8 * nwt + 64, stream));
+    KCHECK(katome_dev_extract_tiles(b, d_packed, n_reads, read_len, span, d_skip, b->tile_scratch.as<u64>(), stream));
+    return katome_dev_insert_tiles(b, b->tile_scratch.as<u64>(), n, span, stream);
+}
+
 int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64_t n_records, uint32_t span, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     KCHECK_HIP(hipSetDevice(b->s.device));
@@ -680,7 +739,7 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     if (n_records == 0) return KATOME_OK;
     b->span = span;
     const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
-    if (!b->first_seen && nwt == 2 && b->nw == 1 && !b->tiles_ready && !b->table_ready && !b->tile_recs_closed && sorted_count_mode() && sorted_tiles_mode() == 2) {
+    if (keeps_tile_recs(b, nwt)) {
         bool kept = false;
         PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
         KCHECK(keep_tile_recs(b, d_records, n_records, nwt, &kept, stream));
@@ -773,6 +832,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
     KCHECK_HIP(hipSetDevice(b->s.device));
     if (!b->edges_ready) {
         b->n_edges = 0;
+        b->tile_scratch.release();
         // Counting the last level by sorting instead of in a table (table.hip, lds_count_kernel / lds_count_wide_kernel): k <= 63, by
         // packed key, nothing in the k-mer table yet (left-over windows were kept aside), enough tiles to be worth the extra launches
         const int sorted_count = sorted_count_mode();
@@ -1811,9 +1871,8 @@ static int build_packed_impl(const katome_settings* s, const uint8_t* packed, ui
             for (uint64_t r0 = 0; r0 < n_reads && !rc; r0 += reads_per_batch) {
                 const uint64_t nr = std::min(reads_per_batch, n_reads - r0);
                 if (span > 1) {       // tiled counting: W/span tile records per read, then the windows that are left over
-                    rc = katome_dev_extract_tiles(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len, span,
-                                                  skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);
-                    if (!rc) rc = katome_dev_insert_tiles(b, d_rec.as<u64>(), nr * tiles, span, nullptr);
+                    rc = katome_dev_count_tiles(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len, span,
+                                                skip ? d_skip.as<uint8_t>() + r0 : nullptr, nullptr);
                     if (!rc && rest) {
                         rc = katome_dev_extract_remainder(b, d_packed.as<uint8_t>() + r0 * stride, nr, read_len, span,
                                                           skip ? d_skip.as<uint8_t>() + r0 : nullptr, d_rec.as<u64>(), nullptr);

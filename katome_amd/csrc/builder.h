@@ -49,6 +49,8 @@ struct katome_builder {
     DevBuf tile_recs, tile_recs_count;  // tile_recs_count: device cursor -- the valid ones among them (a skipped read's tiles are all-ones)
     uint64_t tile_recs_n = 0, tile_recs_cap = 0;      // tile_recs_n: records handed over (an upper bound of the cursor)
     bool tile_recs_closed = false;
+    bool tile_recs_exact = false;       // every record handed over so far was valid (tile_recs_n IS the count: katome_dev_count_tiles writes in place)
+    DevBuf tile_scratch;                // katome_dev_count_tiles: a batch's records when they cannot be made where they are kept
     DevBuf rest_k, rest_count;          // rest_count: device cursor -- how many of them are valid records (reads with N leave invalid ones)
     uint64_t rest_n = 0, rest_cap = 0;  // rest_n: records handed over so far (an upper bound of the cursor)
     bool rest_closed = false;           // too many to keep aside: from now on they go into the table directly

@@ -220,11 +220,18 @@ class Builder(_ViewOwner):
         """one batch through the library's plan: tiles (+ left-over windows), or every window on its own"""
         span, tiles, rest = self.tile_plan(read_len)
         if span > 1:
-            self.insert_tiles(self.extract_tiles(packed, n_reads, read_len, span, skip, first_read=first_read), span)
+            self.count_tiles(packed, n_reads, read_len, span, skip, first_read=first_read)
             if rest:
                 self.insert(self.extract_remainder(packed, n_reads, read_len, span, skip, first_read=first_read))
         else:
             self.insert(self.extract_fixed(packed, n_reads, read_len, skip, first_read=first_read))
+
+    def count_tiles(self, packed, n_reads, read_len, span, skip=None, first_read=0):
+        """extract_tiles + insert_tiles without a record buffer of the caller's (the records are made where the builder keeps them)"""
+        stride = (read_len + 3) // 4
+        p = C.c_void_p(packed.data_ptr() + first_read * stride)
+        sk = C.c_void_p(skip.data_ptr() + first_read) if skip is not None else None
+        _check(_lib.lib().katome_dev_count_tiles(self._h, p, n_reads, read_len, span, sk, _stream()))
 
     def insert_tiles(self, records, span):
         n = records.numel() // self.tile_words(span)

@@ -819,6 +819,29 @@ for batch, plain in ((100, False), (100, True), (6000, False)):
     got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
     print("KEPT", batch, int(plain), dg.n_edges, int(len(got) == dg.n_edges and got == want), c["tile_slots"], c["kmer_slots"])
     b.close()
+# no read skipped: katome_dev_count_tiles makes the records where they are kept -- all batches; then with a skip array (of zeros)
+# for every third batch, whose records go through the buffer and the copy, and the two-call boundary in between
+reads2 = o.synth_reads(12, n, L, 25000, 4e-3, 0)
+packed2 = torch.from_numpy(pack_reads_ascii(reads2).reshape(-1).copy()).cuda()
+none_skipped = torch.zeros(n, dtype=torch.uint8, device="cuda")
+ref2 = o.build_ascii(reads2, k, True)
+want2 = {bytes(row): int(w) for row, w in zip(ref2.edge_label, ref2.edge_weight)}
+for mixed in (False, True):
+    b = kd.Builder(k, True, table_slots_hint=1 << 14)
+    span = b.tile_plan(L)[0]
+    for i, r0 in enumerate(range(0, n, 250)):
+        if mixed and i % 3 == 1:
+            b.count_tiles(packed2, 250, L, span, none_skipped, first_read=r0)
+        elif mixed and i % 3 == 2:
+            b.insert_tiles(b.extract_tiles(packed2, 250, L, span, None, first_read=r0), span)
+        else:
+            b.count_tiles(packed2, 250, L, span, None, first_read=r0)
+    dg = b.finalize()
+    c = b.counts()
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
+    print("INPLACE", int(mixed), dg.n_edges, int(len(got) == dg.n_edges and got == want2), c["tile_slots"], c["kmer_slots"])
+    b.close()
 """
 
 
@@ -827,7 +850,8 @@ def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
     batches (room for sixteen to begin with, doubled when that is too little), reads with N in them (their records are dropped),
     batches counted window by window in between -- and, in processes of their own, a limit on what may be kept that is reached
     half-way (the records kept so far go into the tile table, later batches too) and a level below that gives up (the distinct big
-    tiles go into the tile table with their counts) -- against the oracle"""
+    tiles go into the tile table with their counts); and `katome_dev_count_tiles`, which makes a batch's records where they are kept
+    when no read is skipped, alone and mixed with batches that go through a buffer -- against the oracle"""
     import subprocess
     script = tmp_path / "kept.py"
     script.write_text(_KEPT_SCRIPT)
@@ -840,6 +864,9 @@ def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
             env["KATOME_TILE_RECS_LIMIT"] = limit
         out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
+        inplace = [line.split() for line in out.stdout.splitlines() if line.startswith("INPLACE ")]
+        assert len(inplace) == 2 and all(r[3] == "1" for r in inplace), (limit, inplace)
+        assert inplace[0][2] == inplace[1][2]
         rows = [line.split() for line in out.stdout.splitlines() if line.startswith("KEPT ")]
         assert len(rows) == 3
         for r in rows:
