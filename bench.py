@@ -623,9 +623,10 @@ def main():
             parts = parts.get(name, [(exact.get(name, name), 1, name == "extract")])
             t = pmc_traffic(parts, cfg_now) if not use_dist else None
             lps = kernels[name]["launches_per_step"]
-            # (a phase timed once per batch and once at the end -- the big tiles kept aside, then counted -- has its kernels listed
-            # per STEP above: its traffic per "launch" is the step's over the step's launches, as its algorithmic bytes are)
-            per_step = name == "insert_tiles" and name in multi
+            # (a phase whose scope is opened several times a step -- once per batch and once at the end for the big tiles, twice for
+            # the k-mer level -- has its kernels listed per STEP above: its traffic per "launch" is the step's over the step's launches,
+            # as its algorithmic bytes are)
+            per_step = name in multi            # (a phase of several kernels lists its kernels per STEP, however many times its scope was opened)
             traffic = (t["bytes_per_launch"] / (lps if per_step else 1)) if t else None
             return {"kernel": exact[name].replace("void ", "") if (single and name in exact) else None, "kernels": label, "phase": name, "bound": "hbm",
                     "achieved": kernels[name]["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
