@@ -643,6 +643,9 @@ __global__ __launch_bounds__(BLOCK) void list_to_records_kernel(const u64* __res
 // threshold), as one contiguous stretch behind a cursor.
 // ---------------------------------------------------------------------------------------------
 constexpr u32 LC_THREADS = 1024;
+#ifndef KATOME_LC_LU
+#define KATOME_LC_LU 4          // records in flight per thread in the counting loops
+#endif
 // LDS table: 8 B key + 4 B count per slot, LC_THREADS x PER slots (every thread reads PER slots out).  PER = 13: 13312 slots =
 // 156 KiB of the CU's 160 (one workgroup of 1024 per CU either way): groups of 22 k records (2^16 groups at C3) go through in 3
 // sub-rounds instead of the 4 a table of 8192 needs.  PER = 8: groups of 5.5 k records (2^18 groups: the look-back passes of
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
         for (u32 r = 0; r < R; ++r) {
             for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
             __syncthreads();
-            constexpr u32 LU = 4;                            // records in flight per thread (the group is re-read from L2 / Infinity Cache)
+            constexpr u32 LU = KATOME_LC_LU;                            // records in flight per thread (the group is re-read from L2 / Infinity Cache)
             for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
                 u64 kv[LU]; u32 wv[LU];
 #pragma unroll
@@ -833,7 +836,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
         for (u32 r = 0; r < R; ++r) {
             for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
             __syncthreads();
-            constexpr u32 LU = 4;                            // records in flight per thread
+            constexpr u32 LU = KATOME_LC_LU;                            // records in flight per thread
             for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
               Key<NW> kv[LU]; u32 wv[LU];
 #pragma unroll
