@@ -458,6 +458,15 @@ int flush_tile_recs(katome_builder* b, hipStream_t stream) {
         uint64_t n = 0;
         KCHECK(tile_recs_valid(b, &n, stream));
         b->tile_recs_n = 0;
+        if (b->first_seen && n) {            // tagged records: back into keys + their two sequence numbers for the table
+            DevBuf keys(stream), pairs(stream);
+            KCHECK(keys.alloc(n * 8 * nwt + 16)); KCHECK(pairs.alloc(n * 16 + 16));
+            KCHECK(table_tagged_to_pairs(b->tile_recs.as<u64>(), n, nwt, 2ull * (b->seen_read_len - b->s.k + 1), keys.as<u64>(), pairs.as<u64>(), stream));
+            b->tile_recs.release();
+            SeenOrigin origin;
+            origin.pairs = pairs.as<u64>(); origin.rc = b->rc;
+            KCHECK(builder_insert(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 4, keys.as<u64>(), nullptr, n, &origin, PH_INSERT_TILES, stream));
+        } else
         for (uint64_t done = 0; done < n;) {
             uint64_t room = 0;
             KCHECK(ensure_table(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 4, n - done, &room, stream));
@@ -513,7 +522,9 @@ static int reserve_tile_recs(katome_builder* b, uint64_t n, uint32_t nwt, bool* 
 int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uint32_t nwt, bool* kept, hipStream_t stream) {
     *kept = false;
     bool ok = false;
-    KCHECK(reserve_tile_recs(b, n, nwt, &ok, stream));
+    // (first-seen order: a record is kept with its tag -- read << 32 | number of its first window << 16 | of its reverse complement's)
+    const uint32_t words = nwt + (b->first_seen ? 1 : 0);
+    KCHECK(reserve_tile_recs(b, n, words, &ok, stream));
     if (!ok) return KATOME_OK;
     if (!b->tile_recs_count.p) KCHECK(b->tile_recs_count.alloc(8, stream));
     if (b->tile_recs_exact) {
@@ -523,6 +534,11 @@ int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uin
         KCHECK_HIP(hipStreamSynchronize(stream));
         b->tile_recs_exact = false;
     }
+    if (b->first_seen) {
+        const uint32_t W = b->seen_read_len - b->s.k + 1;
+        KCHECK(table_keep_rest(d_records, n, nwt, true, b->reads_inserted, W / b->span, 0, 2 * W, b->tile_recs.as<u64>(), b->tile_recs_count.as<u64>(), stream,
+                               b->span, b->span));
+    } else
     KCHECK(table_keep_rest(d_records, n, nwt, false, 0, 1, 0, 0, b->tile_recs.as<u64>(), b->tile_recs_count.as<u64>(), stream));      // (the valid ones, behind the cursor)
     b->tile_recs_n += n;
     *kept = true;
@@ -632,7 +648,7 @@ int katome_dev_insert_weighted(katome_builder* b, const uint64_t* d_records, con
         if (kept) return KATOME_OK;
     }
     // first-seen order, reads of one length: the windows after the batch's tiles wait as tagged records (table.hip, seen_pack)
-    if (b->first_seen && b->rem_pending && !d_weights && !b->var_prefix && !b->var_seq_base && b->tiles_ready && !b->table_ready && !b->rest_closed &&
+    if (b->first_seen && b->rem_pending && !d_weights && !b->var_prefix && !b->var_seq_base && (b->tiles_ready || b->tile_recs_n) && !b->table_ready && !b->rest_closed &&
         b->nw <= 2 && sorted_count_mode() && b->seen_read_len >= b->s.k && 2ull * (b->seen_read_len - b->s.k + 1) <= 0xFFFFu &&
         b->last_batch_read0 + b->last_batch_reads < (1ull << 32) && n_records == b->last_batch_reads * b->rem_per_read) {
         bool kept = false;
@@ -695,7 +711,10 @@ int katome_dev_insert(katome_builder* b, const uint64_t* d_records, uint64_t n_r
 
 // may this builder keep a batch's tile records aside and count them by sorting at the end?
 static bool keeps_tile_recs(const katome_builder* b, uint32_t nwt) {
-    return !b->first_seen && nwt == 2 && b->nw == 1 && !b->tiles_ready && !b->table_ready && !b->tile_recs_closed && sorted_count_mode() &&
+    // (the reference's numbering: reads of one length whose numbers pack into a record word -- lds_count_seen_kernel's rule)
+    const bool seen_ok = !b->first_seen || (!b->var_prefix && !b->var_seq_base && !b->direct_edges && b->seen_read_len >= b->s.k &&
+                                            2ull * (b->seen_read_len - b->s.k + 1) <= 0xFFFFull && (b->reads_inserted >> 31) == 0);
+    return seen_ok && nwt == 2 && b->nw == 1 && !b->tiles_ready && !b->table_ready && !b->tile_recs_closed && sorted_count_mode() &&
            sorted_tiles_mode() == 2;
 }
 
@@ -712,7 +731,7 @@ int katome_dev_count_tiles(katome_builder* b, const uint8_t* d_packed, uint64_t 
     // No read skipped and every record kept so far valid: the records are made where they are kept -- no buffer in between, no copy
     // (C3: 12.8 GB not read and not written again per build).  Otherwise: into a scratch of the builder's, then as
     // katome_dev_insert_tiles does.
-    if (!d_skip && keeps_tile_recs(b, nwt) && (b->tile_recs_n == 0 || (b->tile_recs_exact && span == b->span))) {
+    if (!d_skip && !b->first_seen && keeps_tile_recs(b, nwt) && (b->tile_recs_n == 0 || (b->tile_recs_exact && span == b->span))) {
         bool ok = false;
         {
             PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
@@ -740,10 +759,18 @@ int katome_dev_insert_tiles(katome_builder* b, const uint64_t* d_records, uint64
     b->span = span;
     const uint32_t nwt = (uint32_t)key_words_for_k(b->s.k + span - 1);
     if (keeps_tile_recs(b, nwt)) {
+        const uint32_t per_read = b->first_seen ? (b->seen_read_len - b->s.k + 1) / span : 1;
+        if (b->first_seen && (per_read == 0 || n_records % per_read)) { set_error("first-seen order: a batch must hold whole reads"); return KATOME_E_ARG; }
         bool kept = false;
         PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
         KCHECK(keep_tile_recs(b, d_records, n_records, nwt, &kept, stream));
-        if (kept) return KATOME_OK;
+        if (kept) {
+            if (b->first_seen) {
+                b->last_batch_read0 = b->reads_inserted; b->last_batch_reads = n_records / per_read;
+                b->reads_inserted += n_records / per_read;
+            }
+            return KATOME_OK;
+        }
     }
     SeenOrigin origin;
     const bool var_tiles = b->first_seen && b->var_prefix != nullptr;
@@ -840,9 +867,9 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
         // ... and the tile levels above it the same way when the tiles were kept as records (katome_dev_insert_tiles): every level is
         // "records -> two hash passes -> counted in LDS -> a compact list of distinct keys with their counts", the next level's
         // records are cut out of that list (table.hip, list_to_records_kernel)
-        if (b->tile_recs_n && (b->table_ready || (b->tile_recs_n * b->span < (1ull << 22) && sorted_count != 2)))
+        if (!b->first_seen && b->tile_recs_n && (b->table_ready || (b->tile_recs_n * b->span < (1ull << 22) && sorted_count != 2)))
             KCHECK(flush_tile_recs(b, stream));      // (k-mers in the table already, or too few tiles to be worth it)
-        if (b->tile_recs_n) {
+        if (!b->first_seen && b->tile_recs_n) {
             const uint32_t k = b->s.k;
             DevBuf rk(stream), rw(stream);
             uint64_t n_rec = 0, n_rest = 0, distinct = 0;
@@ -953,7 +980,86 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
         // (nothing in the k-mer table), so that a record's two sequence numbers pack into one word
         DevBuf raw_w(stream), raw_seq(stream);
         bool counted_seen = false;
-        if (sorted_count && b->first_seen && b->tiles_ready && !b->table_ready && b->nw <= 2 && !b->var_seq_base && !b->var_prefix && !b->direct_edges &&
+        // ... and with the tiles kept as TAGGED records (keep_tile_recs in such a build) every level of it: a level's distinct keys leave
+        // with their counts and their two lowered numbers packed into a tag again (lds_count_seen_kernel, LIST), the next level's tagged
+        // records are cut out of that list (list_to_tagged_records_kernel: a sub-window's numbers are its tile's plus its place in it)
+        if (b->first_seen && b->tile_recs_n && (b->table_ready || (b->tile_recs_n * b->span < (1ull << 22) && sorted_count != 2)))
+            KCHECK(flush_tile_recs(b, stream));
+        if (b->first_seen && b->tile_recs_n) {
+            const uint32_t k = b->s.k, span = b->span, tile_bases = k + span - 1;
+            const uint64_t spr = 2ull * (b->seen_read_len - k + 1);
+            b->span2 = mid_span(span);
+            uint64_t n = 0, n1 = 0, d1 = 0, distinct = 0;
+            KCHECK(tile_recs_valid(b, &n, stream));
+            DevBuf l1(stream), c1(stream);
+            int rc = KATOME_E_UNSUPPORTED;
+            if (n) {
+                PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+                TileLevelScope tl;
+                DevBuf ones(stream);
+                KCHECK(ones.alloc((n + 1) * 4));
+                KCHECK(dev_fill_u32(ones.as<u32>(), n, 1u, stream));
+                rc = tagged_records_sorted(b->tile_recs, ones, n, tile_bases, b->rc, spr, true, l1, c1, &n1, &d1, stream);
+                if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+            }
+            if (rc == KATOME_E_UNSUPPORTED) {
+                KCHECK(flush_tile_recs(b, stream));          // (the records are all still there, in another order: into the table with them)
+            } else {
+                b->tile_recs.release(); b->tile_recs_count.release(); b->tile_recs_n = b->tile_recs_cap = 0;
+                b->tile_recs_exact = false; b->tile_recs_closed = true;
+                b->stat_tiles = n1; b->stat_tile_slots = 0; b->stat_tiles2 = 0; b->stat_tile2_slots = 0;
+                const uint64_t* lk = l1.as<u64>(); const uint32_t* lw = c1.as<u32>();
+                uint64_t n_last = n1; uint32_t last_bases = tile_bases, last_span = span;
+                DevBuf l2(stream), c2(stream);
+                if (b->span2 && n1) {
+                    const uint32_t kk2 = k + b->span2 - 1, n_sub = span / b->span2;
+                    PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
+                    TileLevelScope tl;
+                    DevBuf mk(stream), mw(stream);
+                    uint64_t n_mid = 0, n2 = 0, d2 = 0;
+                    KCHECK(table_list_to_tagged_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream));
+                    rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED : tagged_records_sorted(mk, mw, n_mid, kk2, b->rc, spr, true, l2, c2, &n2, &d2, stream);
+                    if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+                    if (rc == KATOME_OK) { b->stat_tiles2 = n2; lk = l2.as<u64>(); lw = c2.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2; }
+                }
+                if (rc == KATOME_OK) {
+                    PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+                    DevBuf kr(stream), kw(stream);
+                    uint64_t n_rec = 0, n_rest = 0;
+                    KCHECK(rest_valid(b, &n_rest, stream));
+                    KCHECK(table_list_to_tagged_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, kr, kw, &n_rec, stream, n_rest));
+                    l2.release(); c2.release();
+                    if (n_rest) {             // the left-over windows behind them (tagged records already), one each
+                        KCHECK_HIP(hipMemcpyAsync(kr.as<u64>() + n_rec * (b->nw + 1), b->rest_k.p, n_rest * 8 * (b->nw + 1), hipMemcpyDeviceToDevice, stream));
+                        KCHECK(dev_fill_u32(kw.as<u32>() + n_rec, n_rest, 1u, stream));
+                        n_rec += n_rest;
+                    }
+                    rc = sorted_fail("last") ? KATOME_E_UNSUPPORTED
+                        : tagged_records_sorted(kr, kw, n_rec, k, b->rc, spr, false, b->edge_key, raw_seq, &b->n_edges, &distinct, stream);
+                    if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+                }
+                if (rc == KATOME_OK) {
+                    l1.release(); c1.release();
+                    rest_reset(b);
+                    b->stat_kmers = distinct; b->stat_kmer_slots = 0;
+                    counted_seen = true;
+                } else {
+                    // a level below gave up: the distinct big tiles go into the tile table with their counts and their numbers, and the
+                    // build goes on from there as if they had been counted in it
+                    b->n_edges = 0;
+                    l2.release(); c2.release();
+                    const uint32_t nwt = (uint32_t)key_words_for_k(tile_bases);
+                    DevBuf keys(stream), pairs(stream);
+                    KCHECK(keys.alloc(n1 * 8 * nwt + 16)); KCHECK(pairs.alloc(n1 * 16 + 16));
+                    KCHECK(table_tagged_to_pairs(l1.as<u64>(), n1, nwt, spr, keys.as<u64>(), pairs.as<u64>(), stream));
+                    l1.release();
+                    SeenOrigin origin;
+                    origin.pairs = pairs.as<u64>(); origin.rc = b->rc;
+                    KCHECK(builder_insert(b, b->tiles, b->tiles_ready, nwt, b->s.table_slots_hint / 4, keys.as<u64>(), c1.as<u32>(), n1, &origin, PH_INSERT_TILES, stream));
+                }
+            }
+        }
+        if (!counted_seen && sorted_count && b->first_seen && b->tiles_ready && !b->table_ready && b->nw <= 2 && !b->var_seq_base && !b->var_prefix && !b->direct_edges &&
             b->seen_read_len >= b->s.k) {
             uint64_t n_tiles = 0;
             KCHECK(table_occupied(b->tiles, &n_tiles, stream));

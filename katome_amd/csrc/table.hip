@@ -954,7 +954,7 @@ constexpr int KR_ITEMS = 8;            // records per thread and trip: one atomi
                                        // 5e7 records wait 3 ms for its 2e5 turns at that one address)
 template <int NW, bool TAGGED>
 __global__ __launch_bounds__(BLOCK) void keep_rest_kernel(const u64* __restrict__ rec, u64 n, u64 read0, u32 per_read, u32 win0, u32 seq_per_read,
-                                                           u64* __restrict__ out, unsigned long long* cursor) {
+                                                           u64* __restrict__ out, unsigned long long* cursor, u32 win_stride, u32 span) {
     constexpr int WORDS = NW + (TAGGED ? 1 : 0);
     constexpr u32 TILE = BLOCK * KR_ITEMS;
     __shared__ u32 wtot[KR_ITEMS][BLOCK / 64];       // valid records of row j in wave w; then their offset inside the workgroup's claim
@@ -997,7 +997,9 @@ __global__ __launch_bounds__(BLOCK) void keep_rest_kernel(const u64* __restrict_
             for (int q = 0; q < NW; ++q) out[at + q] = key[j].w[q];
             if (TAGGED) {
                 const u64 read = read0 + i / per_read;
-                const u32 w = win0 + (u32)(i % per_read), fwd = w, rev = seq_per_read - 1 - w;      // (insert_kernel's P and Q within the read)
+                // (insert_kernel's P and Q within the read.  A tile of `span` windows, win_stride apart from the next: its first window goes
+                // in at w; its reverse complement is the read's reverse complement's window W - span - w, number 2W - span - w)
+                const u32 w = win0 + (u32)(i % per_read) * win_stride, fwd = w, rev = seq_per_read - span - w;
                 out[at + NW] = seen_pack(read, flipped ? rev : fwd, flipped ? fwd : rev);
             }
         }
@@ -1095,7 +1097,10 @@ __global__ __launch_bounds__(BLOCK) void seen_records_kernel(const typename Slot
 // two edges {key} + {sequence number, weight}.  The slot's first word is the k-mer itself when it has one word (lds_count_kernel's
 // slot) and fingerprint | representative record when it has two (lds_count_wide_kernel's: the full keys are compared in the group).
 constexpr int LCS_PER = 5;                                        // 5120 slots of 28 bytes = 140 KiB
-template <bool RC, int NWK>
+// LIST: a TILE level of such a build -- every distinct key leaves once, as key + tag (the two lowered numbers
+// packed again: both come from the first read that holds the tile on either strand) in out_keys [n][NWK + 1] and its count in
+// out_pairs read as u32 [n]; RC then only says whether the second number is tracked.
+template <bool RC, int NWK, bool LIST = false>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* recs, const u32* wts, const u64* __restrict__ index, u32 gbits, u32 R, u32 k,
                                                                      u64 seq_per_read, u64* out_keys, u64* out_pairs, u64 out_cap,
                                                                      unsigned long long* cursor, unsigned long long* distinct, u32* err, u32 probe_limit) {
@@ -1182,7 +1187,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
 #pragma unroll
                         for (int q = 0; q < NWK; ++q) kk[j].w[q] = recs[rep * STRIDE + q];
                     }
-                    ne[j] = (RC && !key_eq(revcomp(kk[j], k), kk[j])) ? 2 : 1;
+                    ne[j] = (!LIST && RC && !key_eq(revcomp(kk[j], k), kk[j])) ? 2 : 1;
                 }
                 mine += ne[j];
             }
@@ -1204,6 +1209,16 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
                 const unsigned long long a = lA[sidx], b = lB[sidx];
                 const u64 seq_a = (a >> 16) * seq_per_read + (a & 0xFFFFull), seq_b = (b >> 16) * seq_per_read + (b & 0xFFFFull);
                 const u32 c = lcnt[sidx];
+                if (LIST) {
+                    if (pos < out_cap) {
+#pragma unroll
+                        for (int q = 0; q < NWK; ++q) out_keys[pos * STRIDE + q] = kk[j].w[q];
+                        if (RC && (a >> 16) != (b >> 16)) *err = 6;              // (the two numbers of a tile from two reads: cannot be)
+                        out_keys[pos * STRIDE + NWK] = seen_pack(a >> 16, (u32)(a & 0xFFFFull), RC ? (u32)(b & 0xFFFFull) : 0u);
+                        reinterpret_cast<u32*>(out_pairs)[pos] = c;
+                    }
+                    ++pos;
+                } else
                 if (ne[j] == 2) {
                     if (pos + 1 < out_cap) {
                         const Key<NWK> rk = revcomp(kk[j], k);
@@ -1230,6 +1245,31 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
     }
     my_distinct = wave_sum(my_distinct);
     if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
+}
+
+// a list of distinct tiles with their tags and counts (lds_count_seen_kernel, LIST) -> the tagged records of the next level: record p is
+// sub-window p % n_sub of tile p / n_sub; its numbers are the tile's plus the sub-window's place in it (expand_tiles_kernel's rule)
+template <int NWT, int NWK, bool RC>
+__global__ __launch_bounds__(BLOCK) void list_to_tagged_records_kernel(const u64* __restrict__ list, const u32* __restrict__ counts, u64 n_tiles, u32 sub_len,
+                                                                        u32 n_sub, u32 stride, u64* __restrict__ out, u32* __restrict__ out_w) {
+    KATOME_SHIFT64_GUARD(24);        // (<2, 2, false> needs 24 VGPRs with sub_window's shift amount in v23: the gfx950 erratum, common.h)
+    const u64 n = n_tiles * n_sub;
+    for (u64 p = (u64)blockIdx.x * BLOCK + threadIdx.x; p < n; p += (u64)gridDim.x * BLOCK) {
+        const u64 t = p / n_sub;
+        const u32 o = (u32)(p - t * n_sub);
+        Key<NWT> tile;
+#pragma unroll
+        for (int q = 0; q < NWT; ++q) tile.w[q] = list[t * (NWT + 1) + q];
+        const u64 tag = list[t * (NWT + 1) + NWT];
+        Key<NWK> x = sub_window<NWT, NWK>(tile, sub_len, n_sub, stride, o);
+        bool flipped = false;
+        if (RC) x = canonical_flip(x, sub_len, flipped);
+        const u32 a = (u32)((tag >> 16) & 0xFFFFull) + o * stride, b = RC ? (u32)(tag & 0xFFFFull) + (n_sub - 1 - o) * stride : 0u;
+#pragma unroll
+        for (int q = 0; q < NWK; ++q) out[p * (NWK + 1) + q] = x.w[q];
+        out[p * (NWK + 1) + NWK] = seen_pack(tag >> 32, flipped ? b : a, flipped ? a : b);
+        out_w[p] = counts[t];
+    }
 }
 
 // ---- host side --------------------------------------------------------------------------------
@@ -1478,12 +1518,12 @@ int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc
 }
 
 int table_keep_rest(const uint64_t* d_rec, uint64_t n, uint32_t nw, bool tagged, uint64_t read0, uint32_t per_read, uint32_t win0, uint32_t seq_per_read,
-                    uint64_t* d_out, uint64_t* d_cursor, hipStream_t stream) {
+                    uint64_t* d_out, uint64_t* d_cursor, hipStream_t stream, uint32_t win_stride, uint32_t span) {
     if (n == 0) return KATOME_OK;
     const dim3 grid(grid_for(n, BLOCK * KR_ITEMS, 256u * 8u)), block(BLOCK);
     unsigned long long* cur = reinterpret_cast<unsigned long long*>(d_cursor);
     if (!per_read) per_read = 1;
-#define KATOME_KR(NWV, TAG) hipLaunchKernelGGL((keep_rest_kernel<NWV, TAG>), grid, block, 0, stream, d_rec, n, read0, per_read, win0, seq_per_read, d_out, cur)
+#define KATOME_KR(NWV, TAG) hipLaunchKernelGGL((keep_rest_kernel<NWV, TAG>), grid, block, 0, stream, d_rec, n, read0, per_read, win0, seq_per_read, d_out, cur, win_stride, span)
     if (nw == 1) { if (tagged) KATOME_KR(1, true); else KATOME_KR(1, false); }
     else         { if (tagged) KATOME_KR(2, true); else KATOME_KR(2, false); }
 #undef KATOME_KR
@@ -1495,6 +1535,30 @@ int table_tagged_to_pairs(const uint64_t* d_tagged, uint64_t n, uint32_t nw, uin
     const dim3 grid(grid_for(n, BLOCK, 256u * 16u)), block(BLOCK);
     if (nw == 1) hipLaunchKernelGGL(tagged_to_pairs_kernel<1>, grid, block, 0, stream, d_tagged, n, seq_per_read, d_keys, d_pairs);
     else         hipLaunchKernelGGL(tagged_to_pairs_kernel<2>, grid, block, 0, stream, d_tagged, n, seq_per_read, d_keys, d_pairs);
+    KCHECK_HIP(hipGetLastError());
+    return KATOME_OK;
+}
+
+// the tagged records of the next level out of a list of distinct tiles with their tags and counts (list_to_tagged_records_kernel)
+int table_list_to_tagged_records(const uint64_t* d_list, const uint32_t* d_counts, uint64_t n_tiles, uint32_t tile_bases, uint32_t sub_len, uint32_t n_sub,
+                                 uint32_t stride, bool rc, DevBuf& recs, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room) {
+    const uint32_t nwt = (uint32_t)key_words_for_k(tile_bases), nwk = (uint32_t)key_words_for_k(sub_len);
+    *n_records = n_tiles * n_sub;
+    KCHECK(recs.alloc((*n_records + extra_room + 1) * 8 * (nwk + 1), stream));
+    KCHECK(weights.alloc((*n_records + extra_room + 1) * 4, stream));
+    if (*n_records == 0) return KATOME_OK;
+    const dim3 grid(grid_for(*n_records, BLOCK, 256u * 32u)), block(BLOCK);
+    KernelScope ks(K_RECORDS, stream, n_tiles);
+#define KATOME_LT(NWT, NWK)                                                                                                             \
+    do {                                                                                                                              \
+        if (rc) hipLaunchKernelGGL((list_to_tagged_records_kernel<NWT, NWK, true>), grid, block, 0, stream, d_list, d_counts, n_tiles, sub_len, n_sub, stride, recs.as<u64>(), weights.as<u32>()); \
+        else    hipLaunchKernelGGL((list_to_tagged_records_kernel<NWT, NWK, false>), grid, block, 0, stream, d_list, d_counts, n_tiles, sub_len, n_sub, stride, recs.as<u64>(), weights.as<u32>()); \
+    } while (0)
+    if (nwt == 2 && nwk == 2) KATOME_LT(2, 2);
+    else if (nwt == 2 && nwk == 1) KATOME_LT(2, 1);
+    else if (nwt == 1 && nwk == 1) KATOME_LT(1, 1);
+    else { set_error("tagged records of a tile list: tiles of %u words into windows of %u", nwt, nwk); return KATOME_E_UNSUPPORTED; }
+#undef KATOME_LT
     KCHECK_HIP(hipGetLastError());
     return KATOME_OK;
 }
@@ -1515,10 +1579,8 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
     KCHECK(wts.alloc((bound + 1) * 4));
     KCHECK(aux.alloc(64));
     KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
-    unsigned long long* cursor = aux.as<unsigned long long>();
-    unsigned long long* distinct = cursor + 1;
-    u32* err = reinterpret_cast<u32*>(cursor + 2);
-    u64* rec_cursor = reinterpret_cast<u64*>(cursor + 3);
+    u32* err = reinterpret_cast<u32*>(aux.as<unsigned long long>() + 2);
+    u64* rec_cursor = aux.as<u64>() + 3;
     {
         KernelScope ks(K_RECORDS, stream, tiles.cap);
         const dim3 grid(grid_for(tiles.cap, BLOCK * TR_ITEMS, 256u * 8u)), block(BLOCK);
@@ -1546,6 +1608,26 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
         KCHECK(dev_fill_u32(wts.as<u32>() + n, n_extra, 1u, stream));
         n += n_extra;
     }
+    return tagged_records_sorted(recs, wts, n, k, rc, seq_per_read, false, edge_key, seq_weight, n_edges, n_distinct, stream);
+}
+
+// Tagged records [n][nwk + 1] (key, read << 32 | offset << 16 | offset) with their counts -> two hash passes on the key, counted in LDS
+// with the two numbers lowered (lds_count_seen_kernel).  list == false: the oriented edges, out_keys [e][nwk] + out_second [e][2] =
+// {sequence number, weight}.  list == true (a tile level): the distinct keys with their tags, out_keys [d][nwk + 1], and their counts,
+// out_second [d] u32.  The records come back permuted.
+int tagged_records_sorted(DevBuf& recs, DevBuf& wts, uint64_t n, uint32_t k, bool rc, uint64_t seq_per_read, bool list, DevBuf& edge_key,
+                          DevBuf& seq_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream) {
+    *n_edges = 0; *n_distinct = 0;
+    const uint32_t nwk = (uint32_t)key_words_for_k(k), stride = nwk + 1;
+    constexpr u32 FILL = (u32)(LC_THREADS * LCS_PER / 4096.0 * 2900);
+    if (nwk > 2 || seq_per_read == 0 || seq_per_read > 0xFFFFu || n >= (1ull << 32) || (n >> 16) > (u64)LC_MAX_ROUNDS * FILL) return KATOME_E_UNSUPPORTED;
+    DevBuf aux(stream);
+    KCHECK(aux.alloc(64));
+    KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+    unsigned long long* cursor = aux.as<unsigned long long>();
+    unsigned long long* distinct = cursor + 1;
+    u32* err = reinterpret_cast<u32*>(cursor + 2);
+    uint64_t h[4] = {0, 0, 0, 0};
     if (n == 0) { KCHECK(edge_key.alloc(16, stream)); KCHECK(seq_weight.alloc(16, stream)); return KATOME_OK; }
     const u64* ko = nullptr; const u32* wo = nullptr;
     u32 gbits = 16;
@@ -1564,21 +1646,23 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
         if (nwk == 1) hipLaunchKernelGGL((hash_group_index_kernel<1, 2>), igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
         else          hipLaunchKernelGGL((hash_group_index_kernel<2, 3>), igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
     }
-    const uint64_t out_cap = (rc ? 2 : 1) * n + 2;
-    KCHECK(edge_key.alloc(out_cap * 8 * nwk, stream));
-    KCHECK(seq_weight.alloc(out_cap * 16, stream));
+    const uint64_t out_cap = ((rc && !list) ? 2 : 1) * n + 2;
+    KCHECK(edge_key.alloc(out_cap * 8 * (list ? stride : nwk), stream));
+    KCHECK(seq_weight.alloc(out_cap * (list ? 4 : 16), stream));
     auto count = [&](u32 rounds, u32 probe_limit) -> int {
         KCHECK_HIP(hipMemsetAsync(aux.p, 0, 24, stream));
         const size_t lds = (size_t)LC_THREADS * LCS_PER * 28;
         KernelScope ks(K_LDS_COUNT, stream, n);
-#define KATOME_LCS(RCV, NWKV)                                                                                                            \
+#define KATOME_LCS(RCV, NWKV, LISTV)                                                                                                     \
         do {                                                                                                                             \
-            KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_seen_kernel<RCV, NWKV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-            hipLaunchKernelGGL((lds_count_seen_kernel<RCV, NWKV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, rounds, k, \
+            KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_seen_kernel<RCV, NWKV, LISTV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL((lds_count_seen_kernel<RCV, NWKV, LISTV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), gbits, rounds, k, \
                                seq_per_read, edge_key.as<u64>(), seq_weight.as<u64>(), out_cap, cursor, distinct, err, probe_limit);     \
         } while (0)
-        if (nwk == 1) { if (rc) KATOME_LCS(true, 1); else KATOME_LCS(false, 1); }
-        else          { if (rc) KATOME_LCS(true, 2); else KATOME_LCS(false, 2); }
+        if (list)          { if (nwk == 1) { if (rc) KATOME_LCS(true, 1, true); else KATOME_LCS(false, 1, true); }
+                             else          { if (rc) KATOME_LCS(true, 2, true); else KATOME_LCS(false, 2, true); } }
+        else if (nwk == 1) { if (rc) KATOME_LCS(true, 1, false); else KATOME_LCS(false, 1, false); }
+        else               { if (rc) KATOME_LCS(true, 2, false); else KATOME_LCS(false, 2, false); }
 #undef KATOME_LCS
         KCHECK_HIP(hipGetLastError());
         KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
@@ -1589,7 +1673,7 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
     const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / FILL));
     if (R_try < R) { KCHECK(count(R_try, lc_probe_limit())); if ((uint32_t)h[2] == 3) { lc_trace("first-seen order", R_try, R); KCHECK(count(R, LC_THREADS * LCS_PER)); } }
     else KCHECK(count(R, LC_THREADS * LCS_PER));
-    if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;
+    if ((uint32_t)h[2] == 4 || (uint32_t)h[2] == 6) return KATOME_E_UNSUPPORTED;
     if ((uint32_t)h[2]) { set_error("counting in LDS (first-seen order): a sub-round did not fit its table (code %u)", (unsigned)h[2]); return KATOME_E_DEVICE; }
     *n_edges = h[0]; *n_distinct = h[1];
     return KATOME_OK;
