@@ -996,9 +996,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             if (n) {
                 PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
                 TileLevelScope tl;
-                DevBuf ones(stream);
-                KCHECK(ones.alloc((n + 1) * 4));
-                KCHECK(dev_fill_u32(ones.as<u32>(), n, 1u, stream));
+                DevBuf ones(stream);               // (stays empty: the records count once each)
                 rc = tagged_records_sorted(b->tile_recs, ones, n, tile_bases, b->rc, spr, true, l1, c1, &n1, &d1, stream);
                 if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
             }

@@ -20,13 +20,18 @@ constexpr int RADIX = 1 << RADIX_BITS;
 #ifndef KATOME_SORT_ITEMS_WIDE
 #define KATOME_SORT_ITEMS_WIDE 8
 #endif
+#ifndef KATOME_SORT_ITEMS_3
+#define KATOME_SORT_ITEMS_3 5
+#endif
 #ifndef KATOME_SORT_WAVES
 #define KATOME_SORT_WAVES 4      // workgroups per CU the scatter kernel is compiled for (register budget)
 #endif
 // keys per thread and per workgroup tile: 4096 one-word keys, 2048 wider ones -- the same 32 KiB of LDS and the same
 // 128 bytes per digit run either way (a 64 KiB tile of 128-bit keys left two workgroups per CU: C5's passes 13.5 -> 10 ms)
 template <int NW> struct SortTile {
-    static constexpr int ITEMS = NW == 1 ? KATOME_SORT_ITEMS : KATOME_SORT_ITEMS_WIDE;
+    // (three-word records -- 95-base tiles, two-word keys with a tag: 1280 of them = 30 KiB, four workgroups per CU like the others;
+    // at 2048 = 48 KiB there were two)
+    static constexpr int ITEMS = NW == 1 ? KATOME_SORT_ITEMS : NW == 2 ? KATOME_SORT_ITEMS_WIDE : KATOME_SORT_ITEMS_3;
     static constexpr int KEYS = BLOCK * ITEMS;
 };
 // workgroups per offset chunk: the chunk kernel walks a chunk's workgroups serially, the offsets kernel walks the chunks
@@ -329,7 +334,7 @@ struct PassBuffers {
     u32 chunk_blocks = 64;
     int init(u64 n, int nw, hipStream_t stream) {
         counts.stream = chunk.stream = totals.stream = stream;
-        const u64 tile = nw == 1 ? SortTile<1>::KEYS : SortTile<2>::KEYS;
+        const u64 tile = nw == 1 ? SortTile<1>::KEYS : nw == 2 ? SortTile<2>::KEYS : SortTile<3>::KEYS;
         nblocks = (n + tile - 1) / tile;
         chunk_blocks = chunk_blocks_for(nblocks);
         nchunks = (nblocks + chunk_blocks - 1) / chunk_blocks;
@@ -782,8 +787,9 @@ static int tagged_order_t(const u64* d_in, const u32* w_in, u64 n, u64* ka, u64*
     u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
     for (int p = 0; p < 2; ++p) {
         HashTaggedDigit<NW> dg{(u32)(64 - 8 * (2 - p))};
-        KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
-        kin = kdst[p & 1]; win = wdst[p & 1];
+        if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
+        else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream)));      // (records that count once each)
+        kin = kdst[p & 1]; win = w_in ? wdst[p & 1] : nullptr;
     }
     *k_out = kin; *w_out = win;
     return KATOME_OK;

@@ -1136,7 +1136,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
                   if (i < hi) {
 #pragma unroll
                       for (int q = 0; q < NWK; ++q) kv[u].w[q] = recs[i * STRIDE + q];
-                      tv[u] = recs[i * STRIDE + NWK]; wv[u] = wts[i];
+                      tv[u] = recs[i * STRIDE + NWK]; wv[u] = wts ? wts[i] : 1u;        // (no counts: one each -- tiles straight from the reads)
                   }
               }
 #pragma unroll
@@ -1632,7 +1632,9 @@ int tagged_records_sorted(DevBuf& recs, DevBuf& wts, uint64_t n, uint32_t k, boo
     const u64* ko = nullptr; const u32* wo = nullptr;
     u32 gbits = 16;
     DevBuf kb(stream), wb(stream);
-    KCHECK(kb.alloc((n + 1) * 8 * stride)); KCHECK(wb.alloc((n + 1) * 4));
+    const bool unit = wts.p == nullptr;                  // (no counts: every record counts once, and the passes move the records only)
+    KCHECK(kb.alloc((n + 1) * 8 * stride));
+    if (!unit) KCHECK(wb.alloc((n + 1) * 4));
     KCHECK(dev_hash_order_tagged(recs.as<u64>(), wts.as<u32>(), n, nwk, kb.as<u64>(), recs.as<u64>(), wb.as<u32>(), wts.as<u32>(), &ko, &wo, &gbits, stream));
     kb.release(); wb.release();                                      // (two passes: the result is back in recs / wts)
     const u64 avg = n >> gbits;
