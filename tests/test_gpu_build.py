@@ -819,6 +819,20 @@ for batch, plain in ((100, False), (100, True), (6000, False)):
     got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
     print("KEPT", batch, int(plain), dg.n_edges, int(len(got) == dg.n_edges and got == want), c["tile_slots"], c["kmer_slots"])
     b.close()
+# the reference's numbering: the tiles are kept as TAGGED records; array for array against the oracle's petgraph
+ref_fs = o.build_ascii(reads, k, True)
+for batch in (100, 6000):
+    b = kd.Builder(k, True, first_seen_order=True, table_slots_hint=1 << 14)
+    for r0 in range(0, n, batch):
+        b.count_reads(packed, min(batch, n - r0), L, skip, first_read=r0)
+    dg = b.finalize()
+    c = b.counts()
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    same = (dg.n_nodes, dg.n_edges) == (ref_fs.n_nodes, ref_fs.n_edges) and np.array_equal(lab, ref_fs.edge_label) and \
+        np.array_equal(dg.edge_weight.cpu().numpy(), ref_fs.edge_weight) and np.array_equal(dg.edge_src.cpu().numpy(), ref_fs.edge_src) and \
+        np.array_equal(dg.edge_dst.cpu().numpy(), ref_fs.edge_dst)
+    print("SEEN", batch, dg.n_edges, int(same), c["tile_slots"], c["kmer_slots"])
+    b.close()
 # no read skipped: katome_dev_count_tiles makes the records where they are kept -- all batches; then with a skip array (of zeros)
 # for every third batch, whose records go through the buffer and the copy, and the two-call boundary in between
 reads2 = o.synth_reads(12, n, L, 25000, 4e-3, 0)
@@ -851,7 +865,8 @@ def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
     batches counted window by window in between -- and, in processes of their own, a limit on what may be kept that is reached
     half-way (the records kept so far go into the tile table, later batches too) and a level below that gives up (the distinct big
     tiles go into the tile table with their counts); and `katome_dev_count_tiles`, which makes a batch's records where they are kept
-    when no read is skipped, alone and mixed with batches that go through a buffer -- against the oracle"""
+    when no read is skipped, alone and mixed with batches that go through a buffer -- against the oracle; the same limits and
+    give-ups for a build in the reference's numbering (tagged tile records), array for array against the oracle's petgraph"""
     import subprocess
     script = tmp_path / "kept.py"
     script.write_text(_KEPT_SCRIPT)
@@ -867,6 +882,12 @@ def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
         inplace = [line.split() for line in out.stdout.splitlines() if line.startswith("INPLACE ")]
         assert len(inplace) == 2 and all(r[3] == "1" for r in inplace), (limit, inplace)
         assert inplace[0][2] == inplace[1][2]
+        seen = [line.split() for line in out.stdout.splitlines() if line.startswith("SEEN ")]
+        assert len(seen) == 2 and all(r[3] == "1" for r in seen), (limit, seen)
+        if limit is None:
+            assert all(r[4] == "0" and r[5] == "0" for r in seen), seen      # no table at any level
+        elif limit in ("9000", "mid"):
+            assert all(r[4] != "0" for r in seen), (limit, seen)             # the tile table took over
         rows = [line.split() for line in out.stdout.splitlines() if line.startswith("KEPT ")]
         assert len(rows) == 3
         for r in rows:
