@@ -550,7 +550,8 @@ int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uin
 // records are cut out of that list.  KATOME_OK: keys / weights hold *n_records records (room for extra_room more behind them) and
 // the tile records are gone.  KATOME_E_UNSUPPORTED: a level could not be counted this way (or there is nothing to count) -- the
 // tile records, or the distinct big tiles with their counts, are in the tile table instead and the caller goes on in tables.
-int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, uint64_t* n_records, uint64_t extra_room, hipStream_t stream) {
+int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, uint64_t* n_records, uint64_t extra_room, hipStream_t stream,
+                              DevBuf* first_counts) {
     *n_records = 0;
     const uint32_t k = b->s.k, span = b->span, tile_bases = k + span - 1, nwt = (uint32_t)key_words_for_k(tile_bases);
     b->span2 = mid_span(span);
@@ -584,8 +585,10 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
         TileLevelScope tl;
         DevBuf mk(stream), mw(stream);
         uint64_t n_mid = 0, n2 = 0, d2 = 0;
-        KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream));
-        rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED : records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream);
+        DevBuf mid_counts(stream);        // (the first partition pass's digit counts per tile, made while the records are written)
+        KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream, 0, &mid_counts));
+        rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED
+            : records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream, nullptr, mid_counts.as<u32>());
         if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
         if (rc == KATOME_E_UNSUPPORTED) {
             // the mid tiles cannot be counted this way: the distinct big tiles go into the tile table with their counts, and the build
@@ -599,7 +602,8 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
         t1k.release(); t1w.release();
     }
     PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
-    return table_list_to_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, keys, weights, n_records, stream, extra_room);
+    // (first_counts: for a caller that orders exactly these records by the whole k-mer's hash next -- table_list_to_records)
+    return table_list_to_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, keys, weights, n_records, stream, extra_room, first_counts);
 }
 
 // keeps a batch's left-over windows aside (see builder.h); *kept = false: they have to go into the table
@@ -874,7 +878,8 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             DevBuf rk(stream), rw(stream);
             uint64_t n_rec = 0, n_rest = 0, distinct = 0;
             KCHECK(rest_valid(b, &n_rest, stream));
-            int rc = tile_recs_to_kmer_records(b, rk, rw, &n_rec, n_rest, stream);
+            DevBuf first_counts(stream);
+            int rc = tile_recs_to_kmer_records(b, rk, rw, &n_rec, n_rest, stream, &first_counts);
             if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
             if (rc == KATOME_OK) {         // (otherwise the tiles are in their table now, and the blocks below take it from there)
                 {
@@ -886,7 +891,8 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     }
                     rest_reset(b);
                     rc = sorted_fail("last") ? KATOME_E_UNSUPPORTED
-                        : records_to_edges_sorted(rk, rw, n_rec, k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream);
+                        : records_to_edges_sorted(rk, rw, n_rec, k, b->rc, b->prune_weight, b->edge_key, b->edge_weight, &b->n_edges, &distinct, stream, nullptr,
+                                                  n_rest ? nullptr : first_counts.as<u32>());
                     if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
                 }
                 if (rc == KATOME_OK) {

@@ -84,7 +84,8 @@ int flush_rest(katome_builder* b, hipStream_t stream);
 int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uint32_t nwt, bool* kept, hipStream_t stream);   // a batch's valid tile records behind those kept so far
 int tile_recs_valid(katome_builder* b, uint64_t* n, hipStream_t stream);      // how many of them there are
 // ... counted level by level by sorting, down to the (k-mer, count) records of the last tile level (api.hip)
-int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, uint64_t* n_records, uint64_t extra_room, hipStream_t stream);
+int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, uint64_t* n_records, uint64_t extra_room, hipStream_t stream,
+                              DevBuf* first_counts = nullptr);
 int sorted_count_mode();            // KATOME_SORTED_COUNT
 int sorted_tiles_mode();            // KATOME_SORTED_TILES
 bool sorted_fail(const char* level);     // KATOME_SORTED_FAIL (tests)

@@ -193,7 +193,8 @@ int dev_hash_order_tagged(const uint64_t* d_in, const uint32_t* w_in, uint64_t n
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream);
 int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
-                   const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream);
+                   const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream, const uint32_t* first_counts = nullptr);
+uint32_t dev_sort_tile_keys(uint32_t nw);
 int dev_unique(uint64_t* d_keys, uint64_t n, uint32_t nw, uint64_t* n_out, hipStream_t stream);
 int dev_rank(const uint64_t* d_sorted, uint64_t n_sorted, uint32_t nw, uint32_t key_bits, const uint64_t* d_q, uint64_t nq,
              uint64_t* d_out, hipStream_t stream);
@@ -318,7 +319,9 @@ int table_expand_tiles(Table& tiles, uint64_t slot0, uint64_t slot1, Table& kmer
 int table_expand_tiles_to_records(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights,
                                   uint64_t* n_records, hipStream_t stream, DevBuf* seen = nullptr);
 int table_list_to_records(const uint64_t* d_tiles, const uint32_t* d_counts, uint64_t n_tiles, uint32_t tile_bases, uint32_t k, uint32_t span, uint32_t stride, bool rc,
-                          DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room = 0);
+                          DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room = 0, DevBuf* first_counts = nullptr);
+// (first_counts: filled with the digit counts per tile of the first partition pass over these records -- dev_hash_order's first_counts --
+// when the kernel can make them as it writes; released otherwise)
 // (extra_room: records the caller will append behind them -- the windows left over after the tiles)
 int table_tiles_to_records_fast(Table& tiles, uint32_t k, uint32_t span, bool rc, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream,
                                 uint64_t extra_room = 0);
@@ -344,7 +347,8 @@ struct OwnerSplit {
     uint64_t base[KATOME_MAX_RANKS] = {0}, count[KATOME_MAX_RANKS] = {0};
 };
 int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
-                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, OwnerSplit* split = nullptr);
+                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, OwnerSplit* split = nullptr,
+                            const uint32_t* first_counts = nullptr);
 int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, DevBuf* seen_pairs = nullptr);
 int table_expand_tiles_to_subtiles(Table& tiles, uint32_t k, uint32_t span, uint32_t stride, bool rc, DevBuf& keys, DevBuf& weights,
                                    uint64_t* n_records, hipStream_t stream, DevBuf* seen = nullptr);

@@ -354,10 +354,11 @@ template <int NW> struct DigitTimers<OwnerDigit<NW>> { static constexpr int HIST
 template <> struct DigitTimers<RangeDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 
 template <int NW, bool HAS_VAL, class Digit>
-static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout, u32* vout, PassBuffers& pb, hipStream_t stream) {
+static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout, u32* vout, PassBuffers& pb, hipStream_t stream,
+                      bool have_counts = false) {
     if (pb.nblocks > 0x7fffffffull) { set_error("radix pass: %llu keys exceed the grid limit", (unsigned long long)n); return KATOME_E_ARG; }
     dim3 block(BLOCK);
-    {
+    if (!have_counts) {          // (have_counts: whoever wrote the records counted this pass's digits per tile as it went -- pb.counts holds them)
         KernelScope ks(DigitTimers<Digit>::HIST, stream, n);
         hipLaunchKernelGGL((radix_hist_kernel<NW, Digit>), dim3((unsigned)pb.nblocks), block, 0, stream, kin, n, dg, pb.counts.as<u32>());
     }
@@ -756,15 +757,18 @@ int dev_partition_range(const uint64_t* d_vals, const uint32_t* idx_in, uint64_t
 // Result lands in `bufs[passes & 1]` where bufs = {scratch_a, scratch_b}; returns that pointer.
 template <int NW>
 static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u64* ka, u64* kb, u32* wa, u32* wb,
-                          const u64** k_out, const u32** w_out, hipStream_t stream) {
+                          const u64** k_out, const u32** w_out, hipStream_t stream, const u32* first_counts = nullptr) {
     PassBuffers pb;
     KCHECK(pb.init(n, NW, stream));
+    // (first_counts: the first pass's digit counts per tile, [ceil(n / dev_sort_tile_keys)][256], made while the records were written)
+    if (first_counts) KCHECK_HIP(hipMemcpyAsync(pb.counts.p, first_counts, pb.nblocks * RADIX * sizeof(u32), hipMemcpyDeviceToDevice, stream));
     const u64* kin = d_in; const u32* win = w_in;
     u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
     for (int p = 0; p < passes; ++p) {
         HashDigit<NW> dg{(u32)(64 - 8 * (passes - p))};     // least significant region byte first
-        if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
-        else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream)));
+        const bool have = p == 0 && first_counts != nullptr;
+        if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream, have)));
+        else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream, have)));
         kin = kdst[p & 1]; win = w_in ? wdst[p & 1] : nullptr;
     }
     *k_out = kin; *w_out = win;
@@ -773,11 +777,14 @@ static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u
 // (k-mer, count) records of one or two words ordered by the top 16 bits of the k-mer's hash, for the counting in LDS (table.hip): two
 // stable 8-bit passes.  The result is where *k_out / *w_out point (one of the two buffer pairs); *group_bits = 16.
 int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
-                   const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream) {
+                   const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream, const uint32_t* first_counts) {
     *group_bits = 16;
-    if (nw == 1) return region_order_t<1>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
-    return region_order_t<2>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream);
+    if (nw == 1) return region_order_t<1>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream, first_counts);
+    return region_order_t<2>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream, first_counts);
 }
+// records per tile of a partition pass over records of nw words, and the digit of dev_hash_order's first pass (for a kernel that
+// writes such records and counts that pass's digits per tile as it goes: table.hip, list_to_records_kernel)
+uint32_t dev_sort_tile_keys(uint32_t nw) { return nw == 1 ? SortTile<1>::KEYS : nw == 2 ? SortTile<2>::KEYS : SortTile<3>::KEYS; }
 // records of nwk + 1 words (k-mer, tag) with their counts, ordered by the top 16 bits of the K-MER's hash (two stable passes)
 template <int NW>
 static int tagged_order_t(const u64* d_in, const u32* w_in, u64 n, u64* ka, u64* kb, u32* wa, u32* wb, const u64** k_out, const u32** w_out, hipStream_t stream) {

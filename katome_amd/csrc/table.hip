@@ -634,6 +634,39 @@ __global__ __launch_bounds__(BLOCK) void list_to_records_kernel(const u64* __res
     }
 }
 
+// The same records written tile by tile of the partition pass that follows -- `tile_keys` consecutive records per trip of a workgroup
+// -- with that pass's digit (bits 48..55 of the record's hash: dev_hash_order's first pass) counted per tile in LDS as they are made:
+// counts[tile][digit] is what radix_hist_kernel would count, without reading the records back (C3: 17 + 15 GB not read per build).
+template <int NWT, int NWK, bool RC>
+__global__ __launch_bounds__(BLOCK) void list_to_records_hist_kernel(const u64* __restrict__ tiles, const u32* __restrict__ counts, u64 n_tiles, u32 k, u32 span,
+                                                                      u32 stride, u64* __restrict__ out_keys, u32* __restrict__ out_w, u32 tile_keys,
+                                                                      u32* __restrict__ digit_counts) {
+    static_assert(BLOCK == 256, "one thread per digit");
+    __shared__ u32 h[256];
+    const u64 n = n_tiles * span, n_out_tiles = (n + tile_keys - 1) / tile_keys;
+    for (u64 ot = blockIdx.x; ot < n_out_tiles; ot += gridDim.x) {
+        h[threadIdx.x] = 0;
+        __syncthreads();
+        const u64 p0 = ot * tile_keys, p1 = p0 + tile_keys < n ? p0 + tile_keys : n;
+        for (u64 p = p0 + threadIdx.x; p < p1; p += BLOCK) {
+            const u64 t = p / span;
+            const u32 o = (u32)(p - t * span);
+            Key<NWT> tile;
+#pragma unroll
+            for (int q = 0; q < NWT; ++q) tile.w[q] = tiles[t * NWT + q];
+            Key<NWK> x = sub_window<NWT, NWK>(tile, k, span, stride, o);
+            if (RC) x = canonical(x, k);
+#pragma unroll
+            for (int q = 0; q < NWK; ++q) out_keys[p * NWK + q] = x.w[q];
+            out_w[p] = counts[t];
+            atomicAdd(&h[(u32)(hash_key(x) >> 48) & 255u], 1u);
+        }
+        __syncthreads();
+        digit_counts[ot * 256 + threadIdx.x] = h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The last level without device-scope atomics.  The (k-mer, count) records of the distinct tiles are ordered by the top 16
 // bits of their hash (two stable 8-bit passes of radix.hip, HashDigit), which cuts them into 65536 groups; a workgroup takes a
@@ -1463,12 +1496,34 @@ int table_to_records(Table& t, DevBuf& keys, DevBuf& weights, uint64_t* n_record
 
 // the (sub-window, count) records of a compact list of distinct tiles (list_to_records_kernel); extra_room: see below
 int table_list_to_records(const uint64_t* d_tiles, const uint32_t* d_counts, uint64_t n_tiles, uint32_t tile_bases, uint32_t k, uint32_t span, uint32_t stride, bool rc,
-                          DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room) {
+                          DevBuf& keys, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room, DevBuf* first_counts) {
     const uint32_t nwt = (uint32_t)key_words_for_k(tile_bases), nwk = (uint32_t)key_words_for_k(k);
     *n_records = n_tiles * span;
     KCHECK(keys.alloc((*n_records + extra_room + 1) * 8 * nwk, stream));
     KCHECK(weights.alloc((*n_records + extra_room + 1) * 4, stream));
     if (*n_records == 0) return KATOME_OK;
+    // (first_counts: the caller sorts exactly these records next -- nothing appended -- and wants the first pass's digit counts per tile;
+    // KATOME_FUSED_HIST=0: the pass counts them itself)
+    static const bool fused_hist = !getenv("KATOME_FUSED_HIST") || atoi(getenv("KATOME_FUSED_HIST")) != 0;
+    if (first_counts && fused_hist && !extra_room && ((nwt == 2 && nwk <= 2) || (nwt == 1 && nwk == 1))) {
+        const uint32_t tile_keys = dev_sort_tile_keys(nwk);
+        const uint64_t n_out_tiles = (*n_records + tile_keys - 1) / tile_keys;
+        KCHECK(first_counts->alloc(n_out_tiles * 256 * 4 + 16, stream));
+        const dim3 hgrid(grid_for(n_out_tiles, 1, 256u * 32u)), block(BLOCK);
+        KernelScope ks(K_RECORDS, stream, n_tiles);
+#define KATOME_LRH(NWT, NWK)                                                                                                            \
+        do {                                                                                                                          \
+            if (rc) hipLaunchKernelGGL((list_to_records_hist_kernel<NWT, NWK, true>), hgrid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>(), tile_keys, first_counts->as<u32>()); \
+            else    hipLaunchKernelGGL((list_to_records_hist_kernel<NWT, NWK, false>), hgrid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>(), tile_keys, first_counts->as<u32>()); \
+        } while (0)
+        if (nwt == 2 && nwk == 2) KATOME_LRH(2, 2);
+        else if (nwt == 2 && nwk == 1) KATOME_LRH(2, 1);
+        else KATOME_LRH(1, 1);
+#undef KATOME_LRH
+        KCHECK_HIP(hipGetLastError());
+        return KATOME_OK;
+    }
+    if (first_counts) first_counts->release();
     const dim3 grid(grid_for(*n_records, BLOCK, 256u * 32u)), block(BLOCK);
     KernelScope ks(K_RECORDS, stream, n_tiles);
 #define KATOME_LR(NWT, NWK)                                                                                                             \
@@ -1685,7 +1740,8 @@ int tagged_records_sorted(DevBuf& recs, DevBuf& wts, uint64_t n, uint32_t k, boo
 // by sorting instead of in a table (see lds_count_kernel).  keys/weights: the records (consumed).  KATOME_E_UNSUPPORTED when
 // the input is out of the kernel's range (the caller counts in the table instead).
 int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t k, bool rc, uint32_t min_weight, DevBuf& edge_key,
-                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, OwnerSplit* split) {
+                            DevBuf& edge_weight, uint64_t* n_edges, uint64_t* n_distinct, hipStream_t stream, OwnerSplit* split,
+                            const uint32_t* first_counts) {
     *n_edges = 0; *n_distinct = 0;
     const uint32_t nw = (uint32_t)key_words_for_k(k);
     if (nw > 2) return KATOME_E_UNSUPPORTED;
@@ -1705,7 +1761,8 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         // two passes: the first one's output goes to the scratch, the second one's lands in keys / weights again
         if (split) KCHECK(dev_hash_order_core(keys.as<u64>(), weights.as<u32>(), n, split->core_shift, split->core_bases, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(),
                                               weights.as<u32>(), &ko, &wo, &gbits, stream));
-        else KCHECK(dev_hash_order(keys.as<u64>(), weights.as<u32>(), n, nw, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, &gbits, stream));
+        else KCHECK(dev_hash_order(keys.as<u64>(), weights.as<u32>(), n, nw, kb.as<u64>(), keys.as<u64>(), wb.as<u32>(), weights.as<u32>(), &ko, &wo, &gbits, stream,
+                                   first_counts));
     }
     // the smaller table when a group fits it in one round (less to clear and to read out per group)
     const u64 avg = n >> gbits;
