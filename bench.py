@@ -456,8 +456,9 @@ def main():
                     # (... and are written where they are kept by the extraction: no copy, unless reads are skipped)
                     copy_b = 16 * nwt if (os.environ.get("KATOME_BENCH_TWO_CALLS") == "1" or skip_arg is not None) else 0
                     alg["insert_tiles"] = lambda launches, reads: reads * tiles * (copy_b + 2 * (8 * nwt + 2 * 8 * nwt) + 8 + 8 * nwt) + steps * cnt["distinct_tiles"] * pair_t
+                    hist_m = 8 * nwm * (1 if os.environ.get("KATOME_FUSED_HIST", "1") != "0" else 2)       # (the first pass's digits are counted as the records are written)
                     alg["expand_mid_tiles"] = lambda launches, reads: steps * (
-                        cnt["distinct_tiles"] * pair_t + cnt["distinct_tiles"] * (span // ms2) * (pair_m + 2 * (8 * nwm + 2 * pair_m) + 8 + pair_m)
+                        cnt["distinct_tiles"] * pair_t + cnt["distinct_tiles"] * (span // ms2) * (pair_m + hist_m + 2 * 2 * pair_m + 8 + pair_m)
                         + cnt["distinct_mid_tiles"] * pair_m)
                 elif not cnt["mid_tile_slots"] and cnt["tile_slots"]:
                     # the mid tiles were counted by sorting (api.hip, KATOME_SORTED_TILES): one scan of the big-tile table, a record
@@ -478,7 +479,9 @@ def main():
                                                               else (cnt["tile_slots"], cnt["distinct_tiles"], span, nwt))
                 n_rec = last_tiles * last_span
                 last_read = last_slots * 16 * last_nw if last_slots else last_tiles * (8 * last_nw + 4)      # (a table scanned, or a compact list)
-                alg["expand_tiles"] = lambda launches, reads: steps * (last_read + n_rec * (12 + 2 * (8 + 12 + 12) + 8 + 12) + n_edges * 12)
+                # (records cut out of a list: the first pass's digits are counted as they are written -- one histogram read less)
+                hist_reads = 1 if (not last_slots and not rest and os.environ.get("KATOME_FUSED_HIST", "1") != "0") else 2
+                alg["expand_tiles"] = lambda launches, reads: steps * (last_read + n_rec * (12 + hist_reads * 8 + 2 * (12 + 12) + 8 + 12) + n_edges * 12)
             # dev_sort: passes over the top log2(n)+9 bits (all of them if that saves fewer than four), each reading and writing
             # every (key, weight) pair once, then one more read + write by the run sort
             sort_passes[0] = _sort_passes(2 * wl.k, n_edges)
@@ -488,6 +491,9 @@ def main():
             # one node key probed per target, source and target ids and the node keys written (N ~ E)
             alg["node_set"] = lambda launches, reads: steps * n_edges * (4 * 8 * nw + 8 + 8 + 8 * nw)
             alg["labels"] = lambda launches, reads: steps * n_edges * (8 * nw + 1 + (wl.k + 3) // 4)
+        # the records of a level cut out of a list are written with the first partition pass's digits counted on the way
+        # (table.hip list_to_records_hist_kernel): that pass has no histogram kernel of its own
+        fused_hist = os.environ.get("KATOME_FUSED_HIST", "1") != "0"
         kernel_names = {"extract": "extract_fixed_kernel", "insert": "insert_kernel",
                         "insert_tiles": "insert_kernel", "expand_tiles": "expand_tiles_kernel",
                         "expand_mid_tiles": "expand_tiles_kernel (big tiles -> mid tiles)",
@@ -505,7 +511,7 @@ def main():
                     kernel_names["expand_mid_tiles"] = "tiles_to_records_kernel (big tiles -> mid-tile records) + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no mid-tile table; a compact list of (mid tile, count) is written)"
                 else:
                     kernel_names["insert_tiles"] = "tile records kept aside per batch + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no tile table)"
-                    kernel_names["expand_mid_tiles"] = "list_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no mid-tile table)"
+                    kernel_names["expand_mid_tiles"] = "list_to_records_hist_kernel (records + the first pass's digit counts) + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no mid-tile table)"
         kernels = {}                      # phases of the build (one or several launches each)
         kernel_launches = {}              # single kernels timed launch by launch inside the phases (library: KernelScope)
         reads_per_rank_step = wl.reads / world
@@ -556,7 +562,8 @@ def main():
                              "lds_count_kernel": pair + float(pair) * n_edges / n_rec})
                 kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nw, nw),
                                "radix_hist_kernel<HashDigit>": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nw, nw),
-                               "tiles_to_records_kernel": ("void list_to_records_kernel<%d, %d, %s>" if sorted_tiles else "void tiles_to_records_kernel<%d, %d, %s>") % (last_nw, nw, rcs),
+                               "tiles_to_records_kernel": (("void list_to_records_hist_kernel<%d, %d, %s>" if (fused_hist and not rest) else "void list_to_records_kernel<%d, %d, %s>")
+                                                           if sorted_tiles else "void tiles_to_records_kernel<%d, %d, %s>") % (last_nw, nw, rcs),
                                "hash_group_index_kernel": "void hash_group_index_kernel<%d, %d>" % (nw, nw),
                                "lds_count_kernel": ("void lds_count_kernel<%s, %d>" % (rcs, per)) if nw == 1 else ("void lds_count_wide_kernel<%s, %d, %d>" % (rcs, per, nw))})
             if sorted_last_level and cnt.get("mid_span") and not cnt.get("mid_tile_slots") and nwt == _katome_lib().katome_tile_words(wl.k, cnt["mid_span"]):
@@ -577,7 +584,8 @@ def main():
                              "lds_count_kernel (tile records)": (float(pair_m) * n_mid + rec_big * n_big + float(pair_m) * d_all) / max(n_all, 1)})
                 kexact.update({"radix_scatter_kernel<HashDigit> (tile records)": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nwm, nwm),
                                "radix_hist_kernel<HashDigit> (tile records)": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nwm, nwm),
-                               "tiles_to_records_kernel (tile records)": ("void tiles_to_records_kernel<%d, %d, %s>" if cnt["tile_slots"] else "void list_to_records_kernel<%d, %d, %s>") % (nwt, nwm, rcs),
+                               "tiles_to_records_kernel (tile records)": ("void tiles_to_records_kernel<%d, %d, %s>" if cnt["tile_slots"] else
+                                                                          "void list_to_records_hist_kernel<%d, %d, %s>" if fused_hist else "void list_to_records_kernel<%d, %d, %s>") % (nwt, nwm, rcs),
                                "lds_count_kernel (tile records)": ("void lds_count_kernel<false, %d>" % per_m) if nwm == 1 else ("void lds_count_wide_kernel<false, %d, %d>" % (per_m, nwm))})
         for name, ph in phases.items():
             if not name.startswith("k:"):
@@ -604,13 +612,15 @@ def main():
                                     ("radix_chunk_kernel", passes, True)]}
             label = kernel_names.get(name, name)
             if sorted_last_level and "tiles_to_records_kernel" in kexact:     # (the phase is five kernels: records, two partition passes with their histograms, index, counting)
+                n_hist = 1 if "list_to_records_hist_kernel" in kexact["tiles_to_records_kernel"] else 2
                 parts["expand_tiles"] = [(kexact["tiles_to_records_kernel"], 1, True), (kexact["radix_scatter_kernel<HashDigit>"], 2, True),
-                                         (kexact["radix_hist_kernel<HashDigit>"], 2, True), (kexact["hash_group_index_kernel"], 1, True),
+                                         (kexact["radix_hist_kernel<HashDigit>"], n_hist, True), (kexact["hash_group_index_kernel"], 1, True),
                                          (kexact["lds_count_kernel"], 1, False)]
             if "lds_count_kernel (tile records)" in kexact:          # (the mid tiles counted by sorting: the same five kernels)
                 t_ = " (tile records)"
+                n_hist_m = 1 if "list_to_records_hist_kernel" in kexact["tiles_to_records_kernel" + t_] else 2
                 parts["expand_mid_tiles"] = [(kexact["tiles_to_records_kernel" + t_], 1, True), (kexact["radix_scatter_kernel<HashDigit>" + t_], 2, True),
-                                             (kexact["radix_hist_kernel<HashDigit>" + t_], 2, True), (kexact["hash_group_index_kernel"].replace("<1, 1>", "<2, 2>"), 1, True),
+                                             (kexact["radix_hist_kernel<HashDigit>" + t_], n_hist_m, True), (kexact["hash_group_index_kernel"].replace("<1, 1>", "<2, 2>"), 1, True),
                                              (kexact["lds_count_kernel" + t_], 1, False)]
                 if not cnt.get("tile_slots"):      # (... and the big tiles: their records copied batch by batch, keys-only passes)
                     n_batches = -(-int(reads_per_rank_step) // int(batch_reads))
