@@ -1021,8 +1021,10 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     TileLevelScope tl;
                     DevBuf mk(stream), mw(stream);
                     uint64_t n_mid = 0, n2 = 0, d2 = 0;
-                    KCHECK(table_list_to_tagged_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream));
-                    rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED : tagged_records_sorted(mk, mw, n_mid, kk2, b->rc, spr, true, l2, c2, &n2, &d2, stream);
+                    DevBuf mid_counts(stream);         // (the first partition pass's digit counts per tile, made while the records are written)
+                    KCHECK(table_list_to_tagged_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream, 0, &mid_counts));
+                    rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED
+                        : tagged_records_sorted(mk, mw, n_mid, kk2, b->rc, spr, true, l2, c2, &n2, &d2, stream, mid_counts.as<u32>());
                     if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
                     if (rc == KATOME_OK) { b->stat_tiles2 = n2; lk = l2.as<u64>(); lw = c2.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2; }
                 }
@@ -1031,7 +1033,8 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     DevBuf kr(stream), kw(stream);
                     uint64_t n_rec = 0, n_rest = 0;
                     KCHECK(rest_valid(b, &n_rest, stream));
-                    KCHECK(table_list_to_tagged_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, kr, kw, &n_rec, stream, n_rest));
+                    DevBuf last_counts(stream);
+                    KCHECK(table_list_to_tagged_records(lk, lw, n_last, last_bases, k, last_span, 1, b->rc, kr, kw, &n_rec, stream, n_rest, &last_counts));
                     l2.release(); c2.release();
                     if (n_rest) {             // the left-over windows behind them (tagged records already), one each
                         KCHECK_HIP(hipMemcpyAsync(kr.as<u64>() + n_rec * (b->nw + 1), b->rest_k.p, n_rest * 8 * (b->nw + 1), hipMemcpyDeviceToDevice, stream));
@@ -1039,7 +1042,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                         n_rec += n_rest;
                     }
                     rc = sorted_fail("last") ? KATOME_E_UNSUPPORTED
-                        : tagged_records_sorted(kr, kw, n_rec, k, b->rc, spr, false, b->edge_key, raw_seq, &b->n_edges, &distinct, stream);
+                        : tagged_records_sorted(kr, kw, n_rec, k, b->rc, spr, false, b->edge_key, raw_seq, &b->n_edges, &distinct, stream, last_counts.as<u32>());
                     if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
                 }
                 if (rc == KATOME_OK) {

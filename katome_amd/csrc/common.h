@@ -189,7 +189,7 @@ int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, Dev
 int dev_hash_order_core(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t core_shift, uint32_t core_bases, uint64_t* ka, uint64_t* kb,
                         uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream);
 int dev_hash_order_tagged(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nwk, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
-                          const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream);
+                          const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream, const uint32_t* first_counts = nullptr);
 int dev_region_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, int passes, uint64_t* ka, uint64_t* kb,
                      uint32_t* wa, uint32_t* wb, const uint64_t** k_out, const uint32_t** w_out, hipStream_t stream);
 int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
@@ -335,9 +335,10 @@ int tiles_to_edges_sorted_seen(Table& tiles, uint32_t k, uint32_t span, bool rc,
 int table_keep_rest(const uint64_t* d_rec, uint64_t n, uint32_t nw, bool tagged, uint64_t read0, uint32_t per_read, uint32_t win0, uint32_t seq_per_read,
                     uint64_t* d_out, uint64_t* d_cursor, hipStream_t stream, uint32_t win_stride = 1, uint32_t span = 1);
 int tagged_records_sorted(DevBuf& recs, DevBuf& wts, uint64_t n, uint32_t k, bool rc, uint64_t seq_per_read, bool list, DevBuf& out_keys,
-                          DevBuf& out_second, uint64_t* n_out, uint64_t* n_distinct, hipStream_t stream);
+                          DevBuf& out_second, uint64_t* n_out, uint64_t* n_distinct, hipStream_t stream, const uint32_t* first_counts = nullptr);
 int table_list_to_tagged_records(const uint64_t* d_list, const uint32_t* d_counts, uint64_t n_tiles, uint32_t tile_bases, uint32_t sub_len, uint32_t n_sub,
-                                 uint32_t stride, bool rc, DevBuf& recs, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room = 0);
+                                 uint32_t stride, bool rc, DevBuf& recs, DevBuf& weights, uint64_t* n_records, hipStream_t stream, uint64_t extra_room = 0,
+                                 DevBuf* first_counts = nullptr);
 int table_tagged_to_pairs(const uint64_t* d_tagged, uint64_t n, uint32_t nw, uint64_t seq_per_read, uint64_t* d_keys, uint64_t* d_pairs, hipStream_t stream);
 // A rank's own distinct k-mers on their way to their owners (sharded build): with an OwnerSplit the records are grouped by the hash
 // of their CORE instead of the whole k-mer's, and every group's keys are written into its owner's stretch of the output -- base[p],

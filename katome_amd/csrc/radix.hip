@@ -787,15 +787,18 @@ int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint3
 uint32_t dev_sort_tile_keys(uint32_t nw) { return nw == 1 ? SortTile<1>::KEYS : nw == 2 ? SortTile<2>::KEYS : SortTile<3>::KEYS; }
 // records of nwk + 1 words (k-mer, tag) with their counts, ordered by the top 16 bits of the K-MER's hash (two stable passes)
 template <int NW>
-static int tagged_order_t(const u64* d_in, const u32* w_in, u64 n, u64* ka, u64* kb, u32* wa, u32* wb, const u64** k_out, const u32** w_out, hipStream_t stream) {
+static int tagged_order_t(const u64* d_in, const u32* w_in, u64 n, u64* ka, u64* kb, u32* wa, u32* wb, const u64** k_out, const u32** w_out, hipStream_t stream,
+                          const u32* first_counts = nullptr) {
     PassBuffers pb;
     KCHECK(pb.init(n, NW, stream));
+    if (first_counts) KCHECK_HIP(hipMemcpyAsync(pb.counts.p, first_counts, pb.nblocks * RADIX * sizeof(u32), hipMemcpyDeviceToDevice, stream));
     const u64* kin = d_in; const u32* win = w_in;
     u64* kdst[2] = {ka, kb}; u32* wdst[2] = {wa, wb};
     for (int p = 0; p < 2; ++p) {
         HashTaggedDigit<NW> dg{(u32)(64 - 8 * (2 - p))};
-        if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream)));
-        else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream)));      // (records that count once each)
+        const bool have = p == 0 && first_counts != nullptr;       // (counted by whoever wrote the records: table.hip list_to_tagged_records_kernel)
+        if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream, have)));
+        else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream, have)));      // (records that count once each)
         kin = kdst[p & 1]; win = w_in ? wdst[p & 1] : nullptr;
     }
     *k_out = kin; *w_out = win;
@@ -818,10 +821,10 @@ int dev_hash_order_core(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, 
     return KATOME_OK;
 }
 int dev_hash_order_tagged(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nwk, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
-                          const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream) {
+                          const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream, const uint32_t* first_counts) {
     *group_bits = 16;
-    if (nwk == 1) return tagged_order_t<2>(d_in, w_in, n, ka, kb, wa, wb, k_out, w_out, stream);
-    if (nwk == 2) return tagged_order_t<3>(d_in, w_in, n, ka, kb, wa, wb, k_out, w_out, stream);
+    if (nwk == 1) return tagged_order_t<2>(d_in, w_in, n, ka, kb, wa, wb, k_out, w_out, stream, first_counts);
+    if (nwk == 2) return tagged_order_t<3>(d_in, w_in, n, ka, kb, wa, wb, k_out, w_out, stream, first_counts);
     set_error("tagged records: k-mers of one or two words");
     return KATOME_E_UNSUPPORTED;
 }
