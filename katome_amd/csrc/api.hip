@@ -429,14 +429,14 @@ int flush_rest(katome_builder* b, hipStream_t stream) {
     return KATOME_OK;
 }
 
-// KATOME_SORTED_TILES: 2 (default) both tile levels are counted by sorting -- the big tiles' records are kept aside batch by batch
-// (two-word tiles, by packed key; anything else takes the table) --, 1 the big tiles in their table and only the mid tiles by
-// sorting, out of that table; 0 both tile levels in tables.  C3: 222 / 232 / 257 ms per build.
 // KATOME_SORTED_FAIL=mid|last: that level's counting by sorting reports a group too large -- tests of the way back into the tables
 bool sorted_fail(const char* level) {
     static const char* at = getenv("KATOME_SORTED_FAIL");
     return at && !strcmp(at, level);
 }
+// KATOME_SORTED_TILES: 2 (default) both tile levels are counted by sorting -- the big tiles' records are kept aside batch by batch
+// (two-word tiles of one-word k-mers, either numbering; anything else takes the table) --, 1 the big tiles in their table and only
+// the mid tiles by sorting, out of that table; 0 both tile levels in tables.  C3 by packed key: 200 / 210 / 239 ms per build.
 int sorted_tiles_mode() {
     static const int mode = getenv("KATOME_SORTED_TILES") ? atoi(getenv("KATOME_SORTED_TILES")) : 2;
     return mode;
@@ -917,11 +917,10 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
             const bool shapes = (b->nw == 1 && nwt <= 2) || (b->nw == 2 && (nwt == 2 || nwt == 3));      // (what tiles_to_records streams)
             if (shapes && (bound >= (1ull << 22) || (sorted_count == 2 && bound)) && (bound >> 21) <= 2900) {      // (2: however few -- tests)
                 Table* last = nullptr; uint32_t last_span = 1;
-                // The mid tiles are counted by sorting as well (KATOME_SORTED_TILES, default on): the big tiles' sub-tiles leave the
-                // tile table as records, two hash passes, counted in LDS into a compact list of (mid tile, count), and the k-mer
-                // records are cut out of that list -- no mid-tile table, no 7e8 128-bit upserts (C3: 45 -> 32 ms for the level).
-                // The big tiles stay in their table: their records are 20 bytes each, 8e8 of them, and sorting those costs more
-                // than the upserts do (C3: 68 against 42 ms, KATOME_SORTED_TILES=2).
+                // Big tiles that are in their table (KATOME_SORTED_TILES=1, a build that could not keep them aside as records, or one
+                // that had to give them up half-way): the mid tiles are counted by sorting all the same -- the big tiles' sub-tiles
+                // leave the tile table as records, two hash passes, counted in LDS into a compact list of (mid tile, count), and the
+                // k-mer records are cut out of that list -- no mid-tile table, no 7e8 128-bit upserts (C3: 45 -> 32 ms for the level).
                 DevBuf t2k(stream), t2w(stream);
                 uint64_t n_mid_list = 0;
                 bool mid_sorted = false;
