@@ -442,6 +442,16 @@ int sorted_tiles_mode() {
     return mode;
 }
 
+// Tile / k-mer shapes whose levels are all counted by sorting: tiles of two or three words (32..95 bases) over k-mers of one or two
+// (round 4: three-word tiles -- every k from 32 to 63 at 150 bp, the reference's example k = 40 and BASELINE's k = 63 -- and two-word
+// tiles of two-word k-mers); in the reference's numbering two-word tiles of one-word k-mers (the tagged kernels' shapes).
+// KATOME_SORTED_WIDE=0: the round-3 rule (A/B against the tables).
+bool tile_recs_shape(uint32_t nwt, uint32_t nw, bool first_seen) {
+    static const bool wide = !getenv("KATOME_SORTED_WIDE") || atoi(getenv("KATOME_SORTED_WIDE")) != 0;
+    if (first_seen || !wide) return nwt == 2 && nw == 1;
+    return (nwt == 2 || nwt == 3) && nw <= 2 && nw <= nwt;
+}
+
 // the tile records kept aside (builder.h) go into the tile table after all: another consumer wants the table, or the sorted
 // counting of the tiles gave up
 int tile_recs_valid(katome_builder* b, uint64_t* n, hipStream_t stream) {
@@ -718,7 +728,7 @@ static bool keeps_tile_recs(const katome_builder* b, uint32_t nwt) {
     // (the reference's numbering: reads of one length whose numbers pack into a record word -- lds_count_seen_kernel's rule)
     const bool seen_ok = !b->first_seen || (!b->var_prefix && !b->var_seq_base && !b->direct_edges && b->seen_read_len >= b->s.k &&
                                             2ull * (b->seen_read_len - b->s.k + 1) <= 0xFFFFull && (b->reads_inserted >> 31) == 0);
-    return seen_ok && nwt == 2 && b->nw == 1 && !b->tiles_ready && !b->table_ready && !b->tile_recs_closed && sorted_count_mode() &&
+    return seen_ok && tile_recs_shape(nwt, b->nw, b->first_seen) && !b->tiles_ready && !b->table_ready && !b->tile_recs_closed && sorted_count_mode() &&
            sorted_tiles_mode() == 2;
 }
 

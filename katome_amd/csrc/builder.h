@@ -88,6 +88,7 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
                               DevBuf* first_counts = nullptr);
 int sorted_count_mode();            // KATOME_SORTED_COUNT
 int sorted_tiles_mode();            // KATOME_SORTED_TILES
+bool tile_recs_shape(uint32_t nwt, uint32_t nw, bool first_seen);   // tile / k-mer word counts whose levels are all counted by sorting
 bool sorted_fail(const char* level);     // KATOME_SORTED_FAIL (tests)
 int flush_tile_recs(katome_builder* b, hipStream_t stream);    // the tile records kept aside -> b->tiles         // the left-over windows kept aside -> b->table
 uint32_t mid_span(uint32_t span);      // span of the mid tiles a big tile is broken into (0: expanded directly)

@@ -660,7 +660,7 @@ int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint6
                 b->span = d->span;
                 // (one GPU's rule: two-word tiles of one-word k-mers by packed key wait as records and are counted by sorting at the end)
                 bool kept = false;
-                if (!d->first_seen && d->nwt == 2 && nw == 1 && !b->tiles_ready && !b->tile_recs_closed && sorted_count_mode() && sorted_tiles_mode() == 2) {
+                if (!d->first_seen && tile_recs_shape(d->nwt, nw, false) && !b->tiles_ready && !b->tile_recs_closed && sorted_count_mode() && sorted_tiles_mode() == 2) {
                     PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
                     KCHECK(keep_tile_recs(b, recbuf.as<u64>(), nr * per_read, d->nwt, &kept, stream));
                 }
@@ -965,6 +965,7 @@ int katome_dist_gather(katome_dist_builder* d, int root, katome_builder** root_b
     d->comm->use_stream(stream);
     if (root_builder) *root_builder = nullptr;
     if (!d->finalized || !d->first_seen) { set_error("katome_dist_gather: a finalized FIRST_SEEN_ORDER build only (its indices place the edges)"); return KATOME_E_ARG; }
+    if (d->gathered) { set_error("katome_dist_gather: the ranks' shares were gathered already"); return KATOME_E_ARG; }
     const int world = d->world(), rank = d->rank();
     if (root < 0 || root >= world) { set_error("root out of range"); return KATOME_E_ARG; }
     const uint32_t nw = d->nw;
@@ -1041,7 +1042,9 @@ int katome_dist_gather(katome_dist_builder* d, int root, katome_builder** root_b
     KCHECK_HIP(hipStreamSynchronize(stream));
     // the ranks' shares have been consumed
     d->edge_src.release(); d->edge_dst.release(); d->edge_label.release(); d->node_key.release(); d->edge_gid.release(); d->node_gid.release();
-    d->n_edges = d->n_nodes = 0;
+    d->edge_lsrc.release(); d->edge_drank.release(); d->edge_dlocal.release(); d->edge_age.release();
+    d->n_edges = d->n_nodes = d->n_src = 0;
+    d->gathered = true;
     return KATOME_OK;
 }
 

@@ -34,6 +34,8 @@ struct katome_dist_builder {
     DevBuf edge_lsrc, edge_drank, edge_dlocal;
     DevBuf edge_age;                         // after katome_dist_remove_dead_paths: first-seen index each surviving edge had (u64)
     uint64_t n_src = 0;                      // this rank's nodes [0, n_src) have out-edges (ascending by key), the rest do not
+    bool dead_paths_removed = false;         // katome_dist_remove_dead_paths has run to its fixpoint on this sharded graph
+    bool gathered = false;                   // katome_dist_gather has consumed the ranks' shares
 
     int world() const { return comm->world(); }
     int rank() const { return comm->rank(); }
@@ -45,7 +47,10 @@ struct katome_dist_builder {
              bool one_round = false, uint64_t known_max = katome_comm::MAX_UNKNOWN, const uint64_t* send_off = nullptr) {
         const katome::ExchangeStats before = comm->stats;
         hipEvent_t ea = nullptr, eb = nullptr;
-        const bool timed = b->prof.on && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
+        bool timed = b->prof.on && hipEventCreate(&ea) == hipSuccess;
+        if (timed && hipEventCreate(&eb) != hipSuccess) { (void)hipEventDestroy(ea); ea = nullptr; timed = false; }
+        // (the sharded pruning makes dozens of exchanges per pass: finished pairs are folded into the phase's time instead of piling up)
+        if (timed && xevents.size() >= 256) fold_xevents();
         if (timed) (void)hipEventRecord(ea, stream);
         const int rc = comm->exchange(send, send_cnt, recv, recv_cnt, elem_bytes, 1, stream, one_round, known_max, send_off);
         if (timed) { (void)hipEventRecord(eb, stream); xevents.push_back({phase, ea, eb}); }
@@ -56,6 +61,18 @@ struct katome_dist_builder {
         if (!timed) x.ms += comm->stats.ms - before.ms;
         for (int p = 0; p < world(); ++p) if (p != rank()) x.max_pair_bytes = std::max<uint64_t>(x.max_pair_bytes, send_cnt[p] * elem_bytes);
         return KATOME_OK;
+    }
+    // the pairs whose second event has completed: their time goes to their phase, the events are destroyed
+    void fold_xevents() {
+        size_t kept = 0;
+        for (auto& e : xevents) {
+            float ms = 0;
+            if (hipEventQuery(e.b) == hipSuccess) {
+                if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) xstats[e.phase].ms += ms;
+                (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b);
+            } else xevents[kept++] = e;
+        }
+        xevents.resize(kept);
     }
     ~katome_dist_builder() {
         for (auto& e : xevents) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }

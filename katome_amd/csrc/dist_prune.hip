@@ -544,11 +544,31 @@ struct Router {
     }
 };
 
+// KATOME_DIST_PRUNE_FAIL=edges|nodes: rank 0's replay of that kind reports a failure in the first pass -- tests of "every rank
+// leaves with the same error, nobody is left waiting in a collective"
+static bool fail_at(const char* what) {
+    const char* at = getenv("KATOME_DIST_PRUNE_FAIL");
+    return at && !strcmp(at, what);
+}
+// what rank 0 could not do, as every rank's return value (rank 0 keeps its own message)
+static int root_failed(int rank, int neg_status, const char* what) {
+    if (rank != 0) set_error("distributed pruning: rank 0 failed in %s (status %d)", what, -neg_status);
+    return -neg_status;
+}
+
 }  // namespace
 
 extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist_graph* out, katome_prune_stats* st_out, void* stream_) {
     if (!d) { set_error("null argument"); return KATOME_E_ARG; }
     if (!d->finalized || !d->first_seen) { set_error("katome_dist_remove_dead_paths: a finalized FIRST_SEEN_ORDER build only (petgraph's numbering decides what a repeated index removes)"); return KATOME_E_ARG; }
+    if (d->gathered) { set_error("katome_dist_remove_dead_paths: the ranks' shares were gathered (katome_dist_gather); prune the gathered graph on its root"); return KATOME_E_ARG; }
+    if (d->dead_paths_removed) {
+        // Called again (the reference's pipeline does: asm/basic_assembler.rs:59,73): the first call ran to the fixpoint, nothing has
+        // changed the sharded graph since (every other stage works on the gathered one), so the reference's loop would make one pass,
+        // find no dead path and leave (pruner.rs:69-72).  Every rank takes this branch: no collective is needed.
+        if (st_out) { memset(st_out, 0, sizeof *st_out); st_out->passes = 1; }
+        return katome_dist_current_graph(d, out);
+    }
     hipStream_t stream = (hipStream_t)stream_;
     katome_builder* b = d->b;
     KCHECK_HIP(hipSetDevice(d->s.device));
@@ -559,8 +579,13 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
     const double t_begin = now_ms();
     katome_prune_stats st;
     memset(&st, 0, sizeof st);
-    if (E >= 0xFFFFFFFFull || N >= 0xFFFFFFFFull) { set_error("more than 2^32 edges or nodes on one rank"); return KATOME_E_UNSUPPORTED; }
-    if (two_k > 255) { set_error("k too large for the walker's step counter"); return KATOME_E_UNSUPPORTED; }
+    if (two_k > 255) { set_error("k too large for the walker's step counter"); return KATOME_E_UNSUPPORTED; }       // (the same on every rank)
+    {   // a rank whose share cannot be pruned says so to all of them: nobody may leave alone before a collective the others wait in
+        uint64_t bad = (E >= 0xFFFFFFFFull || N >= 0xFFFFFFFFull) ? 1 : (E && (!d->edge_lsrc.p || !d->edge_drank.p || !d->edge_dlocal.p)) ? 2 : 0;
+        KCHECK(d->comm->allreduce(&bad, 1, OP_MAX));
+        if (bad == 1) { set_error("more than 2^32 edges or nodes on one rank"); return KATOME_E_UNSUPPORTED; }
+        if (bad) { set_error("katome_dist_remove_dead_paths: a rank's local source / target indices are gone"); return KATOME_E_ARG; }
+    }
     Router router(d, stream);
     KCHECK(router.init());
     const u64* lsrc = d->edge_lsrc.as<u64>(); const u64* drank = d->edge_drank.as<u64>(); const u64* dlocal = d->edge_dlocal.as<u64>();
@@ -780,7 +805,9 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
         DevBuf victims(stream), to_e(stream), from_e(stream), vict_sorted(stream), vict_ord(stream), from_sorted(stream), from_idx(stream);
         ReplayScratch sc(stream);
         uint64_t m_removed = 0, E_new = TE, n_moves = 0, dups = 0;
-        if (rank == 0) {
+        // (what fails on rank 0 alone must not leave the others waiting in the next collective: its status travels with the counts
+        // every rank agrees on below, and all of them return it)
+        auto root_edge_replay = [&]() -> int {
             const uint64_t u = marks.n;
             DevBuf m32(stream);
             KCHECK(m32.alloc((u + 1) * 4));
@@ -802,10 +829,14 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
                 KCHECK(dev_sort(from_sorted.as<u64>(), from_idx.as<u32>(), n_moves, 1, pos_bits, stream));
             }
             KCHECK_HIP(hipGetLastError());
-        }
+            return KATOME_OK;
+        };
+        int root_rc = rank == 0 ? root_edge_replay() : KATOME_OK;
+        if (rank == 0 && root_rc == KATOME_OK && fail_at("edges")) { set_error("distributed pruning: KATOME_DIST_PRUNE_FAIL=edges"); root_rc = KATOME_E_UNSUPPORTED; }
         lap(1);
-        uint64_t agreed[3] = {rank == 0 ? TE - E_new : 0, rank == 0 ? dups : 0, 0};
-        KCHECK(d->comm->allreduce(agreed, 2, OP_MAX));
+        uint64_t agreed[3] = {rank == 0 && root_rc == KATOME_OK ? TE - E_new : 0, rank == 0 ? dups : 0, (uint64_t)(-root_rc)};
+        KCHECK(d->comm->allreduce(agreed, 3, OP_MAX));
+        if (agreed[2]) return root_failed(rank, (int)agreed[2], "the replay of the removed edges");
         m_removed = agreed[0]; E_new = TE - m_removed;
         st.removed_edges += m_removed; st.removed_by_duplicates += agreed[1];
         // ---- every rank asks for the fate of its candidate edges -----------------------------------------------------------
@@ -871,16 +902,17 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
         KCHECK(router.send(X.as<u64>(), Y.as<u64>(), h[0], dies));
         DevBuf to_n(stream), from_n(stream), nfrom_sorted(stream), nfrom_idx(stream);
         uint64_t n_nmoves = 0, N_new = TN;
-        if (rank == 0) {
+        auto root_node_replay = [&]() -> int {
             DevBuf die(stream);
             NodeReplayScratch nsc(stream);
             KCHECK(die.alloc((2 * m_removed + 2) * 8));
             KLAUNCH(fill64_kernel, 2 * m_removed, stream, die.as<u64>(), 2 * m_removed, NONE64);
             if (dies.n) KLAUNCH(scatter64_kernel, dies.n, stream, dies.a.as<u64>(), dies.b.as<u64>(), dies.n, die.as<u64>());
             KCHECK_HIP(hipGetLastError());
-            int fell_back = 0;
+            int fell_back = 0;      // (1: the pass's node moves chained further than the device form follows and were replayed on the host)
+            const double t_replay = now_ms();
             KCHECK(dev_replay_nodes64(die.as<u64>(), m_removed, TN, nsc, to_n, from_n, &n_nmoves, &N_new, &fell_back, stream));
-            if (fell_back) { set_error("distributed pruning: the node moves of a pass chain further than the device replay follows"); return KATOME_E_UNSUPPORTED; }
+            if (fell_back) st.host_ms += now_ms() - t_replay;
             KCHECK(nfrom_sorted.alloc((n_nmoves + 1) * 8)); KCHECK(nfrom_idx.alloc((n_nmoves + 1) * 4));
             if (n_nmoves) {
                 KCHECK_HIP(hipMemcpyAsync(nfrom_sorted.p, from_n.p, n_nmoves * 8, hipMemcpyDeviceToDevice, stream));
@@ -888,12 +920,16 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
                 KCHECK(dev_sort(nfrom_sorted.as<u64>(), nfrom_idx.as<u32>(), n_nmoves, 1, pos_bits, stream));
             }
             KCHECK_HIP(hipGetLastError());
-        }
+            return KATOME_OK;
+        };
+        root_rc = rank == 0 ? root_node_replay() : KATOME_OK;
+        if (rank == 0 && root_rc == KATOME_OK && fail_at("nodes")) { set_error("distributed pruning: KATOME_DIST_PRUNE_FAIL=nodes"); root_rc = KATOME_E_UNSUPPORTED; }
         lap(4);
-        uint64_t removed_nodes = rank == 0 ? TN - N_new : 0;
-        KCHECK(d->comm->allreduce(&removed_nodes, 1, OP_MAX));
-        N_new = TN - removed_nodes;
-        st.removed_nodes += removed_nodes;
+        uint64_t removed_nodes[2] = {rank == 0 && root_rc == KATOME_OK ? TN - N_new : 0, (uint64_t)(-root_rc)};
+        KCHECK(d->comm->allreduce(removed_nodes, 2, OP_MAX));
+        if (removed_nodes[1]) return root_failed(rank, (int)removed_nodes[1], "the replay of the removed nodes");
+        N_new = TN - removed_nodes[0];
+        st.removed_nodes += removed_nodes[0];
         {   // the nodes in the vacated tail that stay ask where they go
             DevBuf nq(stream), nwho(stream), nans(stream);
             KCHECK(nq.alloc((N + 1) * 8)); KCHECK(nwho.alloc((N + 1) * 4));
@@ -994,6 +1030,7 @@ extern "C" int katome_dist_remove_dead_paths(katome_dist_builder* d, katome_dist
     KCHECK_HIP(hipStreamSynchronize(stream));
     b->n_edges = E2;
     d->n_edges = E2; d->n_nodes = N2; d->total_edges = TE; d->total_nodes = TN; d->n_src = 0;
+    d->dead_paths_removed = true;
     {   // the walks and marks of all ranks
         uint64_t sums[3] = {st.walks, st.dead_walks, st.marked};
         KCHECK(d->comm->allreduce(sums, 3, OP_SUM));

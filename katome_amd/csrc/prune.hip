@@ -924,9 +924,29 @@ int dev_replay_nodes(const uint32_t* d_die, uint64_t m, uint64_t N, NodeReplaySc
                      uint64_t* n_left, int* fell_back, hipStream_t stream) {
     return replay_nodes_t<u32>(d_die, m, N, sc, to_n, from_n, n_moves, n_left, fell_back, stream);
 }
+// (64-bit positions: the sharded graph's replay on rank 0, dist_prune.hip.  A pass whose node moves chain further than the device
+// form follows -- or KATOME_PRUNE_HOST_NODES, as on one GPU -- is replayed by the sequential statement of prune_replay.h on the
+// host instead: *fell_back = 1 then only reports that, the moves are produced either way)
 int dev_replay_nodes64(const uint64_t* d_die, uint64_t m, uint64_t N, NodeReplayScratch& sc, DevBuf& to_n, DevBuf& from_n, uint64_t* n_moves,
                        uint64_t* n_left, int* fell_back, hipStream_t stream) {
-    return replay_nodes_t<u64>(d_die, m, N, sc, to_n, from_n, n_moves, n_left, fell_back, stream);
+    *fell_back = getenv("KATOME_PRUNE_HOST_NODES") != nullptr;
+    if (!*fell_back) KCHECK(replay_nodes_t<u64>(d_die, m, N, sc, to_n, from_n, n_moves, n_left, fell_back, stream));
+    if (!*fell_back) return KATOME_OK;
+    PodBuf<uint64_t> h_die;
+    h_die.need(2 * m + 1);
+    if (!h_die.p) { set_error("out of host memory"); return KATOME_E_OOM; }
+    if (m) KCHECK_HIP(hipMemcpyAsync(h_die.p, d_die, 2 * m * 8, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    NodeReplayT<uint64_t> nr;
+    replay_nodes<uint64_t>(h_die.p, m, N, nr);
+    *n_moves = nr.move_to.size(); *n_left = nr.n_new;
+    KCHECK(to_n.alloc((*n_moves + 1) * 8)); KCHECK(from_n.alloc((*n_moves + 1) * 8));
+    if (*n_moves) {
+        KCHECK_HIP(hipMemcpyAsync(to_n.p, nr.move_to.p, *n_moves * 8, hipMemcpyHostToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(from_n.p, nr.move_from.p, *n_moves * 8, hipMemcpyHostToDevice, stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));           // (the host vectors go out of scope)
+    return KATOME_OK;
 }
 
 int dev_remove_dead_paths(PruneGraph& g, uint32_t k, katome_prune_stats* st, hipStream_t stream) {

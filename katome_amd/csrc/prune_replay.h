@@ -12,22 +12,24 @@ constexpr uint32_t REPLAY_NONE = 0xFFFFFFFFu;
 
 // grow-only array of u32 without value-initialisation: the first pass of a big graph fills hundreds of MiB, and touching
 // that memory twice (zero-fill, then the real values) or copying it while a vector doubles costs as much as the replay
-struct U32Buf {
-    uint32_t* p = nullptr;
+template <typename T>
+struct PodBuf {
+    T* p = nullptr;
     size_t cap = 0, n = 0;
-    U32Buf() {}
-    U32Buf(const U32Buf&) = delete;
-    U32Buf& operator=(const U32Buf&) = delete;
-    ~U32Buf() { free(p); }
+    PodBuf() {}
+    PodBuf(const PodBuf&) = delete;
+    PodBuf& operator=(const PodBuf&) = delete;
+    ~PodBuf() { free(p); }
     void need(size_t c) {                  // contents are NOT kept
-        if (c > cap) { free(p); p = (uint32_t*)malloc((c + c / 8 + 64) * 4); cap = p ? c + c / 8 + 64 : 0; }
+        if (c > cap) { free(p); p = (T*)malloc((c + c / 8 + 64) * sizeof(T)); cap = p ? c + c / 8 + 64 : 0; }
         n = 0;
     }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
-    const uint32_t* data() const { return p; }
-    uint32_t operator[](size_t i) const { return p[i]; }
+    const T* data() const { return p; }
+    T operator[](size_t i) const { return p[i]; }
 };
+typedef PodBuf<uint32_t> U32Buf;
 
 // Edges (remove_paths, pruner.rs:199-217): the collected indices arrive ascending with multiplicities and are
 // consumed from the top, as the reference's descending sort does.  remove_edge(d) moves the edge at the last
@@ -77,23 +79,28 @@ inline void replay_edges(const uint32_t* pos, const uint32_t* mult, uint64_t u, 
 // (source, target) that removal t leaves without edges (REPLAY_NONE = stays); when both go, the one with the larger
 // CURRENT index goes first.  remove_node moves the last node into the freed index, so only nodes of the tail that
 // disappears are ever re-labelled: two arrays over that tail hold the whole state.
-struct NodeReplay {
-    U32Buf move_to, move_from;
-    U32Buf tail_pos, tail_occ;
+// (I = uint32_t on one GPU; uint64_t for the sharded graph, whose indices pass 2^32 -- dist_prune.hip's fall-back)
+template <typename I>
+struct NodeReplayT {
+    PodBuf<I> move_to, move_from;
+    PodBuf<I> tail_pos, tail_occ;
     uint64_t n_new = 0;
 };
-inline void replay_nodes(const uint32_t* die, uint64_t m, uint64_t n_nodes, NodeReplay& out) {
+typedef NodeReplayT<uint32_t> NodeReplay;
+template <typename I>
+inline void replay_nodes(const I* die, uint64_t m, uint64_t n_nodes, NodeReplayT<I>& out) {
+    const I REPLAY_NONE = (I)~(I)0;
     uint64_t n_die = 0;
     for (uint64_t i = 0; i < 2 * m; ++i) n_die += die[i] != REPLAY_NONE;
     const uint64_t base = n_nodes - n_die;
     out.tail_pos.need(n_die); out.tail_occ.need(n_die);
-    uint32_t* tail_pos = out.tail_pos.p;               // current index of tail node base+i (REPLAY_NONE once removed)
-    uint32_t* tail_occ = out.tail_occ.p;               // node at tail index base+i
-    for (uint64_t i = 0; i < n_die; ++i) tail_pos[i] = tail_occ[i] = (uint32_t)(base + i);
+    I* tail_pos = out.tail_pos.p;               // current index of tail node base+i (REPLAY_NONE once removed)
+    I* tail_occ = out.tail_occ.p;               // node at tail index base+i
+    for (uint64_t i = 0; i < n_die; ++i) tail_pos[i] = tail_occ[i] = (I)(base + i);
     uint64_t size = n_nodes;
-    auto pos_of = [&](uint32_t v) -> uint32_t { return v < base ? v : tail_pos[v - base]; };
-    auto remove = [&](uint32_t v, uint32_t p) {
-        const uint32_t top = (uint32_t)(size - 1), y = tail_occ[top - base];
+    auto pos_of = [&](I v) -> I { return v < base ? v : tail_pos[v - base]; };
+    auto remove = [&](I v, I p) {
+        const I top = (I)(size - 1), y = tail_occ[top - base];
         if (p != top) {
             if (p >= base) tail_occ[p - base] = y;
             tail_pos[y - base] = p;
@@ -102,9 +109,9 @@ inline void replay_nodes(const uint32_t* die, uint64_t m, uint64_t n_nodes, Node
         --size;
     };
     for (uint64_t t = 0; t < m; ++t) {
-        const uint32_t a = die[2 * t], b = die[2 * t + 1];
+        const I a = die[2 * t], b = die[2 * t + 1];
         if (a != REPLAY_NONE && b != REPLAY_NONE) {
-            const uint32_t pa = pos_of(a), pb = pos_of(b);
+            const I pa = pos_of(a), pb = pos_of(b);
             if (pa < pb) { remove(b, pb); remove(a, pos_of(a)); } else { remove(a, pa); remove(b, pos_of(b)); }
         } else if (a != REPLAY_NONE) {
             remove(a, pos_of(a));
@@ -116,7 +123,7 @@ inline void replay_nodes(const uint32_t* die, uint64_t m, uint64_t n_nodes, Node
     out.move_to.need(n_die); out.move_from.need(n_die);
     uint64_t nm = 0;
     for (uint64_t i = 0; i < n_die; ++i)
-        if (tail_pos[i] != REPLAY_NONE) { out.move_to.p[nm] = tail_pos[i]; out.move_from.p[nm] = (uint32_t)(base + i); ++nm; }
+        if (tail_pos[i] != REPLAY_NONE) { out.move_to.p[nm] = tail_pos[i]; out.move_from.p[nm] = (I)(base + i); ++nm; }
     out.move_to.n = out.move_from.n = nm;
 }
 

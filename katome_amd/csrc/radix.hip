@@ -774,12 +774,13 @@ static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u
     *k_out = kin; *w_out = win;
     return KATOME_OK;
 }
-// (k-mer, count) records of one or two words ordered by the top 16 bits of the k-mer's hash, for the counting in LDS (table.hip): two
+// (k-mer, count) records of one to three words ordered by the top 16 bits of the k-mer's hash, for the counting in LDS (table.hip): two
 // stable 8-bit passes.  The result is where *k_out / *w_out point (one of the two buffer pairs); *group_bits = 16.
 int dev_hash_order(const uint64_t* d_in, const uint32_t* w_in, uint64_t n, uint32_t nw, uint64_t* ka, uint64_t* kb, uint32_t* wa, uint32_t* wb,
                    const uint64_t** k_out, const uint32_t** w_out, uint32_t* group_bits, hipStream_t stream, const uint32_t* first_counts) {
     *group_bits = 16;
     if (nw == 1) return region_order_t<1>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream, first_counts);
+    if (nw == 3) return region_order_t<3>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream, first_counts);      // (tiles of 64..95 bases)
     return region_order_t<2>(d_in, w_in, n, 2, ka, kb, wa, wb, k_out, w_out, stream, first_counts);
 }
 // records per tile of a partition pass over records of nw words, and the digit of dev_hash_order's first pass (for a kernel that

@@ -1518,7 +1518,7 @@ int table_list_to_records(const uint64_t* d_tiles, const uint32_t* d_counts, uin
     // (first_counts: the caller sorts exactly these records next -- nothing appended -- and wants the first pass's digit counts per tile;
     // KATOME_FUSED_HIST=0: the pass counts them itself)
     static const bool fused_hist = !getenv("KATOME_FUSED_HIST") || atoi(getenv("KATOME_FUSED_HIST")) != 0;
-    if (first_counts && fused_hist && !extra_room && ((nwt == 2 && nwk <= 2) || (nwt == 1 && nwk == 1))) {
+    if (first_counts && fused_hist && !extra_room && ((nwt == 3 && nwk >= 2) || (nwt == 2 && nwk <= 2) || (nwt == 1 && nwk == 1))) {
         const uint32_t tile_keys = dev_sort_tile_keys(nwk);
         const uint64_t n_out_tiles = (*n_records + tile_keys - 1) / tile_keys;
         KCHECK(first_counts->alloc(n_out_tiles * 256 * 4 + 16, stream));
@@ -1529,7 +1529,9 @@ int table_list_to_records(const uint64_t* d_tiles, const uint32_t* d_counts, uin
             if (rc) hipLaunchKernelGGL((list_to_records_hist_kernel<NWT, NWK, true>), hgrid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>(), tile_keys, first_counts->as<u32>()); \
             else    hipLaunchKernelGGL((list_to_records_hist_kernel<NWT, NWK, false>), hgrid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>(), tile_keys, first_counts->as<u32>()); \
         } while (0)
-        if (nwt == 2 && nwk == 2) KATOME_LRH(2, 2);
+        if (nwt == 3 && nwk == 3) KATOME_LRH(3, 3);
+        else if (nwt == 3 && nwk == 2) KATOME_LRH(3, 2);
+        else if (nwt == 2 && nwk == 2) KATOME_LRH(2, 2);
         else if (nwt == 2 && nwk == 1) KATOME_LRH(2, 1);
         else KATOME_LRH(1, 1);
 #undef KATOME_LRH
@@ -1544,7 +1546,9 @@ int table_list_to_records(const uint64_t* d_tiles, const uint32_t* d_counts, uin
         if (rc) hipLaunchKernelGGL((list_to_records_kernel<NWT, NWK, true>), grid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>()); \
         else    hipLaunchKernelGGL((list_to_records_kernel<NWT, NWK, false>), grid, block, 0, stream, d_tiles, d_counts, n_tiles, k, span, stride, keys.as<u64>(), weights.as<u32>()); \
     } while (0)
-    if (nwt == 2 && nwk == 2) KATOME_LR(2, 2);
+    if (nwt == 3 && nwk == 3) KATOME_LR(3, 3);
+    else if (nwt == 3 && nwk == 2) KATOME_LR(3, 2);
+    else if (nwt == 2 && nwk == 2) KATOME_LR(2, 2);
     else if (nwt == 2 && nwk == 1) KATOME_LR(2, 1);
     else if (nwt == 1 && nwk == 1) KATOME_LR(1, 1);
     else { set_error("records of a tile list: tiles of %u words into windows of %u", nwt, nwk); return KATOME_E_UNSUPPORTED; }
@@ -1592,7 +1596,9 @@ int table_keep_rest(const uint64_t* d_rec, uint64_t n, uint32_t nw, bool tagged,
     unsigned long long* cur = reinterpret_cast<unsigned long long*>(d_cursor);
     if (!per_read) per_read = 1;
 #define KATOME_KR(NWV, TAG) hipLaunchKernelGGL((keep_rest_kernel<NWV, TAG>), grid, block, 0, stream, d_rec, n, read0, per_read, win0, seq_per_read, d_out, cur, win_stride, span)
+    if (nw == 3 && tagged) { set_error("tagged records: keys of one or two words"); return KATOME_E_UNSUPPORTED; }
     if (nw == 1) { if (tagged) KATOME_KR(1, true); else KATOME_KR(1, false); }
+    else if (nw == 3) KATOME_KR(3, false);
     else         { if (tagged) KATOME_KR(2, true); else KATOME_KR(2, false); }
 #undef KATOME_KR
     KCHECK_HIP(hipGetLastError());
@@ -1765,7 +1771,7 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
                             const uint32_t* first_counts) {
     *n_edges = 0; *n_distinct = 0;
     const uint32_t nw = (uint32_t)key_words_for_k(k);
-    if (nw > 2) return KATOME_E_UNSUPPORTED;
+    if (nw > 3 || (nw == 3 && (rc || min_weight))) return KATOME_E_UNSUPPORTED;      // (three words: tiles of 64..95 bases -- never k-mers, so never oriented)
     if (split && (nw != 1 || rc || min_weight || split->n_parts == 0 || split->n_parts > (uint32_t)KATOME_MAX_RANKS)) {
         set_error("records by owner: one-word k-mers, one record per k-mer"); return KATOME_E_ARG;
     }
@@ -1774,7 +1780,7 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     u32 gbits = 16;
     // (weights not allocated: every record counts once; the passes move keys only.  Two-word keys: lds_count_wide_kernel)
     const bool unit = weights.p == nullptr;
-    if (unit && (nw != 2 || split)) { set_error("records without weights: two-word keys"); return KATOME_E_ARG; }
+    if (unit && (nw < 2 || split)) { set_error("records without weights: keys of two or three words"); return KATOME_E_ARG; }
     {
         DevBuf kb(stream), wb(stream);
         KCHECK(kb.alloc((n + 1) * 8 * nw));
@@ -1799,6 +1805,7 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         const dim3 igrid(grid_for((1ull << gbits) + 1, BLOCK));
         if (split)   hipLaunchKernelGGL(core_group_index_kernel, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, split->core_shift, split->core_bases, index.as<u64>());
         else if (nw == 1) hipLaunchKernelGGL(hash_group_index_kernel<1>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
+        else if (nw == 3) hipLaunchKernelGGL(hash_group_index_kernel<3>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
         else         hipLaunchKernelGGL(hash_group_index_kernel<2>, igrid, dim3(BLOCK), 0, stream, ko, n, gbits, index.as<u64>());
     }
     const uint64_t out_cap = (rc ? 2 : 1) * n + 1;
@@ -1833,6 +1840,8 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         if (nw == 1) {
             if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 8>), 8); else KATOME_LC_LAUNCH((lds_count_kernel<false, 8>), 8); }
             else       { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 13>), 13); else KATOME_LC_LAUNCH((lds_count_kernel<false, 13>), 13); }
+        } else if (nw == 3) {
+            if (small) KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 3>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 3>), 13);
         } else {
             if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 8, 2>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 2>), 8); }
             else       { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 13, 2>), 13); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 2>), 13); }

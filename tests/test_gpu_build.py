@@ -862,6 +862,69 @@ for mixed in (False, True):
 """
 
 
+_WIDE_TILES_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+# (k, read length, reverse complement): k = 40 at 150 bp -- the reference's example setting -- and k = 63 (BASELINE config 5) make
+# THREE-word tiles of two-word k-mers; k = 33 at 50 bp one two-word tile of two-word k-mers; k = 50 at 100 bp three-word tiles and
+# left-over windows; k = 36 without the reverse strand
+for k, L, rc in ((40, 150, True), (63, 150, True), (33, 50, True), (50, 100, True), (36, 150, False)):
+    n = 4000
+    reads = o.synth_reads(20 + k, n, L, 20000, 4e-3, 3)
+    has_n = (reads == ord("N")).any(axis=1)
+    clean = reads.copy()
+    clean[clean == ord("N")] = ord("A")
+    packed = torch.from_numpy(pack_reads_ascii(clean).reshape(-1).copy()).cuda()
+    skip = torch.from_numpy(has_n.astype(np.uint8)).cuda()
+    ref = o.build_ascii(reads, k, rc)
+    want = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
+    for batch in (500, 4000):
+        b = kd.Builder(k, rc, table_slots_hint=1 << 14)
+        span, tiles, rest = b.tile_plan(L)
+        for r0 in range(0, n, batch):
+            # (alternately with and without a skip array: without one the records are made where they are kept)
+            use_skip = skip if (r0 // batch) % 2 == 0 or has_n[r0:r0 + batch].any() else None
+            b.count_reads(packed, min(batch, n - r0), L, use_skip, first_read=r0)
+        dg = b.finalize()
+        c = b.counts()
+        lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+        got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
+        h = hashlib.sha256()
+        for t in (dg.edge_key, dg.edge_weight, dg.edge_src, dg.edge_dst, dg.node_key, dg.edge_label):
+            h.update(t.cpu().numpy().tobytes())
+        ok = len(got) == dg.n_edges and got == want and (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
+        print("W3", k, L, batch, b.tile_words(span), dg.n_edges, int(ok), "tables" if (c["tile_slots"] or c["mid_tile_slots"] or c["kmer_slots"]) else "sorted", h.hexdigest())
+        b.close()
+"""
+
+
+def test_three_word_tiles_and_two_word_kmers_counted_by_sorting(tmp_path):
+    """round 4: the tile levels of k = 32..63 at 150 bp (three-word tiles: the reference's example k = 40, BASELINE config 5's k = 63)
+    and of two-word tiles over two-word k-mers are counted by sorting like the headline shape's -- no table is touched -- and give the
+    oracle's graph; the same builds with the round-3 rule (KATOME_SORTED_WIDE=0: those levels in the HBM tables) byte for byte"""
+    import subprocess
+    script = tmp_path / "wide.py"
+    script.write_text(_WIDE_TILES_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra):
+        env = dict(os.environ, KATOME_SORTED_COUNT="2", **extra)
+        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return [line.split() for line in out.stdout.splitlines() if line.startswith("W3 ")]
+    new, old = run({}), run({"KATOME_SORTED_WIDE": "0"})
+    assert len(new) == len(old) == 10
+    for a, b in zip(new, old):
+        assert a[6] == "1" and b[6] == "1", (a, b)              # both equal the oracle's multiset and counts
+        assert a[7] == "sorted", a                                 # every level by sorting: no tile table, no k-mer table
+        assert a[8] == b[8], (a, b)                                # ... and byte for byte what the tables give
+    assert {int(a[4]) for a in new} == {2, 3}                      # two- and three-word tiles both ran
+    assert any(b[7] == "tables" for b in old)
+
+
 def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
     """the big tiles of a build by packed key are kept aside as records and counted by sorting (api.hip keep_tile_recs): sixty
     batches (room for sixteen to begin with, doubled when that is too little), reads with N in them (their records are dropped),

@@ -102,6 +102,82 @@ def test_config5_shape_pruned_on_the_sharded_route(oracle, monkeypatch, world, k
         assert g.edge_age is not None and np.array_equal(g.edge_age.astype(np.uint64) + 1, ref.edge_slot)
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("where", ["edges", "nodes"])
+def test_a_failure_on_rank_0_inside_the_pruning_reaches_every_rank(oracle, monkeypatch, where):
+    """rank 0 alone replays the removals of a pass; when that fails (here: forced, KATOME_DIST_PRUNE_FAIL) its status travels
+    with the counts all ranks agree on next, so every rank returns the error -- none is left waiting in a collective.  The
+    thread ranks of an n_devices build join before katome_build_packed returns: a rank still waiting would hang this test."""
+    from katome_amd.build import GpuGraph, KatomePanic
+    monkeypatch.setenv("KATOME_DIST_PRUNE_FAIL", where)
+    ascii_reads, packed, skip = _reads(oracle, 400, 150, 4000, 5e-4, 1)
+    with pytest.raises(KatomePanic) as e:
+        GpuGraph.create_from_packed(packed, 400, 150, skip=skip, reverse_complement=True, k=63, n_devices=3,
+                                    ranks_share_device=True, first_seen_order=True, remove_dead_paths=True)
+    assert "E_UNSUPPORTED" in str(e.value) or "distributed pruning" in str(e.value)
+    monkeypatch.delenv("KATOME_DIST_PRUNE_FAIL")
+    g, _ = GpuGraph.create_from_packed(packed, 400, 150, skip=skip, reverse_complement=True, k=63, n_devices=3,
+                                       ranks_share_device=True, first_seen_order=True, remove_dead_paths=True)
+    _same_arrays(g, oracle.build_ascii(ascii_reads, 63, True, remove_dead_paths=True))      # (and the library is fine afterwards)
+
+
+@pytest.mark.parametrize("world,k,rc,n,L,genome,err", [(2, 63, True, 400, 150, 4000, 5e-4), (3, 31, True, 1500, 150, 9000, 1e-2)])
+def test_sharded_pruning_with_the_node_replay_on_the_host(oracle, monkeypatch, world, k, rc, n, L, genome, err):
+    """a pass whose node moves chain further than the device replay follows is replayed by the sequential statement on rank 0's
+    host (64-bit positions; forced here with KATOME_PRUNE_HOST_NODES): the same arrays"""
+    from katome_amd.build import GpuGraph
+    monkeypatch.setenv("KATOME_PRUNE_HOST_NODES", "1")
+    ascii_reads, packed, skip = _reads(oracle, n, L, genome, err, 1)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world,
+                                        ranks_share_device=True, first_seen_order=True, remove_dead_paths=True)
+    ref = oracle.build_ascii(ascii_reads, k, rc, remove_dead_paths=True)
+    _same_arrays(g, ref)
+    if ref.n_edges:
+        assert np.array_equal(g.edge_age.astype(np.uint64) + 1, ref.edge_slot)
+
+
+def test_sharded_pruning_called_twice_and_after_a_gather(oracle):
+    """Prunable::remove_dead_paths may be called again (asm/basic_assembler.rs:59,73): on the sharded graph the second call is the
+    reference's one empty pass -- the same share, no device fault --; once the shares were gathered it is an error, like a second
+    gather, never a walk over released arrays"""
+    from katome_amd import shard as ks
+    from katome_amd.build import KatomePanic
+    k, rc, n, L = 31, True, 1500, 150
+    ascii_reads, packed, skip = _reads(oracle, n, L, 9000, 1e-2, 1)
+    pt = torch.from_numpy(np.concatenate([packed, np.zeros(32, np.uint8)])).cuda()
+    st = torch.from_numpy(np.concatenate([skip, np.zeros(16, np.uint8)])).cuda()
+    comm = ks.Comm.rccl(0, 1, 0)
+    b = ks.ShardedBuilder(comm, k, rc, 0, first_seen_order=True)
+    try:
+        b.add_reads(pt, 0, n, L, st, 0)
+        g = b.finalize()
+        full_edges = g.total_edges
+        del g
+        pg, s1 = b.remove_dead_paths()
+        ref = oracle.build_ascii(ascii_reads, k, rc, remove_dead_paths=True)
+        assert (pg.total_nodes, pg.total_edges) == (ref.n_nodes, ref.n_edges) and ref.n_edges < full_edges
+        first = (pg.edge_id.cpu().numpy().copy(), pg.edge_src.cpu().numpy().copy(), pg.edge_weight.cpu().numpy().copy())
+        del pg
+        pg2, s2 = b.remove_dead_paths()
+        assert s2["passes"] == 1 and s2["removed_edges"] == 0 and s1["removed_edges"] == full_edges - ref.n_edges
+        assert (pg2.total_nodes, pg2.total_edges) == (ref.n_nodes, ref.n_edges)
+        assert np.array_equal(pg2.edge_id.cpu().numpy(), first[0]) and np.array_equal(pg2.edge_src.cpu().numpy(), first[1])
+        assert np.array_equal(pg2.edge_weight.cpu().numpy(), first[2])
+        del pg2
+        root = b.gather(0)
+        dg = root.graph()
+        assert (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
+        assert np.array_equal(dg.edge_src.cpu().numpy().astype(np.uint64), ref.edge_src)
+        del dg, root
+        with pytest.raises(KatomePanic):
+            b.remove_dead_paths()
+        with pytest.raises(KatomePanic):
+            b.gather(0)
+    finally:
+        b.close()
+        comm.close()
+
+
 def test_every_stage_after_a_sharded_build(oracle, tmp_path):
     """katome_build_files_staged with n_devices: the FASTQ fixture sharded over three ranks, every stage of
     assemble_with_graph before collapse on the gathered graph; the graph collapse() receives, index for index"""
