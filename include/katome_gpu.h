@@ -377,9 +377,19 @@ void katome_contigs_free(katome_contigs *c);
  * result is a separate set of device arrays owned by the builder (valid until the next call or destroy):
  *   d_edge_label: the paths in compress_edge format (compress.rs:250-271: [pad][packed bases, left-aligned]), edge i
  *   at bytes [d_edge_label_off[i], d_edge_label_off[i+1]); d_edge_kmers[i] = k-mers merged into edge i.
- * The SET of merged edges (sequence, weight, end vertices) is the reference's wherever its traversal starts from a
- * vertex without incoming edges; the numbering is this library's (edges in the order of their first k-mer in the
- * input graph, vertices in their input order) -- see DESIGN.md "shrink" for what the reference's order depends on. */
+ * Two forms (katome_dev_shrink_mode):
+ *  - KATOME_SHRINK_EXACT: the reference's own result -- where ShrinkTraverse (shrinker.rs:62-135) cuts paths on tangled graphs
+ *    and cycles, and the edge / node indices petgraph's swap_removes and add_edges leave (shrink_single_path 178-209,
+ *    remove_single_vertices) -- index for index.  That order is a sequential depth-first traversal interleaved with the
+ *    mutation, so it is computed on one host core over petgraph's own layout (csrc/shrink_exact.h; *host_ms reports it);
+ *    adjacency order (edge ages) before and weights, k-mer counts and labels after are the device's.
+ *  - KATOME_SHRINK_FAST: everything on the device, traversal-free: the same SET of merged edges wherever the reference's
+ *    traversal starts from a vertex without incoming edges, cycles of inner vertices cut at their smallest vertex; numbering
+ *    = edges in the order of their first k-mer in the input graph, vertices in their input order.
+ *  - KATOME_SHRINK_AUTO (katome_dev_shrink): exact on a FIRST_SEEN_ORDER builder, fast otherwise. */
+#define KATOME_SHRINK_AUTO  0u
+#define KATOME_SHRINK_FAST  1u
+#define KATOME_SHRINK_EXACT 2u
 typedef struct {
     uint64_t  n_nodes, n_edges, label_bytes;
     uint32_t  key_words, _pad;
@@ -390,6 +400,7 @@ typedef struct {
     uint64_t *d_node_key;
 } katome_dev_contigs;
 int katome_dev_shrink(katome_builder *b, katome_dev_contigs *out, void *stream);
+int katome_dev_shrink_mode(katome_builder *b, uint32_t mode, katome_dev_contigs *out, double *host_ms, void *stream);
 
 /* first half of finalize only: sorted distinct edges (key, weight); used by the multi-GPU
  * driver, which resolves node ids across ranks itself                                      */

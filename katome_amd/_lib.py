@@ -132,6 +132,7 @@ SYMBOLS = {
     "katome_dev_standardize_contigs": (_i, [_vp, _vp]),
     "katome_dev_standardize_edges": (_i, [_vp, _u64, _u32, _vp]),
     "katome_dev_shrink": (_i, [_vp, C.POINTER(DevContigs), _vp]),
+    "katome_dev_shrink_mode": (_i, [_vp, C.c_uint32, C.POINTER(DevContigs), C.POINTER(C.c_double), _vp]),
     "katome_dev_current_graph": (_i, [_vp, C.POINTER(DevGraph)]),
     "katome_dev_scan_counts": (_i, [_i, _vp, _u64, _vp, _vp]),
     "katome_dev_replay_node_removals": (_i, [_i, _vp, _u64, _u64, _vp, _vp, _vp, _vp]),

@@ -275,6 +275,8 @@ struct ShrinkOutput {
     uint64_t n_edges = 0, n_nodes = 0, label_bytes = 0;
 };
 int dev_shrink(const ShrinkInput& g, ShrinkOutput& out, hipStream_t stream);
+// the reference's own result: its cuts and petgraph's numbering (shrink_exact.h on the host for the order, the device for the bytes)
+int dev_shrink_exact(const ShrinkInput& g, const uint32_t* edge_age, ShrinkOutput& out, double* host_ms, hipStream_t stream);
 
 constexpr int KATOME_MAX_RANKS = 16;      // ranks of a sharded build (an MI355X node has 8 GPUs)
 

@@ -13,8 +13,11 @@
 //     with the smallest id (what the reference's traversal does when it enters the cycle there).
 // Output order (ours): merged edges in the order of their head edges, surviving vertices in their old order.
 #include <algorithm>
+#include <chrono>
+#include <new>
 
 #include "common.h"
+#include "shrink_exact.h"
 
 namespace katome {
 namespace {
@@ -167,6 +170,53 @@ __global__ __launch_bounds__(BLOCK) void gather_nodes_kernel(const u32* __restri
         for (u32 w = 0; w < nw; ++w) out[i * nw + w] = node_key[(u64)kept[i] * nw + w];
 }
 
+// ---- the exact form (shrink_exact.h decides what is merged and where everything ends up; these write the bytes) -------------------
+__global__ __launch_bounds__(BLOCK) void narrow_ids_kernel(const u64* __restrict__ in, u64 n, u32* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) out[i] = (u32)in[i];
+}
+__global__ __launch_bounds__(BLOCK) void widen_ids_kernel(const u32* __restrict__ in, u64 n, u64* __restrict__ out) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) out[i] = in[i];
+}
+__global__ __launch_bounds__(BLOCK) void age_keys_kernel(const u32* __restrict__ age, u64 n, u64* __restrict__ keys, u32* __restrict__ idx) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) { keys[i] = age[i]; idx[i] = (u32)i; }
+}
+// per final edge: the original edges on its chain (= k-mers it spells), the bytes its label takes, its weight (its slot's: the first edge's)
+__global__ __launch_bounds__(BLOCK) void chain_measure_kernel(const u32* __restrict__ slot, u64 n, const u32* __restrict__ chain_next,
+                                                              const u32* __restrict__ weight, u32 k, u32* __restrict__ path_len,
+                                                              u32* __restrict__ label_bytes, u32* __restrict__ o_weight) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u32 h = slot[i];
+        u32 m = 1;
+        for (u32 c = chain_next[h]; c != NO_EDGE; c = chain_next[c]) ++m;
+        path_len[i] = m;
+        label_bytes[i] = 1 + (k + m - 1 + 3) / 4;
+        o_weight[i] = weight[h];
+    }
+}
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void chain_write_kernel(const u32* __restrict__ slot, u64 n, const u32* __restrict__ chain_next,
+                                                            const u64* __restrict__ key, const u32* __restrict__ path_len,
+                                                            const u64* __restrict__ label_off, u32 k, uint8_t* __restrict__ o_label) {
+    for (u64 i = (u64)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (u64)gridDim.x * BLOCK) {
+        const u32 h = slot[i], len = k + path_len[i] - 1;
+        uint8_t* out = o_label + label_off[i];
+        *out++ = (uint8_t)((4 - len % 4) % 4);                   // compress_edge: padding byte first
+        Key<NW> hk;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) hk.w[j] = key[(u64)h * NW + j];
+        u32 acc = 0, have = 0;
+        for (u32 j = 0; j < k; ++j) {                             // the first edge's k bases, most significant first
+            acc = (acc << 2) | key_digit(hk, 2 * (k - 1 - j), 2);
+            if (++have == 4) { *out++ = (uint8_t)acc; acc = 0; have = 0; }
+        }
+        for (u32 c = chain_next[h]; c != NO_EDGE; c = chain_next[c]) {       // then the last base of every further edge (its remainder)
+            acc = (acc << 2) | (u32)(key[(u64)c * NW + NW - 1] & 3);
+            if (++have == 4) { *out++ = (uint8_t)acc; acc = 0; have = 0; }
+        }
+        if (have) *out = (uint8_t)(acc << (2 * (4 - have)));
+    }
+}
+
 int compact(const u32* flag, u64 n, DevBuf& out_pos, u32* rank_of, u64* n_out, hipStream_t stream) {
     const u64 nblocks = (n + (u64)BLOCK * ITEMS - 1) / ((u64)BLOCK * ITEMS);
     DevBuf counts(stream), offs(stream);
@@ -233,6 +283,95 @@ int dev_shrink(const ShrinkInput& g, ShrinkOutput& out, hipStream_t stream) {
                            g.edge_weight, g.edge_key, word.as<u64>(), path_len.as<u32>(), label_off.as<u64>(), end_node.as<u64>(),
                            new_id.as<u32>(), k, out.edge_src.as<u64>(), out.edge_dst.as<u64>(), out.edge_weight.as<u32>(), out.edge_label.as<uint8_t>());
     if (NK) hipLaunchKernelGGL(gather_nodes_kernel, dim3(grid_for(NK, BLOCK, 256u * 32u)), blk, 0, stream, kept.as<u32>(), NK, g.node_key, nw,
+                               out.node_key.as<u64>());
+    KCHECK_HIP(hipGetLastError());
+    {
+        const size_t nb = label_off.bytes; out.edge_label_off.adopt(label_off.take(), nb);
+        const size_t pb = path_len.bytes; out.edge_kmers.adopt(path_len.take(), pb);
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    out.n_edges = H; out.n_nodes = NK; out.label_bytes = total_bytes;
+    return KATOME_OK;
+}
+
+// Shrinkable::shrink exactly as the reference computes it (see shrink_exact.h): the device orders the edges by age (petgraph's
+// adjacency order) and hands the end points to the sequential statement on the host; what comes back -- for every edge of the shrunk
+// graph its slot, its end points under the final numbering, and the chains of original edges behind the slots -- is turned into
+// weights, k-mer counts and compress_edge labels on the device again.  edge_age: the index every edge had when it was added (null:
+// the edges are still in that order).
+int dev_shrink_exact(const ShrinkInput& g, const uint32_t* edge_age, ShrinkOutput& out, double* host_ms, hipStream_t stream) {
+    const u64 E = g.n_edges, N = g.n_nodes;
+    const u32 nw = g.nw, k = g.k;
+    out.n_edges = out.n_nodes = out.label_bytes = 0;
+    if (host_ms) *host_ms = 0;
+    if (E >= 0xFFFFFFFFull || N >= 0xFFFFFFFFull) { set_error("shrink: more than 2^32 edges or nodes on one GPU"); return KATOME_E_UNSUPPORTED; }
+    if (E == 0) return KATOME_OK;
+    const dim3 ge(grid_for(E, BLOCK, 256u * 32u)), blk(BLOCK);
+    std::vector<uint32_t> h_src, h_dst, h_order;
+    try { h_src.resize(E); h_dst.resize(E); if (edge_age) h_order.resize(E); }
+    catch (const std::bad_alloc&) { set_error("shrink: out of host memory"); return KATOME_E_OOM; }
+    {
+        DevBuf s32(stream), d32(stream);
+        KCHECK(s32.alloc((E + 1) * 4)); KCHECK(d32.alloc((E + 1) * 4));
+        hipLaunchKernelGGL(narrow_ids_kernel, ge, blk, 0, stream, g.edge_src, E, s32.as<u32>());
+        hipLaunchKernelGGL(narrow_ids_kernel, ge, blk, 0, stream, g.edge_dst, E, d32.as<u32>());
+        KCHECK_HIP(hipGetLastError());
+        KCHECK_HIP(hipMemcpyAsync(h_src.data(), s32.p, E * 4, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipMemcpyAsync(h_dst.data(), d32.p, E * 4, hipMemcpyDeviceToHost, stream));
+        if (edge_age) {
+            DevBuf keys(stream), idx(stream);
+            KCHECK(keys.alloc((E + 1) * 8)); KCHECK(idx.alloc((E + 1) * 4));
+            hipLaunchKernelGGL(age_keys_kernel, ge, blk, 0, stream, edge_age, E, keys.as<u64>(), idx.as<u32>());
+            KCHECK_HIP(hipGetLastError());
+            KCHECK(dev_sort(keys.as<u64>(), idx.as<u32>(), E, 1, 32, stream));
+            KCHECK_HIP(hipMemcpyAsync(h_order.data(), idx.p, E * 4, hipMemcpyDeviceToHost, stream));
+        }
+        KCHECK_HIP(hipStreamSynchronize(stream));
+    }
+    ShrinkExact sx;
+    std::vector<uint32_t> kept;
+    const auto t0 = std::chrono::steady_clock::now();
+    try {
+        sx.init(h_src.data(), h_dst.data(), edge_age ? h_order.data() : nullptr, (uint32_t)E, (uint32_t)N);
+        std::vector<uint32_t>().swap(h_src); std::vector<uint32_t>().swap(h_dst); std::vector<uint32_t>().swap(h_order);
+        sx.run(kept);
+    } catch (const std::bad_alloc&) { set_error("shrink: out of host memory"); return KATOME_E_OOM; }
+    if (host_ms) *host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const u64 H = sx.n_edges, NK = kept.size();
+    DevBuf slot(stream), chain(stream), s32(stream), d32(stream), kept_d(stream), path_len(stream), label_bytes(stream), label_off(stream);
+    KCHECK(slot.alloc((H + 1) * 4)); KCHECK(chain.alloc((E + 1) * 4)); KCHECK(s32.alloc((H + 1) * 4)); KCHECK(d32.alloc((H + 1) * 4));
+    KCHECK(kept_d.alloc((NK + 1) * 4)); KCHECK(path_len.alloc((H + 1) * 4)); KCHECK(label_bytes.alloc((H + 1) * 4)); KCHECK(label_off.alloc((H + 2) * 8));
+    KCHECK_HIP(hipMemcpyAsync(chain.p, sx.chain_next.data(), E * 4, hipMemcpyHostToDevice, stream));
+    if (H) {
+        KCHECK_HIP(hipMemcpyAsync(slot.p, sx.edge_slot.data(), H * 4, hipMemcpyHostToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(s32.p, sx.edge_node[0].data(), H * 4, hipMemcpyHostToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(d32.p, sx.edge_node[1].data(), H * 4, hipMemcpyHostToDevice, stream));
+    }
+    if (NK) KCHECK_HIP(hipMemcpyAsync(kept_d.p, kept.data(), NK * 4, hipMemcpyHostToDevice, stream));
+    KCHECK(out.edge_src.alloc((H + 1) * 8, stream)); KCHECK(out.edge_dst.alloc((H + 1) * 8, stream));
+    KCHECK(out.edge_weight.alloc((H + 1) * 4, stream)); KCHECK(out.node_key.alloc((NK + 1) * 8 * nw, stream));
+    const dim3 gh(grid_for(std::max<u64>(H, 1), BLOCK, 256u * 32u));
+    u64 total_bytes = 0;
+    if (H) {
+        hipLaunchKernelGGL(widen_ids_kernel, gh, blk, 0, stream, s32.as<u32>(), H, out.edge_src.as<u64>());
+        hipLaunchKernelGGL(widen_ids_kernel, gh, blk, 0, stream, d32.as<u32>(), H, out.edge_dst.as<u64>());
+        hipLaunchKernelGGL(chain_measure_kernel, gh, blk, 0, stream, slot.as<u32>(), H, chain.as<u32>(), g.edge_weight, k, path_len.as<u32>(),
+                           label_bytes.as<u32>(), out.edge_weight.as<u32>());
+        KCHECK_HIP(hipGetLastError());
+        KCHECK(dev_scan_counts(label_bytes.as<u32>(), H, label_off.as<u64>(), stream));
+        KCHECK_HIP(hipMemcpyAsync(&total_bytes, label_off.as<u64>() + H, 8, hipMemcpyDeviceToHost, stream));
+    } else {
+        KCHECK_HIP(hipMemsetAsync(label_off.p, 0, 8, stream));
+    }
+    KCHECK_HIP(hipStreamSynchronize(stream));          // (total_bytes; and the host vectors may go)
+    KCHECK(out.edge_label.alloc(total_bytes + 16, stream));
+    if (H) {
+        if (nw == 1) hipLaunchKernelGGL(chain_write_kernel<1>, gh, blk, 0, stream, slot.as<u32>(), H, chain.as<u32>(), g.edge_key, path_len.as<u32>(),
+                                        label_off.as<u64>(), k, out.edge_label.as<uint8_t>());
+        else         hipLaunchKernelGGL(chain_write_kernel<2>, gh, blk, 0, stream, slot.as<u32>(), H, chain.as<u32>(), g.edge_key, path_len.as<u32>(),
+                                        label_off.as<u64>(), k, out.edge_label.as<uint8_t>());
+    }
+    if (NK) hipLaunchKernelGGL(gather_nodes_kernel, dim3(grid_for(NK, BLOCK, 256u * 32u)), blk, 0, stream, kept_d.as<u32>(), NK, g.node_key, nw,
                                out.node_key.as<u64>());
     KCHECK_HIP(hipGetLastError());
     {

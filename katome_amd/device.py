@@ -292,10 +292,16 @@ class Builder(_ViewOwner):
         """Standardizable::standardize_edges (standardizer.rs:42-70): scale, round, remove_weak_edges(1)"""
         _check(_lib.lib().katome_dev_standardize_edges(self._h, original_genome_length, threshold, _stream()))
 
-    def shrink(self):
-        """Shrinkable::shrink (shrinker.rs:165-209) of the finalized graph as it stands -> DeviceContigs"""
+    def shrink(self, mode=None):
+        """Shrinkable::shrink (shrinker.rs:165-209) of the finalized graph as it stands -> DeviceContigs.  mode "exact": the
+        reference's own cuts and numbering, index for index (its traversal order on one host core, the bytes on the device);
+        "fast": traversal-free, all on the device, this library's numbering; None: exact on a first-seen-order builder.
+        `self.last_shrink_host_ms`: the sequential part of the last exact call"""
         dc = _lib.DevContigs()
-        _check(_lib.lib().katome_dev_shrink(self._h, C.byref(dc), _stream()))
+        host_ms = C.c_double(0)
+        _check(_lib.lib().katome_dev_shrink_mode(self._h, {None: 0, "auto": 0, "fast": 1, "exact": 2}[mode], C.byref(dc), C.byref(host_ms),
+                                                 _stream()))
+        self.last_shrink_host_ms = host_ms.value
         return DeviceContigs(dc, self, self.tdev)
 
     def graph(self):

@@ -178,6 +178,95 @@ def test_tangled_graphs_where_the_traversal_order_cannot_matter(oracle, seed):
         b.close()
 
 
+def _same_as_reference(dc, want, k):
+    """the shrunk graph index for index: end points, weights, sequences, in petgraph's numbering after shrink
+    (shrinker.rs:165-209: swap_removes and add_edges, then remove_single_vertices)"""
+    assert (dc.n_nodes, dc.n_edges) == (want.n_nodes, want.n_edges)
+    assert dc.edge_src.cpu().tolist() == want.edge_src.tolist() and dc.edge_dst.cpu().tolist() == want.edge_dst.tolist()
+    assert dc.edge_weight.cpu().numpy().view(np.uint32).tolist() == want.edge_weight.tolist()
+    assert dc.sequences() == want.edge_seq
+    _contigs(dc, k)                      # (labels against end vertices' keys and path lengths: the node keys follow the numbering too)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_exact_shrink_on_tangled_graphs_index_for_index(oracle, seed):
+    """the tangles of the test above -- branches, self-loops, two-cycles, parts no vertex without incoming edges reaches -- through
+    the EXACT form: where the reference's traversal cuts, which restarts it makes (and which its offset makes it skip), and the
+    indices its swap_removes leave; every array against the oracle's literal petgraph"""
+    from katome_amd import device as kd
+    k = [5, 6, 7, 8, 9, 11, 13, 17][seed % 8]
+    rng = np.random.default_rng(50 + seed)
+    genome = rng.integers(0, 4, 200 + 60 * seed)
+    L = k + 6 + seed % 9
+    reads = np.zeros((60 + 25 * seed, L), np.uint8)
+    for i in range(len(reads)):
+        s0 = rng.integers(0, len(genome) - L + 1)
+        r = genome[s0:s0 + L].copy()
+        m = rng.random(L) < 0.03
+        r[m] = rng.integers(0, 4, int(m.sum()))
+        reads[i] = np.frombuffer(b"ACGT", np.uint8)[r]
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    for rc in (False, True):
+        b = _build(kd, packed, len(reads), L, k, rc, first_seen=True)
+        _same_as_reference(b.shrink("exact"), oracle.build_ascii(reads, k, rc, stages="s"), k)
+        # the fast form on the same graph: the same k-mers in its merged edges, its own numbering
+        assert sum(b.shrink("fast").edge_kmers.cpu().tolist()) == oracle.build_ascii(reads, k, rc).n_edges
+        b.close()
+
+
+@pytest.mark.parametrize("k,rc", [(11, False), (16, True), (31, True)])
+def test_exact_shrink_of_cycles_index_for_index(oracle, k, rc):
+    """reads off circular sequences only: no vertex to start from, the traversal's restarts decide where each circle is cut"""
+    from katome_amd import device as kd
+    rng = np.random.default_rng(k)
+    reads = []
+    for n in (300, 170, 90):
+        circle = "".join("ACGT"[c] for c in rng.integers(0, 4, n))
+        reads += [[ord(c) for c in (circle * 3)[s:s + 60]] for s in range(0, n, 7)]
+    order = rng.permutation(len(reads))
+    reads = np.array([reads[i] for i in order], dtype=np.uint8)
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    b = _build(kd, packed, len(reads), 60, k, rc, first_seen=True)
+    _same_as_reference(b.shrink(), oracle.build_ascii(reads, k, rc, stages="s"), k)       # (auto = exact on this builder)
+    b.close()
+
+
+@pytest.mark.parametrize("k,rc,n,L,glen,err", [(31, True, 4000, 100, 30000, 5e-3), (21, False, 3000, 80, 20000, 1e-2),
+                                               (40, True, 2500, 103, 20000, 5e-3), (15, True, 3000, 60, 8000, 1e-2)])
+def test_exact_shrink_after_pruning_index_for_index(oracle, k, rc, n, L, glen, err):
+    """the assembler's order (asm/basic_assembler.rs:58-65; collapser.rs:31): remove_dead_paths, whose swap_removes leave the edges
+    out of age order (the adjacency lists still follow the ages), then shrink -- and shrink alone"""
+    from katome_amd import device as kd
+    ascii_reads = oracle.synth_reads(0, n, L, glen, err, 0)
+    packed = torch.from_numpy(pack_reads_ascii(ascii_reads).reshape(-1).copy()).cuda()
+    b = _build(kd, packed, n, L, k, rc, first_seen=True)
+    _same_as_reference(b.shrink("exact"), oracle.build_ascii(ascii_reads, k, rc, stages="s"), k)
+    b.remove_dead_paths()
+    want = oracle.build_ascii(ascii_reads, k, rc, stages="ds")
+    if want.n_edges:
+        _same_as_reference(b.shrink("exact"), want, k)
+        assert b.last_shrink_host_ms > 0
+    b.close()
+
+
+@pytest.mark.parametrize("i", [0, 1, 2])
+def test_exact_shrink_of_the_reference_fixtures(oracle, golden_dir, i):
+    """tests/shrinker.rs:33-36's counts again, and every array of the three fixtures' shrunk graphs"""
+    from katome_amd import device as kd
+    from katome_amd.build import ingest_files, InputFileType
+    pinned = json.load(open(os.path.join(golden_dir, "pinned.json")))
+    path, k = os.path.join(golden_dir, pinned["fixtures"][i]), pinned["k"]
+    r = ingest_files([path], InputFileType.Fastq, k)
+    packed = torch.from_numpy(r["packed"].copy()).cuda()
+    for rc in (False, True):
+        b = _build(kd, packed, r["n_reads"], r["fixed_len"], k, rc, True)
+        dc = b.shrink("exact")
+        if not rc:
+            assert [dc.n_nodes, dc.n_edges] == pinned["shrink"]["counts"][i]
+        _same_as_reference(dc, oracle.build_files([path], k, rc, stages="s"), k)
+        b.close()
+
+
 @pytest.mark.parametrize("name,k,rc,prune", [("data2.txt", 40, False, False), ("data3.txt", 40, True, True), ("data3.txt", 21, True, True),
                                              ("data2.txt", 63, True, False)])
 def test_host_entry(oracle, golden_dir, name, k, rc, prune):
