@@ -240,7 +240,7 @@ def next_stages(wl, sample_reads):
         ms, dc = timed(lambda: b.shrink("exact"))
         out["shrink_exact_ms"] = ms
         out["shrink_exact_host_ms"] = b.last_shrink_host_ms
-        assert dc.n_edges == out["edges_after_shrink"] or True
+        out["edges_after_shrink_exact"] = dc.n_edges
         # the rest of assemble_with_graph up to collapse (asm/basic_assembler.rs:63-72), threshold 2
         ms1, _ = timed(b.standardize_contigs)
         ms2, _ = timed(lambda: b.remove_weak_edges(2))
@@ -367,7 +367,14 @@ def main():
                                       device=local_rank)
         skip_arg = skip if wl.n_inject_percent else None
         accepted = wl.reads - (int(skip[:wl.reads].sum().item()) if wl.n_inject_percent else 0)
-        recbuf = torch.empty(min(batch_reads, wl.reads) * W * kd.record_words(wl.k), dtype=torch.int64,
+        # (a record buffer of the caller's is only needed for windows counted one by one: reads that are not whole tiles, the
+        # two-call boundary, or no tiling at all -- 16 GB that a tiled build does not take from the card)
+        from katome_amd._lib import lib as _kl
+        import ctypes as _Ct
+        _sp, _tl, _rs = _Ct.c_uint32(), _Ct.c_uint32(), _Ct.c_uint32()
+        _kl().katome_tile_plan(wl.k, wl.read_len, _Ct.byref(_sp), _Ct.byref(_tl), _Ct.byref(_rs))
+        per_read_buf = W if (_sp.value <= 1 or os.environ.get("KATOME_BENCH_TWO_CALLS") == "1") else _rs.value
+        recbuf = torch.empty(max(min(batch_reads, wl.reads) * per_read_buf * kd.record_words(wl.k), 1), dtype=torch.int64,
                              device=packed.device)
 
         def step():
@@ -703,9 +710,9 @@ def main():
                        "tile_span": span, "order": "first-seen (petgraph)" if (args.first_seen_order or args.prune) else "by packed key",
                        "min_weight": args.min_weight,
                        "parallelism": "reads sharded by index over %d GPU(s); %s" % (
-                           world, "every rank counts its reads, distinct k-mers routed by hash (one all-to-all)"
-                           if os.environ.get("KATOME_DIST_ROUTE", "local" if world <= 2 else "tiles") == "local"
-                           else "tiles, mid tiles and k-mer records routed by hash (three all-to-alls)")
+                           world, {"local": "every rank counts its reads, distinct k-mers routed by hash (one all-to-all)",
+                                   "supermers": "reads cut into supermers (runs of windows with one minimizer), routed once by a hash of the minimizer BEFORE any counting (one all-to-all of 16-byte records); every rank counts what it receives",
+                                   "tiles": "tiles, mid tiles and k-mer records routed by hash (three all-to-alls)"}.get(getattr(job, "route", ""), getattr(job, "route", "?")))
                        if use_dist else "1 GPU"},
             "distinct_edges": n_edges, "nodes": n_nodes, "distinct_edges_per_s": n_edges / (ms_per_step * 1e-3),
             "roofline": roofline, "roofline_streaming": roofline_streaming, "roofline_phase": roof_phase(dom), "roofline_extract": roof_phase("extract"),
@@ -730,6 +737,8 @@ def main():
                             "link_peak_GBs": 153.0}
             line["exchange"] = ex
             line["config"]["transport"] = comm.kind
+            line["config"]["route"] = getattr(job, "route", None)
+            line["config"]["comm_ranks"] = comm.world          # (the communicator's own rank count: RCCL saw this many ranks)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
         if world == 1 and not use_dist and not args.no_extras:

@@ -168,6 +168,7 @@ SYMBOLS = {
     "katome_dist_finalize": (_i, [_vp, C.POINTER(DistGraph), _vp]),
     "katome_dist_gather": (_i, [_vp, _i, C.POINTER(_vp), _vp]),
     "katome_dist_inner": (_vp, [_vp]),
+    "katome_dist_route": (C.c_char_p, [_vp]),
     "katome_dist_remove_dead_paths": (_i, [_vp, C.POINTER(DistGraph), C.POINTER(PruneStats), _vp]),
     "katome_dist_current_graph": (_i, [_vp, C.POINTER(DistGraph)]),
     "katome_dist_exchange_count": (_u32, []),

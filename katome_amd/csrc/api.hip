@@ -555,6 +555,39 @@ int keep_tile_recs(katome_builder* b, const uint64_t* d_records, uint64_t n, uin
     return KATOME_OK;
 }
 
+// Device memory a counting level may plan with: what the driver has free plus what the library's cache holds idle
+// (KATOME_LEVEL_BUDGET: no more than this many bytes -- tests of the ways back into the tables at sizes the oracle can check)
+static uint64_t level_budget() {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return ~0ull; }
+    const uint64_t avail = (uint64_t)free_b + dev_cached_bytes();
+    const char* e = getenv("KATOME_LEVEL_BUDGET");
+    return e ? std::min<uint64_t>(avail, strtoull(e, nullptr, 10)) : avail;
+}
+// a level counted by sorting holds its records, the partition passes' scratch of the same size and an output list sized for the case
+// that no record repeats: three times the records (oriented edges: the output twice over)
+static bool level_fits(uint64_t n_records, uint32_t key_words, bool oriented, const char* what) {
+    const char* sl = getenv("KATOME_LEVEL_SLACK");           // (room left for everything else: group index, cursors, the allocator's rounding)
+    const uint64_t slack = sl ? strtoull(sl, nullptr, 10) : (256ull << 20);
+    const uint64_t pair = 8ull * key_words + 4, need = n_records * pair * (oriented ? 4 : 3) + slack, have = level_budget();
+    if (need <= have) return true;
+    if (getenv("KATOME_LEVEL_TRACE"))
+        fprintf(stderr, "[katome levels] %s: %llu records need %.1f GiB by sorting, %.1f GiB available -- this level and those below are counted in tables\n",
+                what, (unsigned long long)n_records, need / 1073741824.0, have / 1073741824.0);
+    return false;
+}
+// a list that was sized for its records and holds far fewer keys moves into a buffer of its own size (thin coverage: the room is needed)
+static int shrink_to_fit(DevBuf& buf, size_t used, hipStream_t stream) {
+    if (!buf.p || buf.bytes < (1ull << 30) || used * 2 > buf.bytes) return KATOME_OK;
+    DevBuf small(stream);
+    if (small.alloc(used + 64) != KATOME_OK) return KATOME_OK;          // (no room for the copy: the list stays where it is)
+    if (used) KCHECK_HIP(hipMemcpyAsync(small.p, buf.p, used, hipMemcpyDeviceToDevice, stream));
+    const size_t n = small.bytes;
+    buf.adopt(small.take(), n);
+    buf.stream = stream;
+    return KATOME_OK;
+}
+
 // The tile records kept aside -> the (k-mer, count) records of the last tile level, every level counted by sorting (DESIGN.md
 // section 4): records -> two hash passes -> counted in LDS -> a compact list of distinct tiles with their counts; the next level's
 // records are cut out of that list.  KATOME_OK: keys / weights hold *n_records records (room for extra_room more behind them) and
@@ -586,6 +619,7 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
     b->tile_recs_exact = false;
     b->tile_recs_closed = true;
     b->stat_tiles = n1; b->stat_tile_slots = 0; b->stat_tiles2 = 0; b->stat_tile2_slots = 0;
+    KCHECK(shrink_to_fit(t1k, n1 * 8 * nwt, stream)); KCHECK(shrink_to_fit(t1w, n1 * 4, stream));
     const uint64_t* lk = t1k.as<u64>(); const uint32_t* lw = t1w.as<u32>();
     uint64_t n_last = n1; uint32_t last_bases = tile_bases, last_span = span;
     DevBuf t2k(stream), t2w(stream);
@@ -596,9 +630,13 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
         DevBuf mk(stream), mw(stream);
         uint64_t n_mid = 0, n2 = 0, d2 = 0;
         DevBuf mid_counts(stream);        // (the first partition pass's digit counts per tile, made while the records are written)
-        KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream, 0, &mid_counts));
-        rc = sorted_fail("mid") ? KATOME_E_UNSUPPORTED
-            : records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream, nullptr, mid_counts.as<u32>());
+        // (input whose tiles hardly repeat -- thin coverage -- multiplies records level by level: a level that would not fit the card
+        // by sorting is counted in a table, which takes its upserts in slot ranges of any size)
+        if (sorted_fail("mid") || !level_fits(n1 * n_sub, (uint32_t)key_words_for_k(kk2), false, "mid tiles")) rc = KATOME_E_UNSUPPORTED;
+        else {
+            KCHECK(table_list_to_records(lk, lw, n1, tile_bases, kk2, n_sub, b->span2, b->rc, mk, mw, &n_mid, stream, 0, &mid_counts));
+            rc = records_to_edges_sorted(mk, mw, n_mid, kk2, false, 0, t2k, t2w, &n2, &d2, stream, nullptr, mid_counts.as<u32>());
+        }
         if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
         if (rc == KATOME_E_UNSUPPORTED) {
             // the mid tiles cannot be counted this way: the distinct big tiles go into the tile table with their counts, and the build
@@ -608,8 +646,23 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
             return KATOME_E_UNSUPPORTED;
         }
         b->stat_tiles2 = n2;
-        lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
         t1k.release(); t1w.release();
+        mk.release(); mw.release();
+        KCHECK(shrink_to_fit(t2k, n2 * 8 * key_words_for_k(kk2), stream)); KCHECK(shrink_to_fit(t2w, n2 * 4, stream));
+        lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
+    }
+    if (n_last && !level_fits(n_last * last_span + extra_room, b->nw, b->rc, "k-mers")) {
+        // the k-mer level would not fit by sorting: the distinct tiles of the last level go into their table with their counts (the mid
+        // tiles into `tiles2`, with nothing in `tiles`: expand_to_last_level's "done before" state) and the k-mers are counted in theirs
+        const uint32_t nwl = (uint32_t)key_words_for_k(last_bases);
+        if (b->span2) {
+            KCHECK(builder_insert(b, b->tiles2, b->tiles2_ready, nwl, std::max<uint64_t>(b->s.table_slots_hint / 4, n_last * 2), lk, lw, n_last, nullptr, PH_EXPAND_MID, stream));
+            b->tiles_ready = true;                   // (with b->tiles empty)
+            b->stat_tile2_slots = b->tiles2.cap;
+        } else {
+            KCHECK(builder_insert(b, b->tiles, b->tiles_ready, nwl, b->s.table_slots_hint / 4, lk, lw, n_last, nullptr, PH_INSERT_TILES, stream));
+        }
+        return KATOME_E_UNSUPPORTED;
     }
     PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
     // (first_counts: for a caller that orders exactly these records by the whole k-mer's hash next -- table_list_to_records)
@@ -919,7 +972,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 }
             }
         }
-        if (!counted && sorted_count && b->tiles_ready && !b->table_ready && !b->first_seen && b->nw <= 2) {
+        if (!counted && sorted_count && b->tiles_ready && b->tiles.cap && !b->table_ready && !b->first_seen && b->nw <= 2) {
             uint64_t n_tiles = 0;
             KCHECK(table_occupied(b->tiles, &n_tiles, stream));
             const uint64_t bound = n_tiles * b->span + b->rest_n;        // the k-mer records can be no more than this
@@ -935,7 +988,8 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 uint64_t n_mid_list = 0;
                 bool mid_sorted = false;
                 const uint32_t sp2 = mid_span(b->span);
-                if (sorted_tiles_mode() && nwt == 2 && b->nw == 1 && sp2 && !b->tiles2_ready && b->tiles.cap && n_tiles) {
+                if (sorted_tiles_mode() && nwt == 2 && b->nw == 1 && sp2 && !b->tiles2_ready && b->tiles.cap && n_tiles &&
+                    level_fits(n_tiles * (b->span / sp2), (uint32_t)key_words_for_k(b->s.k + sp2 - 1), false, "mid tiles (big tiles in their table)")) {
                     const uint32_t kk2 = b->s.k + sp2 - 1, n_sub = b->span / sp2;
                     PhaseScope ps(b->prof, PH_EXPAND_MID, stream);
                     TileLevelScope tl;
@@ -952,7 +1006,12 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     } else { t2k.release(); t2w.release(); }
                 }
                 if (!mid_sorted) KCHECK(expand_to_last_level(b, &last, &last_span, stream));
-                const bool last_ok = mid_sorted || (b->nw == 1 && last->nw <= 2) || (b->nw == 2 && (last->nw == 2 || last->nw == 3));
+                bool last_ok = mid_sorted || (b->nw == 1 && last->nw <= 2) || (b->nw == 2 && (last->nw == 2 || last->nw == 3));
+                if (last_ok) {        // (... and the records of the level fit the card with their scratch and their output)
+                    uint64_t last_tiles = n_mid_list;
+                    if (!mid_sorted) KCHECK(table_occupied(*last, &last_tiles, stream));
+                    last_ok = level_fits(last_tiles * last_span + b->rest_n, b->nw, b->rc, "k-mers (tiles in their table)");
+                }
                 if (last_ok) {
                     DevBuf rk(stream), rw(stream);
                     uint64_t n_rec = 0, distinct = 0;

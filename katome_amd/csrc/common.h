@@ -181,7 +181,17 @@ int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32
 struct DevBuf;
 int dev_sort_bufs(DevBuf& keys, DevBuf* vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
-                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift = 0, uint32_t core_bases = 0);
+                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift = 0, uint32_t core_bases = 0, uint32_t minimizer = 0);
+// supermer.hip: the sharded build's exchange unit
+constexpr uint32_t SUPERMER_M = 11;        // bases of the minimizer that names a k-mer's owner on the supermer route
+uint32_t supermer_slots(uint32_t k, uint32_t read_len, uint32_t m);
+bool supermer_route_takes(uint32_t k, uint32_t read_len, uint32_t m);
+int dev_supermers_extract(const uint8_t* d_packed, uint64_t n_reads, uint32_t read_len, const uint8_t* d_skip, uint32_t k, uint32_t m, bool rc,
+                          uint32_t n_owners, uint32_t slots, uint64_t* d_out, uint64_t* d_spill, uint64_t spill_cap, uint64_t* d_spill_cursor,
+                          hipStream_t stream);
+int dev_supermers_expand(const uint64_t* d_list, const uint32_t* d_counts, uint64_t n, uint32_t k, bool rc, DevBuf& keys, DevBuf& weights,
+                         uint64_t* n_records, hipStream_t stream);
+int dev_partition_supermers(const uint64_t* d_in, uint64_t n, uint32_t n_parts, uint64_t* d_out, uint64_t* h_counts, hipStream_t stream);
 int dev_partition_range(const uint64_t* d_vals, const uint32_t* idx_in, uint64_t n, const uint64_t* d_bounds, uint32_t n_parts,
                         uint64_t* d_out, uint32_t* idx_out, uint64_t* h_counts, hipStream_t stream);
 int dev_source_ids(const uint64_t* d_edge_key, uint64_t n_edges, uint32_t k, DevBuf& node_key, uint64_t* d_edge_src, uint64_t* n_src,
@@ -289,7 +299,7 @@ struct Table {
     uint64_t cap = 0;
     uint32_t nw = 1;
     size_t slot_bytes() const { return nw == 1 ? 16 : 32; }
-    void release() { slots.release(); counter.release(); seen.release(); }
+    void release() { slots.release(); counter.release(); seen.release(); cap = 0; }      // (cap == 0: "no table" -- expand_to_last_level's test)
 };
 // where a batch of records sits in the read-ordered stream (first-seen-order mode)
 struct SeenOrigin {

@@ -587,8 +587,16 @@ int katome_dist_create(const katome_settings* s, katome_comm* comm, katome_dist_
     katome_dist_builder* d = new (std::nothrow) katome_dist_builder();
     if (!d) { katome_builder_destroy(b); set_error("out of host memory"); return KATOME_E_OOM; }
     d->s = *s; d->comm = comm; d->b = b; d->nw = b->nw; d->rc = b->rc; d->first_seen = b->first_seen;
+    // routes (KATOME_DIST_ROUTE=supermers|local|tiles overrides): few ranks -- every rank counts its own reads and
+    // routes its distinct k-mers; from three ranks on -- the reads travel as supermers, once, before anything is counted (by packed key,
+    // k <= 31; the reference's numbering and longer k-mers: tiles, mid tiles and k-mer records routed level by level)
     d->local_first = comm->world() <= 2;
-    if (const char* e = getenv("KATOME_DIST_ROUTE")) d->local_first = strcmp(e, "local") == 0 ? true : strcmp(e, "tiles") == 0 ? false : d->local_first;
+    d->want_supermers = comm->world() > 2 && !d->first_seen;
+    if (const char* e = getenv("KATOME_DIST_ROUTE")) {
+        d->local_first = strcmp(e, "local") == 0 ? true : (strcmp(e, "tiles") == 0 || strcmp(e, "supermers") == 0) ? false : d->local_first;
+        d->want_supermers = strcmp(e, "supermers") == 0 ? !d->first_seen : (strcmp(e, "local") == 0 || strcmp(e, "tiles") == 0) ? false : d->want_supermers;
+    }
+    if (d->want_supermers) d->local_first = false;
     *out = d;
     return KATOME_OK;
 }
@@ -601,6 +609,9 @@ void katome_dist_destroy(katome_dist_builder* d) {
 }
 
 katome_builder* katome_dist_inner(katome_dist_builder* d) { return d ? d->b : nullptr; }
+const char* katome_dist_route(const katome_dist_builder* d) {
+    return !d ? "" : d->supermers ? "supermers" : d->local_first ? "local" : (d->planned || d->finalized) && !d->want_supermers ? "tiles" : d->want_supermers ? "supermers (if the reads allow)" : "tiles";
+}
 
 int katome_dist_current_graph(katome_dist_builder* d, katome_dist_graph* out) {
     if (!d) { set_error("null argument"); return KATOME_E_ARG; }
@@ -628,12 +639,46 @@ int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint6
         d->read_len = read_len; d->W = read_len - k + 1;
         if (!katome_tile_plan_limited(k, read_len, 3, &d->span, &d->tiles_per_read, &d->rest)) { d->span = 1; d->tiles_per_read = 0; d->rest = d->W; }
         d->nwt = d->span > 1 ? katome_tile_words(k, d->span) : nw;
+        d->supermers = d->want_supermers && nw == 1 && supermer_route_takes(k, read_len, SUPERMER_M);
+        if (d->want_supermers && !d->supermers) d->want_supermers = false;          // (these reads take the level-by-level route)
+        if (d->supermers) { d->owner_m = SUPERMER_M; d->sm_slots = supermer_slots(k, read_len, SUPERMER_M); }
         d->planned = true;
     } else if (read_len != d->read_len) {
         set_error("the sharded build takes reads of one length (%u, then %u)", d->read_len, read_len);
         return KATOME_E_UNSUPPORTED;
     }
     const int world = d->world();
+    if (d->supermers) {
+        // the reads' supermer records wait for the one exchange (katome_dist_finalize): slots per read, then this call's spill region
+        const uint64_t spill_cap = std::max<uint64_t>(1024, n_reads / 8), add = n_reads * d->sm_slots + spill_cap;
+        if (d->sm_n + add > d->sm_cap) {
+            const uint64_t want = d->sm_n ? std::max(d->sm_n + add, d->sm_cap * 2) : add;
+            DevBuf grown(stream);
+            KCHECK(grown.alloc(want * 16 + 64));
+            if (d->sm_n) KCHECK_HIP(hipMemcpyAsync(grown.p, d->sm_recs.p, d->sm_n * 16, hipMemcpyDeviceToDevice, stream));
+            const size_t bytes = grown.bytes;
+            d->sm_recs.stream = stream; d->sm_recs.adopt(grown.take(), bytes);
+            d->sm_cap = want;
+        }
+        u64* slots_at = d->sm_recs.as<u64>() + d->sm_n * 2;
+        u64* spill_at = slots_at + n_reads * d->sm_slots * 2;
+        DevBuf cursor(stream);
+        KCHECK(cursor.alloc(8));
+        KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+        KCHECK_HIP(hipMemsetAsync(spill_at, 0xFF, spill_cap * 16, stream));
+        {
+            PhaseScope ps(b->prof, PH_EXTRACT, stream);
+            KCHECK(dev_supermers_extract(d_packed, n_reads, read_len, d_skip, k, d->owner_m, d->rc, (uint32_t)world, d->sm_slots, slots_at, spill_at, spill_cap,
+                                         cursor.as<u64>(), stream));
+        }
+        uint64_t spilled = 0;
+        KCHECK_HIP(hipMemcpyAsync(&spilled, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        if (spilled > spill_cap) { set_error("supermers: reads with unusually many runs (%llu records beyond the reads' slots, room for %llu)", (unsigned long long)spilled, (unsigned long long)spill_cap); return KATOME_E_UNSUPPORTED; }
+        d->sm_n += add;
+        d->reads_end = std::max(d->reads_end, first_read + n_reads);
+        return KATOME_OK;
+    }
     const bool tiled = d->span > 1;
     const uint32_t per_read = tiled ? d->tiles_per_read : d->W, nwr = tiled ? d->nwt : nw, stride = (read_len + 3) / 4;
     if (d->local_first) {
@@ -750,6 +795,60 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     KCHECK(d->comm->allreduce(plan, 2, OP_MAX));
     const bool tiled = plan[0] > 1;
     const uint64_t total_reads = plan[1];
+    {   // (a rank that was given no reads made no plan: it takes the route of those that did)
+        uint64_t route = d->planned ? (d->supermers ? 2 : 1) : 0;
+        KCHECK(d->comm->allreduce(&route, 1, OP_MAX));
+        if (!d->planned && route == 2) { d->supermers = true; d->owner_m = SUPERMER_M; }
+        if (d->planned && d->supermers != (route == 2)) { set_error("the ranks of a sharded build took different routes"); return KATOME_E_ARG; }
+    }
+    if (d->supermers) {
+        // ---- the one exchange: supermer records to their owners, then this rank counts what it received ------------------------------
+        DevBuf part(stream), recv(stream);
+        std::vector<uint64_t> counts(world, 0), rcnt(world, 0);
+        KCHECK(part.alloc((d->sm_n + 1) * 16));
+        {
+            PhaseScope ps(b->prof, PH_REGION_ORDER, stream);          // ("region_order" doubles as the routing pass, as on the other routes)
+            KCHECK(dev_partition_supermers(d->sm_recs.as<u64>(), d->sm_n, (uint32_t)world, part.as<u64>(), counts.data(), stream));
+        }
+        d->sm_recs.release(); d->sm_n = d->sm_cap = 0;
+        uint64_t pair_max = 0;
+        KCHECK(d->comm->exchange_counts(counts.data(), rcnt.data(), &pair_max));
+        const uint64_t nR = sum(rcnt);
+        KCHECK(recv.alloc((nR + 1) * 16));
+        KCHECK(d->xchg(X_RECORDS, part.p, counts.data(), recv.p, rcnt.data(), 16, stream, false, pair_max));
+        KCHECK_HIP(hipStreamSynchronize(stream));
+        part.release();
+        if (getenv("KATOME_DIST_STATS"))
+            fprintf(stderr, "[dist] rank %d of %d: %llu supermer records sent, %llu received\n", rank, world, (unsigned long long)sum(counts), (unsigned long long)nR);
+        // distinct supermers with their counts (as one GPU counts its tiles: two hash passes, counted in LDS)
+        DevBuf lk(stream), lw(stream);
+        uint64_t n1 = 0, d1 = 0;
+        int rc = KATOME_E_UNSUPPORTED;
+        if (nR) {
+            PhaseScope ps(b->prof, PH_INSERT_TILES, stream);
+            TileLevelScope tl;
+            DevBuf ones(stream);                                      // (stays empty: every record counts once)
+            rc = records_to_edges_sorted(recv, ones, nR, 40 /* any k of two words: the records are opaque 128-bit keys here */, false, 0, lk, lw, &n1, &d1, stream);
+            if (rc != KATOME_OK && rc != KATOME_E_UNSUPPORTED) return rc;
+            if (rc == KATOME_E_UNSUPPORTED) {                         // (out of the LDS count's range: every record on its own, once)
+                const size_t bytes = recv.bytes;
+                lk.stream = stream; lk.adopt(recv.take(), bytes);
+                KCHECK(lw.alloc((nR + 1) * 4));
+                KCHECK(dev_fill_u32(lw.as<u32>(), nR, 1u, stream));
+                n1 = nR;
+            }
+        }
+        recv.release();
+        b->stat_tiles = n1; b->stat_tile_slots = 0; b->span = 0; b->span2 = 0;
+        Collected got(stream);
+        {
+            PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+            KCHECK(dev_supermers_expand(lk.as<u64>(), lw.as<u32>(), n1, k, d->rc, got.keys, got.weights, &got.n, stream));
+        }
+        got.cap = got.n;
+        lk.release(); lw.release();
+        KCHECK(count_collected(d, got, stream));
+    } else
     if (d->local_first) {
         // every rank finishes its own counting; its DISTINCT k-mers (count, earliest sequence numbers) go to their owners, which
         // add them up in a fresh table
@@ -828,7 +927,7 @@ int katome_dist_finalize(katome_dist_builder* d, katome_dist_graph* out, void* s
     if (E) {
         KCHECK(dev_endpoints(keys, E, k, nullptr, T.as<u64>(), stream));
         KCHECK(dev_iota(origin.as<u32>(), E, stream));
-        KCHECK(dev_partition(T.as<u64>(), origin.as<u32>(), E, nw, world, P.as<u64>(), porigin.as<u32>(), counts.data(), stream, 0, k - 2));
+        KCHECK(dev_partition(T.as<u64>(), origin.as<u32>(), E, nw, world, P.as<u64>(), porigin.as<u32>(), counts.data(), stream, 0, k - 2, d->owner_m));
     }
     T.release(); origin.release();
     uint64_t pair_max = 0;

@@ -24,6 +24,14 @@ struct katome_dist_builder {
     // sends each DISTINCT k-mer once ("local first": one exchange, 12 B per k-mer and rank).  Many ranks: tiles, mid tiles and
     // k-mer records are routed to owners level by level (no level is counted twice, at the price of three exchanges).
     bool local_first = false;
+    // Round 4, the default from three ranks on (by packed key, k <= 31, reads of one length): ONE exchange before anything is counted --
+    // a read travels as its supermers (supermer.hip: runs of windows with one minimizer, a 16-byte record each, owner = a hash of the
+    // minimizer), every rank then counts what it received as one GPU counts its own reads.  `owner_m` > 0: a k-mer's / node's owner
+    // is named by the minimizer of that many bases of its core (the finalize's target look-ups use the same function).
+    bool want_supermers = false, supermers = false;
+    uint32_t owner_m = 0, sm_slots = 0;
+    DevBuf sm_recs;                          // [sm_n][2]: per add_reads call the reads' slots, then that call's spill region
+    uint64_t sm_n = 0, sm_cap = 0;
     hipStream_t xstream = nullptr;           // the exchanges of route_weighted run here, beside the insertions on the build's stream
     // this rank's share of the numbered graph
     DevBuf edge_src, edge_dst, edge_label, node_key, edge_gid, node_gid;

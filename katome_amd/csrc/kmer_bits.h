@@ -206,6 +206,40 @@ template <int NW> KD u64 core_owner(const Key<NW>& a, u32 shift, u32 core, u64 n
     return core_group_owner(core_hash(a, shift, core) >> (64 - CORE_GROUP_BITS), n);
 }
 
+// ---- owner by minimizer (the supermer route of the sharded build) -------------------------------------------
+// A core's MINIMIZER: among its core - m + 1 m-mers, each taken canonically (the smaller of it and its reverse complement), the one
+// whose hash is lowest.  A core and its reverse complement hold the same canonical m-mers, so the minimizer -- like core_hash -- is
+// the same for a k-mer and its reverse complement; and consecutive windows of a read mostly share it (it changes about every
+// (core - m + 2) / 2 windows), which is what lets a read travel as a dozen SUPERMERS -- runs of windows with one minimizer, hence one
+// owner -- instead of as 120 k-mer records.  The hash is the top 32 bits of mix64: four bytes per position in the extraction kernel.
+constexpr u64 MINIMIZER_SALT = 0xD6E8FEB86659FD93ull;
+KD u32 mmer_hash(u64 fwd, u64 rev) { return (u32)(mix64(fwd < rev ? fwd : rev) >> 32); }
+// lowest mmer_hash over the m-mers of the `core` bases that end `shift` bits above the key's low end (m <= 31, m <= core)
+template <int NW> KD u32 core_minimizer(const Key<NW>& a, u32 shift, u32 core, u32 m) {
+    const Key<NW> c = key_low_bits(key_shr(a, shift), 2 * core);
+    const u64 mask = (1ull << (2 * m)) - 1;
+    u64 f = 0, r = 0;
+    u32 best = 0xFFFFFFFFu;
+    for (u32 j = 0; j < core; ++j) {
+        const u64 base = key_digit(c, 2 * (core - 1 - j), 2);
+        f = ((f << 2) | base) & mask;
+        r = (r >> 2) | ((3 - base) << (2 * (m - 1)));
+        if (j + 1 >= m) { const u32 h = mmer_hash(f, r); best = h < best ? h : best; }
+    }
+    return best;
+}
+KD u64 minimizer_owner_of(u32 min_hash, u64 n) { return hash_to_range(mix64((u64)min_hash ^ MINIMIZER_SALT), n); }
+template <int NW> KD u64 minimizer_owner(const Key<NW>& a, u32 shift, u32 core, u32 m, u64 n) {
+    return minimizer_owner_of(core_minimizer(a, shift, core, m), n);
+}
+// Supermer record (k <= 31: two words): the run's nwin + k - 1 bases right-aligned in the low bits (canonical when both strands are
+// counted: a run and its reverse complement are one record), the owner in bits 116..119, nwin in bits 120..124 of the 128
+constexpr u32 SUPERMER_OWNER_SHIFT = 52, SUPERMER_LEN_SHIFT = 56;        // (bit positions inside w[0])
+constexpr u32 SUPERMER_MAX_WINDOWS = 24;                                  // nwin + k - 1 <= 54 bases = 108 bits
+KD u32 supermer_windows(const Key<2>& s) { return (u32)(s.w[0] >> SUPERMER_LEN_SHIFT) & 31u; }
+KD u32 supermer_owner(const Key<2>& s) { return (u32)(s.w[0] >> SUPERMER_OWNER_SHIFT) & 15u; }
+KD Key<2> supermer_bases(const Key<2>& s) { Key<2> r = s; r.w[0] &= (1ull << SUPERMER_OWNER_SHIFT) - 1; return r; }
+
 template <int NW> KD Key<NW> source_node(const Key<NW>& kmer) { return key_shr(kmer, 2); }
 template <int NW> KD Key<NW> target_node(const Key<NW>& kmer, u32 k) { return key_low_bits(kmer, 2 * (k - 1)); }
 

@@ -50,12 +50,19 @@ template <int NW> struct RadixDigit {
 template <int NW> struct OwnerDigit {
     u64 n_parts;
     u32 core_shift, core_bases;          // core_bases == 0: owner by the whole key; else kmer_bits.h core_owner
+    u32 minimizer = 0;                   // ... or, > 0, by the core's minimizer of that many bases (kmer_bits.h minimizer_owner)
     __device__ __forceinline__ u32 operator()(const Key<NW>& k0) const {
         if (!key_valid(k0)) return (u32)n_parts;
         Key<NW> k = k0;
         k.w[0] &= ~RC_MARK;              // first-seen-order records carry the orientation they dropped: not part of the key
+        if (minimizer) return (u32)minimizer_owner(k, core_shift, core_bases, minimizer, n_parts);
         return core_bases ? (u32)core_owner(k, core_shift, core_bases, n_parts) : (u32)whole_key_owner(k, n_parts);
     }
+};
+// supermer records name their owner themselves (kmer_bits.h): a slot a read did not fill is invalid and goes last
+struct SupermerOwnerDigit {
+    u32 n_parts;
+    __device__ __forceinline__ u32 operator()(const Key<2>& k) const { return key_valid(k) ? supermer_owner(k) : n_parts; }
 };
 // owner = the part of an ascending list of u64 values a value falls into: bounds[p] = first value of part p + 1
 // (n_parts - 1 of them); used to spread sequence numbers over the ranks for a global ranking
@@ -351,6 +358,7 @@ template <int NW> struct DigitTimers<HashDigit<NW>> { static constexpr int HIST 
 template <int NW> struct DigitTimers<HashTaggedDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
 template <int NW> struct DigitTimers<CoreHashDigit<NW>> { static constexpr int HIST = K_HASH_HIST, SCATTER = K_HASH_SCATTER; };
 template <int NW> struct DigitTimers<OwnerDigit<NW>> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
+template <> struct DigitTimers<SupermerOwnerDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 template <> struct DigitTimers<RangeDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 
 template <int NW, bool HAS_VAL, class Digit>
@@ -705,8 +713,9 @@ int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32
 // group records by owner rank; invalid records go last (part n_parts) and are not counted.
 // Optional u32 values travel with their records.
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
-                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift, uint32_t core_bases) {
+                  uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift, uint32_t core_bases, uint32_t minimizer) {
     if (core_bases && (core_shift + 2 * core_bases > 64u * nw || 2 * core_bases > 190)) { set_error("partition: core outside the key"); return KATOME_E_ARG; }
+    if (minimizer && (minimizer > 31 || minimizer > core_bases)) { set_error("partition: minimizer longer than the core"); return KATOME_E_ARG; }
     if (n_parts == 0 || n_parts >= (u32)RADIX) { set_error("n_parts must be 1..255"); return KATOME_E_ARG; }
     if (nw < 1 || nw > 3) { set_error("key_words must be 1..3"); return KATOME_E_ARG; }
     if ((v_in == nullptr) != (v_out == nullptr)) { set_error("partition: values in and out must both be given"); return KATOME_E_ARG; }
@@ -715,18 +724,34 @@ int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32
     PassBuffers pb;
     KCHECK(pb.init(n, (int)nw, stream));
     if (nw == 1) {
-        OwnerDigit<1> dg{n_parts, core_shift, core_bases};
+        OwnerDigit<1> dg{n_parts, core_shift, core_bases, minimizer};
         if (v_in) KCHECK((radix_pass<1, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
         else      KCHECK((radix_pass<1, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
     } else if (nw == 2) {
-        OwnerDigit<2> dg{n_parts, core_shift, core_bases};
+        OwnerDigit<2> dg{n_parts, core_shift, core_bases, minimizer};
         if (v_in) KCHECK((radix_pass<2, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
         else      KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
     } else {                          // three-word tiles (k > 32 with a useful span: C5's 90-mers)
-        OwnerDigit<3> dg{n_parts, core_shift, core_bases};
+        OwnerDigit<3> dg{n_parts, core_shift, core_bases, minimizer};
         if (v_in) KCHECK((radix_pass<3, true>(d_in, v_in, n, dg, d_out, v_out, pb, stream)));
         else      KCHECK((radix_pass<3, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
     }
+    u64 totals[RADIX];
+    KCHECK_HIP(hipMemcpyAsync(totals, pb.totals.p, sizeof totals, hipMemcpyDeviceToHost, stream));
+    KCHECK_HIP(hipStreamSynchronize(stream));
+    for (u32 p = 0; p < n_parts; ++p) h_counts[p] = totals[p];
+    return KATOME_OK;
+}
+
+// supermer records (two words, owner inside: kmer_bits.h) grouped by owner; slots left invalid are dropped
+int dev_partition_supermers(const uint64_t* d_in, uint64_t n, uint32_t n_parts, uint64_t* d_out, uint64_t* h_counts, hipStream_t stream) {
+    if (n_parts == 0 || n_parts > 16) { set_error("supermers: 1..16 owners"); return KATOME_E_ARG; }
+    for (u32 p = 0; p < n_parts; ++p) h_counts[p] = 0;
+    if (n == 0) return KATOME_OK;
+    PassBuffers pb;
+    KCHECK(pb.init(n, 2, stream));
+    SupermerOwnerDigit dg{n_parts};
+    KCHECK((radix_pass<2, false>(d_in, nullptr, n, dg, d_out, nullptr, pb, stream)));
     u64 totals[RADIX];
     KCHECK_HIP(hipMemcpyAsync(totals, pb.totals.p, sizeof totals, hipMemcpyDeviceToHost, stream));
     KCHECK_HIP(hipStreamSynchronize(stream));

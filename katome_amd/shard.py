@@ -214,6 +214,11 @@ class ShardedBuilder(_ViewOwner):
         """the rank's single-GPU builder (a fresh handle wrapper per access: no reference cycle with this object)"""
         return _InnerBuilder(_lib.lib().katome_dist_inner(self._h), self.k, self.rc, self.device, parent=self)
 
+    @property
+    def route(self):
+        """which records travel: "supermers" / "local" / "tiles" (katome_dist_route)"""
+        return _lib.lib().katome_dist_route(self._h).decode()
+
     def add_reads(self, packed, first_read, n_reads, read_len, skip=None, batch_reads=0):
         _check(_lib.lib().katome_dist_add_reads(self._h, _ptr(packed), first_read, n_reads, read_len, _ptr(skip), batch_reads, _stream()))
 
@@ -287,6 +292,7 @@ class DistBuild:
             if self.min_weight:
                 b.remove_weak_edges(self.min_weight)
             b.add_reads(self.packed, self.first, self.n_local, wl.read_len, self.skip, self.batch_reads)
+            self.route = b.route
             g = b.finalize()
             n_edges, n_nodes = g.total_edges, g.total_nodes
             if self.prune:                                  # BASELINE config 5: the pruner pass, on the sharded graph

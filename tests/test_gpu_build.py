@@ -925,6 +925,72 @@ def test_three_word_tiles_and_two_word_kmers_counted_by_sorting(tmp_path):
     assert any(b[7] == "tables" for b in old)
 
 
+_BUDGET_SCRIPT = r"""
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+# thin coverage: 6000 reads over a genome so long that tiles hardly repeat -- every level multiplies its records
+for k, L in ((31, 150), (40, 150)):
+    n = 6000
+    reads = o.synth_reads(31 + k, n, L, 600000, 2e-3, 0)
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    ref = o.build_ascii(reads, k, True)
+    want = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
+    b = kd.Builder(k, True, table_slots_hint=0)
+    for r0 in range(0, n, 1500):
+        b.count_reads(packed, 1500, L, None, first_read=r0)
+    dg = b.finalize()
+    c = b.counts()
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    got = {bytes(row): int(w) for row, w in zip(lab, dg.edge_weight.cpu().numpy())}
+    h = hashlib.sha256()
+    for t in (dg.edge_key, dg.edge_weight, dg.edge_src, dg.edge_dst, dg.node_key, dg.edge_label):
+        h.update(t.cpu().numpy().tobytes())
+    ok = len(got) == dg.n_edges and got == want and (dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges)
+    print("BUDGET", k, int(ok), int(c["tile_slots"] > 0), int(c["mid_tile_slots"] > 0), int(c["kmer_slots"] > 0), c["distinct_tiles"], c["distinct_mid_tiles"], h.hexdigest())
+    b.close()
+"""
+
+
+def test_levels_that_do_not_fit_the_card_by_sorting_are_counted_in_tables(tmp_path):
+    """input whose tiles hardly repeat (coverage of a few fold instead of C3's 300) multiplies records level by level; a level whose
+    records, scratch and output would not fit what the card has free goes the table way from there on (api.hip level_fits) instead of
+    dying in an allocation: forced at a small size with KATOME_LEVEL_BUDGET -- (a) nothing fits: the mid tiles and the k-mers in
+    tables, (b) the mid level fits, the k-mer level does not: the distinct mid tiles go into their table with their counts and the
+    k-mers are counted in theirs, (c) everything fits: no table.  The oracle's graph each time, byte for byte the same arrays"""
+    import subprocess
+    script = tmp_path / "budget.py"
+    script.write_text(_BUDGET_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(budget):
+        env = dict(os.environ, KATOME_SORTED_COUNT="2", KATOME_LEVEL_SLACK="0")
+        if budget is not None:
+            env["KATOME_LEVEL_BUDGET"] = str(budget)
+        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        return [line.split() for line in out.stdout.splitlines() if line.startswith("BUDGET ")]
+    everything = run(None)
+    assert [r[2:6] for r in everything] == [["1", "0", "0", "0"]] * 2                 # all three levels by sorting
+    nothing = run(1)
+    assert [r[2:6] for r in nothing] == [["1", "1", "1", "1"]] * 2                    # big tiles, mid tiles, k-mers in tables
+    for full, tight in zip(everything, nothing):
+        assert full[8] == tight[8]
+    # between the two needs: the mid level's records (distinct big tiles x sub-tiles x 3 x record size) fit, the k-mer level's do not
+    for i, row in enumerate(everything):
+        k = int(row[1])
+        nwm, nw = (2, 1) if k == 31 else (2, 2)
+        n_sub, span2 = (5, 6) if k == 31 else (3, 9)
+        need_mid = int(row[6]) * n_sub * (8 * nwm + 4) * 3
+        need_last = int(row[7]) * span2 * (8 * nw + 4) * 4
+        assert need_mid < need_last
+        mid = run((need_mid + need_last) // 2)[i]
+        assert mid[2:6] == ["1", "0", "1", "1"], mid                                   # mid tiles and k-mers in tables, no big-tile table
+        assert mid[8] == row[8]
+
+
 def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
     """the big tiles of a build by packed key are kept aside as records and counted by sorting (api.hip keep_tile_recs): sixty
     batches (room for sixteen to begin with, doubled when that is too little), reads with N in them (their records are dropped),

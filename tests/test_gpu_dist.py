@@ -282,6 +282,45 @@ def test_both_routes_of_the_sharded_build(oracle, monkeypatch, route, world, k, 
     _same_arrays(g, oracle.build_ascii(ascii_reads, k, rc))
 
 
+@pytest.mark.parametrize("world,k,rc,n,L", [(3, 31, True, 1500, 150), (8, 31, True, 2500, 150), (2, 21, False, 900, 100), (4, 15, True, 700, 53),
+                                            (3, 31, True, 400, 31), (8, 27, False, 1200, 101), (5, 31, True, 64, 150)])
+def test_supermer_route_of_the_sharded_build(oracle, monkeypatch, world, k, rc, n, L):
+    """The route of three ranks and more by packed key (dist.hip, supermer.hip): every read is cut into runs of windows whose cores
+    share a minimizer, each run travels ONCE as a 16-byte record to the rank a hash of the minimizer names, and every rank counts what
+    it received -- distinct supermers, then their k-mers.  Reads with N (skipped whole), reads of exactly k bases (one window), ranks
+    without reads; against the oracle's sequential build: the edge multiset, every k-mer on one rank, every node owned once, end
+    points and labels"""
+    from katome_amd.build import GpuGraph
+    monkeypatch.setenv("KATOME_DIST_ROUTE", "supermers")
+    ascii_reads, packed, skip = _reads(oracle, n, L, 9000, 4e-3, 3)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world, ranks_share_device=True)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert rb == ref.read_bytes
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges)
+    assert g.multiset() == ref.multiset()
+    ek, nk = g.key_ints("edge"), g.key_ints("node")
+    assert len(set(ek)) == len(ek) and len(set(nk)) == len(nk)
+    mask = (1 << (2 * (k - 1))) - 1
+    for e in range(g.n_edges):
+        assert nk[int(g.edge_src[e])] == ek[e] >> 2 and nk[int(g.edge_dst[e])] == ek[e] & mask
+    assert set(g.edge_src.tolist()) | set(g.edge_dst.tolist()) == set(range(g.n_nodes))
+
+
+def test_supermer_route_is_the_default_from_three_ranks_on(oracle):
+    """katome_dist_route: by packed key and k <= 31 three ranks and more exchange supermers; two ranks count locally; the reference's
+    numbering and two-word k-mers keep the level-by-level route"""
+    from katome_amd import _lib
+    from katome_amd import shard as ks
+    comm = ks.Comm.rccl(0, 1, 0)
+    try:
+        for k, fs, want in ((31, False, b"local"), (31, True, b"local")):
+            b = ks.ShardedBuilder(comm, k, True, 0, first_seen_order=fs)
+            assert _lib.lib().katome_dist_route(b._h) == want
+            b.close()
+    finally:
+        comm.close()
+
+
 def test_rccl_transport_at_world_size_one(oracle):
     """RCCL itself (ncclCommInitRank from a unique id, grouped send/recv to self, allreduce): the process-per-GPU route
     of bench.py with one rank -- same graph as the oracle's, exchange accounting readable"""
@@ -491,7 +530,7 @@ sb.close(); comm.close()
 """
 
 
-@pytest.mark.parametrize("route", ["local", "tiles"])
+@pytest.mark.parametrize("route", ["local", "tiles", "supermers"])
 def test_sharded_routes_with_the_last_level_counted_by_sorting(tmp_path, route):
     """by packed key the k-mer records that reach their owners are kept and counted by sorting (from 4 M records on; forced here
     with KATOME_SORTED_COUNT=2, in a process of its own: the switch is read once) -- same graph as the oracle's and as the
@@ -512,17 +551,17 @@ def test_sharded_routes_with_the_last_level_counted_by_sorting(tmp_path, route):
 
 
 def test_sharded_build_at_a_size_where_the_routes_run_in_earnest():
-    """8 thread ranks on 8 M reads through the level-by-level route against the one-GPU build of the same reads (order-free
+    """8 thread ranks on 8 M reads through the supermer route (the default there) and the level-by-level route against the one-GPU build of the same reads (order-free
     checksums of edges, weights, nodes; every edge's end points) -- and in reasonable time: while a tile's owner was the hash
     range its table slot came from, every rank crowded its keys into an eighth of its tables and this build took 40 s"""
     import subprocess
     import time
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     t0 = time.time()
-    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_sharded_scale.py"), "8000000", "8", "tiles"],
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_sharded_scale.py"), "8000000", "8", "supermers,tiles"],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
     assert "same: True" in out.stdout and "OK" in out.stdout.splitlines()[-1]
     took = [float(line.split()[-2]) for line in out.stdout.splitlines() if line.startswith("8 ranks")]
-    assert took and took[0] < 15.0, out.stdout
-    assert time.time() - t0 < 120
+    assert len(took) == 2 and max(took) < 15.0, out.stdout
+    assert time.time() - t0 < 150

@@ -15,12 +15,12 @@ try:
     print(int(c["VRAM Total Used Memory (B)"]))
 except Exception: pass'; sleep 0.2; done ) > $OUT/mem_$G.txt &
   SAMPLER=$!
-  timeout -k 10 420 python3 bench.py --reads $READS --genome-len $G --steps 2 --warmup 0 --no-cpu-baseline --no-extras \
+  KATOME_LEVEL_TRACE=1 timeout -k 10 420 python3 bench.py --reads $READS --genome-len $G --steps 2 --warmup 0 --no-cpu-baseline --no-extras \
       > $OUT/line_$G.json 2> $OUT/err_$G.log
   RC=$?
   kill $SAMPLER 2>/dev/null; wait $SAMPLER 2>/dev/null
   PEAK=$(sort -n $OUT/mem_$G.txt | tail -1)
   echo "{\"reads\": $READS, \"genome_len\": $G, \"rc\": $RC, \"peak_vram_bytes\": ${PEAK:-null}}" >> $OUT/summary.jsonl
-  echo "genome $G rc=$RC peak=${PEAK:-?}"; tail -3 $OUT/err_$G.log
+  echo "genome $G rc=$RC peak=${PEAK:-?}"; grep -h "katome levels" $OUT/err_$G.log | sort | uniq -c; tail -2 $OUT/err_$G.log; python3 -c "import json,sys; d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); print(json.dumps({k: d[k] for k in (\"ms_per_step\", \"distinct_edges\", \"nodes\", \"counts\")}))" $OUT/line_$G.json 2>/dev/null
   if [ $RC -ne 0 ] && [ $RC -ne 1 ]; then echo "stopping after rc=$RC"; break; fi
 done
