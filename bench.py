@@ -555,12 +555,12 @@ def main():
         kalg, kexact = {}, {}       # kalg: algorithmic bytes per ELEMENT the kernel processes (keys of a pass, slots of a scan)
         if not use_dist and cnt and not (args.first_seen_order or args.prune):
             pair = 8 * nw + 4
-            kalg.update({"radix_scatter_kernel<RadixDigit>": 2 * pair, "radix_hist_kernel<RadixDigit>": 8 * nw, "run_sort_kernel": 2 * pair,
+            kalg.update({"radix_scatter_kernel<RadixDigit>": 2 * pair, "radix_hist_kernel<RadixDigit>": 8 * nw, "run_sort": 2 * pair,       # (the library times both run sorts under this name; `kernel` below says which one ran)
                          "src_count+src_write": (2 * 8 * nw + 8 + 8 * nw * n_nodes / max(n_edges, 1)) / 2.0,       # two launches, each reads the keys
                          "dst_merge_kernel": 8 * nw + 8 + 8 * nw * n_nodes / max(n_edges, 1)})
             kexact.update({"radix_scatter_kernel<RadixDigit>": exact["sort_edges"],
                            "radix_hist_kernel<RadixDigit>": "void radix_hist_kernel<%d, RadixDigit<%d> >" % (nw, nw),
-                           "run_sort_kernel": ("void run_sort_kernel<%d, true>" if os.environ.get("KATOME_RUN_SORT") == "1" else "void run_sort_wave_kernel<%d, true>") % nw,
+                           "run_sort": ("void run_sort_kernel<%d, true>" if os.environ.get("KATOME_RUN_SORT") == "1" else "void run_sort_wave_kernel<%d, true>") % nw,
                            "dst_merge_kernel": "void dst_merge_kernel<%d, false>" % nw})
             if sorted_last_level:
                 ms2 = cnt.get("mid_span", 0)

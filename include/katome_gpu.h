@@ -493,9 +493,9 @@ int  katome_dist_remove_dead_paths(katome_dist_builder *d, katome_dist_graph *ou
 int  katome_dist_current_graph(katome_dist_builder *d, katome_dist_graph *out);
 /* the rank's single-GPU builder underneath (per-phase kernel timing: katome_builder_profile*) */
 katome_builder *katome_dist_inner(katome_dist_builder *d);
-/* which records travel in this build: "supermers" (one exchange before any counting: the default from three ranks on, by packed
- * key, k <= 31), "local" (every rank counts its own reads, distinct k-mers routed: up to two ranks), "tiles" (tiles, mid tiles and
- * k-mer records routed level by level: the reference's numbering, k > 31); KATOME_DIST_ROUTE overrides */
+/* which records travel in this build: "local" (every rank counts its own reads, distinct k-mers routed: up to two ranks), "tiles"
+ * (tiles, mid tiles and k-mer records routed level by level: three ranks and more), "supermers" (one exchange of 16-byte supermer
+ * records before any counting: KATOME_DIST_ROUTE=supermers, by packed key, k <= 31); KATOME_DIST_ROUTE overrides the choice */
 const char *katome_dist_route(const katome_dist_builder *d);
 /* exchange accounting since the last read: katome_dist_exchange_count() phases named by katome_dist_exchange_name(),
  * out[4*i..] = {calls, bytes that left this rank, largest single (rank -> peer) message, microseconds inside the exchange} */

@@ -88,12 +88,12 @@ enum Phase { PH_EXTRACT, PH_REGION_ORDER, PH_INSERT, PH_EMIT_EDGES, PH_SORT_EDGE
 static const char* const PHASE_NAMES[PH_COUNT] = {
     "extract", "region_order", "insert", "emit_edges", "sort_edges", "node_set", "rank", "labels", "insert_tiles", "expand_tiles",
     "expand_mid_tiles", "first_seen_order", "remove_dead_paths", "shrink",
-    "k:radix_scatter_kernel<RadixDigit>", "k:radix_hist_kernel<RadixDigit>", "k:run_sort_kernel", "k:radix_scatter_kernel<HashDigit>",
+    "k:radix_scatter_kernel<RadixDigit>", "k:radix_hist_kernel<RadixDigit>", "k:run_sort", "k:radix_scatter_kernel<HashDigit>",
     "k:radix_hist_kernel<HashDigit>", "k:radix_scatter_kernel<OwnerDigit>", "k:radix_hist_kernel<OwnerDigit>", "k:radix_chunk+offsets",
     "k:tiles_to_records_kernel", "k:hash_group_index_kernel", "k:lds_count_kernel", "k:src_count+src_write", "k:dst_merge_kernel",
     "k:expand_tiles_kernel",
     // (the keys-only instantiations -- the small sort of the nodes without out-edges -- are kernels of their own in a trace)
-    "k:radix_scatter_kernel<RadixDigit> (keys only)", "k:run_sort_kernel (keys only)",
+    "k:radix_scatter_kernel<RadixDigit> (keys only)", "k:run_sort (keys only)",
     // (the same kernels counting a TILE level by sorting -- other record sizes, so timed apart: TileLevelScope)
     "k:radix_scatter_kernel<HashDigit> (tile records)", "k:radix_hist_kernel<HashDigit> (tile records)", "k:tiles_to_records_kernel (tile records)",
     "k:hash_group_index_kernel (tile records)", "k:lds_count_kernel (tile records)"};

@@ -587,14 +587,16 @@ int katome_dist_create(const katome_settings* s, katome_comm* comm, katome_dist_
     katome_dist_builder* d = new (std::nothrow) katome_dist_builder();
     if (!d) { katome_builder_destroy(b); set_error("out of host memory"); return KATOME_E_OOM; }
     d->s = *s; d->comm = comm; d->b = b; d->nw = b->nw; d->rc = b->rc; d->first_seen = b->first_seen;
-    // routes (KATOME_DIST_ROUTE=supermers|local|tiles overrides): few ranks -- every rank counts its own reads and
-    // routes its distinct k-mers; from three ranks on -- the reads travel as supermers, once, before anything is counted (by packed key,
-    // k <= 31; the reference's numbering and longer k-mers: tiles, mid tiles and k-mer records routed level by level)
+    // routes (KATOME_DIST_ROUTE=local|tiles|supermers overrides): few ranks -- every rank counts its own reads and
+    // routes its distinct k-mers ("local"); from three ranks on -- tiles, mid tiles and k-mer records routed level by level ("tiles").
+    // "supermers": the reads travel as supermers, ONCE, before anything is counted (by packed key, k <= 31) -- SURVEY 8(e)'s single
+    // exchange, built and measured in round 4: an eighth of C3 per rank costs 65.7 ms of GPU time that way against 52.2 level by level
+    // (a read makes 12.9 supermer records against 4 tiles; profiles/r04_share.md), so it is offered, not the default.
     d->local_first = comm->world() <= 2;
-    d->want_supermers = comm->world() > 2 && !d->first_seen;
+    d->want_supermers = false;
     if (const char* e = getenv("KATOME_DIST_ROUTE")) {
         d->local_first = strcmp(e, "local") == 0 ? true : (strcmp(e, "tiles") == 0 || strcmp(e, "supermers") == 0) ? false : d->local_first;
-        d->want_supermers = strcmp(e, "supermers") == 0 ? !d->first_seen : (strcmp(e, "local") == 0 || strcmp(e, "tiles") == 0) ? false : d->want_supermers;
+        d->want_supermers = strcmp(e, "supermers") == 0 && !d->first_seen;
     }
     if (d->want_supermers) d->local_first = false;
     *out = d;

@@ -24,7 +24,7 @@ struct katome_dist_builder {
     // sends each DISTINCT k-mer once ("local first": one exchange, 12 B per k-mer and rank).  Many ranks: tiles, mid tiles and
     // k-mer records are routed to owners level by level (no level is counted twice, at the price of three exchanges).
     bool local_first = false;
-    // Round 4, the default from three ranks on (by packed key, k <= 31, reads of one length): ONE exchange before anything is counted --
+    // Round 4 (KATOME_DIST_ROUTE=supermers; by packed key, k <= 31, reads of one length): ONE exchange before anything is counted --
     // a read travels as its supermers (supermer.hip: runs of windows with one minimizer, a 16-byte record each, owner = a hash of the
     // minimizer), every rank then counts what it received as one GPU counts its own reads.  `owner_m` > 0: a k-mer's / node's owner
     // is named by the minimizer of that many bases of its core (the finalize's target look-ups use the same function).

@@ -211,19 +211,21 @@ template <int NW> KD u64 core_owner(const Key<NW>& a, u32 shift, u32 core, u64 n
 // whose hash is lowest.  A core and its reverse complement hold the same canonical m-mers, so the minimizer -- like core_hash -- is
 // the same for a k-mer and its reverse complement; and consecutive windows of a read mostly share it (it changes about every
 // (core - m + 2) / 2 windows), which is what lets a read travel as a dozen SUPERMERS -- runs of windows with one minimizer, hence one
-// owner -- instead of as 120 k-mer records.  The hash is the top 32 bits of mix64: four bytes per position in the extraction kernel.
+// owner -- instead of as 120 k-mer records.
 constexpr u64 MINIMIZER_SALT = 0xD6E8FEB86659FD93ull;
-KD u32 mmer_hash(u64 fwd, u64 rev) { return (u32)(mix64(fwd < rev ? fwd : rev) >> 32); }
-// lowest mmer_hash over the m-mers of the `core` bases that end `shift` bits above the key's low end (m <= 31, m <= core)
+// (m <= 16: a canonical m-mer is a 32-bit value and its hash a 32-bit finalizer -- two multiplies -- because the hash runs once per
+// position in the extraction kernel and core - m + 1 times per key wherever an owner is asked for pointwise)
+KD u32 fmix32(u32 h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+KD u32 mmer_hash(u32 fwd, u32 rev) { return fmix32(fwd < rev ? fwd : rev); }
+// lowest mmer_hash over the m-mers of the `core` bases that end `shift` bits above the key's low end (m <= 16, m <= core)
 template <int NW> KD u32 core_minimizer(const Key<NW>& a, u32 shift, u32 core, u32 m) {
     const Key<NW> c = key_low_bits(key_shr(a, shift), 2 * core);
-    const u64 mask = (1ull << (2 * m)) - 1;
-    u64 f = 0, r = 0;
-    u32 best = 0xFFFFFFFFu;
+    const u32 mask = m >= 16 ? 0xFFFFFFFFu : (1u << (2 * m)) - 1;
+    u32 f = 0, r = 0, best = 0xFFFFFFFFu;
     for (u32 j = 0; j < core; ++j) {
-        const u64 base = key_digit(c, 2 * (core - 1 - j), 2);
+        const u32 base = key_digit(c, 2 * (core - 1 - j), 2);
         f = ((f << 2) | base) & mask;
-        r = (r >> 2) | ((3 - base) << (2 * (m - 1)));
+        r = (r >> 2) | ((3u - base) << (2 * (m - 1)));
         if (j + 1 >= m) { const u32 h = mmer_hash(f, r); best = h < best ? h : best; }
     }
     return best;

@@ -715,7 +715,7 @@ int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
                   uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift, uint32_t core_bases, uint32_t minimizer) {
     if (core_bases && (core_shift + 2 * core_bases > 64u * nw || 2 * core_bases > 190)) { set_error("partition: core outside the key"); return KATOME_E_ARG; }
-    if (minimizer && (minimizer > 31 || minimizer > core_bases)) { set_error("partition: minimizer longer than the core"); return KATOME_E_ARG; }
+    if (minimizer && (minimizer > 16 || minimizer > core_bases)) { set_error("partition: minimizer longer than the core (or than 16 bases)"); return KATOME_E_ARG; }
     if (n_parts == 0 || n_parts >= (u32)RADIX) { set_error("n_parts must be 1..255"); return KATOME_E_ARG; }
     if (nw < 1 || nw > 3) { set_error("key_words must be 1..3"); return KATOME_E_ARG; }
     if ((v_in == nullptr) != (v_out == nullptr)) { set_error("partition: values in and out must both be given"); return KATOME_E_ARG; }

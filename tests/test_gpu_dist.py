@@ -306,16 +306,18 @@ def test_supermer_route_of_the_sharded_build(oracle, monkeypatch, world, k, rc, 
     assert set(g.edge_src.tolist()) | set(g.edge_dst.tolist()) == set(range(g.n_nodes))
 
 
-def test_supermer_route_is_the_default_from_three_ranks_on(oracle):
-    """katome_dist_route: by packed key and k <= 31 three ranks and more exchange supermers; two ranks count locally; the reference's
-    numbering and two-word k-mers keep the level-by-level route"""
+def test_route_names(oracle, monkeypatch):
+    """katome_dist_route: what a builder will send -- "local" up to two ranks, KATOME_DIST_ROUTE overrides (supermers only by packed key)"""
     from katome_amd import _lib
     from katome_amd import shard as ks
     comm = ks.Comm.rccl(0, 1, 0)
     try:
-        for k, fs, want in ((31, False, b"local"), (31, True, b"local")):
-            b = ks.ShardedBuilder(comm, k, True, 0, first_seen_order=fs)
-            assert _lib.lib().katome_dist_route(b._h) == want
+        for env, fs, want in ((None, False, b"local"), ("tiles", False, b"tiles"), ("supermers", False, b"supermers (if the reads allow)"),
+                              ("supermers", True, b"tiles")):
+            if env:
+                monkeypatch.setenv("KATOME_DIST_ROUTE", env)
+            b = ks.ShardedBuilder(comm, 31, True, 0, first_seen_order=fs)
+            assert _lib.lib().katome_dist_route(b._h) == want, (env, fs)
             b.close()
     finally:
         comm.close()
@@ -551,7 +553,7 @@ def test_sharded_routes_with_the_last_level_counted_by_sorting(tmp_path, route):
 
 
 def test_sharded_build_at_a_size_where_the_routes_run_in_earnest():
-    """8 thread ranks on 8 M reads through the supermer route (the default there) and the level-by-level route against the one-GPU build of the same reads (order-free
+    """8 thread ranks on 8 M reads through the supermer route and the level-by-level route (the default there) against the one-GPU build of the same reads (order-free
     checksums of edges, weights, nodes; every edge's end points) -- and in reasonable time: while a tile's owner was the hash
     range its table slot came from, every rank crowded its keys into an eighth of its tables and this build took 40 s"""
     import subprocess

@@ -70,7 +70,7 @@ if fs:
     for route in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("tiles", "local")):
         os.environ["KATOME_DIST_ROUTE"] = route
         t0 = time.time()
-        g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=True,
+        g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=os.environ.get("KATOME_REAL_DEVICES") != "1",
                                             first_seen_order=True, remove_dead_paths=True, table_slots_hint=hint)
         got = arrays(g)
         print("%d ranks %s" % (world, route), got, "same:", got == want, "%.1f s" % (time.time() - t0), flush=True)
@@ -87,7 +87,7 @@ bad = not ok
 for route in (sys.argv[3].split(",") if len(sys.argv) > 3 else ("tiles", "local")):
     os.environ["KATOME_DIST_ROUTE"] = route
     t0 = time.time()
-    g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=True,
+    g, _ = GpuGraph.create_from_packed(packed, n, L, reverse_complement=True, k=k, n_devices=world, ranks_share_device=os.environ.get("KATOME_REAL_DEVICES") != "1",
                                         table_slots_hint=hint)
     got, ok = digest(g)
     print("%d ranks %s" % (world, route), got, "end points ok:", ok, "same:", got == want, "%.1f s" % (time.time() - t0), flush=True)

@@ -21,27 +21,53 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 SHIFTS = ("v_lshlrev_b64", "v_lshrrev_b64", "v_ashrrev_i64")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+STRICT = os.environ.get("KATOME_SCAN_STRICT") == "1"      # LLVM's rule: also a hit when no instruction names the next register
 
 
-def is_hit(reg, vgpr_count):
-    """LLVM's condition for gfx90a: the amount is the last register of an allocation block and the next one is not in use"""
-    return (reg & 7) == 7 and reg + 1 >= vgpr_count
+def is_hit(reg, arch_vgprs, used=None):
+    """LLVM's condition for gfx90a (GCNHazardRecognizer::fixShift64HighRegBug): the amount is the last register of an allocation
+    block (8n + 7) and the next ARCHITECTURAL register is not in use -- beyond the kernel's arch-VGPR count (the unified file's
+    AGPRs behind it do not count), or, when the registers the function names are known, named by no instruction of it"""
+    if (reg & 7) != 7:
+        return False
+    return reg + 1 >= arch_vgprs or (used is not None and (reg + 1) not in used)
+
+
+_VREG = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
 
 
 def scan_lines(lines, vgprs, label_re):
-    hits, func = [], None
+    """vgprs: function -> arch-VGPR count.  Two passes per function: the VGPRs any instruction names, then the shifts"""
+    funcs, func = {}, None                    # function -> [(line number, text)]
     for n, line in enumerate(lines, 1):
         t = line.strip()
         m = label_re.match(t)
         if m:
             func = m.group(1)
+            funcs.setdefault(func, [])
             continue
-        op = t.split()[0] if t else ""
-        if op.replace("_e64", "") in SHIFTS and func in vgprs:
-            args = [a.strip() for a in t[len(op):].split("//")[0].split(",")]
-            m = re.fullmatch(r"v(\d+)", args[1]) if len(args) > 1 else None
-            if m and is_hit(int(m.group(1)), vgprs[func]):
-                hits.append((func, n, t.split("//")[0].strip(), vgprs[func]))
+        if func is not None and t and not t.startswith((".", "//", ";")):
+            funcs[func].append((n, t.split("//")[0].strip()))
+    hits = []
+    for func, body in funcs.items():
+        if func not in vgprs:
+            continue
+        used = set()
+        for _, t in body:
+            for m in _VREG.finditer(t):
+                if m.group(1) is not None:
+                    used.add(int(m.group(1)))
+                else:
+                    used.update(range(int(m.group(2)), int(m.group(3)) + 1))
+        for n, t in body:
+            op = t.split()[0] if t else ""
+            if op.replace("_e64", "") in SHIFTS:
+                args = [a.strip() for a in t[len(op):].split(",")]
+                m = re.fullmatch(r"v(\d+)", args[1]) if len(args) > 1 else None
+                # (`used` is not consulted: the hardware's condition is the allocation's end, and KATOME_SHIFT64_GUARD moves that
+                # end by clobbering the next register without an instruction that names it; pass it to apply LLVM's stricter rule)
+                if m and is_hit(int(m.group(1)), vgprs[func], used if STRICT else None):
+                    hits.append((func, n, t, vgprs[func]))
     return hits
 
 
@@ -49,7 +75,9 @@ def scan_asm(path):
     text = open(path).read()
     vgprs = {}
     for m in re.finditer(r"\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel", text, re.S):
-        vgprs[m.group(1)] = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1))
+        total = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1))
+        acc = re.search(r"\.amdhsa_accum_offset (\d+)", m.group(2))       # (where the AGPRs begin in the unified file, a multiple of 4)
+        vgprs[m.group(1)] = min(total, int(acc.group(1))) if acc else total
     return scan_lines(text.splitlines(), vgprs, re.compile(r"^(_Z[\w.$]+):")), len(vgprs)
 
 
@@ -77,14 +105,20 @@ def scan_binary(path):
             elf = os.path.join(tmp, "co%d.elf" % k)
             open(elf, "wb").write(co)
             notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", elf], capture_output=True, text=True, check=True).stdout
-            vgprs, name = {}, None
+            vgprs, agprs, name, pending_agprs = {}, {}, None, 0
             for line in notes.splitlines():
+                m = re.match(r"\s*-\s*\.agpr_count:\s+(\d+)", line) or re.match(r"\s*\.agpr_count:\s+(\d+)", line)
+                if m:                                  # (a kernel's keys come sorted: .agpr_count ahead of its .name)
+                    pending_agprs = int(m.group(1))
                 m = re.match(r"\s*-?\s*\.name:\s+(\S+)", line)
                 if m:
                     name = m.group(1)
+                    agprs[name], pending_agprs = pending_agprs, 0
                 m = re.match(r"\s*-?\s*\.vgpr_count:\s+(\d+)", line)
                 if m and name:
                     vgprs[name] = int(m.group(1))
+            for fn in vgprs:                      # (.vgpr_count is the unified total: the arch registers are what is left of it)
+                vgprs[fn] -= agprs.get(fn, 0)
             kernels += len(vgprs)
             dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", elf], capture_output=True, text=True, check=True).stdout
             hits += scan_lines(dis.splitlines(), vgprs, re.compile(r"^[0-9a-f]+ <([\w.$]+)>:"))

@@ -8,6 +8,6 @@ rocprofv3 --kernel-trace --stats -f csv -d $OUT -o t -- python3 $REPO/bench.py -
 python3 - <<PY
 import csv, glob
 f = glob.glob("$OUT/**/*kernel_stats.csv", recursive=True)[0]
-for row in list(csv.DictReader(open(f)))[:22]:
+for row in list(csv.DictReader(open(f)))[:40]:
     print("%-70s calls %4s avg %10.1f us total %9.2f ms" % (row["Name"].replace("katome::","").split("(")[0][:70], row["Calls"], float(row["AverageNs"])/1e3, float(row["TotalDurationNs"])/1e6))
 PY
