@@ -24,6 +24,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+# what the card reaches for the partition pass's MEMORY PATTERN with the ranking work taken out (4096-record tiles written as 128-byte
+# stretches into 256 streams; tools/microbench_scatter.hip, profiles/r04_scatter_ceiling.txt) and for a plain copy of the same bytes
+SCATTER_PATTERN_CEILING_GBS = 4870.0
+COPY_CEILING_GBS = 5620.0
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_latest.json")   # written from tools/profile_round.sh output
 
 
@@ -542,6 +546,7 @@ def main():
             kernels[name] = entry
         cfg_now = {"reads": wl.reads, "read_len": wl.read_len, "k": wl.k, "batch_reads": batch_reads, "tile_span": span}
         rcs = "true" if wl.reverse_complement else "false"
+        even_s = "true" if (wl.reverse_complement and wl.k % 2 == 0) else "false"       # (lds_count_kernel<RC, PER, EVEN_K>)
         exact = {"extract": "void extract_fixed_kernel<%d, %s, %d>" % (nwt, rcs, 256 if wl.stride <= 64 else 64), "insert": "void insert_kernel<%d>" % nw,
                  "insert_tiles": "void insert_kernel<%d>" % nwt,
                  "expand_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (
@@ -579,7 +584,7 @@ def main():
                                "tiles_to_records_kernel": (("void list_to_records_hist_kernel<%d, %d, %s>" if (fused_hist and not rest) else "void list_to_records_kernel<%d, %d, %s>")
                                                            if sorted_tiles else "void tiles_to_records_kernel<%d, %d, %s>") % (last_nw, nw, rcs),
                                "hash_group_index_kernel": "void hash_group_index_kernel<%d, %d>" % (nw, nw),
-                               "lds_count_kernel": ("void lds_count_kernel<%s, %d>" % (rcs, per)) if nw == 1 else ("void lds_count_wide_kernel<%s, %d, %d>" % (rcs, per, nw))})
+                               "lds_count_kernel": ("void lds_count_kernel<%s, %d, %s>" % (rcs, per, even_s)) if nw == 1 else ("void lds_count_wide_kernel<%s, %d, %d, %s>" % (rcs, per, nw, even_s))})
             if sorted_last_level and cnt.get("mid_span") and not cnt.get("mid_tile_slots") and nwt == _katome_lib().katome_tile_words(wl.k, cnt["mid_span"]):
                 # the tile levels counted by sorting: the same kernels on tile records (two-word keys, 20 bytes) -- the mid tiles'
                 # (cut out of the big-tile table, or out of the list of big tiles) and, without a tile table, the big tiles' as well
@@ -600,7 +605,7 @@ def main():
                                "radix_hist_kernel<HashDigit> (tile records)": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nwm, nwm),
                                "tiles_to_records_kernel (tile records)": ("void tiles_to_records_kernel<%d, %d, %s>" if cnt["tile_slots"] else
                                                                           "void list_to_records_hist_kernel<%d, %d, %s>" if fused_hist else "void list_to_records_kernel<%d, %d, %s>") % (nwt, nwm, rcs),
-                               "lds_count_kernel (tile records)": ("void lds_count_kernel<false, %d>" % per_m) if nwm == 1 else ("void lds_count_wide_kernel<false, %d, %d>" % (per_m, nwm))})
+                               "lds_count_kernel (tile records)": ("void lds_count_kernel<false, %d, false>" % per_m) if nwm == 1 else ("void lds_count_wide_kernel<false, %d, %d, false>" % (per_m, nwm))})
         for name, ph in phases.items():
             if not name.startswith("k:"):
                 continue
@@ -664,8 +669,15 @@ def main():
             e = kernel_launches[kn]
             streaming = not kn.startswith("lds_count_kernel")
             t = pmc_traffic([(kexact[kn], 1, streaming)], cfg_now) if kn in kexact and not use_dist else None
+            scatter = kn.startswith("radix_scatter_kernel")
             return {"kernel": kexact.get(kn, kn).replace("void ", ""), "bound": "hbm", "achieved": e["achieved_GBs"], "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": e["frac_of_hbm_peak"], "traffic": t["bytes_per_launch"] if t else None, "traffic_detail": t,
+                    "unit": "GB/s", "frac": e["frac_of_hbm_peak"],
+                    # (measured on this card type, not live: the same bytes moved in the kernel's memory pattern with no other work)
+                    "ceiling": SCATTER_PATTERN_CEILING_GBS if scatter else COPY_CEILING_GBS,
+                    "ceiling_what": ("4096-record tiles scattered as 128-byte stretches into 256 streams, no ranking (tools/microbench_scatter.hip)"
+                                     if scatter else "plain copy of the same bytes (tools/microbench_scatter.hip)"),
+                    "frac_of_ceiling": e["achieved_GBs"] / (SCATTER_PATTERN_CEILING_GBS if scatter else COPY_CEILING_GBS),
+                    "traffic": t["bytes_per_launch"] if t else None, "traffic_detail": t,
                     "alg_bytes_per_launch": e["alg_bytes_per_launch"], "avg_launch_ms": e["avg_ms"],
                     "launches_per_step": e["launches_per_step"], "ms_per_step": e["ms_per_step"],
                     "timed": "HIP events around every launch of this kernel on the build's stream (library KernelScope)"}

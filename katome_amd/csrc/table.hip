@@ -722,7 +722,10 @@ __global__ __launch_bounds__(BLOCK) void hash_group_index_kernel(const u64* __re
     }
 }
 
-template <bool RC, int PER>
+// (EVEN_K: only a k-mer of even length can be its own reverse complement; for odd k -- the headline's k = 31 -- the read-out's count step
+// takes no reverse complement at all.  A TEMPLATE parameter, not a test of k at run time: with a uniform term inside the divergent
+// condition hipcc 7.2 dropped the assignment on the divergent edge, profiles/r04_wrong_code.md)
+template <bool RC, int PER, bool EVEN_K>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
                                                                 u32 R, u32 k, u32 min_weight, u64* out_keys,
                                                                 u32* out_w, u64 out_cap, unsigned long long* cursor,
@@ -780,8 +783,8 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                 if (v & OCC) {
                     kk[j].w[0] = v & KEYBITS; cc[j] = lcnt[sidx];
                     ++my_distinct;
-                    ne[j] = 1;
-                    if (RC && !key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 2;
+                    ne[j] = RC ? 2 : 1;
+                    if (RC && EVEN_K && key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 1;
                     if ((cc[j] << ((RC && ne[j] == 1) ? 1u : 0u)) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
                 }
                 mine += ne[j];
@@ -847,7 +850,7 @@ __global__ void owner_bases_kernel(const u64* __restrict__ index, u32 gbits, u32
 // and the position (within the group, < 2^20) of a REPRESENTATIVE record; a record whose fingerprint meets an occupied slot's
 // compares its whole key with the representative's (read back from the group: L2 / Infinity Cache) and only then adds its
 // count -- exact whatever the fingerprints do.  The read-out fetches each distinct key through its representative.
-template <bool RC, int PER, int NW>
+template <bool RC, int PER, int NW, bool EVEN_K>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 gbits,
                                                                      u32 R, u32 k, u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap,
                                                                      unsigned long long* cursor, unsigned long long* distinct, u32* err, u32 probe_limit,
@@ -925,8 +928,8 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                     for (int q = 0; q < NW; ++q) kk[j].w[q] = keys[rep * NW + q];
                     cc[j] = lcnt[sidx];
                     ++my_distinct;
-                    ne[j] = 1;
-                    if (RC && !key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 2;
+                    ne[j] = RC ? 2 : 1;
+                    if (RC && EVEN_K && key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 1;
                     if ((cc[j] << ((RC && ne[j] == 1) ? 1u : 0u)) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
                 }
                 mine += ne[j];
@@ -1837,14 +1840,15 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
                                min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err,                  \
                                std::min<u32>(probe_limit, LcTable<PERV>::SLOTS), owner_cursor, n_owners);                              \
         } while (0)
+        const bool even = (k & 1) == 0;          // (only read when rc: a tile level's records are never oriented)
         if (nw == 1) {
-            if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 8>), 8); else KATOME_LC_LAUNCH((lds_count_kernel<false, 8>), 8); }
-            else       { if (rc) KATOME_LC_LAUNCH((lds_count_kernel<true, 13>), 13); else KATOME_LC_LAUNCH((lds_count_kernel<false, 13>), 13); }
+            if (small) { if (!rc) KATOME_LC_LAUNCH((lds_count_kernel<false, 8, false>), 8); else if (even) KATOME_LC_LAUNCH((lds_count_kernel<true, 8, true>), 8); else KATOME_LC_LAUNCH((lds_count_kernel<true, 8, false>), 8); }
+            else       { if (!rc) KATOME_LC_LAUNCH((lds_count_kernel<false, 13, false>), 13); else if (even) KATOME_LC_LAUNCH((lds_count_kernel<true, 13, true>), 13); else KATOME_LC_LAUNCH((lds_count_kernel<true, 13, false>), 13); }
         } else if (nw == 3) {
-            if (small) KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 3>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 3>), 13);
+            if (small) KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 3, false>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 3, false>), 13);
         } else {
-            if (small) { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 8, 2>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 2>), 8); }
-            else       { if (rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 13, 2>), 13); else KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 2>), 13); }
+            if (small) { if (!rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 8, 2, false>), 8); else if (even) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 8, 2, true>), 8); else KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 8, 2, false>), 8); }
+            else       { if (!rc) KATOME_LC_LAUNCH((lds_count_wide_kernel<false, 13, 2, false>), 13); else if (even) KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 13, 2, true>), 13); else KATOME_LC_LAUNCH((lds_count_wide_kernel<true, 13, 2, false>), 13); }
         }
 #undef KATOME_LC_LAUNCH
         KCHECK_HIP(hipGetLastError());

@@ -82,6 +82,30 @@ _Z6kernelPm:
     assert mod.is_hit(31, 40, {0, 31, 33}) and not mod.is_hit(31, 40, {0, 31, 32}) and not mod.is_hit(31, 40, None)
 
 
+def test_scanner_recognises_a_dropped_masked_assignment(tmp_path):
+    """profiles/r04_wrong_code.md: hipcc 7.2 dropped `ne = 2` under `uniform || divergent` in lds_count_wide_kernel's read-out and left
+    an empty masked region behind -- `s_and_saveexec_b64 sX, cond` followed at once by `s_or_b64 exec, exec, sX`"""
+    kernel = """
+	.text
+_Z6kernelPm:
+	v_cmp_ne_u64_e32 vcc, v[8:9], v[18:19]
+	s_and_saveexec_b64 s[12:13], vcc
+%s	s_or_b64 exec, exec, s[12:13]
+	s_endpgm
+	.amdhsa_kernel _Z6kernelPm
+		.amdhsa_next_free_vgpr 24
+		.amdhsa_accum_offset 24
+	.end_amdhsa_kernel
+"""
+    def hits(body):
+        path = tmp_path / "m.s"
+        path.write_text(kernel % body)
+        return len(_scanner().scan_asm(str(path))[0])
+    assert hits("") == 1
+    assert hits("; %bb.1:\n") == 1                                   # (comments and labels of the listing in between do not hide it)
+    assert hits("\tv_mov_b32_e32 v4, 2\n") == 0                      # the assignment is there: fine
+
+
 def test_shipped_library_is_clear_of_the_shape():
     lib = os.path.join(ROOT, "katome_amd", "lib", "libkatome_gpu.so")
     assert os.path.exists(lib), "build the library first (__graft_entry__.build())"
@@ -89,4 +113,4 @@ def test_shipped_library_is_clear_of_the_shape():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     last = out.stdout.strip().splitlines()[-1]
     n_kernels = int(last.split()[0])
-    assert n_kernels > 200 and " 0 64-bit shifts" in last, last               # every code object of the library was read
+    assert n_kernels > 200 and " 0 64-bit shifts" in last and "empty masked regions" in last, last       # every code object of the library was read

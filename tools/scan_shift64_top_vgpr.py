@@ -71,6 +71,33 @@ def scan_lines(lines, vgprs, label_re):
     return hits
 
 
+_SAVEEXEC = re.compile(r"s_and_saveexec_b64 (s\[\d+:\d+\]), ")
+
+
+def scan_empty_masked_regions(lines, label_re):
+    """Second shape (profiles/r04_wrong_code.md): `s_and_saveexec_b64 sX, cond` followed at once by `s_or_b64 exec, exec, sX` -- a
+    masked region with nothing in it.  hipcc 7.2 leaves that behind where it has DROPPED an assignment made under
+    `uniform_flag || divergent_condition`: the value is set on the uniform-true edge only, the lanes of the divergent edge keep the
+    default (lds_count_wide_kernel's read-out with `(k & 1) ||` in front of the palindrome test: every k-mer of an even k came out as
+    its own reverse complement).  No kernel of the library has the shape; a new one fails the build and gets looked at."""
+    hits, func = [], None
+    body = [(n, line.strip()) for n, line in enumerate(lines, 1)]
+    for idx, (n, t) in enumerate(body):
+        m = label_re.match(t)
+        if m:
+            func = m.group(1)
+            continue
+        m = _SAVEEXEC.search(t)
+        if not m or func is None:
+            continue
+        j = idx + 1
+        while j < len(body) and (not body[j][1] or body[j][1].startswith((";", "//"))):
+            j += 1
+        if j < len(body) and re.search(r"s_or_b64 exec, exec, " + re.escape(m.group(1)) + r"\s*($|;|//)", body[j][1]):
+            hits.append((func, n, t.split("//")[0].strip(), 0))
+    return hits
+
+
 def scan_asm(path):
     text = open(path).read()
     vgprs = {}
@@ -78,7 +105,8 @@ def scan_asm(path):
         total = int(re.search(r"\.amdhsa_next_free_vgpr (\d+)", m.group(2)).group(1))
         acc = re.search(r"\.amdhsa_accum_offset (\d+)", m.group(2))       # (where the AGPRs begin in the unified file, a multiple of 4)
         vgprs[m.group(1)] = min(total, int(acc.group(1))) if acc else total
-    return scan_lines(text.splitlines(), vgprs, re.compile(r"^(_Z[\w.$]+):")), len(vgprs)
+    label = re.compile(r"^(_Z[\w.$]+):")
+    return scan_lines(text.splitlines(), vgprs, label) + [h[:3] + (-1,) for h in scan_empty_masked_regions(text.splitlines(), label)], len(vgprs)
 
 
 def code_objects(path):
@@ -121,7 +149,9 @@ def scan_binary(path):
                 vgprs[fn] -= agprs.get(fn, 0)
             kernels += len(vgprs)
             dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--mcpu=gfx950", elf], capture_output=True, text=True, check=True).stdout
-            hits += scan_lines(dis.splitlines(), vgprs, re.compile(r"^[0-9a-f]+ <([\w.$]+)>:"))
+            label = re.compile(r"^[0-9a-f]+ <([\w.$]+)>:")
+            hits += scan_lines(dis.splitlines(), vgprs, label)
+            hits += [h[:3] + (-1,) for h in scan_empty_masked_regions(dis.splitlines(), label)]
     return hits, kernels
 
 
@@ -133,8 +163,11 @@ def main(argv):
         kernels += n
         for func, line, t, v in hits:
             bad += 1
-            print("%s: %s\n    in %s (%d VGPRs in use: the amount is the last register of its allocation)" % (os.path.basename(f), t, func[:110], v))
-    print("%d kernels scanned; %d 64-bit shifts with their amount in the last allocated VGPR" % (kernels, bad))
+            if v < 0:
+                print("%s: %s\n    in %s (an empty masked region: a masked assignment was dropped -- profiles/r04_wrong_code.md)" % (os.path.basename(f), t, func[:110]))
+            else:
+                print("%s: %s\n    in %s (%d VGPRs in use: the amount is the last register of its allocation)" % (os.path.basename(f), t, func[:110], v))
+    print("%d kernels scanned; %d 64-bit shifts with their amount in the last allocated VGPR or empty masked regions" % (kernels, bad))
     if kernels == 0:
         print("no gfx950 kernels found in", files)
         return 2
