@@ -962,7 +962,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                     b->stat_kmers = distinct; b->stat_kmer_slots = 0;
                     rk.release(); rw.release();
                     PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
-                    KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * k, stream));
+                    KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * k, stream, true));
                     counted = true;
                 } else {
                     // the k-mers cannot be counted this way (a hash group beyond the LDS route): their records, counts and all, go
@@ -1042,7 +1042,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                         for (int i = 0; i < 2; ++i) { b->scratch_k[i].release(); b->scratch_w[i].release(); }
                         rk.release(); rw.release();
                         PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
-                        KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream));
+                        KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream, true));
                         counted = true;
                     } else {
                         b->n_edges = 0;           // (a group too large for the LDS route: the table counts, from the tiles that are still there)
@@ -1188,7 +1188,7 @@ int katome_dev_edges(katome_builder* b, uint64_t** d_edge_key, uint32_t** d_edge
                 KCHECK(b->edge_seq.alloc((b->n_edges + 1) * 8, stream));
                 KCHECK(dev_gather_seq_weight(raw_seq.as<u64>(), idx.as<u32>(), b->n_edges, b->edge_seq.as<u64>(), b->edge_weight.as<u32>(), stream));
             } else {
-                KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream));
+                KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * b->s.k, stream, true));
             }
         } else if (!counted) {
             KCHECK(b->edge_key.alloc(16, stream)); KCHECK(b->edge_weight.alloc(16, stream));

@@ -179,7 +179,8 @@ int launch_extract_var(uint32_t k, bool rc, const uint8_t* d_packed, uint64_t pa
 // radix.hip
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
 struct DevBuf;
-int dev_sort_bufs(DevBuf& keys, DevBuf* vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream);
+// (distinct_keys: no two keys are equal -- the first pass then need not be stable: radix.hip)
+int dev_sort_bufs(DevBuf& keys, DevBuf* vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream, bool distinct_keys = false);
 int dev_partition(const uint64_t* d_in, const uint32_t* v_in, uint64_t n, uint32_t nw, uint32_t n_parts, uint64_t* d_out,
                   uint32_t* v_out, uint64_t* h_counts, hipStream_t stream, uint32_t core_shift = 0, uint32_t core_bases = 0, uint32_t minimizer = 0);
 // supermer.hip: the sharded build's exchange unit

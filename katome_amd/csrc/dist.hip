@@ -388,7 +388,7 @@ int count_collected(katome_dist_builder* d, Collected& c, hipStream_t stream) {
             b->stat_kmers = distinct; b->stat_kmer_slots = 0;
             c.keys.release(); c.weights.release();
             PhaseScope ps(b->prof, PH_SORT_EDGES, stream);
-            KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * d->s.k, stream));
+            KCHECK(dev_sort_bufs(b->edge_key, &b->edge_weight, b->n_edges, b->nw, 2 * d->s.k, stream, true));
             b->edges_ready = true;
             return KATOME_OK;
         }

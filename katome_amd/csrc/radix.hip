@@ -208,7 +208,12 @@ __global__ __launch_bounds__(BLOCK) void radix_offsets_kernel(u64* __restrict__ 
 // match masks (rank = keys of the same digit earlier in the wave); a cross-wave prefix gives the
 // key's place in the tile's digit-sorted order, the tile is reordered through LDS and written out
 // so that consecutive lanes store consecutive addresses of each digit's run.
-template <int NW, bool HAS_VAL, class Digit>
+// STABLE = false (round 4): a pass that nothing depends on the order of -- the FIRST pass of a level's two hash passes and of a sort
+// of distinct keys: whatever order the records arrive in is as good as any other -- ranks a record with one LDS atomic on its digit's
+// counter instead of the eight ballots of the match step.  Built to close the gap to the pass's memory-pattern ceiling
+// (profiles/r04_scatter_ceiling.txt: 0.80 of it) and measured at C3 on one box, A/B/A/B: 203.8 / 205.8 / 207.3 / 205.1 ms per build --
+// nothing: the LDS atomics cost what the ballots cost.  Kept behind KATOME_UNSTABLE_FIRST=1, off by default.
+template <int NW, bool HAS_VAL, class Digit, bool STABLE = true>
 __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel(const u64* __restrict__ keys_in, const u32* __restrict__ vals_in,
                                                                u64 n, Digit dg, const u32* __restrict__ rel,
                                                                const u64* __restrict__ chunk_off, u64* __restrict__ keys_out,
@@ -250,6 +255,11 @@ __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel
 #endif
             d = dg(key[j]);
         }
+        if (!STABLE) {
+            dig[j] = d;
+            rnk[j] = valid ? atomicAdd(&whist[0][d], 1u) : 0u;       // (place among the tile's records of this digit, in arrival order)
+            continue;
+        }
         // the lanes of this row that hold the same digit: a lane differs from another where, for some bit, the row's vote on that bit
         // and its own bit disagree.  `mine` is the lane's bit spread over a word (0 / ~0), so a bit costs one compare (the vote), two
         // xors and two ors; as `bit ? vote : ~vote` on 64-bit masks hipcc 7.2 spent eleven VALU operations per bit and so many
@@ -276,8 +286,11 @@ __global__ __launch_bounds__(BLOCK, KATOME_SORT_WAVES) void radix_scatter_kernel
     {   // thread = digit: wave-exclusive prefixes, tile-wide digit starts, global run bases
         const u32 d = tid;
         u32 run = 0;
+        if (!STABLE) { run = whist[0][d]; whist[0][d] = 0; }       // (one counter per digit: the ranks are tile-wide already)
+        else {
 #pragma unroll
         for (int w = 0; w < BLOCK / 64; ++w) { u32 c = whist[w][d]; whist[w][d] = run; run += c; }
+        }
         u32 incl = run;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { u32 v = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += v; }
@@ -361,7 +374,11 @@ template <int NW> struct DigitTimers<OwnerDigit<NW>> { static constexpr int HIST
 template <> struct DigitTimers<SupermerOwnerDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 template <> struct DigitTimers<RangeDigit> { static constexpr int HIST = K_OWNER_HIST, SCATTER = K_OWNER_SCATTER; };
 
-template <int NW, bool HAS_VAL, class Digit>
+static bool unstable_first() {
+    static const bool on = getenv("KATOME_UNSTABLE_FIRST") && atoi(getenv("KATOME_UNSTABLE_FIRST")) != 0;      // (off: measured, no gain -- see the kernel)
+    return on;
+}
+template <int NW, bool HAS_VAL, class Digit, bool STABLE = true>
 static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout, u32* vout, PassBuffers& pb, hipStream_t stream,
                       bool have_counts = false) {
     if (pb.nblocks > 0x7fffffffull) { set_error("radix pass: %llu keys exceed the grid limit", (unsigned long long)n); return KATOME_E_ARG; }
@@ -377,13 +394,13 @@ static int radix_pass(const u64* kin, const u32* vin, u64 n, Digit dg, u64* kout
     }
     const size_t lds = (size_t)SortTile<NW>::KEYS * NW * 8;
     if (lds > (64u << 10)) {          // three-word records: 96 KiB of the CU's 160 KiB
-        KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        KCHECK_HIP(hipFuncSetAttribute((const void*)radix_scatter_kernel<NW, HAS_VAL, Digit, STABLE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     {
         static const bool xcd_aware = !getenv("KATOME_XCD_TILES") || atoi(getenv("KATOME_XCD_TILES")) != 0;       // (0: workgroup i takes tile i)
         const u32 xcd_tiles = xcd_aware && pb.nblocks >= 64 ? (u32)((pb.nblocks + 7) / 8) : 0u;
         KernelScope ks((!HAS_VAL && DigitTimers<Digit>::SCATTER == K_SORT_SCATTER) ? (int)K_SORT_SCATTER_KEYS : (int)DigitTimers<Digit>::SCATTER, stream, n);
-        hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit>), dim3(xcd_tiles ? xcd_tiles * 8u : (unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
+        hipLaunchKernelGGL((radix_scatter_kernel<NW, HAS_VAL, Digit, STABLE>), dim3(xcd_tiles ? xcd_tiles * 8u : (unsigned)pb.nblocks), block, lds, stream, kin, vin, n, dg,
                            pb.counts.as<u32>(), pb.chunk.as<u64>(), kout, vout, pb.chunk_blocks, xcd_tiles);
     }
     KCHECK_HIP(hipGetLastError());
@@ -630,7 +647,8 @@ static u32 top_passes_for(u64 n) {
 // own_k / own_v (optional): the buffers that hold d_keys / d_vals.  An odd number of passes leaves the result in the
 // temporaries; with the owners given they simply take those over (no copy back: 24 B per pair saved).
 template <int NW, bool HAS_VAL>
-static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream, DevBuf* own_k = nullptr, DevBuf* own_v = nullptr) {
+static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t stream, DevBuf* own_k = nullptr, DevBuf* own_v = nullptr,
+                  bool distinct_keys = false) {
     if (n < 2) return KATOME_OK;
     PassBuffers pb;
     KCHECK(pb.init(n, NW, stream));
@@ -640,9 +658,14 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
     u64* kin = d_keys; u64* kout = tk.as<u64>();
     u32* vin = d_vals; u32* vout = tv.as<u32>();
     auto flip = [&]() { u64* t = kin; kin = kout; kout = t; u32* tv2 = vin; vin = vout; vout = tv2; };
+    bool first = true;
     auto pass = [&](u32 shift) -> int {
         RadixDigit<NW> dg{shift, (key_bits - shift) < (u32)RADIX_BITS ? (key_bits - shift) : (u32)RADIX_BITS};
-        KCHECK((radix_pass<NW, HAS_VAL>(kin, vin, n, dg, kout, vout, pb, stream)));
+        // (keys that are all different end up in key order whatever order equal DIGITS keep in the first pass; later passes must keep
+        // what earlier ones established)
+        if (first && distinct_keys && unstable_first()) KCHECK((radix_pass<NW, HAS_VAL, RadixDigit<NW>, false>(kin, vin, n, dg, kout, vout, pb, stream)));
+        else KCHECK((radix_pass<NW, HAS_VAL>(kin, vin, n, dg, kout, vout, pb, stream)));
+        first = false;
         flip();
         return KATOME_OK;
     };
@@ -696,12 +719,12 @@ static int sort_t(u64* d_keys, u32* d_vals, u64 n, u32 key_bits, hipStream_t str
 
 // keys (and values) held in DevBufs: sorted "in place" from the caller's point of view, but the buffers may be exchanged for
 // the sort's temporaries instead of copied back (pointers taken from them before the call are stale afterwards)
-int dev_sort_bufs(DevBuf& keys, DevBuf* vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream) {
+int dev_sort_bufs(DevBuf& keys, DevBuf* vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream, bool distinct_keys) {
     if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
     if (key_bits == 0 || key_bits > 64 * nw) { set_error("key_bits out of range"); return KATOME_E_ARG; }
     if (keys.bytes < n * 8 * nw || (vals && vals->bytes < n * 4)) { set_error("sort: buffer too small"); return KATOME_E_ARG; }
-    if (nw == 1) return vals ? sort_t<1, true>(keys.as<u64>(), vals->as<u32>(), n, key_bits, stream, &keys, vals) : sort_t<1, false>(keys.as<u64>(), nullptr, n, key_bits, stream, &keys, nullptr);
-    return vals ? sort_t<2, true>(keys.as<u64>(), vals->as<u32>(), n, key_bits, stream, &keys, vals) : sort_t<2, false>(keys.as<u64>(), nullptr, n, key_bits, stream, &keys, nullptr);
+    if (nw == 1) return vals ? sort_t<1, true>(keys.as<u64>(), vals->as<u32>(), n, key_bits, stream, &keys, vals, distinct_keys) : sort_t<1, false>(keys.as<u64>(), nullptr, n, key_bits, stream, &keys, nullptr, distinct_keys);
+    return vals ? sort_t<2, true>(keys.as<u64>(), vals->as<u32>(), n, key_bits, stream, &keys, vals, distinct_keys) : sort_t<2, false>(keys.as<u64>(), nullptr, n, key_bits, stream, &keys, nullptr, distinct_keys);
 }
 int dev_sort(uint64_t* d_keys, uint32_t* d_vals, uint64_t n, uint32_t nw, uint32_t key_bits, hipStream_t stream) {
     if (nw != 1 && nw != 2) { set_error("key_words must be 1 or 2"); return KATOME_E_ARG; }
@@ -792,6 +815,10 @@ static int region_order_t(const u64* d_in, const u32* w_in, u64 n, int passes, u
     for (int p = 0; p < passes; ++p) {
         HashDigit<NW> dg{(u32)(64 - 8 * (passes - p))};     // least significant region byte first
         const bool have = p == 0 && first_counts != nullptr;
+        if (p == 0 && unstable_first()) {          // (nothing is ordered yet: the first pass need not be stable)
+            if (w_in) KCHECK((radix_pass<NW, true, HashDigit<NW>, false>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream, have)));
+            else      KCHECK((radix_pass<NW, false, HashDigit<NW>, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream, have)));
+        } else
         if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream, have)));
         else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream, have)));
         kin = kdst[p & 1]; win = w_in ? wdst[p & 1] : nullptr;
@@ -823,6 +850,10 @@ static int tagged_order_t(const u64* d_in, const u32* w_in, u64 n, u64* ka, u64*
     for (int p = 0; p < 2; ++p) {
         HashTaggedDigit<NW> dg{(u32)(64 - 8 * (2 - p))};
         const bool have = p == 0 && first_counts != nullptr;       // (counted by whoever wrote the records: table.hip list_to_tagged_records_kernel)
+        if (p == 0 && unstable_first()) {
+            if (w_in) KCHECK((radix_pass<NW, true, HashTaggedDigit<NW>, false>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream, have)));
+            else      KCHECK((radix_pass<NW, false, HashTaggedDigit<NW>, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream, have)));
+        } else
         if (w_in) KCHECK((radix_pass<NW, true>(kin, win, n, dg, kdst[p & 1], wdst[p & 1], pb, stream, have)));
         else      KCHECK((radix_pass<NW, false>(kin, nullptr, n, dg, kdst[p & 1], nullptr, pb, stream, have)));      // (records that count once each)
         kin = kdst[p & 1]; win = w_in ? wdst[p & 1] : nullptr;

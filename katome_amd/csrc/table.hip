@@ -914,22 +914,30 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
               }
             }
             __syncthreads();
-            Key<NW> kk[PER]; u32 cc[PER], ne[PER]; u32 mine = 0;
+            // (the slots' keys are fetched where they are written, not held across the scan in between: PER keys of NW words were 2 * PER * NW
+            // registers -- three-word tiles at PER = 13 spilled to scratch -- and only a k-mer of even length is looked at before that)
+            constexpr bool LOOK = RC && EVEN_K;                  // (then the keys are fetched once, here, and kept)
+            u32 rp[PER], cc[PER], ne[PER]; u32 mine = 0;
+            Key<NW> kk[LOOK ? PER : 1];
 #pragma unroll
             for (u32 j = 0; j < (u32)PER; ++j) {
                 const u32 sidx = tid * PER + j;
                 const unsigned long long v = lkey[sidx];
-                ne[j] = 0; cc[j] = 0;
+                ne[j] = 0; cc[j] = 0; rp[j] = 0;
+                if (LOOK) {
 #pragma unroll
-                for (int q = 0; q < NW; ++q) kk[j].w[q] = 0;
+                    for (int q = 0; q < NW; ++q) kk[LOOK ? j : 0].w[q] = 0;
+                }
                 if (v & OCC) {
-                    const u64 rep = lo + (v & REP_MASK);
-#pragma unroll
-                    for (int q = 0; q < NW; ++q) kk[j].w[q] = keys[rep * NW + q];
+                    rp[j] = (u32)(v & REP_MASK);
                     cc[j] = lcnt[sidx];
                     ++my_distinct;
                     ne[j] = RC ? 2 : 1;
-                    if (RC && EVEN_K && key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 1;
+                    if (LOOK) {
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) kk[LOOK ? j : 0].w[q] = keys[(lo + rp[j]) * NW + q];
+                        if (key_eq(revcomp(kk[LOOK ? j : 0], k), kk[LOOK ? j : 0])) ne[j] = 1;
+                    }
                     if ((cc[j] << ((RC && ne[j] == 1) ? 1u : 0u)) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
                 }
                 mine += ne[j];
@@ -949,14 +957,17 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
             for (u32 j = 0; j < (u32)PER; ++j) {
                 if (!ne[j]) continue;
                 const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);       // (as a shift: see lds_count_kernel)
+                Key<NW> x;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) x.w[q] = LOOK ? kk[LOOK ? j : 0].w[q] : keys[(lo + rp[j]) * NW + q];
                 if (pos < out_cap) {
 #pragma unroll
-                    for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = kk[j].w[q];
+                    for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = x.w[q];
                     out_w[pos] = w;
                 }
                 ++pos;
                 if (ne[j] == 2) {
-                    const Key<NW> rk = revcomp(kk[j], k);
+                    const Key<NW> rk = revcomp(x, k);
                     if (pos < out_cap) {
 #pragma unroll
                         for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rk.w[q];

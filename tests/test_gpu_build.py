@@ -342,8 +342,12 @@ def _need_whole_gpu(need_gib=200):
     torch.cuda.empty_cache()
     kd.release_cache()
     free_b, total_b = torch.cuda.mem_get_info()
-    if free_b >= need_gib << 30:
-        return
+    import time
+    for _ in range(60):                # (a child process that has just exited -- the full-size A/B build -- gets its memory unmapped by
+        if free_b >= need_gib << 30:   # the driver over some seconds: that is not something "left behind")
+            return
+        time.sleep(0.5)
+        free_b, total_b = torch.cuda.mem_get_info()
     msg = "needs %d GiB free, has %.1f of %.1f GiB; the library still holds %r" % (
         need_gib, free_b / 2**30, total_b / 2**30, kd.cache_stats())
     if total_b >= 250 << 30:
@@ -410,11 +414,56 @@ def test_properties_at_full_c3_size():
             y |= (3 - ((x >> (2 * i)) & 3)) << (2 * (k - 1 - i))
         r = kd.rank_in_sorted(dg.edge_key.reshape(-1), y.contiguous(), 2 * k, 1)
         assert bool((r >= 0).all()) and bool((dg.edge_weight[r] == dg.edge_weight[sample]).all())
+        return E, N, _array_checksums(dg)
     try:
-        body()
+        got = body()
     finally:
         del packed, _skip
         _close_and_release(b)
+    # The same build by the OTHER counting implementation -- both tile levels in the HBM atomics tables (KATOME_SORTED_TILES=0),
+    # the k-mers still by sorting -- in a process of its own (the switch is read once; this process has given its memory back):
+    # position-weighted 64-bit checksums of edge_key / edge_weight / edge_src / edge_dst / node_key must agree at C3 in full
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _FULL_C3_CHILD, root], env=dict(os.environ, KATOME_SORTED_TILES="0"),
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [x for x in out.stdout.splitlines() if x.startswith("FULLC3 ")][-1].split()
+    assert (int(line[1]), int(line[2])) == got[:2]
+    assert [int(x) for x in line[3:]] == got[2], (line, got)
+
+
+def _array_checksums(dg):
+    """sum of a[i] * (2 i + 1) mod 2^64 over every word of the graph's arrays, in chunks on the device"""
+    out = []
+    for a in (dg.edge_key.reshape(-1), dg.edge_weight, dg.edge_src, dg.edge_dst, dg.node_key.reshape(-1)):
+        total = 0
+        n = a.numel()
+        for i in range(0, n, 1 << 27):
+            z = min(n, i + (1 << 27))
+            w = torch.arange(i, z, device=a.device, dtype=torch.int64) * 2 + 1
+            total = (total + int((a[i:z].to(torch.int64) * w).sum().item())) & ((1 << 64) - 1)
+        out.append(total)
+    return out
+
+
+_FULL_C3_CHILD = r"""
+import sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import torch
+from katome_amd import device as kd
+from katome_amd.workloads import WORKLOADS
+from test_gpu_build import _array_checksums
+wl = WORKLOADS["c3"]
+packed, _ = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, 0)
+b = kd.Builder(wl.k, True, table_slots_hint=int(wl.expected_distinct_canonical() * 2.2))
+for r0 in range(0, wl.reads, 4 << 20):
+    b.count_reads(packed, min(4 << 20, wl.reads - r0), wl.read_len, None, first_read=r0)
+dg = b.finalize()
+c = b.counts()
+assert c["tile_slots"] > 0 and c["mid_tile_slots"] > 0, c            # the tile levels really were counted in their tables
+print("FULLC3", dg.n_edges, dg.n_nodes, *_array_checksums(dg))
+"""
 
 
 def test_properties_at_c5_share_size():
