@@ -553,7 +553,7 @@ def main():
                      _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or span), nw, rcs),
                  "expand_mid_tiles": "void expand_tiles_kernel<%d, %d, %s, true>" % (
                      nwt, _katome_lib().katome_tile_words(wl.k, cnt.get("mid_span") or 1), rcs),
-                 "sort_edges": "void radix_scatter_kernel<%d, true, RadixDigit<%d> >" % (nw, nw),
+                 "sort_edges": "void radix_scatter_kernel<%d, true, RadixDigit<%d>, true>" % (nw, nw),
                  "emit_edges": "void emit_edges_kernel<%d, %s, %d>" % (nw, rcs, 4 if (args.first_seen_order or args.prune or nw > 1) else 8)}
         # per-kernel algorithmic bytes of ONE launch (the default build on one GPU only: other routes run the same kernels on
         # other record counts), and the name rocprofv3 lists the kernel under
@@ -579,7 +579,7 @@ def main():
                              "tiles_to_records_kernel": (16 * last_nw + float(pair) * n_rec / last_slots) if last_slots else (8 * last_nw + 4 + pair * last_span),
                              "hash_group_index_kernel": 65537.0 * (31 * 8 * nw + 8) / max(n_rec, 1),
                              "lds_count_kernel": pair + float(pair) * n_edges / n_rec})
-                kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nw, nw),
+                kexact.update({"radix_scatter_kernel<HashDigit>": "void radix_scatter_kernel<%d, true, HashDigit<%d>, true>" % (nw, nw),
                                "radix_hist_kernel<HashDigit>": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nw, nw),
                                "tiles_to_records_kernel": (("void list_to_records_hist_kernel<%d, %d, %s>" if (fused_hist and not rest) else "void list_to_records_kernel<%d, %d, %s>")
                                                            if sorted_tiles else "void tiles_to_records_kernel<%d, %d, %s>") % (last_nw, nw, rcs),
@@ -601,7 +601,7 @@ def main():
                              "tiles_to_records_kernel (tile records)": (16 * nwt + float(pair_m) * n_mid / cnt["tile_slots"]) if cnt["tile_slots"]
                              else pair_m + pair_m * (span // ms2),
                              "lds_count_kernel (tile records)": (float(pair_m) * n_mid + rec_big * n_big + float(pair_m) * d_all) / max(n_all, 1)})
-                kexact.update({"radix_scatter_kernel<HashDigit> (tile records)": "void radix_scatter_kernel<%d, true, HashDigit<%d> >" % (nwm, nwm),
+                kexact.update({"radix_scatter_kernel<HashDigit> (tile records)": "void radix_scatter_kernel<%d, true, HashDigit<%d>, true>" % (nwm, nwm),
                                "radix_hist_kernel<HashDigit> (tile records)": "void radix_hist_kernel<%d, HashDigit<%d> >" % (nwm, nwm),
                                "tiles_to_records_kernel (tile records)": ("void tiles_to_records_kernel<%d, %d, %s>" if cnt["tile_slots"] else
                                                                           "void list_to_records_hist_kernel<%d, %d, %s>" if fused_hist else "void list_to_records_kernel<%d, %d, %s>") % (nwt, nwm, rcs),

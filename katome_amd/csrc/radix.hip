@@ -555,30 +555,43 @@ __global__ __launch_bounds__(BLOCK) void run_sort_wave_kernel(const u64* __restr
     const u64 per_xcd = (n_chunks + 7) / 8, xcd = blockIdx.x & 7u;
     const u64 wave = ((u64)(blockIdx.x >> 3) * BLOCK + threadIdx.x) >> 6, n_waves = ((u64)(gridDim.x >> 3) * BLOCK) >> 6;
     const u64 c_end = (xcd + 1) * per_xcd < n_chunks ? (xcd + 1) * per_xcd : n_chunks;
-    // (the next stretch's loads are issued before this one is worked on)
-    auto fetch = [&](u64 c, Key<NW>& key, u32& val) {
+    // A wave works through a CONTIGUOUS block of stretches (round 4): the 2 * RW_REACH records two neighbouring stretches share are
+    // then in this wave's own registers -- the last lanes of the stretch before -- and every key is fetched once (with the stretches
+    // dealt out round-robin the halo was fetched again by another wave: 1.5 x the algorithmic read, profiles/r03_summary.md).
+    const u64 per_wave = (per_xcd + n_waves - 1) / n_waves;
+    const u64 c_first = xcd * per_xcd + wave * per_wave, c_last = c_first + per_wave < c_end ? c_first + per_wave : c_end;
+    // (the next stretch's loads are issued before this one is worked on; `all`: every lane loads, else only the lanes whose record the
+    // stretch before did not hold)
+    auto fetch = [&](u64 c, bool all, Key<NW>& key, u32& val) {
         const long long j = (long long)(c * RW_OWN) - (long long)RW_REACH + (long long)lane;
-        const bool there = c < n_chunks && j >= 0 && (u64)j < n;
+        const bool there = c < n_chunks && j >= 0 && (u64)j < n, fresh = there && (all || lane >= 2 * RW_REACH);
 #pragma unroll
         for (int q = 0; q < NW; ++q) key.w[q] = 0;
         val = 0;
+        // (a value is only ever read by the lane that owns its record: every own lane loads its own, carried key or not)
 #if KATOME_STREAM_LOADS >= 3
-        if (there) key = load_key_stream<NW>(keys_in, (u64)j);
+        if (fresh) key = load_key_stream<NW>(keys_in, (u64)j);
         if (HAS_VAL && there && lane >= RW_REACH && lane < RW_REACH + RW_OWN) val = __builtin_nontemporal_load(&vals_in[j]);
 #else
-        if (there) key = load_key<NW>(keys_in, (u64)j);
+        if (fresh) key = load_key<NW>(keys_in, (u64)j);
         if (HAS_VAL && there && lane >= RW_REACH && lane < RW_REACH + RW_OWN) val = vals_in[j];
 #endif
     };
     Key<NW> key_next; u32 val_next;
-    fetch(xcd * per_xcd + wave < c_end ? xcd * per_xcd + wave : n_chunks, key_next, val_next);
-    for (u64 c = xcd * per_xcd + wave; c < c_end; c += n_waves) {
+    fetch(c_first < c_last ? c_first : n_chunks, true, key_next, val_next);
+    for (u64 c = c_first; c < c_last; ++c) {
         const long long j = (long long)(c * RW_OWN) - (long long)RW_REACH + (long long)lane;         // the record this lane looks at
         const bool there = j >= 0 && (u64)j < n;
         const bool own = there && lane >= RW_REACH && lane < RW_REACH + RW_OWN;
         const Key<NW> key = key_next;
         const u32 val = val_next;
-        fetch(c + n_waves < c_end ? c + n_waves : n_chunks, key_next, val_next);
+        fetch(c + 1 < c_last ? c + 1 : n_chunks, false, key_next, val_next);
+        {   // the first 2 * RW_REACH records of the next stretch are this stretch's last ones: lane l takes lane l + RW_OWN's
+            Key<NW> carried;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) carried.w[q] = __shfl(key.w[q], (int)((lane + RW_OWN) & 63u), 64);
+            if (lane < 2 * RW_REACH && c + 1 < c_last) key_next = carried;
+        }
         const Key<NW> top = key_shr(key, low);
         // to the left: records of the run with a key <= this one come first; to the right: only strictly smaller keys
         u32 left = 0, before = 0;
