@@ -1860,8 +1860,9 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
     std::vector<katome_comm*> comms(n, nullptr);
     const char* transport = getenv("KATOME_COMM");
     auto sync = std::make_shared<LocalGroup>(n);                 // host rendezvous of the rank threads, whatever moves the data
+    std::shared_ptr<LocalGroup> group;                           // (the local transport's own rendezvous, poisoned with `sync`)
     if (share || (transport && !strcmp(transport, "local"))) {
-        auto group = std::make_shared<LocalGroup>(n);
+        group = std::make_shared<LocalGroup>(n);
         for (int r = 0; r < n; ++r) KCHECK(make_local_comm(group, r, devices[r], &comms[r]));
     } else {
         KCHECK(make_rccl_comms_all(devices.data(), n, comms.data()));
@@ -1895,6 +1896,9 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
             }
             if ((rc = katome_dist_add_reads(d, d_packed.as<uint8_t>(), first, cnt, read_len, skip ? d_skip.as<uint8_t>() : nullptr, 0, stream))) break;
             d_packed.release(); d_skip.release();
+            // a rank whose reads could not be taken (memory, reads the route does not take) must not leave the others waiting inside
+            // finalize's exchange: everybody meets here first, and a failed rank has poisoned the meeting
+            if (!sync->barrier()) { set_error("another rank of this build failed"); rc = KATOME_E_DEVICE; break; }
             katome_dist_graph g;
             if ((rc = katome_dist_finalize(d, &g, stream))) break;
             if (first_seen && !direct) {
@@ -2002,7 +2006,7 @@ static int build_packed_multi(const katome_settings* s, const uint8_t* packed, u
         threads.emplace_back([&, r]() {
             const int rc = body(r);
             sh.rc[r] = rc;
-            if (rc) { sh.err[r] = get_error(); sync->poison(); }     // (ranks waiting at a host rendezvous give up)
+            if (rc) { sh.err[r] = get_error(); sync->poison(); if (group) group->poison(); }     // (ranks waiting at a host rendezvous give up)
         });
     for (auto& t : threads) t.join();
     for (int r = 0; r < n; ++r) katome_comm_destroy(comms[r]);

@@ -650,33 +650,43 @@ int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint6
         return KATOME_E_UNSUPPORTED;
     }
     const int world = d->world();
+    if (const char* f = getenv("KATOME_DIST_ADD_FAIL"))          // (tests: this rank's reads are refused, as a failed allocation would refuse them)
+        if (atoi(f) == d->comm->rank()) { set_error("reads refused (KATOME_DIST_ADD_FAIL)"); return KATOME_E_OOM; }
     if (d->supermers) {
-        // the reads' supermer records wait for the one exchange (katome_dist_finalize): slots per read, then this call's spill region
-        const uint64_t spill_cap = std::max<uint64_t>(1024, n_reads / 8), add = n_reads * d->sm_slots + spill_cap;
-        if (d->sm_n + add > d->sm_cap) {
-            const uint64_t want = d->sm_n ? std::max(d->sm_n + add, d->sm_cap * 2) : add;
-            DevBuf grown(stream);
-            KCHECK(grown.alloc(want * 16 + 64));
-            if (d->sm_n) KCHECK_HIP(hipMemcpyAsync(grown.p, d->sm_recs.p, d->sm_n * 16, hipMemcpyDeviceToDevice, stream));
-            const size_t bytes = grown.bytes;
-            d->sm_recs.stream = stream; d->sm_recs.adopt(grown.take(), bytes);
-            d->sm_cap = want;
-        }
-        u64* slots_at = d->sm_recs.as<u64>() + d->sm_n * 2;
-        u64* spill_at = slots_at + n_reads * d->sm_slots * 2;
+        // the reads' supermer records wait for the one exchange (katome_dist_finalize): slots per read, then this call's spill region.
+        // How many records spill is a property of the reads (short minimizer windows at small k cut a read into more runs than it has
+        // slots); the kernel counts them all, so a region that proved too small is made the size it takes and the call's reads are cut
+        // again -- never an error on one rank alone, which would leave the others waiting in the exchange
+        uint64_t spill_cap = std::max<uint64_t>(1024, n_reads / 8), add = 0;
         DevBuf cursor(stream);
         KCHECK(cursor.alloc(8));
-        KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
-        KCHECK_HIP(hipMemsetAsync(spill_at, 0xFF, spill_cap * 16, stream));
-        {
-            PhaseScope ps(b->prof, PH_EXTRACT, stream);
-            KCHECK(dev_supermers_extract(d_packed, n_reads, read_len, d_skip, k, d->owner_m, d->rc, (uint32_t)world, d->sm_slots, slots_at, spill_at, spill_cap,
-                                         cursor.as<u64>(), stream));
+        for (int attempt = 0;; ++attempt) {
+            add = n_reads * d->sm_slots + spill_cap;
+            if (d->sm_n + add > d->sm_cap) {
+                const uint64_t want = d->sm_n ? std::max(d->sm_n + add, d->sm_cap * 2) : add;
+                DevBuf grown(stream);
+                KCHECK(grown.alloc(want * 16 + 64));
+                if (d->sm_n) KCHECK_HIP(hipMemcpyAsync(grown.p, d->sm_recs.p, d->sm_n * 16, hipMemcpyDeviceToDevice, stream));
+                const size_t bytes = grown.bytes;
+                d->sm_recs.stream = stream; d->sm_recs.adopt(grown.take(), bytes);
+                d->sm_cap = want;
+            }
+            u64* slots_at = d->sm_recs.as<u64>() + d->sm_n * 2;
+            u64* spill_at = slots_at + n_reads * d->sm_slots * 2;
+            KCHECK_HIP(hipMemsetAsync(cursor.p, 0, 8, stream));
+            KCHECK_HIP(hipMemsetAsync(spill_at, 0xFF, spill_cap * 16, stream));
+            {
+                PhaseScope ps(b->prof, PH_EXTRACT, stream);
+                KCHECK(dev_supermers_extract(d_packed, n_reads, read_len, d_skip, k, d->owner_m, d->rc, (uint32_t)world, d->sm_slots, slots_at, spill_at, spill_cap,
+                                             cursor.as<u64>(), stream));
+            }
+            uint64_t spilled = 0;
+            KCHECK_HIP(hipMemcpyAsync(&spilled, cursor.p, 8, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipStreamSynchronize(stream));
+            if (spilled <= spill_cap) break;
+            if (attempt) { set_error("supermers: %llu records beyond the reads' slots on the second cut, %llu on the first", (unsigned long long)spilled, (unsigned long long)spill_cap); return KATOME_E_UNSUPPORTED; }
+            spill_cap = spilled;
         }
-        uint64_t spilled = 0;
-        KCHECK_HIP(hipMemcpyAsync(&spilled, cursor.p, 8, hipMemcpyDeviceToHost, stream));
-        KCHECK_HIP(hipStreamSynchronize(stream));
-        if (spilled > spill_cap) { set_error("supermers: reads with unusually many runs (%llu records beyond the reads' slots, room for %llu)", (unsigned long long)spilled, (unsigned long long)spill_cap); return KATOME_E_UNSUPPORTED; }
         d->sm_n += add;
         d->reads_end = std::max(d->reads_end, first_read + n_reads);
         return KATOME_OK;
@@ -736,13 +746,20 @@ int katome_dist_add_reads(katome_dist_builder* d, const uint8_t* d_packed, uint6
     uint64_t batch = batch_reads ? batch_reads : (tiled ? (16ull << 20) : (4ull << 20));
     batch = std::max<uint64_t>(64, batch / 64 * 64);
     uint64_t nb = (n_reads + batch - 1) / batch;
-    KCHECK(d->comm->allreduce(&nb, 1, OP_MAX));                    // every rank takes part in every exchange
     const uint64_t cap_reads = std::min(batch, std::max<uint64_t>(n_reads, 1));
     const uint32_t first_rest = tiled ? d->tiles_per_read * d->span : 0;
     DevBuf recbuf(stream), part(stream), idx(stream), pidx(stream);
     const uint64_t cap_rec = cap_reads * std::max<uint32_t>(per_read, d->rest);
-    KCHECK(recbuf.alloc(cap_rec * 8 * nwr + 64)); KCHECK(part.alloc(cap_rec * 8 * nwr + 64));
-    if (d->first_seen) { KCHECK(idx.alloc(cap_rec * 4 + 64)); KCHECK(pidx.alloc(cap_rec * 4 + 64)); }
+    // the batch buffers first, and whether every rank got them travels with the number of rounds: a rank that could not must not
+    // leave the others waiting in the first exchange (every rank takes part in every exchange)
+    int mine = recbuf.alloc(cap_rec * 8 * nwr + 64);
+    if (!mine) mine = part.alloc(cap_rec * 8 * nwr + 64);
+    if (!mine && d->first_seen) { mine = idx.alloc(cap_rec * 4 + 64); if (!mine) mine = pidx.alloc(cap_rec * 4 + 64); }
+    uint64_t agree[2] = {nb, (uint64_t)(mine != KATOME_OK)};
+    KCHECK(d->comm->allreduce(agree, 2, OP_MAX));
+    nb = agree[0];
+    if (mine) return mine;
+    if (agree[1]) { set_error("another rank of this build could not allocate its batch buffers"); return KATOME_E_OOM; }
     for (uint64_t i = 0; i < nb; ++i) {
         const uint64_t r0 = std::min(n_reads, i * batch), nr = std::min(batch, n_reads - r0);
         const uint8_t* p = d_packed ? d_packed + r0 * stride : nullptr;

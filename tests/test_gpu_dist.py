@@ -121,6 +121,40 @@ def test_a_failure_on_rank_0_inside_the_pruning_reaches_every_rank(oracle, monke
     _same_arrays(g, oracle.build_ascii(ascii_reads, 63, True, remove_dead_paths=True))      # (and the library is fine afterwards)
 
 
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("route", ["local", "tiles", "supermers"])
+def test_a_rank_whose_reads_are_refused_does_not_leave_the_others_in_the_exchange(oracle, monkeypatch, route):
+    """a rank that fails BEFORE the exchange (its reads do not fit, or are of a kind the route does not take: forced here with
+    KATOME_DIST_ADD_FAIL) never enters finalize's collectives; the thread ranks of an n_devices build meet once between taking
+    the reads and finalize, the failed rank has poisoned that meeting, and katome_build_packed returns ITS error instead of
+    hanging in the others' exchange"""
+    from katome_amd.build import GpuGraph, KatomePanic
+    monkeypatch.setenv("KATOME_DIST_ROUTE", route)
+    monkeypatch.setenv("KATOME_DIST_ADD_FAIL", "1")
+    ascii_reads, packed, skip = _reads(oracle, 600, 100, 4000, 1e-3, 1)
+    with pytest.raises(KatomePanic) as e:
+        GpuGraph.create_from_packed(packed, 600, 100, skip=skip, reverse_complement=True, k=21, n_devices=3, ranks_share_device=True)
+    assert "rank 1 of 3" in str(e.value) and "KATOME_DIST_ADD_FAIL" in str(e.value)
+    monkeypatch.delenv("KATOME_DIST_ADD_FAIL")
+    g, _ = GpuGraph.create_from_packed(packed, 600, 100, skip=skip, reverse_complement=True, k=21, n_devices=3, ranks_share_device=True)
+    assert g.multiset() == oracle.build_ascii(ascii_reads, 21, True).multiset()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world,k,rc,n,L", [(3, 16, False, 293, 123), (2, 15, True, 5000, 142), (4, 18, True, 900, 140)])
+def test_supermer_route_with_more_runs_than_slots(oracle, monkeypatch, world, k, rc, n, L):
+    """short minimizer windows (k = 15..18: w = 3..6) cut a long read into more runs than it has slots and more than a lane lists:
+    the rest goes window by window into the call's spill region, and a region that proves too small is made the size the kernel
+    counted and the reads are cut again (dist.hip katome_dist_add_reads) -- never an error on one rank alone.  (The first case
+    is one a fuzz run found hanging: one rank's region overflowed, the others waited for it in the exchange)"""
+    from katome_amd.build import GpuGraph
+    monkeypatch.setenv("KATOME_DIST_ROUTE", "supermers")
+    ascii_reads, packed, skip = _reads(oracle, n, L, 4000, 1e-3, 0)
+    g, rb = GpuGraph.create_from_packed(packed, n, L, skip=skip, reverse_complement=rc, k=k, n_devices=world, ranks_share_device=True)
+    ref = oracle.build_ascii(ascii_reads, k, rc)
+    assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges) and g.multiset() == ref.multiset()
+
+
 @pytest.mark.parametrize("world,k,rc,n,L,genome,err", [(2, 63, True, 400, 150, 4000, 5e-4), (3, 31, True, 1500, 150, 9000, 1e-2)])
 def test_sharded_pruning_with_the_node_replay_on_the_host(oracle, monkeypatch, world, k, rc, n, L, genome, err):
     """a pass whose node moves chain further than the device replay follows is replayed by the sequential statement on rank 0's

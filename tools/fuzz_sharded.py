@@ -22,7 +22,7 @@ for c in range(cases):
     glen = max(L + 1, int(rng.choice([L + 9, 400, 4000, 30000])))
     rc, first_seen = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
     prune = first_seen and L > k and rng.random() < 0.4
-    route = str(rng.choice(["local", "tiles"]))
+    route = str(rng.choice(["local", "tiles", "supermers"]))          # (supermers: by packed key, k = 15..31, else the level-by-level route)
     os.environ["KATOME_DIST_ROUTE"] = route
     if world == 1:
         os.environ["KATOME_FORCE_SHARDED"] = "1"
@@ -32,6 +32,7 @@ for c in range(cases):
     has_n = (reads == ord("N")).any(axis=1)
     clean = reads.copy(); clean[clean == ord("N")] = ord("G")
     what = dict(case=c, world=world, k=k, L=L, n=n, glen=glen, rc=rc, first_seen=first_seen, prune=prune, route=route)
+    print("case", what, file=sys.stderr, flush=True)                 # (a case that never returns is the last one named)
     try:
         g, rb = GpuGraph.create_from_packed(pack_reads_ascii(clean).reshape(-1).copy(), n, L, skip=has_n.astype(np.uint8), reverse_complement=rc,
                                             k=k, n_devices=world, ranks_share_device=True, first_seen_order=first_seen, remove_dead_paths=prune)

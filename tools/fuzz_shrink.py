@@ -1,6 +1,8 @@
-"""Random small builds through shrink (unitig compaction) against the oracle's literal shrink, on the graphs where the
-reference's result does not depend on its traversal order (every vertex reachable from a vertex without incoming edges;
-DESIGN.md section 10).  usage: python tools/fuzz_shrink.py [cases=200] [seed=0]"""
+"""Random small builds through shrink (unitig compaction) against the oracle's literal shrink.  The EXACT form (first-seen-order
+builders; optionally after remove_dead_paths): every array index for index, on ANY graph -- tangles, cycles, parts only the
+traversal's restarts reach.  The traversal-free form: the multiset of merged edges on the graphs where the reference's result does
+not depend on its traversal order (every vertex reachable from a vertex without incoming edges).
+usage: python tools/fuzz_shrink.py [cases=200] [seed=0]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -23,16 +25,28 @@ for c in range(cases):
     err = float(rng.choice([0.0, 0.0, 5e-3, 2e-2]))
     reads = o.synth_reads(int(rng.integers(0, 1000)), n, L, glen, err, 0)
     full = o.build_ascii(reads, k, rc)
-    if not _reaches_everything_from_inputs(full):
+    exact = bool(rng.integers(0, 2))
+    prune = exact and bool(rng.integers(0, 2))
+    if not exact and not _reaches_everything_from_inputs(full):
         continue
     packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
-    b = kd.Builder(k, rc, first_seen_order=bool(rng.integers(0, 2)))
+    b = kd.Builder(k, rc, first_seen_order=exact or bool(rng.integers(0, 2)))
     try:
         b.count_reads(packed, n, L)
         b.finalize()
-        dc = b.shrink()
-        want = o.build_ascii(reads, k, rc, stages="s")
-        ok = (dc.n_nodes, dc.n_edges) == (want.n_nodes, want.n_edges) and _contigs(dc, k) == want.contigs()
+        if prune:
+            b.remove_dead_paths()
+        want = o.build_ascii(reads, k, rc, stages="ds" if prune else "s")
+        if exact and want.n_edges:
+            dc = b.shrink("exact")
+            ok = ((dc.n_nodes, dc.n_edges) == (want.n_nodes, want.n_edges) and dc.edge_src.cpu().tolist() == want.edge_src.tolist()
+                  and dc.edge_dst.cpu().tolist() == want.edge_dst.tolist()
+                  and dc.edge_weight.cpu().numpy().view(np.uint32).tolist() == want.edge_weight.tolist() and dc.sequences() == want.edge_seq)
+        elif exact:
+            ok = True
+        else:
+            dc = b.shrink("fast")
+            ok = (dc.n_nodes, dc.n_edges) == (want.n_nodes, want.n_edges) and _contigs(dc, k) == want.contigs()
     except AssertionError:
         ok = False
     finally:
@@ -40,6 +54,6 @@ for c in range(cases):
     compared += 1
     if not ok:
         bad += 1
-        print("MISMATCH case %d: k=%d L=%d n=%d glen=%d rc=%s err=%g" % (c, k, L, n, glen, rc, err), flush=True)
+        print("MISMATCH case %d: k=%d L=%d n=%d glen=%d rc=%s err=%g exact=%s prune=%s" % (c, k, L, n, glen, rc, err, exact, prune), flush=True)
 print("%d cases, %d compared, %d mismatches" % (cases, compared, bad))
 sys.exit(1 if bad else 0)
