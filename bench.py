@@ -74,6 +74,31 @@ def pmc_traffic(parts, config):
 DEFAULT_BATCH_READS = 16 * 1024 * 1024
 
 
+def lc_phases(reset):
+    """experiment builds of the library (-DKATOME_LC_PHASES, KATOME_LIB=...) add up the shader clocks the LDS counting kernels spend per
+    phase; the shipped library does not export this.  reset=None: is it there?  True: zero it.  False: per-phase shares"""
+    import ctypes as C
+    from katome_amd._lib import lib
+    try:
+        f = lib().katome_debug_lc_phases
+    except AttributeError:
+        return None
+    if reset is None:
+        return True
+    out = (C.c_uint64 * 16)()
+    f.argtypes = [C.POINTER(C.c_uint64)]
+    f(out)
+    if reset:
+        return None
+    names = ["clear", "insert", "read_out_scan", "write"]
+    res = {}
+    for base, kernel in ((0, "lds_count_kernel"), (4, "lds_count_wide_kernel")):
+        tot = sum(out[base:base + 4]) or 1
+        res[kernel] = {n: round(out[base + i] / tot, 3) for i, n in enumerate(names)}
+        res[kernel]["clocks"] = int(tot)
+    return res
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -419,6 +444,7 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    lc_phases(True)
     t0 = time.perf_counter()
     n_edges = n_nodes = 0
     for _ in range(args.steps):
@@ -732,6 +758,7 @@ def main():
             # and the HBM traffic of its kernels from the committed PMC passes
             "roofline_levels": [roof_phase(n) for n in ("insert_tiles", "expand_mid_tiles", "expand_tiles") if kernels.get(n, {}).get("alg_bytes_per_launch", 0) > 0],
             "kernels": kernels, "kernel_launches": kernel_launches, "counts": cnt, "source_id": source_id(),
+            **({"lc_phases": lc_phases(False)} if lc_phases(None) else {}),
         }
         if args.prune:
             line["config"]["pruner"] = "remove_dead_paths after the build (reference order%s)" % (", on the graph gathered to rank 0" if use_dist else "")

@@ -676,6 +676,16 @@ __global__ __launch_bounds__(BLOCK) void list_to_records_hist_kernel(const u64* 
 // threshold), as one contiguous stretch behind a cursor.
 // ---------------------------------------------------------------------------------------------
 constexpr u32 LC_THREADS = 1024;
+// (-DKATOME_LC_PHASES: an experiment build that adds up, per phase of the two counting kernels, the shader clocks thread 0 of every
+// workgroup sees go by -- tools/lc_phases.py reads them through katome_debug_lc_phases; never defined in the shipped library)
+#ifdef KATOME_LC_PHASES
+__device__ unsigned long long lc_phase_cycles[16];
+#define LC_PHASE_BEGIN() unsigned long long lc_t0 = clock64()
+#define LC_PHASE(i) do { if (threadIdx.x == 0) { const unsigned long long lc_t = clock64(); atomicAdd(&lc_phase_cycles[i], lc_t - lc_t0); lc_t0 = lc_t; } } while (0)
+#else
+#define LC_PHASE_BEGIN() do {} while (0)
+#define LC_PHASE(i) do {} while (0)
+#endif
 #ifndef KATOME_LC_LU
 #define KATOME_LC_LU 4          // records in flight per thread in the counting loops
 #endif
@@ -689,6 +699,18 @@ template <int PER> struct LcTable {
     static constexpr u32 FILL = (u32)(SLOTS / 4096.0 * 2900);   // records a sub-round may hold at most on average (all new: load 0.71)
 };
 constexpr u32 LC_MAX_ROUNDS = 32;
+// the probe sequence of the LDS tables: s, s + step, s + 2 step ... (mod SLOTS) with an odd step < 1024 taken from hash bits the slot
+// does not use, coprime to SLOTS = 1024 * PER -- LDS has no lines to stay within, and a full neighbourhood is left at once
+// (-DKATOME_LC_LINEAR: step 1, the rounds 1-3 form, for the A/B)
+template <int PER> KD u32 lc_step(u64 h) {
+#ifdef KATOME_LC_LINEAR
+    return 1u;
+#else
+    u32 step = (u32)((h >> 33) & 0x1FFu) * 2u + 1u;
+    if ((PER & (PER - 1)) != 0 && step % (u32)PER == 0) step += 2;       // (PER = 13, 8: 13 is prime; a step of 13 j + 2 is not a multiple of it)
+    return step;
+#endif
+}
 // the optimistic attempt's patience with a full table (KATOME_LC_PROBE_LIMIT: tests make the first attempt fail with it)
 static u32 lc_probe_limit() {
     static const u32 v = getenv("KATOME_LC_PROBE_LIMIT") ? (u32)std::max(1, atoi(getenv("KATOME_LC_PROBE_LIMIT"))) : 128u;
@@ -739,6 +761,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
     __shared__ unsigned long long base_sh;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 my_distinct = 0;
+    LC_PHASE_BEGIN();
     const u32 n_groups = 1u << gbits, sub_shift = 64 - gbits - 16;     // (the group is the hash's top gbits, the sub-round its next 16)
     for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const u64 lo = index[g], hi = index[g + 1];
@@ -746,6 +769,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
         for (u32 r = 0; r < R; ++r) {
             for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
             __syncthreads();
+            LC_PHASE(0);
             constexpr u32 LU = KATOME_LC_LU;                            // records in flight per thread (the group is re-read from L2 / Infinity Cache)
             for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
                 u64 kv[LU]; u32 wv[LU];
@@ -760,11 +784,12 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                     if (R > 1 && (u32)((((h >> sub_shift) & 0xFFFFull) * R) >> 16) != r) continue;
                     const unsigned long long want = key.w[0] | OCC;
                     u32 s = (u32)(((h & 0x3FFFFFFFull) * LC_SLOTS) >> 30);                         // (bits 0..29: below every sub-round bit)
+                    const u32 step = lc_step<PER>(h);
                     u32 probes = 0;
                     for (; probes < probe_limit; ++probes) {
                         const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
                         if (cur == 0ull || cur == want) { atomicAdd(&lcnt[s], wv[u]); break; }
-                        if (++s == LC_SLOTS) s = 0;
+                        s += step; if (s >= LC_SLOTS) s -= LC_SLOTS;
                     }
                     // (with the guaranteed number of sub-rounds this cannot happen: a sub-round holds fewer records than slots; the
                     // optimistic first attempt -- records_to_edges_sorted -- gives up here and the host counts again)
@@ -772,6 +797,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
                 }
             }
             __syncthreads();
+            LC_PHASE(1);
             // read-out: every thread owns LC_SLOTS / LC_THREADS consecutive slots
 
             Key<1> kk[PER]; u32 cc[PER], ne[PER]; u32 mine = 0;
@@ -801,21 +827,39 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
             if (tid == 0) base_sh = !total ? 0ull : owner_cursor ? atomicAdd(&owner_cursor[core_group_owner(g, n_owners)], (unsigned long long)total)
                                                                : atomicAdd(cursor, (unsigned long long)total);
             __syncthreads();
-            u64 pos = base_sh + woff + (incl - mine);
+            LC_PHASE(2);
+            // the sub-round's edges leave through the table's own LDS (every thread holds its slots in registers by now): a thread's
+            // edges are consecutive, so written straight from the registers a wave's store touched 64 lines, 96 bytes apart (38 % of
+            // the kernel's clocks, profiles/r04_lc_phases.md); staged, the workgroup writes them as one stretch.  (C at a time: a
+            // sub-round of more edges than slots -- a full table of k-mers on both strands -- takes two turns)
+            {
+                unsigned long long* skey = lc_mem;                     // [LC_SLOTS]
+                u32* sw = lcnt;                                         // [LC_SLOTS]
+                const u32 p0 = woff + (incl - mine);
+                for (u32 c0 = 0; c0 < total; c0 += LC_SLOTS) {
+                    u32 p = p0 - c0;                                    // (before the chunk: wraps to a large number, fails the test)
 #pragma unroll
-            for (u32 j = 0; j < PER; ++j) {
-                if (!ne[j]) continue;
-                // (self-complementary k-mer: both strands are one edge.  Written as a shift: as `ne == 1 ? 2 * c : c` hipcc 7.2
-                // lowered the select to a switch on ne whose default arm left the weight register unset for the ne == 2 lanes)
-                const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);
-                if (pos < out_cap) { out_keys[pos] = kk[j].w[0]; out_w[pos] = w; }
-                ++pos;
-                if (ne[j] == 2) {
-                    if (pos < out_cap) { out_keys[pos] = revcomp(kk[j], k).w[0]; out_w[pos] = w; }
-                    ++pos;
+                    for (u32 j = 0; j < PER; ++j) {
+                        if (!ne[j]) continue;
+                        // (self-complementary k-mer: both strands are one edge.  Written as a shift: as `ne == 1 ? 2 * c : c` hipcc 7.2
+                        // lowered the select to a switch on ne whose default arm left the weight register unset for the ne == 2 lanes)
+                        const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);
+                        if (p < LC_SLOTS) { skey[p] = kk[j].w[0]; sw[p] = w; }
+                        ++p;
+                        if (ne[j] == 2) {
+                            if (p < LC_SLOTS) { skey[p] = revcomp(kk[j], k).w[0]; sw[p] = w; }
+                            ++p;
+                        }
+                    }
+                    __syncthreads();
+                    const u32 nc = total - c0 < LC_SLOTS ? total - c0 : LC_SLOTS;
+                    const u64 o0 = base_sh + c0;
+                    for (u32 i = tid; i < nc; i += LC_THREADS)
+                        if (o0 + i < out_cap) { out_keys[o0 + i] = skey[i]; out_w[o0 + i] = sw[i]; }
+                    __syncthreads();
                 }
             }
-            __syncthreads();
+            LC_PHASE(3);
         }
     }
     my_distinct = wave_sum(my_distinct);
@@ -864,6 +908,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
     __shared__ unsigned long long base_sh;
     const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     u32 my_distinct = 0;
+    LC_PHASE_BEGIN();
     const u32 n_groups = 1u << gbits, sub_shift = 64 - gbits - 16;
     for (u32 g = blockIdx.x; g < n_groups; g += gridDim.x) {
         const u64 lo = index[g], hi = index[g + 1];
@@ -872,6 +917,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
         for (u32 r = 0; r < R; ++r) {
             for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
             __syncthreads();
+            LC_PHASE(4);
             constexpr u32 LU = KATOME_LC_LU;                            // records in flight per thread
             for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
               Key<NW> kv[LU]; u32 wv[LU];
@@ -897,6 +943,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                 const unsigned long long want = OCC | (((h >> 5) & ((1ull << 43) - 1)) << 20) | (unsigned long long)(i - lo);
                 const u32 w = wv[u];
                 u32 s = (u32)(((h & 0x3FFFFFFFull) * LC_SLOTS) >> 30);
+                const u32 step = lc_step<PER>(h);
                 u32 probes = 0;
                 for (; probes < probe_limit; ++probes) {
                     const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
@@ -908,12 +955,13 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                         for (int q = 0; q < NW; ++q) mine = mine && keys[j * NW + q] == key.w[q];
                     }
                     if (mine) { atomicAdd(&lcnt[s], w); break; }
-                    if (++s == LC_SLOTS) s = 0;
+                    s += step; if (s >= LC_SLOTS) s -= LC_SLOTS;
                 }
                 if (probes == probe_limit) *err = 3;
               }
             }
             __syncthreads();
+            LC_PHASE(5);
             // (the slots' keys are fetched where they are written, not held across the scan in between: PER keys of NW words were 2 * PER * NW
             // registers -- three-word tiles at PER = 13 spilled to scratch -- and only a k-mer of even length is looked at before that)
             constexpr bool LOOK = RC && EVEN_K;                  // (then the keys are fetched once, here, and kept)
@@ -952,31 +1000,48 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
             for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
             if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
             __syncthreads();
-            u64 pos = base_sh + woff + (incl - mine);
+            LC_PHASE(6);
+            // (out through the table's LDS, SC entries at a time, as lds_count_kernel's: one stretch per workgroup instead of 64 lines per store)
+            {
+                constexpr u32 SC = LC_SLOTS * 12 / (8 * NW + 4);
+                unsigned long long* skey = lc_mem;                     // [SC][NW]
+                u32* sw = reinterpret_cast<u32*>(lc_mem + (size_t)SC * NW);      // [SC]
+                const u32 p0 = woff + (incl - mine);
+                for (u32 c0 = 0; c0 < total; c0 += SC) {
+                    u32 p = p0 - c0;
 #pragma unroll
-            for (u32 j = 0; j < (u32)PER; ++j) {
-                if (!ne[j]) continue;
-                const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);       // (as a shift: see lds_count_kernel)
-                Key<NW> x;
+                    for (u32 j = 0; j < (u32)PER; ++j) {
+                        if (!ne[j]) continue;
+                        const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);       // (as a shift: see lds_count_kernel)
+                        if (p < SC || (ne[j] == 2 && p + 1 < SC)) {
+                            Key<NW> x;
 #pragma unroll
-                for (int q = 0; q < NW; ++q) x.w[q] = LOOK ? kk[LOOK ? j : 0].w[q] : keys[(lo + rp[j]) * NW + q];
-                if (pos < out_cap) {
+                            for (int q = 0; q < NW; ++q) x.w[q] = LOOK ? kk[LOOK ? j : 0].w[q] : keys[(lo + rp[j]) * NW + q];
+                            if (p < SC) {
 #pragma unroll
-                    for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = x.w[q];
-                    out_w[pos] = w;
-                }
-                ++pos;
-                if (ne[j] == 2) {
-                    const Key<NW> rk = revcomp(x, k);
-                    if (pos < out_cap) {
+                                for (int q = 0; q < NW; ++q) skey[p * NW + q] = x.w[q];
+                                sw[p] = w;
+                            }
+                            if (ne[j] == 2 && p + 1 < SC) {
+                                const Key<NW> rk = revcomp(x, k);
 #pragma unroll
-                        for (int q = 0; q < NW; ++q) out_keys[pos * NW + q] = rk.w[q];
-                        out_w[pos] = w;
+                                for (int q = 0; q < NW; ++q) skey[(p + 1) * NW + q] = rk.w[q];
+                                sw[p + 1] = w;
+                            }
+                        }
+                        p += ne[j];
                     }
-                    ++pos;
+                    __syncthreads();
+                    const u32 nc = total - c0 < SC ? total - c0 : SC;
+                    const u64 o0 = base_sh + c0;
+                    const u64 room = o0 < out_cap ? out_cap - o0 : 0;
+                    const u32 nk = (u32)(room < nc ? room : nc);
+                    for (u32 i = tid; i < nk * NW; i += LC_THREADS) out_keys[o0 * NW + i] = skey[i];
+                    for (u32 i = tid; i < nk; i += LC_THREADS) out_w[o0 + i] = sw[i];
+                    __syncthreads();
                 }
             }
-            __syncthreads();
+            LC_PHASE(7);
         }
     }
     my_distinct = wave_sum(my_distinct);
@@ -1927,3 +1992,15 @@ int table_emit_edges(Table& t, uint32_t k, bool rc, uint32_t min_weight, DevBuf&
 }
 
 }  // namespace katome
+
+#ifdef KATOME_LC_PHASES
+// (experiment builds only: the clocks added up per phase -- 0-3 lds_count_kernel's clear / insert / read-out + scan / write, 4-7 the
+// wide kernel's --, and back to zero)
+extern "C" int katome_debug_lc_phases(uint64_t* out16) {
+    unsigned long long h[16];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(katome::lc_phase_cycles), sizeof h) != hipSuccess) return -1;
+    for (int i = 0; i < 16; ++i) out16[i] = h[i];
+    memset(h, 0, sizeof h);
+    return hipMemcpyToSymbol(HIP_SYMBOL(katome::lc_phase_cycles), h, sizeof h) == hipSuccess ? 0 : -1;
+}
+#endif
