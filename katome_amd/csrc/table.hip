@@ -962,29 +962,25 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
             }
             __syncthreads();
             LC_PHASE(5);
-            // (the slots' keys are fetched where they are written, not held across the scan in between: PER keys of NW words were 2 * PER * NW
-            // registers -- three-word tiles at PER = 13 spilled to scratch -- and only a k-mer of even length is looked at before that)
-            constexpr bool LOOK = RC && EVEN_K;                  // (then the keys are fetched once, here, and kept)
+            // (the slots' keys are fetched where they are staged, not held across the scan in between: PER keys of NW words were 2 * PER * NW
+            // registers -- spilled to scratch -- and only a k-mer of even length is looked at before that)
+            constexpr bool LOOK = RC && EVEN_K;                  // (then a slot's key is fetched here too, looked at and let go again)
             u32 rp[PER], cc[PER], ne[PER]; u32 mine = 0;
-            Key<NW> kk[LOOK ? PER : 1];
 #pragma unroll
             for (u32 j = 0; j < (u32)PER; ++j) {
                 const u32 sidx = tid * PER + j;
                 const unsigned long long v = lkey[sidx];
                 ne[j] = 0; cc[j] = 0; rp[j] = 0;
-                if (LOOK) {
-#pragma unroll
-                    for (int q = 0; q < NW; ++q) kk[LOOK ? j : 0].w[q] = 0;
-                }
                 if (v & OCC) {
                     rp[j] = (u32)(v & REP_MASK);
                     cc[j] = lcnt[sidx];
                     ++my_distinct;
                     ne[j] = RC ? 2 : 1;
                     if (LOOK) {
+                        Key<NW> x;
 #pragma unroll
-                        for (int q = 0; q < NW; ++q) kk[LOOK ? j : 0].w[q] = keys[(lo + rp[j]) * NW + q];
-                        if (key_eq(revcomp(kk[LOOK ? j : 0], k), kk[LOOK ? j : 0])) ne[j] = 1;
+                        for (int q = 0; q < NW; ++q) x.w[q] = keys[(lo + rp[j]) * NW + q];
+                        if (key_eq(revcomp(x, k), x)) ne[j] = 1;
                     }
                     if ((cc[j] << ((RC && ne[j] == 1) ? 1u : 0u)) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
                 }
@@ -1016,7 +1012,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                         if (p < SC || (ne[j] == 2 && p + 1 < SC)) {
                             Key<NW> x;
 #pragma unroll
-                            for (int q = 0; q < NW; ++q) x.w[q] = LOOK ? kk[LOOK ? j : 0].w[q] : keys[(lo + rp[j]) * NW + q];
+                            for (int q = 0; q < NW; ++q) x.w[q] = keys[(lo + rp[j]) * NW + q];
                             if (p < SC) {
 #pragma unroll
                                 for (int q = 0; q < NW; ++q) skey[p * NW + q] = x.w[q];
