@@ -92,7 +92,7 @@ def lc_phases(reset):
         return None
     names = ["clear", "insert", "read_out_scan", "write"]
     res = {}
-    for base, kernel in ((0, "lds_count_kernel"), (4, "lds_count_wide_kernel")):
+    for base, kernel in ((0, "lds_count_kernel"), (4, "lds_count_wide_kernel"), (8, "lds_count_packed_kernel")):
         tot = sum(out[base:base + 4]) or 1
         res[kernel] = {n: round(out[base + i] / tot, 3) for i, n in enumerate(names)}
         res[kernel]["clocks"] = int(tot)

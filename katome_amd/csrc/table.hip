@@ -866,6 +866,149 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
     if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
 }
 
+// One-word k-mers, ONE visit per record: the hash that cuts the groups is a bijection of the key (mix64 = murmur3's finalizer), so
+// inside group g a key IS the low 48 bits of its hash -- and a slot of 8 bytes holds them with a 16-bit count: 19456 slots where the
+// 12-byte slots of lds_count_kernel are 13312, which takes C3's groups (22 k records of 12.3 k k-mers) in one round at load 0.63
+// instead of two at 0.46 -- every record loaded, hashed and tested once, one table cleared and read out per group.  A record reads
+// its slot first (most probes end there: a plain 8-byte read), claims an empty one with a compare-and-swap of remainder | count, or
+// adds its count to the slot that holds its remainder; the read-out inverts the hash.  A count that does not fit 16 bits (or a
+// record that brings one) sets err 5 and the caller counts with lds_count_kernel; a full table err 3, as there.  Both strands: odd k
+// only (the caller keeps even k, where a k-mer can be its own reverse complement, with lds_count_kernel).
+constexpr u32 LP_PER = 19;
+constexpr u32 LP_SLOTS = LC_THREADS * LP_PER;                    // 19456 x 8 B = 152 KiB
+constexpr u32 LP_STAGE = LP_SLOTS * 8 / 12;                      // edges (8 B + 4 B) the same LDS stages at a time
+KD u64 unmix64(u64 x) {                                          // mix64's inverse (a xor-shift by 33 undoes itself; the multipliers' inverses mod 2^64)
+    x ^= x >> 33; x *= 0x9cb4b2f8129337dbull;
+    x ^= x >> 33; x *= 0x4f74430c22a54005ull;
+    x ^= x >> 33;
+    return x;
+}
+template <bool RC>
+__global__ __launch_bounds__(LC_THREADS) void lds_count_packed_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 R, u32 k,
+                                                                       u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap, unsigned long long* cursor,
+                                                                       unsigned long long* distinct, u32* err, u32 probe_limit) {
+    constexpr unsigned long long REM = (1ull << 48) - 1;
+    extern __shared__ unsigned long long lc_mem[];
+    unsigned long long* slot = lc_mem;                                   // [LP_SLOTS]: remainder << 16 | count; 0 = empty
+    __shared__ u32 wtot[LC_THREADS / 64];
+    __shared__ unsigned long long base_sh;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 my_distinct = 0;
+    LC_PHASE_BEGIN();
+    for (u32 g = blockIdx.x; g < (1u << 16); g += gridDim.x) {
+        const u64 lo = index[g], hi = index[g + 1];
+        if (lo == hi) continue;
+        for (u32 r = 0; r < R; ++r) {
+            for (u32 i = tid; i < LP_SLOTS; i += LC_THREADS) slot[i] = 0ull;
+            __syncthreads();
+            LC_PHASE(8);
+            // A wave runs as many probe steps as its slowest lane needs -- at this load ~6 with one slot per step -- and the instructions
+            // of a step, not its waits, are what the insert phase costs (issuing a turn's swaps and adds together so that their LDS
+            // round trips overlap made it slower: 17.7 ms against 13.8, profiles/r04_lc_phases.md).  So a step looks at FOUR slots:
+            // two 16-byte buckets of two slots, one 16-byte read each, at b and b + step of the record's sequence of buckets.  A
+            // record adds to the slot that holds its remainder, else claims the first empty one of the four in sequence order (slots
+            // never empty again, so its remainder cannot sit behind an empty slot), else steps on -- a lane rarely needs a second step.
+            constexpr u32 LU = KATOME_LC_LU;
+            constexpr u32 NB = LP_SLOTS / 2;                                      // buckets: 9728 = 2^9 * 19
+            for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
+                u64 kv[LU]; u32 wv[LU];
+#pragma unroll
+                for (u32 u = 0; u < LU; ++u) { const u64 i = i0 + (u64)u * LC_THREADS; kv[u] = 0; wv[u] = 0; if (i < hi) { kv[u] = keys[i]; wv[u] = wts[i]; } }
+#pragma unroll
+                for (u32 u = 0; u < LU; ++u) {
+                    const u64 i = i0 + (u64)u * LC_THREADS;
+                    if (i >= hi) continue;
+                    const u64 h = mix64(kv[u]);
+                    if (R > 1 && (u32)((((h >> 32) & 0xFFFFull) * R) >> 16) != r) continue;
+                    const u32 w = wv[u];
+                    if (w == 0u || w > 0xFFFFu) { *err = 5; continue; }
+                    const unsigned long long rem = h & REM, mine = (rem << 16) | w;
+                    u32 b0 = (u32)(((h & 0x3FFFFFFFull) * NB) >> 30);
+                    const u32 step = lc_step<LP_PER>(h);                            // (odd, no multiple of 19: coprime to NB)
+                    u32 probes = 0;
+                    for (; probes < probe_limit; ++probes) {
+                        u32 b1 = b0 + step; if (b1 >= NB) b1 -= NB;
+                        const ulonglong2 x = *reinterpret_cast<const ulonglong2*>(slot + 2 * b0), y = *reinterpret_cast<const ulonglong2*>(slot + 2 * b1);
+                        const unsigned long long c[4] = {x.x, x.y, y.x, y.y};
+                        u32 at = ~0u; bool have = false;                            // the slot to add to / to claim
+#pragma unroll
+                        for (int j = 3; j >= 0; --j) if ((c[j] >> 16) == rem && c[j] != 0ull) { at = (j < 2 ? 2 * b0 : 2 * b1 - 2) + j; have = true; }
+                        if (!have) {
+#pragma unroll
+                            for (int j = 3; j >= 0; --j) if (c[j] == 0ull) at = (j < 2 ? 2 * b0 : 2 * b1 - 2) + j;
+                            if (at == ~0u) { b0 = b1 + step; if (b0 >= NB) b0 -= NB; continue; }      // four slots of other k-mers: on
+                            const unsigned long long cur = atomicCAS(&slot[at], 0ull, mine);
+                            if (cur == 0ull) break;                                // claimed: remainder and count are in
+                            if ((cur >> 16) != rem) continue;                      // (somebody else's k-mer got there first: look at the four again)
+                        }
+                        const unsigned long long old = atomicAdd(&slot[at], (unsigned long long)w);
+                        if ((old & 0xFFFFull) + w > 0xFFFFull) *err = 5;              // (the carry went into the remainder: nothing of this attempt is used)
+                        break;
+                    }
+                    if (probes == probe_limit) *err = 3;
+                }
+            }
+            __syncthreads();
+            LC_PHASE(9);
+            // read-out: every thread LP_PER consecutive slots, their k-mers (the hash inverted) and counts in registers -- the staging
+            // below overwrites the table.  Staged is ONE entry per k-mer; with both strands the writer makes two edges of it (thread o
+            // takes entry o / 2 and, odd, its reverse complement): k is odd here, no k-mer is its own reverse complement
+            Key<1> kk[LP_PER]; u32 cc[LP_PER]; u32 keep = 0;
+#pragma unroll
+            for (u32 j = 0; j < LP_PER; ++j) {
+                const unsigned long long v = slot[tid * LP_PER + j];
+                kk[j].w[0] = 0; cc[j] = 0;
+                if (v) {
+                    ++my_distinct;
+                    cc[j] = (u32)v & 0xFFFFu;
+                    kk[j].w[0] = unmix64(((u64)g << 48) | (v >> 16));
+                    if (cc[j] >= min_weight) keep |= 1u << j;                       // Clean::remove_weak_edges (pruner.rs:89-92)
+                }
+            }
+            const u32 mine = (u32)__popc(keep);
+            u32 incl = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+            if (lane == 63) wtot[wave] = incl;
+            __syncthreads();
+            u32 woff = 0, total = 0;
+#pragma unroll
+            for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+            constexpr u32 F = RC ? 2 : 1;                                            // edges per k-mer
+            if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total * F) : 0ull;
+            __syncthreads();
+            LC_PHASE(10);
+            {
+                unsigned long long* skey = lc_mem;                                  // [LP_STAGE]
+                u32* sw = reinterpret_cast<u32*>(lc_mem + LP_STAGE);                 // [LP_STAGE]
+                const u32 p0 = woff + (incl - mine);
+                for (u32 c0 = 0; c0 < total; c0 += LP_STAGE) {
+                    u32 p = p0 - c0;                                                 // (before the chunk: wraps to a large number, fails the test)
+#pragma unroll
+                    for (u32 j = 0; j < LP_PER; ++j) {
+                        if (!((keep >> j) & 1u)) continue;
+                        if (p < LP_STAGE) { skey[p] = kk[j].w[0]; sw[p] = cc[j]; }
+                        ++p;
+                    }
+                    __syncthreads();
+                    const u32 nc = total - c0 < LP_STAGE ? total - c0 : LP_STAGE;
+                    const u64 o0 = base_sh + (u64)c0 * F;
+                    for (u32 o = tid; o < nc * F; o += LC_THREADS) {
+                        const u32 e = RC ? o >> 1 : o;
+                        Key<1> x; x.w[0] = skey[e];
+                        if (RC && (o & 1u)) x = revcomp(x, k);
+                        if (o0 + o < out_cap) { out_keys[o0 + o] = x.w[0]; out_w[o0 + o] = sw[e]; }
+                    }
+                    __syncthreads();
+                }
+            }
+            LC_PHASE(11);
+        }
+    }
+    my_distinct = wave_sum(my_distinct);
+    if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
+}
+
 // group boundaries when the records are ordered by the hash of their core (dev_hash_order_core), and the owners' first positions:
 // owner p's groups are [ceil(p * 2^gbits / n), ceil((p + 1) * 2^gbits / n))
 __global__ __launch_bounds__(BLOCK) void core_group_index_kernel(const u64* __restrict__ keys, u64 n, u32 gbits, u32 core_shift, u32 core_bases,
@@ -1928,10 +2071,35 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         KCHECK_HIP(hipStreamSynchronize(stream));
         return KATOME_OK;
     };
+    const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / fill));
+    // One-word k-mers whose groups would take several visits: 8-byte slots, one visit (lds_count_packed_kernel), sized on the guess that
+    // 56 % of a group's records are distinct (C3: 0.56; more and the table fills: err 3, then as before).  KATOME_LC_PACKED=0: never
+    static const int packed_mode = getenv("KATOME_LC_PACKED") ? atoi(getenv("KATOME_LC_PACKED")) : 1;      // (2: whenever the keys allow -- tests)
+    if (nw == 1 && !split && !unit && gbits == 16 && (R_try > 1 || packed_mode == 2) && !(rc && (k & 1) == 0)) {
+        const u32 R_p = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * 0.56 / (LP_SLOTS * 0.66)));
+        if (packed_mode == 2 || (packed_mode && R_p < R_try)) {
+            KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+            const size_t lds = (size_t)LP_SLOTS * 8;
+#define KATOME_LP_LAUNCH(RCV)                                                                                                           \
+            do {                                                                                                                      \
+                KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_packed_kernel<RCV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                KernelScope ks(K_LDS_COUNT, stream, n);                                                                               \
+                hipLaunchKernelGGL((lds_count_packed_kernel<RCV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), R_p, k,  \
+                                   min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), out_cap, cursor, distinct, err, std::min<u32>(lc_probe_limit(), LP_SLOTS)); \
+            } while (0)
+            if (!rc) KATOME_LP_LAUNCH(false); else KATOME_LP_LAUNCH(true);
+#undef KATOME_LP_LAUNCH
+            KCHECK_HIP(hipGetLastError());
+            KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipStreamSynchronize(stream));
+            if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] 8-byte slots, %u visit(s) per record: code %u\n", R_p, (unsigned)h[2]);
+            if ((uint32_t)h[2] == 0) { *n_edges = h[0]; *n_distinct = h[1]; return KATOME_OK; }
+            if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] 8-byte slots: %s; counting with the 12-byte slots\n", (uint32_t)h[2] == 5 ? "a count beyond 16 bits" : "a table filled");
+        }
+    }
     // First with fewer sub-rounds than would hold a group of DISTINCT records: the k-mers of reads repeat (C3: 1.8 records per
     // k-mer at this level), so the table is half empty at the guaranteed number.  An attempt that fills its table gives up after
     // lc_probe_limit() = 128 probes (err 3, nothing it wrote is used) and the guaranteed number runs.
-    const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / fill));
     if (R_try < R) { KCHECK(count(R_try, lc_probe_limit())); if ((uint32_t)h[2] == 3) { lc_trace("packed key", R_try, R); KCHECK(count(R, ~0u)); } }
     else KCHECK(count(R, ~0u));
     if ((uint32_t)h[2] == 4) return KATOME_E_UNSUPPORTED;          // (a group too large for the representative's 20 bits: the caller counts in the table)

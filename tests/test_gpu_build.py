@@ -839,8 +839,53 @@ def test_round_one_paths_give_the_same_arrays(tmp_path):
                   {"KATOME_SORTED_COUNT": "2", "KATOME_MID_SPAN": "10"},
                   # the first partition pass of a level counts its digits itself instead of the records kernel on the way; the passes'
                   # tiles in plain order
-                  {"KATOME_SORTED_COUNT": "2", "KATOME_FUSED_HIST": "0"}, {"KATOME_SORTED_COUNT": "2", "KATOME_XCD_TILES": "0"}):
+                  {"KATOME_SORTED_COUNT": "2", "KATOME_FUSED_HIST": "0"}, {"KATOME_SORTED_COUNT": "2", "KATOME_XCD_TILES": "0"},
+                  # the k-mers counted in 8-byte LDS slots, one visit per record (table.hip lds_count_packed_kernel; by default only
+                  # where a group would take two visits), and never
+                  {"KATOME_SORTED_COUNT": "2", "KATOME_LC_PACKED": "2"}, {"KATOME_SORTED_COUNT": "2", "KATOME_LC_PACKED": "0"}):
         assert run(extra) == want, extra
+
+
+_PACKED_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+for k, rc, L, n, many in ((31, True, 150, 4000, 0), (31, False, 100, 3000, 0), (21, True, 60, 5000, 0), (16, False, 40, 3000, 0), (31, True, 40, 2000, 70000),
+                          (30, False, 64, 2500, 0), (30, True, 64, 2500, 0)):
+    reads = o.synth_reads(k + n, n, L, 20000, 2e-3, 0)
+    if many:                                   # one read `many` times: a k-mer whose count does not fit the slot's 16 bits
+        reads = np.concatenate([reads, np.repeat(reads[:1], many, axis=0)])
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc)
+    b.count_reads(packed, len(reads), L, None, first_read=0)
+    dg = b.finalize()
+    ref = o.build_ascii(reads, k, rc)
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    got = sorted((bytes(r), int(w)) for r, w in zip(lab, dg.edge_weight.cpu().numpy().view(np.uint32)))
+    want = sorted((bytes(r), int(w)) for r, w in zip(ref.edge_label, ref.edge_weight))
+    print("PACKED", k, int(rc), many, int((dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges) and got == want), max(w for _, w in want))
+    b.close()
+"""
+
+
+def test_kmers_counted_in_eight_byte_lds_slots(tmp_path):
+    """lds_count_packed_kernel (table.hip): the k-mer level's records counted in one visit -- a slot is the low 48 bits of the k-mer's
+    (bijective) hash and a 16-bit count, the read-out inverts the hash.  Forced at small sizes (KATOME_LC_PACKED=2) against the
+    oracle: both strand modes, k with one-word keys, a k-mer seen 70 001 times (the count does not fit: the library says so under
+    KATOME_LC_TRACE and counts with the 12-byte slots), and even k with both strands, which stays with the 12-byte slots"""
+    import subprocess
+    script = tmp_path / "packed.py"
+    script.write_text(_PACKED_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KATOME_SORTED_COUNT="2", KATOME_LC_PACKED="2", KATOME_LC_TRACE="1")
+    out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rows = [line.split() for line in out.stdout.splitlines() if line.startswith("PACKED ")]
+    assert len(rows) == 7 and all(r[4] == "1" for r in rows), rows
+    assert out.stderr.count("8-byte slots, 1 visit(s) per record: code 0") >= 5, out.stderr[-800:]        # (levels of one-word tiles take them too)
+    assert out.stderr.count("a count beyond 16 bits") == 1 and int(rows[4][5]) > 0xFFFF, out.stderr[-800:]
 
 
 _KEPT_SCRIPT = r"""
