@@ -1061,21 +1061,26 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
             for (u32 i = tid; i < LC_SLOTS; i += LC_THREADS) { lkey[i] = 0ull; lcnt[i] = 0u; }
             __syncthreads();
             LC_PHASE(4);
-            constexpr u32 LU = KATOME_LC_LU;                            // records in flight per thread
+            constexpr u32 LU = KATOME_LC_LU;                            // records per thread and turn
+            Key<NW> kv[LU]; u32 wv[LU];
+            auto fetch = [&](u64 i0, Key<NW>* kk, u32* ww) {
+#pragma unroll
+                for (u32 u = 0; u < LU; ++u) {
+                    const u64 i = i0 + (u64)u * LC_THREADS;
+                    ww[u] = 0;
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) kk[u].w[q] = 0;
+                    if (i < hi) {
+#pragma unroll
+                        for (int q = 0; q < NW; ++q) kk[u].w[q] = keys[i * NW + q];
+                        ww[u] = wts ? wts[i] : 1u;         // (no weights: every record counts once -- a level's records straight from the reads)
+                    }
+                }
+            };
+            fetch(lo + tid, kv, wv);
             for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
-              Key<NW> kv[LU]; u32 wv[LU];
-#pragma unroll
-              for (u32 u = 0; u < LU; ++u) {
-                  const u64 i = i0 + (u64)u * LC_THREADS;
-                  wv[u] = 0;
-#pragma unroll
-                  for (int q = 0; q < NW; ++q) kv[u].w[q] = 0;
-                  if (i < hi) {
-#pragma unroll
-                      for (int q = 0; q < NW; ++q) kv[u].w[q] = keys[i * NW + q];
-                      wv[u] = wts ? wts[i] : 1u;         // (no weights: every record counts once -- a level's records straight from the reads)
-                  }
-              }
+              Key<NW> kn[LU]; u32 wn[LU];
+              fetch(i0 + (u64)LC_THREADS * LU, kn, wn);                 // the next turn's records are on their way while this turn's are counted (19.2 -> 18.4 ms at C3)
 #pragma unroll
               for (u32 u = 0; u < LU; ++u) {
                 const u64 i = i0 + (u64)u * LC_THREADS;
@@ -1102,6 +1107,8 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                 }
                 if (probes == probe_limit) *err = 3;
               }
+#pragma unroll
+              for (u32 u = 0; u < LU; ++u) { kv[u] = kn[u]; wv[u] = wn[u]; }
             }
             __syncthreads();
             LC_PHASE(5);
@@ -1401,6 +1408,7 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
                 const unsigned long long want = NWK == 1 ? (OCC | key.w[0]) : (OCC | (((h >> 5) & ((1ull << 43) - 1)) << 20) | (unsigned long long)(i - lo));
                 const u32 w = wv[u];
                 u32 s = (u32)(((h & 0x3FFFFFFFull) * SLOTS) >> 30);
+                const u32 step = lc_step<LCS_PER>(h);
                 u32 probes = 0;
                 for (; probes < probe_limit; ++probes) {
                     const unsigned long long cur = atomicCAS(&lkey[s], 0ull, want);
@@ -1417,20 +1425,22 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
                         if (RC) atomicMin(&lB[s], (tag >> 32) << 16 | (tag & 0xFFFFull));
                         break;
                     }
-                    if (++s == SLOTS) s = 0;
+                    s += step; if (s >= SLOTS) s -= SLOTS;
                 }
                 if (probes == probe_limit) *err = 3;
               }
             }
             __syncthreads();
-            Key<NWK> kk[LCS_PER]; u32 ne[LCS_PER]; u32 mine = 0;
+            // (a slot's numbers and count are read out with its key: the staging below overwrites the table)
+            Key<NWK> kk[LCS_PER]; u32 ne[LCS_PER]; unsigned long long sa[LCS_PER], sb[LCS_PER]; u32 sc[LCS_PER]; u32 mine = 0;
 #pragma unroll
             for (u32 j = 0; j < (u32)LCS_PER; ++j) {
                 const unsigned long long v = lkey[tid * LCS_PER + j];
-                ne[j] = 0;
+                ne[j] = 0; sa[j] = 0; sb[j] = 0; sc[j] = 0;
 #pragma unroll
                 for (int q = 0; q < NWK; ++q) kk[j].w[q] = 0;
                 if (v & OCC) {
+                    sa[j] = lA[tid * LCS_PER + j]; sb[j] = lB[tid * LCS_PER + j]; sc[j] = lcnt[tid * LCS_PER + j];
                     ++my_distinct;
                     if (NWK == 1) kk[j].w[0] = v & KEYBITS;
                     else {
@@ -1452,46 +1462,68 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_seen_kernel(const u64* r
             for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
             if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
             __syncthreads();
-            u64 pos = base_sh + woff + (incl - mine);
+            // out through the table's LDS, one stretch per workgroup (as lds_count_kernel's: a thread's entries are consecutive, so written
+            // from the registers a wave's store touched 64 lines).  An entry: KW key words (+ the packed numbers of a list entry) and PW
+            // words of payload -- a list entry's count, or an edge's {sequence number, count}; SC entries at a time
+            {
+                constexpr u32 KW = LIST ? STRIDE : NWK;
+                constexpr u32 ENTRY = KW * 8 + (LIST ? 4 : 16);
+                constexpr u32 SC = SLOTS * 28 / ENTRY;
+                unsigned long long* skey = lcs_mem;                                 // [SC][KW]
+                unsigned long long* spair = lcs_mem + (size_t)SC * KW;               // edges: [SC][2]
+                u32* scount = reinterpret_cast<u32*>(spair);                        // list: [SC]
+                const u32 p0 = woff + (incl - mine);
+                for (u32 c0 = 0; c0 < total; c0 += SC) {
+                    u32 p = p0 - c0;                                                 // (before the chunk: wraps to a large number, fails the tests)
 #pragma unroll
-            for (u32 j = 0; j < (u32)LCS_PER; ++j) {
-                if (!ne[j]) continue;
-                const u32 sidx = tid * LCS_PER + j;
-                const unsigned long long a = lA[sidx], b = lB[sidx];
-                const u64 seq_a = (a >> 16) * seq_per_read + (a & 0xFFFFull), seq_b = (b >> 16) * seq_per_read + (b & 0xFFFFull);
-                const u32 c = lcnt[sidx];
-                if (LIST) {
-                    if (pos < out_cap) {
+                    for (u32 j = 0; j < (u32)LCS_PER; ++j) {
+                        if (!ne[j]) continue;
+                        const unsigned long long a = sa[j], b = sb[j];
+                        const u64 seq_a = (a >> 16) * seq_per_read + (a & 0xFFFFull), seq_b = (b >> 16) * seq_per_read + (b & 0xFFFFull);
+                        const u32 c = sc[j];
+                        if (LIST) {
+                            if (p < SC) {
 #pragma unroll
-                        for (int q = 0; q < NWK; ++q) out_keys[pos * STRIDE + q] = kk[j].w[q];
-                        if (RC && (a >> 16) != (b >> 16)) *err = 6;              // (the two numbers of a tile from two reads: cannot be)
-                        out_keys[pos * STRIDE + NWK] = seen_pack(a >> 16, (u32)(a & 0xFFFFull), RC ? (u32)(b & 0xFFFFull) : 0u);
-                        reinterpret_cast<u32*>(out_pairs)[pos] = c;
+                                for (int q = 0; q < NWK; ++q) skey[(size_t)p * KW + q] = kk[j].w[q];
+                                if (RC && (a >> 16) != (b >> 16)) *err = 6;              // (the two numbers of a tile from two reads: cannot be)
+                                skey[(size_t)p * KW + NWK] = seen_pack(a >> 16, (u32)(a & 0xFFFFull), RC ? (u32)(b & 0xFFFFull) : 0u);
+                                scount[p] = c;
+                            }
+                        } else if (ne[j] == 2) {
+                            if (p < SC) {
+#pragma unroll
+                                for (int q = 0; q < NWK; ++q) skey[(size_t)p * KW + q] = kk[j].w[q];
+                                spair[2 * (size_t)p] = seq_a; spair[2 * (size_t)p + 1] = c;
+                            }
+                            if (p + 1 < SC) {
+                                const Key<NWK> rk = revcomp(kk[j], k);
+#pragma unroll
+                                for (int q = 0; q < NWK; ++q) skey[(size_t)(p + 1) * KW + q] = rk.w[q];
+                                spair[2 * (size_t)(p + 1)] = seq_b; spair[2 * (size_t)(p + 1) + 1] = c;
+                            }
+                        } else {
+                            // one edge: no reverse complements in this build, or a k-mer that is its own (added twice per window: both numbers
+                            // are insertions of this edge)
+                            if (p < SC) {
+#pragma unroll
+                                for (int q = 0; q < NWK; ++q) skey[(size_t)p * KW + q] = kk[j].w[q];
+                                spair[2 * (size_t)p] = RC ? (seq_a < seq_b ? seq_a : seq_b) : seq_a;
+                                spair[2 * (size_t)p + 1] = RC ? (u64)(c << 1) : (u64)c;
+                            }
+                        }
+                        p += ne[j];
                     }
-                    ++pos;
-                } else
-                if (ne[j] == 2) {
-                    if (pos + 1 < out_cap) {
-                        const Key<NWK> rk = revcomp(kk[j], k);
-#pragma unroll
-                        for (int q = 0; q < NWK; ++q) { out_keys[pos * NWK + q] = kk[j].w[q]; out_keys[(pos + 1) * NWK + q] = rk.w[q]; }
-                        out_pairs[2 * pos] = seq_a; out_pairs[2 * pos + 1] = c;
-                        out_pairs[2 * pos + 2] = seq_b; out_pairs[2 * pos + 3] = c;
-                    }
-                    pos += 2;
-                } else {
-                    // one edge: no reverse complements in this build, or a k-mer that is its own (added twice per window: both numbers
-                    // are insertions of this edge)
-                    if (pos < out_cap) {
-#pragma unroll
-                        for (int q = 0; q < NWK; ++q) out_keys[pos * NWK + q] = kk[j].w[q];
-                        out_pairs[2 * pos] = RC ? (seq_a < seq_b ? seq_a : seq_b) : seq_a;
-                        out_pairs[2 * pos + 1] = RC ? (u64)(c << 1) : (u64)c;
-                    }
-                    ++pos;
+                    __syncthreads();
+                    const u32 nc = total - c0 < SC ? total - c0 : SC;
+                    const u64 o0 = base_sh + c0;
+                    const u64 room = o0 < out_cap ? out_cap - o0 : 0;
+                    const u32 nk = (u32)(room < nc ? room : nc);
+                    for (u32 i = tid; i < nk * KW; i += LC_THREADS) out_keys[o0 * KW + i] = skey[i];
+                    if (LIST) { for (u32 i = tid; i < nk; i += LC_THREADS) reinterpret_cast<u32*>(out_pairs)[o0 + i] = scount[i]; }
+                    else      { for (u32 i = tid; i < nk * 2; i += LC_THREADS) out_pairs[o0 * 2 + i] = spair[i]; }
+                    __syncthreads();
                 }
             }
-            __syncthreads();
         }
     }
     my_distinct = wave_sum(my_distinct);
