@@ -15,6 +15,7 @@ Reads shard by index; records are routed to their owner ranks by RCCL all-to-all
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -611,6 +612,14 @@ def main():
                                                            if sorted_tiles else "void tiles_to_records_kernel<%d, %d, %s>") % (last_nw, nw, rcs),
                                "hash_group_index_kernel": "void hash_group_index_kernel<%d, %d>" % (nw, nw),
                                "lds_count_kernel": ("void lds_count_kernel<%s, %d, %s>" % (rcs, per, even_s)) if nw == 1 else ("void lds_count_wide_kernel<%s, %d, %d, %s>" % (rcs, per, nw, even_s))})
+                # (table.hip, records_to_edges_sorted: one-word k-mers whose groups would take two visits in 12-byte slots are counted in 8-byte
+                # slots, one visit -- unless k is even and both strands are counted)
+                avg_rec = n_rec >> 16
+                fill_rec = 5800 if per == 8 else 9425
+                r_try = max(1, math.ceil(avg_rec * float(os.environ.get("KATOME_LC_OPTIMISM", "0.75")) / fill_rec))
+                r_packed = max(1, math.ceil(avg_rec * 0.56 / (19456 * 0.66)))
+                if nw == 1 and even_s == "false" and os.environ.get("KATOME_LC_PACKED", "1") != "0" and r_try > 1 and r_packed < r_try:
+                    kexact["lds_count_kernel"] = "void lds_count_packed_kernel<%s>" % rcs
             if sorted_last_level and cnt.get("mid_span") and not cnt.get("mid_tile_slots") and nwt == _katome_lib().katome_tile_words(wl.k, cnt["mid_span"]):
                 # the tile levels counted by sorting: the same kernels on tile records (two-word keys, 20 bytes) -- the mid tiles'
                 # (cut out of the big-tile table, or out of the list of big tiles) and, without a tile table, the big tiles' as well
