@@ -111,6 +111,7 @@ def parse_args():
                     help="with --reads: keep this genome length instead of scaling it with the reads (a rank's share of a bigger job)")
     ap.add_argument("--batch-reads", type=int, default=DEFAULT_BATCH_READS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-c2", action="store_true", help="skip the second CPU line: BASELINE configs[1] (1 M reads) in full on one core and on the GPU")
     ap.add_argument("--first-seen-order", action="store_true",
                     help="number edges and nodes in the reference's first-seen (petgraph) order (single GPU)")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU driver even with one rank (testing)")
@@ -326,6 +327,49 @@ def cpu_baseline(wl, sample_reads):
             "distinct_edges_per_s": g.n_edges / dt,
             # the graph the CPU build holds at its peak (resident-set high-water mark minus what the process held before)
             "peak_rss_mib": round((hwm - rss0) / 1024.0, 1) if hwm is not None and rss0 is not None else None}
+
+
+def c2_in_full(torch):
+    """BASELINE.json configs[1] as a whole -- 1 M synthetic 150-bp reads, k = 31, both strands -- on one host core (the oracle) and on the
+    GPU (the same reads, generated on the device by the same generator), with the parity the config asks for: the same node and edge
+    counts, the same sum of weights, the same multiset of (label, weight)"""
+    import numpy as np
+    from katome_amd import device as kd
+    from katome_amd.workloads import WORKLOADS
+    from oracle import oracle as o
+    wl = WORKLOADS["c2"]
+    reads = o.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, wl.n_inject_percent)
+    t0 = time.perf_counter()
+    g = o.build_ascii(reads, wl.k, wl.reverse_complement)
+    cpu_s = time.perf_counter() - t0
+    accepted = g.read_bytes // wl.read_len
+    packed, skip = kd.synth_reads(0, wl.reads, wl.read_len, wl.genome_len, wl.err_rate, wl.n_inject_percent)
+
+    def build():
+        b = kd.Builder(wl.k, wl.reverse_complement, device=packed.device.index)
+        b.count_reads(packed, wl.reads, wl.read_len, skip, first_read=0)
+        return b, b.finalize()
+    b, dg = build()
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    wts = dg.edge_weight.cpu().numpy().view(np.uint32)
+    same = (dg.n_nodes, dg.n_edges) == (g.n_nodes, g.n_edges) and int(wts.astype(np.uint64).sum()) == int(g.edge_weight.astype(np.uint64).sum())
+    if same:          # the multiset, as rows of (label bytes, weight) in sorted order
+        mine = np.concatenate([lab, wts.view(np.uint8).reshape(-1, 4)], axis=1)
+        ref = np.concatenate([g.edge_label.reshape(g.n_edges, -1), g.edge_weight.astype(np.uint32).view(np.uint8).reshape(-1, 4)], axis=1)
+        order = lambda a: a[np.lexsort(a.T[::-1])]
+        same = bool(np.array_equal(order(mine), order(ref)))
+    b.close()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        b, dg = build()
+        b.close()
+    torch.cuda.synchronize()
+    gpu_ms = (time.perf_counter() - t0) * 1e3 / 5
+    kmers = accepted * wl.windows_per_read
+    return {"what": "BASELINE configs[1] in full: %d reads of %d bp, k=%d, rc=%s" % (wl.reads, wl.read_len, wl.k, wl.reverse_complement),
+            "cpu_s": cpu_s, "cpu_kmers_per_s": kmers / cpu_s, "cores": 1, "kind": "port", "gpu_ms": gpu_ms, "gpu_kmers_per_s": kmers / (gpu_ms * 1e-3),
+            "edges": int(g.n_edges), "nodes": int(g.n_nodes), "same_multiset": same}
 
 
 def run_as_parent(args):
@@ -789,6 +833,11 @@ def main():
             line["config"]["comm_ranks"] = comm.world          # (the communicator's own rank count: RCCL saw this many ranks)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(wl, args.cpu_sample_reads)
+            if not args.no_cpu_c2:
+                try:
+                    line["cpu_baseline_c2"] = c2_in_full(torch)
+                except Exception as e:   # noqa: BLE001  (a side line: never the reason the bench line is missing)
+                    line["cpu_baseline_c2"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         if world == 1 and not use_dist and not args.no_extras:
             # Beside the headline (not `value`): the build in the reference's own numbering -- what INTEGRATION.md's GpuGIR binds
             # (flags: 1) --, the build of a caller that passes no table hint, and the end-to-end region incl. H2D/D2H
