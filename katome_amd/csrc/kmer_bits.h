@@ -44,6 +44,15 @@ KD u64 mix64(u64 x) {
     x ^= x >> 33;
     return x;
 }
+// mix64 is a bijection of the 64-bit words (murmur3's finalizer): a xor-shift by 33 undoes itself, the multipliers have inverses mod 2^64.
+// table.hip's lds_count_packed_kernel stores a one-word k-mer as the low bits of its hash and gets it back with this
+// (tests/test_kmer_bits_host.py: unmix64(mix64(x)) == x)
+KD u64 unmix64(u64 x) {
+    x ^= x >> 33; x *= 0x9cb4b2f8129337dbull;
+    x ^= x >> 33; x *= 0x4f74430c22a54005ull;
+    x ^= x >> 33;
+    return x;
+}
 KD u64 hash_key(const Key<1>& k) { return mix64(k.w[0]); }
 KD u64 hash_key(const Key<2>& k) { return mix64(k.w[1] ^ mix64(k.w[0] + 0x9E3779B97F4A7C15ull)); }
 KD u64 hash_key(const Key<3>& k) { return mix64(k.w[2] ^ mix64(k.w[1] ^ mix64(k.w[0] + 0x9E3779B97F4A7C15ull))); }

@@ -877,12 +877,6 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_kernel(const u64* keys, 
 constexpr u32 LP_PER = 19;
 constexpr u32 LP_SLOTS = LC_THREADS * LP_PER;                    // 19456 x 8 B = 152 KiB
 constexpr u32 LP_STAGE = LP_SLOTS * 8 / 12;                      // edges (8 B + 4 B) the same LDS stages at a time
-KD u64 unmix64(u64 x) {                                          // mix64's inverse (a xor-shift by 33 undoes itself; the multipliers' inverses mod 2^64)
-    x ^= x >> 33; x *= 0x9cb4b2f8129337dbull;
-    x ^= x >> 33; x *= 0x4f74430c22a54005ull;
-    x ^= x >> 33;
-    return x;
-}
 template <bool RC>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_packed_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 R, u32 k,
                                                                        u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap, unsigned long long* cursor,

@@ -95,6 +95,9 @@ def hostshim():
         L.hs_digit.restype = C.c_uint32
         L.hs_splitmix64.argtypes = [C.c_uint64]
         L.hs_splitmix64.restype = C.c_uint64
+        for f in ("hs_mix64", "hs_unmix64"):
+            getattr(L, f).argtypes = [C.c_uint64]
+            getattr(L, f).restype = C.c_uint64
         _SHIM = L
     return _SHIM
 

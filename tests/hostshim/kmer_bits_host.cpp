@@ -80,4 +80,6 @@ uint64_t hs_core_owner(const uint64_t* in, int nw, uint32_t shift, uint32_t core
 }
 uint32_t hs_digit(const uint64_t* in, int nw, uint32_t shift, uint32_t bits) { return nw == 1 ? key_digit(ld<1>(in), shift, bits) : key_digit(ld<2>(in), shift, bits); }
 uint64_t hs_splitmix64(uint64_t x) { return splitmix64(x); }
+uint64_t hs_mix64(uint64_t x) { return mix64(x); }
+uint64_t hs_unmix64(uint64_t x) { return unmix64(x); }
 }

@@ -122,6 +122,23 @@ def test_owner_of_a_record_is_independent_of_its_table_slot():
             assert max(hist[r]) < 2.0 * n / stretches and min(hist[r]) > 0.5 * n / stretches, (nw, r, hist[r])
 
 
+def test_the_group_hash_of_one_word_keys_is_a_bijection():
+    """lds_count_packed_kernel (table.hip) keeps a one-word k-mer as the low 48 bits of mix64(k-mer) inside the hash group the top 16
+    bits name, and reads it back with unmix64: the pair must be inverse to each other on all 64-bit words, and one-word keys of a
+    group must differ in their low 48 bits"""
+    L = hostshim()
+    rng = random.Random(64)
+    words = [0, 1, (1 << 62) - 1, (1 << 64) - 1] + [rng.getrandbits(64) for _ in range(20000)] + [rng.getrandbits(62) for _ in range(20000)]
+    for x in words:
+        assert L.hs_unmix64(L.hs_mix64(x)) == x and L.hs_mix64(L.hs_unmix64(x)) == x
+    seen = {}
+    for x in words:                      # (group, remainder) names the key
+        h = L.hs_mix64(x)
+        assert seen.setdefault((h >> 48, h & ((1 << 48) - 1)), x) == x
+    a = (C.c_uint64 * 1)(words[7])
+    assert L.hs_hash(a, 1) == L.hs_mix64(words[7])           # (the partition passes and the group index hash one-word keys with it)
+
+
 def test_splitmix_matches_oracle(oracle):
     L = hostshim()
     for x in (0, 1, 2 ** 63, 0x6B61746F6D650001, 2 ** 64 - 1):
