@@ -94,18 +94,20 @@ KD Key<2> key_shr(const Key<2>& a, u32 s) {
     else { r.w[0] = a.w[0] >> s; r.w[1] = (a.w[1] >> s) | (a.w[0] << (64 - s)); }
     return r;
 }
+// (the words are picked by selects, not by a run-time index: an index into w[] made the compiler keep the key in scratch memory --
+// 32-56 bytes per thread in the record kernels of three-word tiles, which ran at 0.2 of the HBM rate where their one- and two-word
+// forms run at 0.5)
 KD Key<3> key_shr(const Key<3>& a, u32 s) {
-    if (s == 0) return a;
-    Key<3> r; r.w[0] = r.w[1] = r.w[2] = 0;
-    if (s >= 192) return r;
+    Key<3> r;
+    if (s >= 192) { r.w[0] = r.w[1] = r.w[2] = 0; return r; }
     const u32 ws = s >> 6, bs = s & 63;               // whole words, then bits
-    for (int i = 2; i >= 0; --i) {
-        const int j = i - (int)ws;                    // source word of the low part
-        if (j < 0) break;
-        u64 v = a.w[j] >> bs;
-        if (bs && j - 1 >= 0) v |= a.w[j - 1] << (64 - bs);
-        r.w[i] = v;
-    }
+    const u64 x0 = ws == 0 ? a.w[0] : 0;
+    const u64 x1 = ws == 0 ? a.w[1] : ws == 1 ? a.w[0] : 0;
+    const u64 x2 = ws == 0 ? a.w[2] : ws == 1 ? a.w[1] : a.w[0];
+    if (bs == 0) { r.w[0] = x0; r.w[1] = x1; r.w[2] = x2; return r; }
+    r.w[0] = x0 >> bs;
+    r.w[1] = (x1 >> bs) | (x0 << (64 - bs));
+    r.w[2] = (x2 >> bs) | (x1 << (64 - bs));
     return r;
 }
 // keep the low `bits` bits

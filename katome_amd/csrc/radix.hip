@@ -1238,16 +1238,21 @@ __global__ __launch_bounds__(BLOCK) void missing_rank_kernel(const u64* __restri
 #ifndef KATOME_DST_SEG
 #define KATOME_DST_SEG 2048
 #endif
-#ifndef KATOME_DST_ROWS
-#define KATOME_DST_ROWS 2
-#endif
 constexpr u64 DST_IN1 = 1ull << 40;                      // first-seen order: mark in edge_dst, "the target has this in-edge only"
 constexpr u64 DST_FD = 1ull << 41;                       // ... and "this edge is the first to touch its target" (it introduces the node)
 constexpr u64 DST_MARKS = DST_IN1 | DST_FD;
 constexpr u32 DST_SEG = KATOME_DST_SEG;
-constexpr u32 DST_ROWS = KATOME_DST_ROWS;                // edges per thread and trip (loads in flight)
-template <int NW> struct MissCap { static constexpr u32 value = (DST_ROWS > 2 ? 2048 : 1024) / NW; };
-static_assert(MissCap<2>::value >= DST_ROWS * BLOCK, "a whole trip of misses fits the staging buffer");
+// edges per thread and trip (loads and searches in flight): 2 for one-word k-mers, 4 for two-word ones -- measured both ways at C3
+// (11.4 ms with 2, 15.4 with 4) and at k = 40 / 50 M reads (12.0 with 2, 9.2 with 4); -DKATOME_DST_ROWS=n sets both
+template <int NW> struct DstRows {
+#ifdef KATOME_DST_ROWS
+    static constexpr u32 value = KATOME_DST_ROWS;
+#else
+    static constexpr u32 value = NW == 1 ? 2 : 4;
+#endif
+};
+template <int NW> struct MissCap { static constexpr u32 value = (DstRows<NW>::value > 2 ? 2048 : 1024) / NW; };
+static_assert(MissCap<1>::value >= DstRows<1>::value * BLOCK && MissCap<2>::value >= DstRows<2>::value * BLOCK, "a whole trip of misses fits the staging buffer");
 
 template <int NW> __device__ __forceinline__ Key<NW> with_quarter(Key<NW> node, u32 q, u32 node_bits) {
     if (NW == 1) node.w[0] |= (u64)q << node_bits;
@@ -1294,7 +1299,7 @@ __global__ __launch_bounds__(BLOCK) void dst_merge_kernel(const u64* __restrict_
                                                            u64* __restrict__ miss_key, u64* __restrict__ miss_edge, u64 miss_cap, u64* cursor,
                                                            const u64* __restrict__ seq, u64* __restrict__ node_first,
                                                            const u64* __restrict__ edge_src, const u64* __restrict__ seg_edge, u64 n_edges) {
-    constexpr u32 MISS_CAP = MissCap<NW>::value;
+    constexpr u32 MISS_CAP = MissCap<NW>::value, DST_ROWS = DstRows<NW>::value;
     extern __shared__ u64 lmem[];
     u64* ls = lmem;                                     // [DST_SEG * NW] the segment's sources
     u64* lmk = ls + DST_SEG * NW;                       // [MISS_CAP * NW] + [MISS_CAP]: targets not found, and their edges
