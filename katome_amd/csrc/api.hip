@@ -10,6 +10,7 @@
 #include <new>
 #include <string>
 #include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -588,6 +589,61 @@ static int shrink_to_fit(DevBuf& buf, size_t used, hipStream_t stream) {
     return KATOME_OK;
 }
 
+// The k-mer level of an input whose tiles hardly repeat, when its records do not fit the card at once (thin coverage at hundreds of
+// millions of reads): the last tile level's list is taken in P parts -- a part's tiles -> their k-mer records -> counted by sorting,
+// strands not yet told apart, into a list of (canonical k-mer, count) --, and the parts' lists, put behind one another, ARE weighted
+// k-mer records again: the caller counts them once more, as it would have counted the level's records, and has its edges.  A k-mer
+// that several parts hold is counted 1 + 1/P times over instead of once; the alternative is the k-mer table at a third of the speed
+// (profiles/r04_coverage_sweep.jsonl).  KATOME_E_UNSUPPORTED: not this way either (the caller goes on in tables; the list is untouched).
+// KATOME_LEVEL_PARTS=0: never
+static int kmer_records_in_parts(katome_builder* b, const uint64_t* lk, const uint32_t* lw, uint64_t n_last, uint32_t last_bases, uint32_t last_span,
+                                 DevBuf& keys, DevBuf& weights, uint64_t* n_records, uint64_t extra_room, hipStream_t stream) {
+    static const bool on = !getenv("KATOME_LEVEL_PARTS") || atoi(getenv("KATOME_LEVEL_PARTS")) != 0;
+    if (!on) return KATOME_E_UNSUPPORTED;
+    const uint32_t nw = b->nw, k = b->s.k, nwl = (uint32_t)key_words_for_k(last_bases);
+    const uint64_t pair = 8ull * nw + 4, total = n_last * last_span, have = level_budget();
+    const char* sl = getenv("KATOME_LEVEL_SLACK");
+    const uint64_t slack = sl ? strtoull(sl, nullptr, 10) : (256ull << 20);
+    // a part's records, the passes' scratch and its list (three times the records) in half of what is there; the other half holds the lists
+    uint32_t P = 2;
+    while (P <= 64 && (total / P + last_span) * pair * 3 + slack > have / 2) P *= 2;
+    if (P > 64 || n_last < P) return KATOME_E_UNSUPPORTED;
+    if (getenv("KATOME_LEVEL_TRACE")) fprintf(stderr, "[katome levels] k-mers: counted in %u parts of %llu records\n", P, (unsigned long long)(total / P));
+    PhaseScope ps(b->prof, PH_EXPAND_TILES, stream);
+    std::unique_ptr<DevBuf[]> pk(new DevBuf[P]), pw(new DevBuf[P]);
+    for (uint32_t p = 0; p < P; ++p) { pk[p].stream = stream; pw[p].stream = stream; }
+    std::vector<uint64_t> pn(P, 0);
+    uint64_t n_p = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        const uint64_t lo = n_last * p / P, hi = n_last * (p + 1) / P;
+        if (hi == lo) continue;
+        DevBuf rk(stream), rw(stream);
+        uint64_t n_rec = 0, ne = 0, nd = 0;
+        int rc = table_list_to_records(lk + lo * nwl, lw + lo, hi - lo, last_bases, k, last_span, 1, b->rc, rk, rw, &n_rec, stream, 0, nullptr);
+        if (rc == KATOME_OK) rc = records_to_edges_sorted(rk, rw, n_rec, k, false, 0, pk[p], pw[p], &ne, &nd, stream);
+        if (rc == KATOME_E_OOM || rc == KATOME_E_UNSUPPORTED) return KATOME_E_UNSUPPORTED;          // (less room than was planned with: the tables)
+        if (rc != KATOME_OK) return rc;
+        rk.release(); rw.release();
+        KCHECK(shrink_to_fit(pk[p], ne * 8 * nw, stream)); KCHECK(shrink_to_fit(pw[p], ne * 4, stream));
+        pn[p] = ne; n_p += ne;
+    }
+    if (!level_fits(n_p + extra_room, nw, b->rc, "k-mers (the parts' lists)")) return KATOME_E_UNSUPPORTED;
+    if (keys.alloc((n_p + extra_room + 1) * 8 * nw, stream) != KATOME_OK || weights.alloc((n_p + extra_room + 1) * 4, stream) != KATOME_OK) {
+        keys.release(); weights.release();
+        return KATOME_E_UNSUPPORTED;
+    }
+    uint64_t at = 0;
+    for (uint32_t p = 0; p < P; ++p) {
+        if (!pn[p]) continue;
+        KCHECK_HIP(hipMemcpyAsync(keys.as<u64>() + at * nw, pk[p].p, pn[p] * 8 * nw, hipMemcpyDeviceToDevice, stream));
+        KCHECK_HIP(hipMemcpyAsync(weights.as<u32>() + at, pw[p].p, pn[p] * 4, hipMemcpyDeviceToDevice, stream));
+        at += pn[p];
+        pk[p].release(); pw[p].release();
+    }
+    *n_records = n_p;
+    return KATOME_OK;
+}
+
 // The tile records kept aside -> the (k-mer, count) records of the last tile level, every level counted by sorting (DESIGN.md
 // section 4): records -> two hash passes -> counted in LDS -> a compact list of distinct tiles with their counts; the next level's
 // records are cut out of that list.  KATOME_OK: keys / weights hold *n_records records (room for extra_room more behind them) and
@@ -652,6 +708,11 @@ int tile_recs_to_kmer_records(katome_builder* b, DevBuf& keys, DevBuf& weights, 
         lk = t2k.as<u64>(); lw = t2w.as<u32>(); n_last = n2; last_bases = kk2; last_span = b->span2;
     }
     if (n_last && !level_fits(n_last * last_span + extra_room, b->nw, b->rc, "k-mers")) {
+        // in parts first (kmer_records_in_parts): their lists stand in for the level's records
+        if (first_counts) first_counts->release();
+        const int prc = kmer_records_in_parts(b, lk, lw, n_last, last_bases, last_span, keys, weights, n_records, extra_room, stream);
+        if (prc != KATOME_E_UNSUPPORTED) return prc;
+        keys.release(); weights.release(); *n_records = 0;
         // the k-mer level would not fit by sorting: the distinct tiles of the last level go into their table with their counts (the mid
         // tiles into `tiles2`, with nothing in `tiles`: expand_to_last_level's "done before" state) and the k-mers are counted in theirs
         const uint32_t nwl = (uint32_t)key_words_for_k(last_bases);

@@ -1028,7 +1028,7 @@ from katome_amd import device as kd
 # thin coverage: 6000 reads over a genome so long that tiles hardly repeat -- every level multiplies its records
 for k, L in ((31, 150), (40, 150)):
     n = 6000
-    reads = o.synth_reads(31 + k, n, L, 600000, 2e-3, 0)
+    reads = o.synth_reads(31 + k, n, L, int(sys.argv[2]) if len(sys.argv) > 2 else 600000, 2e-3, 0)
     packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
     ref = o.build_ascii(reads, k, True)
     want = {bytes(row): int(w) for row, w in zip(ref.edge_label, ref.edge_weight)}
@@ -1052,19 +1052,22 @@ def test_levels_that_do_not_fit_the_card_by_sorting_are_counted_in_tables(tmp_pa
     """input whose tiles hardly repeat (coverage of a few fold instead of C3's 300) multiplies records level by level; a level whose
     records, scratch and output would not fit what the card has free goes the table way from there on (api.hip level_fits) instead of
     dying in an allocation: forced at a small size with KATOME_LEVEL_BUDGET -- (a) nothing fits: the mid tiles and the k-mers in
-    tables, (b) the mid level fits, the k-mer level does not: the distinct mid tiles go into their table with their counts and the
-    k-mers are counted in theirs, (c) everything fits: no table.  The oracle's graph each time, byte for byte the same arrays"""
+    tables, (b) the mid level fits, the k-mer level does not: in parts by sorting when that is allowed, else the distinct mid tiles
+    go into their table with their counts and the k-mers are counted in theirs, (c) everything fits: no table.  The oracle's graph
+    each time, byte for byte the same arrays"""
     import subprocess
     script = tmp_path / "budget.py"
     script.write_text(_BUDGET_SCRIPT)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-    def run(budget):
-        env = dict(os.environ, KATOME_SORTED_COUNT="2", KATOME_LEVEL_SLACK="0")
+    def run(budget, parts="0", trace=None, genome=600000):
+        env = dict(os.environ, KATOME_SORTED_COUNT="2", KATOME_LEVEL_SLACK="0", KATOME_LEVEL_PARTS=parts, KATOME_LEVEL_TRACE="1")
         if budget is not None:
             env["KATOME_LEVEL_BUDGET"] = str(budget)
-        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
+        out = subprocess.run([sys.executable, str(script), root, str(genome)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stderr[-3000:]
+        if trace is not None:
+            trace.append(out.stderr)
         return [line.split() for line in out.stdout.splitlines() if line.startswith("BUDGET ")]
     everything = run(None)
     assert [r[2:6] for r in everything] == [["1", "0", "0", "0"]] * 2                 # all three levels by sorting
@@ -1083,6 +1086,21 @@ def test_levels_that_do_not_fit_the_card_by_sorting_are_counted_in_tables(tmp_pa
         mid = run((need_mid + need_last) // 2)[i]
         assert mid[2:6] == ["1", "0", "1", "1"], mid                                   # mid tiles and k-mers in tables, no big-tile table
         assert mid[8] == row[8]
+    # The k-mer level IN PARTS (the default; api.hip kmer_records_in_parts): when its records do not fit at once but repeat -- reads at
+    # 22-fold coverage here --, the last tile level's list is cut, every part's k-mers are counted by sorting and the parts' lists are
+    # counted once more: no table at all; with parts switched off the same budget sends the level to the tables
+    deeper = run(None, genome=40000)
+    assert [r[2:6] for r in deeper] == [["1", "0", "0", "0"]] * 2
+    for i, row in enumerate(deeper):
+        k = int(row[1])
+        nw, span2 = (1, 6) if k == 31 else (2, 9)
+        need_last = int(row[7]) * span2 * (8 * nw + 4) * 4
+        said = []
+        parts = run(int(0.85 * need_last), parts="1", trace=said, genome=40000)[i]
+        assert parts[2:6] == ["1", "0", "0", "0"] and parts[8] == row[8], (parts, said[0][-600:])
+        assert "k-mers: counted in" in said[0] and "parts of" in said[0], said[0][-600:]
+        tables = run(int(0.85 * need_last), parts="0", genome=40000)[i]
+        assert tables[2:6] == ["1", "0", "1", "1"] and tables[8] == row[8], tables
 
 
 def test_tile_records_kept_aside_grow_and_can_still_go_into_the_table(tmp_path):
