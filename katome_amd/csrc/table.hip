@@ -1093,8 +1093,10 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                     if (!mine && (cur >> 20) == (want >> 20)) {            // same fingerprint: the same key?
                         const u64 j = lo + (cur & REP_MASK);
                         mine = true;
+#ifndef KATOME_LC_EXPERIMENT_NO_COMPARE          // (an experiment build only: what the representative's fetch costs -- NOT exact)
 #pragma unroll
                         for (int q = 0; q < NW; ++q) mine = mine && keys[j * NW + q] == key.w[q];
+#endif
                     }
                     if (mine) { atomicAdd(&lcnt[s], w); break; }
                     s += step; if (s >= LC_SLOTS) s -= LC_SLOTS;
@@ -1182,6 +1184,131 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
                 }
             }
             LC_PHASE(7);
+        }
+    }
+    my_distinct = wave_sum(my_distinct);
+    if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
+}
+
+// Two-word keys whose DISTINCT keys per group are few (the tile levels of k <= 31: C3's groups hold 12 k records of 2.2 k / 3.7 k tiles;
+// the k-mers of k = 32..63 at the benchmark shapes' coverage): the slot holds the WHOLE key -- 16 bytes + a count, 7168 slots -- so
+// a record that meets its key again compares in LDS: one 16-byte read, one add.  lds_count_wide_kernel's slot has a fingerprint and
+// must fetch the representative's key for every such meeting -- 64 lines from L2 per wave, 80 % of the tile records are repeats --,
+// and that fetch is a third of its time (an experiment build without the comparison: 18.4 -> 11.9 ms at C3, not exact).  A slot is
+// claimed word by word, each by a compare-and-swap from 0 (a word never changes again): whoever sets the first word has the slot for
+// keys with that first word, the first to set the second has it for its key, a record that loses the second word moves on along
+// its own probe sequence -- every key sits on its sequence behind occupied slots only.  The second word is stored XOR a salt so that
+// 0 stays "not set"; the one key whose second word IS the salt cannot be stored (err 7: the caller counts with the wide kernel, as it
+// does when a table fills: err 3).  Which kernel counts a level is decided by counting 256 of its groups first (records_to_edges_sorted).
+constexpr u32 LF_PER = 7, LF_SLOTS = LC_THREADS * LF_PER;        // 7168 x (16 + 4) B = 140 KiB
+constexpr u32 LF_FILL = LF_SLOTS / 10 * 6;                       // distinct keys a group may hold (load 0.6)
+constexpr u64 LF_SALT = 0x9E3779B97F4A7C15ull;
+template <bool RC, bool EVEN_K>
+__global__ __launch_bounds__(LC_THREADS) void lds_count_full_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 groups_run, u32 k,
+                                                                     u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap, unsigned long long* cursor,
+                                                                     unsigned long long* distinct, u32* err, u32 probe_limit) {
+    extern __shared__ unsigned long long lc_mem[];
+    ulonglong2* slot = reinterpret_cast<ulonglong2*>(lc_mem);            // [LF_SLOTS]: {first word | OCC, second word ^ salt}
+    u32* lcnt = reinterpret_cast<u32*>(lc_mem + 2 * (size_t)LF_SLOTS);   // [LF_SLOTS]
+    __shared__ u32 wtot[LC_THREADS / 64];
+    __shared__ unsigned long long base_sh;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 my_distinct = 0;
+    for (u32 g = blockIdx.x; g < groups_run; g += gridDim.x) {
+        const u64 lo = index[g], hi = index[g + 1];
+        if (lo == hi) continue;
+        for (u32 i = tid; i < LF_SLOTS; i += LC_THREADS) { slot[i] = make_ulonglong2(0ull, 0ull); lcnt[i] = 0u; }
+        __syncthreads();
+        constexpr u32 LU = KATOME_LC_LU;
+        u64 ka[LU], kb[LU]; u32 wv[LU];
+        auto fetch = [&](u64 i0, u64* a, u64* b, u32* w) {
+#pragma unroll
+            for (u32 u = 0; u < LU; ++u) {
+                const u64 i = i0 + (u64)u * LC_THREADS;
+                a[u] = 0; b[u] = 0; w[u] = 0;
+                if (i < hi) { const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(keys + 2 * i); a[u] = v.x; b[u] = v.y; w[u] = wts ? wts[i] : 1u; }
+            }
+        };
+        fetch(lo + tid, ka, kb, wv);
+        for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
+            u64 na[LU], nb[LU]; u32 nwv[LU];
+            fetch(i0 + (u64)LC_THREADS * LU, na, nb, nwv);              // (the next turn's records are on their way)
+#pragma unroll
+            for (u32 u = 0; u < LU; ++u) {
+                if (i0 + (u64)u * LC_THREADS >= hi) continue;
+                Key<2> key; key.w[0] = ka[u]; key.w[1] = kb[u];
+                const u64 h = hash_key(key);
+                const unsigned long long A = ka[u] | OCC, B = kb[u] ^ LF_SALT;
+                if (B == 0ull) { *err = 7; continue; }
+                u32 s = (u32)(((h & 0x3FFFFFFFull) * LF_SLOTS) >> 30);
+                const u32 step = lc_step<LF_PER>(h);
+                u32 probes = 0;
+                for (; probes < probe_limit; ++probes) {
+                    const ulonglong2 v = slot[s];
+                    unsigned long long a = v.x, b = v.y;
+                    if (a == 0ull) { a = atomicCAS(&slot[s].x, 0ull, A); if (a == 0ull) a = A; }
+                    if (a == A && b == 0ull) { b = atomicCAS(&slot[s].y, 0ull, B); if (b == 0ull) b = B; }
+                    if (a == A && b == B) { atomicAdd(&lcnt[s], wv[u]); break; }
+                    s += step; if (s >= LF_SLOTS) s -= LF_SLOTS;
+                }
+                if (probes == probe_limit) *err = 3;
+            }
+#pragma unroll
+            for (u32 u = 0; u < LU; ++u) { ka[u] = na[u]; kb[u] = nb[u]; wv[u] = nwv[u]; }
+        }
+        __syncthreads();
+        // read-out: every thread LF_PER consecutive slots, their keys in registers (the staging below overwrites the table)
+        Key<2> kk[LF_PER]; u32 cc[LF_PER], ne[LF_PER]; u32 mine = 0;
+#pragma unroll
+        for (u32 j = 0; j < LF_PER; ++j) {
+            const ulonglong2 v = slot[tid * LF_PER + j];
+            ne[j] = 0; cc[j] = 0; kk[j].w[0] = 0; kk[j].w[1] = 0;
+            if (v.x) {
+                kk[j].w[0] = v.x & ~OCC; kk[j].w[1] = v.y ^ LF_SALT;
+                cc[j] = lcnt[tid * LF_PER + j];
+                ++my_distinct;
+                ne[j] = RC ? 2 : 1;
+                if (RC && EVEN_K && key_eq(revcomp(kk[j], k), kk[j])) ne[j] = 1;
+                if ((cc[j] << ((RC && ne[j] == 1) ? 1u : 0u)) < min_weight) ne[j] = 0;      // Clean::remove_weak_edges (pruner.rs:89-92)
+            }
+            mine += ne[j];
+        }
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+        if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        {   // out through the table's LDS, one stretch per workgroup (an entry is as large as a slot)
+            unsigned long long* skey = lc_mem;                         // [LF_SLOTS][2]
+            u32* sw = lcnt;                                             // [LF_SLOTS]
+            const u32 p0 = woff + (incl - mine);
+            for (u32 c0 = 0; c0 < total; c0 += LF_SLOTS) {
+                u32 p = p0 - c0;                                        // (before the chunk: wraps to a large number, fails the tests)
+#pragma unroll
+                for (u32 j = 0; j < LF_PER; ++j) {
+                    if (!ne[j]) continue;
+                    const u32 w = cc[j] << ((RC && ne[j] == 1) ? 1u : 0u);       // (as a shift: see lds_count_kernel)
+                    if (p < LF_SLOTS) { skey[2 * (size_t)p] = kk[j].w[0]; skey[2 * (size_t)p + 1] = kk[j].w[1]; sw[p] = w; }
+                    ++p;
+                    if (ne[j] == 2) {
+                        if (p < LF_SLOTS) { const Key<2> rk = revcomp(kk[j], k); skey[2 * (size_t)p] = rk.w[0]; skey[2 * (size_t)p + 1] = rk.w[1]; sw[p] = w; }
+                        ++p;
+                    }
+                }
+                __syncthreads();
+                const u32 nc = total - c0 < LF_SLOTS ? total - c0 : LF_SLOTS;
+                const u64 o0 = base_sh + c0;
+                const u64 room = o0 < out_cap ? out_cap - o0 : 0;
+                const u32 nk = (u32)(room < nc ? room : nc);
+                for (u32 i = tid; i < nk * 2; i += LC_THREADS) out_keys[o0 * 2 + i] = skey[i];
+                for (u32 i = tid; i < nk; i += LC_THREADS) out_w[o0 + i] = sw[i];
+                __syncthreads();
+            }
         }
     }
     my_distinct = wave_sum(my_distinct);
@@ -2097,6 +2224,41 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
         KCHECK_HIP(hipStreamSynchronize(stream));
         return KATOME_OK;
     };
+    // Two-word keys: whole keys in the slots (lds_count_full_kernel) when a group's distinct keys fit that smaller table.  How many
+    // they are is known only by counting: the first 256 groups are counted for it (1/256 of the records, nothing written: out_cap 0).
+    // KATOME_LC_FULL=0: never, =1: without asking (tests)
+    if (nw == 2 && !split && gbits == 16) {
+        static const int full_mode = getenv("KATOME_LC_FULL") ? atoi(getenv("KATOME_LC_FULL")) : -1;
+        const bool even = (k & 1) == 0;
+        auto count_full = [&](u32 groups, u64 cap) -> int {
+            KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+            const size_t lds = (size_t)LF_SLOTS * 20;
+#define KATOME_LF_LAUNCH(RCV, EVENV)                                                                                                    \
+            do {                                                                                                                      \
+                KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_full_kernel<RCV, EVENV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                KernelScope ks(K_LDS_COUNT, stream, n);                                                                               \
+                hipLaunchKernelGGL((lds_count_full_kernel<RCV, EVENV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), groups, k, \
+                                   min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), cap, cursor, distinct, err, std::min<u32>(lc_probe_limit(), LF_SLOTS)); \
+            } while (0)
+            if (!rc) KATOME_LF_LAUNCH(false, false); else if (even) KATOME_LF_LAUNCH(true, true); else KATOME_LF_LAUNCH(true, false);
+#undef KATOME_LF_LAUNCH
+            KCHECK_HIP(hipGetLastError());
+            KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipStreamSynchronize(stream));
+            return KATOME_OK;
+        };
+        const u32 all = 1u << gbits, sample = 256u;
+        bool take = full_mode == 1;
+        if (full_mode < 0 && avg > 0 && avg <= 8ull * LF_FILL) {        // (eight records to a key: more repetition than that is not planned with)
+            KCHECK(count_full(sample, 0));
+            take = (uint32_t)h[2] == 0 && h[1] / sample <= LF_FILL;
+        }
+        if (take) {
+            KCHECK(count_full(all, out_cap));
+            if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] whole keys in the slots: code %u\n", (unsigned)h[2]);
+            if ((uint32_t)h[2] == 0) { *n_edges = h[0]; *n_distinct = h[1]; return KATOME_OK; }
+        }
+    }
     const u32 R_try = (u32)std::max<u64>(1, (u64)std::ceil((double)avg * lc_optimism() / fill));
     // One-word k-mers whose groups would take several visits: 8-byte slots, one visit (lds_count_packed_kernel), sized on the guess that
     // 56 % of a group's records are distinct (C3: 0.56; more and the table fills: err 3, then as before).  KATOME_LC_PACKED=0: never

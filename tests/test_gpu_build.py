@@ -842,7 +842,9 @@ def test_round_one_paths_give_the_same_arrays(tmp_path):
                   {"KATOME_SORTED_COUNT": "2", "KATOME_FUSED_HIST": "0"}, {"KATOME_SORTED_COUNT": "2", "KATOME_XCD_TILES": "0"},
                   # the k-mers counted in 8-byte LDS slots, one visit per record (table.hip lds_count_packed_kernel; by default only
                   # where a group would take two visits), and never
-                  {"KATOME_SORTED_COUNT": "2", "KATOME_LC_PACKED": "2"}, {"KATOME_SORTED_COUNT": "2", "KATOME_LC_PACKED": "0"}):
+                  {"KATOME_SORTED_COUNT": "2", "KATOME_LC_PACKED": "2"}, {"KATOME_SORTED_COUNT": "2", "KATOME_LC_PACKED": "0"},
+                  # the tile levels' two-word keys whole in the LDS slots (lds_count_full_kernel; by default a sample decides), and never
+                  {"KATOME_SORTED_COUNT": "2", "KATOME_LC_FULL": "1"}, {"KATOME_SORTED_COUNT": "2", "KATOME_LC_FULL": "0"}):
         assert run(extra) == want, extra
 
 
@@ -886,6 +888,50 @@ def test_kmers_counted_in_eight_byte_lds_slots(tmp_path):
     assert len(rows) == 7 and all(r[4] == "1" for r in rows), rows
     assert out.stderr.count("8-byte slots, 1 visit(s) per record: code 0") >= 5, out.stderr[-800:]        # (levels of one-word tiles take them too)
     assert out.stderr.count("a count beyond 16 bits") == 1 and int(rows[4][5]) > 0xFFFF, out.stderr[-800:]
+
+
+_FULL_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from helpers import pack_reads_ascii
+from oracle import oracle as o
+from katome_amd import device as kd
+SALT = 0x9E3779B97F4A7C15
+salt_bases = np.frombuffer(b"ACGT", np.uint8)[[(SALT >> (2 * (31 - i))) & 3 for i in range(32)]]
+for k, rc, L, n, salted in ((31, True, 150, 4000, 0), (31, False, 150, 3000, 1), (40, True, 150, 3000, 0), (40, False, 120, 3000, 0), (63, True, 150, 3000, 0),
+                            (47, True, 100, 3000, 0), (33, False, 64, 2500, 0)):
+    reads = o.synth_reads(k + n, n, L, 20000, 2e-3, 0)
+    if salted:              # the last 32 bases of a read's first tile (k + span - 1 = 60 bases) spell the salt: that tile cannot be stored
+        reads[:40, 28:60] = salt_bases
+    packed = torch.from_numpy(pack_reads_ascii(reads).reshape(-1).copy()).cuda()
+    b = kd.Builder(k, rc)
+    b.count_reads(packed, len(reads), L, None, first_read=0)
+    dg = b.finalize()
+    ref = o.build_ascii(reads, k, rc)
+    lab = dg.edge_label.cpu().numpy().reshape(dg.n_edges, -1)
+    got = sorted((bytes(r), int(w)) for r, w in zip(lab, dg.edge_weight.cpu().numpy().view(np.uint32)))
+    want = sorted((bytes(r), int(w)) for r, w in zip(ref.edge_label, ref.edge_weight))
+    print("FULL", k, int(rc), salted, int((dg.n_nodes, dg.n_edges) == (ref.n_nodes, ref.n_edges) and got == want))
+    b.close()
+"""
+
+
+def test_two_word_keys_counted_with_whole_keys_in_the_lds_slots(tmp_path):
+    """lds_count_full_kernel (table.hip): two-word keys -- the tiles of k <= 31, the k-mers of k = 32..63 -- counted in LDS slots that
+    hold the whole key, claimed word by word.  Forced at small sizes (KATOME_LC_FULL=1; by default a sample of 256 groups decides)
+    against the oracle: both strand modes, even and odd k, tiles whose second word equals the salt that marks "not set" (the level
+    falls back to the fingerprint slots: code 7 under KATOME_LC_TRACE)"""
+    import subprocess
+    script = tmp_path / "full.py"
+    script.write_text(_FULL_SCRIPT)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KATOME_SORTED_COUNT="2", KATOME_LC_FULL="1", KATOME_LC_TRACE="1")
+    out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rows = [line.split() for line in out.stdout.splitlines() if line.startswith("FULL ")]
+    assert len(rows) == 7 and all(r[4] == "1" for r in rows), rows
+    assert out.stderr.count("whole keys in the slots: code 0") >= 8, out.stderr[-1500:]
+    assert out.stderr.count("whole keys in the slots: code 7") >= 1, out.stderr[-1500:]
 
 
 _KEPT_SCRIPT = r"""
