@@ -593,14 +593,14 @@ def main():
         if sorted_last_level and args.first_seen_order:
             kernel_names["expand_tiles"] = "seen_records_kernel + 2 x radix pass (HashTaggedDigit) + hash_group_index_kernel + lds_count_seen_kernel (no k-mer table; the edges leave with their sequence numbers)"
         elif sorted_last_level:
-            kernel_names["expand_tiles"] = "tiles_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_kernel (no k-mer table; the edges are written here)"
+            kernel_names["expand_tiles"] = "tiles_to_records_kernel + 2 x radix pass (HashDigit) + hash_group_index_kernel + LDS count (lds_count_packed_kernel: 8-byte slots, one visit; lds_count_kernel / _wide / _full for other shapes) (no k-mer table; the edges are written here)"
             if cnt.get("mid_span") and not cnt.get("mid_tile_slots"):
                 kernel_names["expand_tiles"] = kernel_names["expand_tiles"].replace("tiles_to_records_kernel", "list_to_records_kernel")
                 if cnt.get("tile_slots"):
-                    kernel_names["expand_mid_tiles"] = "tiles_to_records_kernel (big tiles -> mid-tile records) + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no mid-tile table; a compact list of (mid tile, count) is written)"
+                    kernel_names["expand_mid_tiles"] = "tiles_to_records_kernel (big tiles -> mid-tile records) + 2 x radix pass (HashDigit) + hash_group_index_kernel + LDS count (lds_count_full_kernel / lds_count_wide_kernel) (no mid-tile table; a compact list of (mid tile, count) is written)"
                 else:
-                    kernel_names["insert_tiles"] = "tile records kept aside per batch + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no tile table)"
-                    kernel_names["expand_mid_tiles"] = "list_to_records_hist_kernel (records + the first pass's digit counts) + 2 x radix pass (HashDigit) + hash_group_index_kernel + lds_count_wide_kernel (no mid-tile table)"
+                    kernel_names["insert_tiles"] = "tile records kept aside per batch + 2 x radix pass (HashDigit) + hash_group_index_kernel + LDS count (lds_count_full_kernel: whole two-word keys in the slots; lds_count_wide_kernel behind it and for three-word keys) (no tile table)"
+                    kernel_names["expand_mid_tiles"] = "list_to_records_hist_kernel (records + the first pass's digit counts) + 2 x radix pass (HashDigit) + hash_group_index_kernel + LDS count (lds_count_full_kernel / lds_count_wide_kernel) (no mid-tile table)"
         kernels = {}                      # phases of the build (one or several launches each)
         kernel_launches = {}              # single kernels timed launch by launch inside the phases (library: KernelScope)
         reads_per_rank_step = wl.reads / world
