@@ -666,10 +666,10 @@ def main():
                     kexact["lds_count_kernel"] = "void lds_count_packed_kernel<%s>" % rcs
                 # (two-word k-mers whose distinct keys per group fit the smaller table of whole keys: lds_count_full_kernel -- the library
                 # decides by counting 256 groups; here: by the distinct keys it reported)
-                lf_fill = 1024 * 7 // 10 * 6
+                lf_fill = 1024 * 7 // 20 * 11
                 lc_full_on = os.environ.get("KATOME_LC_FULL", "-1") != "0"
                 if nw == 2 and lc_full_on and 0 < avg_rec <= 8 * lf_fill and (cnt.get("distinct_kmers", 0) >> 16) <= lf_fill:
-                    kexact["lds_count_kernel"] = "void lds_count_full_kernel<%s, %s>" % (rcs, even_s)
+                    kexact["lds_count_kernel"] = "void lds_count_full_kernel<%s, %s, %d>" % (rcs, even_s, 4 if (cnt.get("distinct_kmers", 0) >> 16) <= 4096 // 20 * 7 else 7)
             if sorted_last_level and cnt.get("mid_span") and not cnt.get("mid_tile_slots") and nwt == _katome_lib().katome_tile_words(wl.k, cnt["mid_span"]):
                 # the tile levels counted by sorting: the same kernels on tile records (two-word keys, 20 bytes) -- the mid tiles'
                 # (cut out of the big-tile table, or out of the list of big tiles) and, without a tile table, the big tiles' as well
@@ -692,8 +692,8 @@ def main():
                                                                           "void list_to_records_hist_kernel<%d, %d, %s>" if fused_hist else "void list_to_records_kernel<%d, %d, %s>") % (nwt, nwm, rcs),
                                "lds_count_kernel (tile records)": ("void lds_count_kernel<false, %d, false>" % per_m) if nwm == 1 else ("void lds_count_wide_kernel<false, %d, %d, false>" % (per_m, nwm))})
                 # (two-word tiles of few distinct keys per group are counted with their whole keys in the slots: lds_count_full_kernel)
-                if nwm == 2 and os.environ.get("KATOME_LC_FULL", "-1") != "0" and max(cnt.get("distinct_tiles", 0), cnt.get("distinct_mid_tiles", 0)) >> 16 <= 1024 * 7 // 10 * 6:
-                    kexact["lds_count_kernel (tile records)"] = "void lds_count_full_kernel<false, false>"
+                if nwm == 2 and os.environ.get("KATOME_LC_FULL", "-1") != "0" and max(cnt.get("distinct_tiles", 0), cnt.get("distinct_mid_tiles", 0)) >> 16 <= 1024 * 7 // 20 * 11:
+                    kexact["lds_count_kernel (tile records)"] = "void lds_count_full_kernel<false, false, 7>"       # (4 for a level of at most 1433 distinct tiles per group)
         for name, ph in phases.items():
             if not name.startswith("k:"):
                 continue

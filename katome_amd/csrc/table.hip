@@ -1200,13 +1200,18 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_wide_kernel(const u64* k
 // its own probe sequence -- every key sits on its sequence behind occupied slots only.  The second word is stored XOR a salt so that
 // 0 stays "not set"; the one key whose second word IS the salt cannot be stored (err 7: the caller counts with the wide kernel, as it
 // does when a table fills: err 3).  Which kernel counts a level is decided by counting 256 of its groups first (records_to_edges_sorted).
-constexpr u32 LF_PER = 7, LF_SLOTS = LC_THREADS * LF_PER;        // 7168 x (16 + 4) B = 140 KiB
-constexpr u32 LF_FILL = LF_SLOTS / 10 * 6;                       // distinct keys a group may hold (load 0.6)
+// (LF_PER slots per thread: 7 -> 7168 slots of 16 + 4 bytes = 140 KiB; 4 -> 4096 slots = 80 KiB for groups of few distinct keys:
+// less to clear and to read out per group)
+template <int LF_PER> struct LfTable {
+    static constexpr u32 SLOTS = LC_THREADS * LF_PER;
+    static constexpr u32 FILL = SLOTS / 20 * 11;                  // distinct keys a group may hold (load 0.55)
+};
 constexpr u64 LF_SALT = 0x9E3779B97F4A7C15ull;
-template <bool RC, bool EVEN_K>
+template <bool RC, bool EVEN_K, int LF_PER>
 __global__ __launch_bounds__(LC_THREADS) void lds_count_full_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 groups_run, u32 k,
                                                                      u32 min_weight, u64* out_keys, u32* out_w, u64 out_cap, unsigned long long* cursor,
                                                                      unsigned long long* distinct, u32* err, u32 probe_limit) {
+    constexpr u32 LF_SLOTS = LfTable<LF_PER>::SLOTS;
     extern __shared__ unsigned long long lc_mem[];
     ulonglong2* slot = reinterpret_cast<ulonglong2*>(lc_mem);            // [LF_SLOTS]: {first word | OCC, second word ^ salt}
     u32* lcnt = reinterpret_cast<u32*>(lc_mem + 2 * (size_t)LF_SLOTS);   // [LF_SLOTS]
@@ -2230,17 +2235,20 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
     if (nw == 2 && !split && gbits == 16) {
         static const int full_mode = getenv("KATOME_LC_FULL") ? atoi(getenv("KATOME_LC_FULL")) : -1;
         const bool even = (k & 1) == 0;
-        auto count_full = [&](u32 groups, u64 cap) -> int {
+        auto count_full = [&](u32 groups, u64 cap, int per) -> int {
             KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
-            const size_t lds = (size_t)LF_SLOTS * 20;
-#define KATOME_LF_LAUNCH(RCV, EVENV)                                                                                                    \
+#define KATOME_LF_LAUNCH(RCV, EVENV, PERV)                                                                                              \
             do {                                                                                                                      \
-                KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_full_kernel<RCV, EVENV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                const size_t lds = (size_t)LfTable<PERV>::SLOTS * 20;                                                                 \
+                KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_full_kernel<RCV, EVENV, PERV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
                 KernelScope ks(K_LDS_COUNT, stream, n);                                                                               \
-                hipLaunchKernelGGL((lds_count_full_kernel<RCV, EVENV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), groups, k, \
-                                   min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), cap, cursor, distinct, err, std::min<u32>(lc_probe_limit(), LF_SLOTS)); \
+                hipLaunchKernelGGL((lds_count_full_kernel<RCV, EVENV, PERV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), groups, k, \
+                                   min_weight, edge_key.as<u64>(), edge_weight.as<u32>(), cap, cursor, distinct, err, std::min<u32>(lc_probe_limit(), LfTable<PERV>::SLOTS)); \
             } while (0)
-            if (!rc) KATOME_LF_LAUNCH(false, false); else if (even) KATOME_LF_LAUNCH(true, true); else KATOME_LF_LAUNCH(true, false);
+#define KATOME_LF_PICK(PERV)                                                                                                            \
+            do { if (!rc) KATOME_LF_LAUNCH(false, false, PERV); else if (even) KATOME_LF_LAUNCH(true, true, PERV); else KATOME_LF_LAUNCH(true, false, PERV); } while (0)
+            if (per == 4) KATOME_LF_PICK(4); else KATOME_LF_PICK(7);
+#undef KATOME_LF_PICK
 #undef KATOME_LF_LAUNCH
             KCHECK_HIP(hipGetLastError());
             KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
@@ -2248,14 +2256,24 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
             return KATOME_OK;
         };
         const u32 all = 1u << gbits, sample = 256u;
+        static const int full_per = getenv("KATOME_LC_FULL_PER") ? atoi(getenv("KATOME_LC_FULL_PER")) : 0;      // (4 or 7: tests)
         bool take = full_mode == 1;
-        if (full_mode < 0 && avg > 0 && avg <= 8ull * LF_FILL) {        // (eight records to a key: more repetition than that is not planned with)
-            KCHECK(count_full(sample, 0));
-            take = (uint32_t)h[2] == 0 && h[1] / sample <= LF_FILL;
+        int per = full_per == 4 ? 4 : 7;
+        if (full_mode < 0 && avg > 0 && avg <= 8ull * LfTable<7>::FILL) {        // (eight records to a key: more repetition than that is not planned with)
+            KCHECK(count_full(sample, 0, 7));
+            const u64 per_group = h[1] / sample;
+            take = (uint32_t)h[2] == 0 && per_group <= LfTable<7>::FILL;
+            // (the smaller table only where it stays a third full: at 0.55 -- C3's big tiles -- its longer probe sequences cost more than
+            // its shorter clear and read-out save: 16.2 against 15.5 ms; at 0.35 -- k = 63's k-mers -- 4.5 against 4.9)
+            if (!full_per) per = per_group <= LfTable<4>::SLOTS / 20 * 7 ? 4 : 7;
         }
         if (take) {
-            KCHECK(count_full(all, out_cap));
-            if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] whole keys in the slots: code %u\n", (unsigned)h[2]);
+            KCHECK(count_full(all, out_cap, per));
+            if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] whole keys in the slots (%d per thread): code %u\n", per, (unsigned)h[2]);
+            if ((uint32_t)h[2] == 3 && per == 4) {               // (a group of more distinct keys than the sample promised: the larger table)
+                KCHECK(count_full(all, out_cap, 7));
+                if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] whole keys in the slots (7 per thread): code %u\n", (unsigned)h[2]);
+            }
             if ((uint32_t)h[2] == 0) { *n_edges = h[0]; *n_distinct = h[1]; return KATOME_OK; }
         }
     }

@@ -925,13 +925,14 @@ def test_two_word_keys_counted_with_whole_keys_in_the_lds_slots(tmp_path):
     script = tmp_path / "full.py"
     script.write_text(_FULL_SCRIPT)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, KATOME_SORTED_COUNT="2", KATOME_LC_FULL="1", KATOME_LC_TRACE="1")
-    out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-3000:]
-    rows = [line.split() for line in out.stdout.splitlines() if line.startswith("FULL ")]
-    assert len(rows) == 7 and all(r[4] == "1" for r in rows), rows
-    assert out.stderr.count("whole keys in the slots: code 0") >= 8, out.stderr[-1500:]
-    assert out.stderr.count("whole keys in the slots: code 7") >= 1, out.stderr[-1500:]
+    for per in ("7", "4"):               # (the table of 7168 slots and the one of 4096 for groups of few distinct keys)
+        env = dict(os.environ, KATOME_SORTED_COUNT="2", KATOME_LC_FULL="1", KATOME_LC_FULL_PER=per, KATOME_LC_TRACE="1")
+        out = subprocess.run([sys.executable, str(script), root], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-3000:]
+        rows = [line.split() for line in out.stdout.splitlines() if line.startswith("FULL ")]
+        assert len(rows) == 7 and all(r[4] == "1" for r in rows), rows
+        assert out.stderr.count("whole keys in the slots (%s per thread): code 0" % per) >= 8, out.stderr[-1500:]
+        assert out.stderr.count("whole keys in the slots (%s per thread): code 7" % per) >= 1, out.stderr[-1500:]
 
 
 _KEPT_SCRIPT = r"""
