@@ -1320,6 +1320,106 @@ __global__ __launch_bounds__(LC_THREADS) void lds_count_full_kernel(const u64* k
     if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
 }
 
+// The same for THREE-word keys (tiles of 64..95 bases: every tile level of k = 32..63 at 150 bp; never oriented, never thresholded): 24 B
+// of key in three arrays + a count, 5120 or 3072 slots; the second and third word XOR a salt each, claimed in turn.  These levels' groups
+// hold a few hundred distinct tiles, so the small table is the usual one.
+template <int PER> struct Lf3Table {
+    static constexpr u32 SLOTS = LC_THREADS * PER;                // PER = 5: 5120 x 28 B = 140 KiB; 3: 3072 x 28 B = 84 KiB
+    static constexpr u32 FILL = SLOTS / 20 * 11;
+};
+constexpr u64 LF_SALT2 = 0xD1B54A32D192ED03ull;
+template <int PER>
+__global__ __launch_bounds__(LC_THREADS) void lds_count_full3_kernel(const u64* keys, const u32* wts, const u64* __restrict__ index, u32 groups_run,
+                                                                      u64* out_keys, u32* out_w, u64 out_cap, unsigned long long* cursor,
+                                                                      unsigned long long* distinct, u32* err, u32 probe_limit) {
+    constexpr u32 SLOTS = Lf3Table<PER>::SLOTS;
+    extern __shared__ unsigned long long lc_mem[];
+    unsigned long long* sa = lc_mem;                                     // [SLOTS] first word | OCC
+    unsigned long long* sb = lc_mem + SLOTS;                             // [SLOTS] second word ^ salt
+    unsigned long long* sc = lc_mem + 2 * (size_t)SLOTS;                 // [SLOTS] third word ^ salt
+    u32* lcnt = reinterpret_cast<u32*>(lc_mem + 3 * (size_t)SLOTS);      // [SLOTS]
+    __shared__ u32 wtot[LC_THREADS / 64];
+    __shared__ unsigned long long base_sh;
+    const u32 tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    u32 my_distinct = 0;
+    for (u32 g = blockIdx.x; g < groups_run; g += gridDim.x) {
+        const u64 lo = index[g], hi = index[g + 1];
+        if (lo == hi) continue;
+        for (u32 i = tid; i < SLOTS; i += LC_THREADS) { sa[i] = 0ull; sb[i] = 0ull; sc[i] = 0ull; lcnt[i] = 0u; }
+        __syncthreads();
+        constexpr u32 LU = 2;
+        for (u64 i0 = lo + tid; i0 < hi; i0 += (u64)LC_THREADS * LU) {
+            u64 ka[LU], kb[LU], kc[LU]; u32 wv[LU];
+#pragma unroll
+            for (u32 u = 0; u < LU; ++u) {
+                const u64 i = i0 + (u64)u * LC_THREADS;
+                ka[u] = 0; kb[u] = 0; kc[u] = 0; wv[u] = 0;
+                if (i < hi) { ka[u] = keys[3 * i]; kb[u] = keys[3 * i + 1]; kc[u] = keys[3 * i + 2]; wv[u] = wts ? wts[i] : 1u; }
+            }
+#pragma unroll
+            for (u32 u = 0; u < LU; ++u) {
+                if (i0 + (u64)u * LC_THREADS >= hi) continue;
+                Key<3> key; key.w[0] = ka[u]; key.w[1] = kb[u]; key.w[2] = kc[u];
+                const u64 h = hash_key(key);
+                const unsigned long long A = ka[u] | OCC, B = kb[u] ^ LF_SALT, C = kc[u] ^ LF_SALT2;
+                if (B == 0ull || C == 0ull) { *err = 7; continue; }
+                u32 s = (u32)(((h & 0x3FFFFFFFull) * SLOTS) >> 30);
+                const u32 step = lc_step<PER>(h);
+                u32 probes = 0;
+                for (; probes < probe_limit; ++probes) {
+                    unsigned long long a = sa[s], b = sb[s], c = sc[s];
+                    if (a == 0ull) { a = atomicCAS(&sa[s], 0ull, A); if (a == 0ull) a = A; }
+                    if (a == A && b == 0ull) { b = atomicCAS(&sb[s], 0ull, B); if (b == 0ull) b = B; }
+                    if (a == A && b == B && c == 0ull) { c = atomicCAS(&sc[s], 0ull, C); if (c == 0ull) c = C; }
+                    if (a == A && b == B && c == C) { atomicAdd(&lcnt[s], wv[u]); break; }
+                    s += step; if (s >= SLOTS) s -= SLOTS;
+                }
+                if (probes == probe_limit) *err = 3;
+            }
+        }
+        __syncthreads();
+        Key<3> kk[PER]; u32 cc[PER]; u32 keep = 0;
+#pragma unroll
+        for (u32 j = 0; j < (u32)PER; ++j) {
+            const u32 x = tid * PER + j;
+            const unsigned long long a = sa[x];
+            kk[j].w[0] = 0; kk[j].w[1] = 0; kk[j].w[2] = 0; cc[j] = 0;
+            if (a) { kk[j].w[0] = a & ~OCC; kk[j].w[1] = sb[x] ^ LF_SALT; kk[j].w[2] = sc[x] ^ LF_SALT2; cc[j] = lcnt[x]; keep |= 1u << j; ++my_distinct; }
+        }
+        const u32 mine = (u32)__popc(keep);
+        u32 incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (lane >= (u32)o) incl += t; }
+        if (lane == 63) wtot[wave] = incl;
+        __syncthreads();
+        u32 woff = 0, total = 0;
+#pragma unroll
+        for (u32 w = 0; w < LC_THREADS / 64; ++w) { if (w < wave) woff += wtot[w]; total += wtot[w]; }
+        if (tid == 0) base_sh = total ? atomicAdd(cursor, (unsigned long long)total) : 0ull;
+        __syncthreads();
+        {   // out through the table's LDS, one stretch per workgroup (an entry is as large as a slot: total <= SLOTS)
+            unsigned long long* skey = lc_mem;                         // [SLOTS][3]
+            u32* sw = lcnt;                                             // [SLOTS]
+            u32 p = woff + (incl - mine);
+#pragma unroll
+            for (u32 j = 0; j < (u32)PER; ++j) {
+                if (!((keep >> j) & 1u)) continue;
+                skey[3 * (size_t)p] = kk[j].w[0]; skey[3 * (size_t)p + 1] = kk[j].w[1]; skey[3 * (size_t)p + 2] = kk[j].w[2]; sw[p] = cc[j];
+                ++p;
+            }
+            __syncthreads();
+            const u64 o0 = base_sh;
+            const u64 room = o0 < out_cap ? out_cap - o0 : 0;
+            const u32 nk = (u32)(room < total ? room : total);
+            for (u32 i = tid; i < nk * 3; i += LC_THREADS) out_keys[o0 * 3 + i] = skey[i];
+            for (u32 i = tid; i < nk; i += LC_THREADS) out_w[o0 + i] = sw[i];
+            __syncthreads();
+        }
+    }
+    my_distinct = wave_sum(my_distinct);
+    if (lane == 0 && my_distinct) atomicAdd(distinct, (unsigned long long)my_distinct);
+}
+
 // ---- first-seen builds: the last level counted by sorting ------------------------------------------------------------------------
 // A k-mer record of such a build has two sequence numbers: the first insertion of the stored (canonical) k-mer and the first
 // insertion of its reverse complement (pt_graph.rs:282-308 adds a read's forward windows, then those of its reverse complement).
@@ -2273,6 +2373,46 @@ int records_to_edges_sorted(DevBuf& keys, DevBuf& weights, uint64_t n, uint32_t 
             if ((uint32_t)h[2] == 3 && per == 4) {               // (a group of more distinct keys than the sample promised: the larger table)
                 KCHECK(count_full(all, out_cap, 7));
                 if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] whole keys in the slots (7 per thread): code %u\n", (unsigned)h[2]);
+            }
+            if ((uint32_t)h[2] == 0) { *n_edges = h[0]; *n_distinct = h[1]; return KATOME_OK; }
+        }
+    }
+    // ... and three-word keys (lds_count_full3_kernel), chosen the same way
+    if (nw == 3 && !split && gbits == 16) {
+        static const int full_mode = getenv("KATOME_LC_FULL") ? atoi(getenv("KATOME_LC_FULL")) : -1;
+        static const int full_per = getenv("KATOME_LC_FULL_PER") ? atoi(getenv("KATOME_LC_FULL_PER")) : 0;      // (tests: 4 -> the small table, 7 -> the large one)
+        auto count_full3 = [&](u32 groups, u64 cap, int per) -> int {
+            KCHECK_HIP(hipMemsetAsync(aux.p, 0, 64, stream));
+#define KATOME_LF3_LAUNCH(PERV)                                                                                                         \
+            do {                                                                                                                      \
+                const size_t lds = (size_t)Lf3Table<PERV>::SLOTS * 28;                                                                \
+                KCHECK_HIP(hipFuncSetAttribute((const void*)lds_count_full3_kernel<PERV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                KernelScope ks(K_LDS_COUNT, stream, n);                                                                               \
+                hipLaunchKernelGGL((lds_count_full3_kernel<PERV>), dim3(256u), dim3(LC_THREADS), lds, stream, ko, wo, index.as<u64>(), groups,  \
+                                   edge_key.as<u64>(), edge_weight.as<u32>(), cap, cursor, distinct, err, std::min<u32>(lc_probe_limit(), Lf3Table<PERV>::SLOTS)); \
+            } while (0)
+            if (per == 3) KATOME_LF3_LAUNCH(3); else KATOME_LF3_LAUNCH(5);
+#undef KATOME_LF3_LAUNCH
+            KCHECK_HIP(hipGetLastError());
+            KCHECK_HIP(hipMemcpyAsync(h, aux.p, 24, hipMemcpyDeviceToHost, stream));
+            KCHECK_HIP(hipStreamSynchronize(stream));
+            return KATOME_OK;
+        };
+        const u32 all = 1u << gbits, sample = 256u;
+        bool take = full_mode == 1;
+        int per = full_per == 4 ? 3 : 5;
+        if (full_mode < 0 && avg > 0 && avg <= 8ull * Lf3Table<5>::FILL) {
+            KCHECK(count_full3(sample, 0, 5));
+            const u64 per_group = h[1] / sample;
+            take = (uint32_t)h[2] == 0 && per_group <= Lf3Table<5>::FILL;
+            if (!full_per) per = per_group <= Lf3Table<3>::SLOTS / 20 * 7 ? 3 : 5;
+        }
+        if (take) {
+            KCHECK(count_full3(all, out_cap, per));
+            if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] whole three-word keys in the slots (%d per thread): code %u\n", per, (unsigned)h[2]);
+            if ((uint32_t)h[2] == 3 && per == 3) {
+                KCHECK(count_full3(all, out_cap, 5));
+                if (getenv("KATOME_LC_TRACE")) fprintf(stderr, "[lds count] whole three-word keys in the slots (5 per thread): code %u\n", (unsigned)h[2]);
             }
             if ((uint32_t)h[2] == 0) { *n_edges = h[0]; *n_distinct = h[1]; return KATOME_OK; }
         }
